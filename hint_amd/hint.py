@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's `hint.py` module surface, backed by the HIP library.
+
+Drop-in for /root/reference/hint.py:
+  linear_subnet_constructor ............ hint.py:10-13
+  HierarchicalAffineCouplingTree ....... hint.py:21-101  (same ctor keywords, same attributes
+                                         split_idx / conditional / leaf / s / t / upper / lower,
+                                         hence the same state_dict keys `tree.s.0.weight` ...)
+  HierarchicalAffineCouplingBlock ...... hint.py:104-133 (FrEIA module protocol: list in / list
+                                         out, cached `self.jac`, jacobian(), output_dims())
+The arithmetic itself runs in hint_amd/csrc (gfx950 kernels) through the C ABI of
+include/hint_amd.h.  There is no CPU implementation here: CPU tensors raise.
+
+Parameters stay ordinary `nn.Parameter`s inside `nn.Linear`s (the training loop rebinds
+`p.data`, clamps `p.grad`, hands them to Adam: train_unconditional.py:140-141,165-176).  For
+the kernels they are kept as views into ONE flat fp32 arena per tree; the arena is
+re-gathered automatically whenever a parameter stops aliasing it (`p.data = ...`, `.to()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import HintAmdError, NodeDesc
+
+__all__ = ["linear_subnet_constructor", "HierarchicalAffineCouplingTree",
+           "HierarchicalAffineCouplingBlock", "HintAmdError"]
+
+_ALIGN = 4  # floats; every tensor starts 16-byte aligned inside the arena
+
+
+def linear_subnet_constructor(c_in, c_out, c_internal):
+    """Linear-ReLU-Linear-ReLU-Linear, the only subnet the kernels implement (hint.py:10-13)."""
+    return nn.Sequential(nn.Linear(c_in, c_internal), nn.ReLU(),
+                         nn.Linear(c_internal, c_internal), nn.ReLU(),
+                         nn.Linear(c_internal, c_out))
+
+
+def conv_subnet_constructor(c_in, c_out, c_internal):
+    raise NotImplementedError("conv subnets (hint.py:15-18) are out of scope: no reference config uses conv=True")
+
+
+class _Engine:
+    """Plan + flat parameter arena of one (root) tree on one device."""
+
+    def __init__(self, tree: "HierarchicalAffineCouplingTree", device: torch.device):
+        self.lib = _lib.load()
+        self.device = device
+        self.d = tree.data_shape[0]
+        self.dc = tree.condition_length
+        nodes = tree._flat_nodes()
+        self.params: List[nn.Parameter] = []
+        self.offsets: List[int] = []
+        descs = (NodeDesc * len(nodes))()
+        cursor = 0
+        for i, (node, off, depth) in enumerate(nodes):
+            D = node.data_shape[0]
+            dsc = descs[i]
+            dsc.off, dsc.D, dsc.k, dsc.r = off, D, node.split_idx, D - node.split_idx
+            dsc.h, dsc.depth = node.s[0].out_features, depth
+            j = 0
+            for net in (node.s, node.t):
+                for li in (0, 2, 4):
+                    for p in (net[li].weight, net[li].bias):
+                        dsc.p_off[j] = cursor
+                        self.params.append(p)
+                        self.offsets.append(cursor)
+                        cursor += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                        j += 1
+        self.total = max(cursor, _ALIGN)
+        self.shapes = [tuple(p.shape) for p in self.params]
+        self.numels = [p.numel() for p in self.params]
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.hint_plan_create(descs, len(nodes), self.d, self.dc, float(tree.clamp),
+                                                 C.byref(handle)), "hint_plan_create")
+        self.plan = handle
+        self.arena: Optional[torch.Tensor] = None
+        self._ext_arena: Optional[torch.Tensor] = None
+        self._ptrs: List[int] = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.hint_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ---- arena management -------------------------------------------------------------
+    def bind_external_arena(self, arena: torch.Tensor):
+        """Use a caller-owned flat buffer (e.g. a slice of a model-wide arena)."""
+        assert arena.dtype == torch.float32 and arena.is_contiguous() and arena.numel() >= self.total
+        self._ext_arena = arena
+        self.arena = None
+        self._ptrs = []
+
+    def _gather(self):
+        arena = self._ext_arena
+        if arena is None or arena.device != self.device:
+            arena = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for p, off, n, shp in zip(self.params, self.offsets, self.numels, self.shapes):
+                if p.dtype != torch.float32:
+                    raise HintAmdError("hint_amd kernels are fp32 only (parameter dtype %s)" % p.dtype)
+                view = arena[off:off + n].view(shp)
+                if p.data.data_ptr() != view.data_ptr() or p.device != self.device:
+                    view.copy_(p.data.to(self.device))
+                    p.data = view
+        self.arena = arena
+        base = arena.data_ptr()
+        self._ptrs = [base + 4 * off for off in self.offsets]
+
+    def ensure_arena(self):
+        if self.arena is None:
+            self._gather()
+            return
+        ptrs = self._ptrs
+        for i, p in enumerate(self.params):
+            if p.data_ptr() != ptrs[i]:
+                self._gather()
+                return
+
+    def split_flat(self, flat: torch.Tensor):
+        return [flat[off:off + n].view(shp) for off, n, shp in zip(self.offsets, self.numels, self.shapes)]
+
+    # ---- kernel launches --------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def apply(self, x: torch.Tensor, c: Optional[torch.Tensor], rev: bool):
+        B = x.shape[0]
+        out = torch.empty_like(x)
+        J = torch.empty(B, dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out, J
+        fn = self.lib.hint_block_inverse if rev else self.lib.hint_block_forward
+        with torch.cuda.device(self.device):
+            st = fn(self.plan, self.arena.data_ptr(), x.data_ptr(), c.data_ptr() if c is not None else None,
+                    out.data_ptr(), J.data_ptr(), B, self._stream())
+        _lib.check(st, "hint_block_inverse" if rev else "hint_block_forward")
+        return out, J
+
+    def backward(self, z, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None):
+        B = z.shape[0]
+        gx = torch.empty_like(z)
+        gc = torch.empty_like(c) if (c is not None and need_gc) else None
+        if g_params is None:
+            g_params = torch.empty(self.total, dtype=torch.float32, device=z.device)
+        if B == 0:
+            g_params.zero_()
+            return gx, gc, g_params
+        nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=z.device)
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_block_backward(
+                self.plan, self.arena.data_ptr(), z.data_ptr(), c.data_ptr() if c is not None else None,
+                gz.data_ptr() if gz is not None else None, gJ.data_ptr() if gJ is not None else None,
+                gx.data_ptr(), gc.data_ptr() if gc is not None else None, g_params.data_ptr(),
+                ws.data_ptr(), nbytes, B, self._stream())
+        _lib.check(st, "hint_block_backward")
+        return gx, gc, g_params
+
+
+class _CouplingFn(torch.autograd.Function):
+    """autograd node of one block forward; backward re-derives activations from the output."""
+
+    @staticmethod
+    def forward(ctx, engine, x, c, *params):
+        z, J = engine.apply(x, c, rev=False)
+        ctx.engine = engine
+        ctx.has_c = c is not None
+        ctx.save_for_backward(z, c) if c is not None else ctx.save_for_backward(z)
+        return z, J
+
+    @staticmethod
+    def backward(ctx, gz, gJ):
+        engine = ctx.engine
+        saved = ctx.saved_tensors
+        z = saved[0]
+        c = saved[1] if ctx.has_c else None
+        gz = gz.contiguous() if gz is not None else None
+        gJ = gJ.contiguous() if gJ is not None else None
+        need_gc = ctx.has_c and ctx.needs_input_grad[2]
+        gx, gc, gflat = engine.backward(z, c, gz, gJ, need_gc)
+        return (None, gx, gc, *engine.split_flat(gflat))
+
+
+def _as_f32_2d(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise HintAmdError(f"hint_amd: {what} is on {t.device}; the coupling block runs on MI355X only "
+                           "(no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise HintAmdError(f"hint_amd: {what} has dtype {t.dtype}; kernels are fp32 only")
+    if t.dim() != 2:
+        raise HintAmdError(f"hint_amd: {what} must be [batch, features], got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class HierarchicalAffineCouplingTree(nn.Module):
+    """Recursive coupling tree (hint.py:21-101).  Parameter container with the reference's
+    layout; `forward` runs the whole (sub)tree in one fused kernel launch."""
+
+    def __init__(self, data_shape, dims_c, conv=False, subnet_constructor=None, c_internal=[], clamp=2,
+                 max_splits=-1, min_split_size=2, reshuffle=False):
+        super().__init__()
+        if conv:
+            raise NotImplementedError("conv=True (hint.py:15-18,29) is out of scope")
+        if subnet_constructor is not None and subnet_constructor is not linear_subnet_constructor:
+            raise NotImplementedError("only linear_subnet_constructor (hint.py:10-13) is implemented in HIP")
+        if reshuffle:
+            raise NotImplementedError("reshuffle=True needs FrEIA's HouseholderPerm (hint.py:36-39); deferred")
+        if len(tuple(data_shape)) != 1:
+            raise NotImplementedError("only flat [B, d] data is supported")
+        self.data_shape = tuple(data_shape)
+        self.clamp = clamp
+        widths = list(c_internal)          # the reference mutates the caller's list here (hint.py:33-34);
+        if len(widths) == 0:               # we compute the same widths without that side effect
+            widths = [self.data_shape[0]]
+        if len(widths) == 1:
+            widths = widths + widths
+        self.perm = None
+        D = self.data_shape[0]
+        self.split_idx = D // 2                                        # hint.py:41
+        self.conditional = len(dims_c) > 0
+        self.condition_length = sum(dims_c[i][0] for i in range(len(dims_c)))
+        self.s = linear_subnet_constructor(self.split_idx + self.condition_length, D - self.split_idx, widths[0])
+        self.t = linear_subnet_constructor(self.split_idx + self.condition_length, D - self.split_idx, widths[0])
+        if D >= 2 * min_split_size and max_splits != 0:                # hint.py:47
+            self.leaf = False
+            self.upper = HierarchicalAffineCouplingTree((self.split_idx,), dims_c, conv, subnet_constructor,
+                                                        widths[1:], clamp, max_splits - 1, min_split_size, reshuffle)
+            self.lower = HierarchicalAffineCouplingTree((D - self.split_idx,), dims_c, conv, subnet_constructor,
+                                                        widths[1:], clamp, max_splits - 1, min_split_size, reshuffle)
+        else:
+            self.leaf = True
+        self._engine: Optional[_Engine] = None
+
+    # same closed forms as hint.py:56-60, kept for API parity (not used by the kernels)
+    def e(self, s):
+        return torch.exp(self.clamp * 0.636 * torch.atan(s))
+
+    def log_e(self, s):
+        return self.clamp * 0.636 * torch.atan(s)
+
+    def _flat_nodes(self, off=0, depth=0):
+        out = [(self, off, depth)]
+        if not self.leaf:
+            out += self.upper._flat_nodes(off, depth + 1)
+            out += self.lower._flat_nodes(off + self.split_idx, depth + 1)
+        return out
+
+    def engine(self, device) -> _Engine:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise HintAmdError("hint_amd: no CPU implementation; move the model and data to the GPU")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._engine is None or self._engine.device != device:
+            ext = self._engine._ext_arena if self._engine is not None else None
+            self._engine = _Engine(self, device)
+            if ext is not None and ext.device == device:
+                self._engine.bind_external_arena(ext)
+        return self._engine
+
+    def forward(self, x, c=[], rev=False):
+        """-> (x_out, J) like hint.py:62-101."""
+        x = _as_f32_2d(x, "x")
+        if x.shape[1] != self.data_shape[0]:
+            raise HintAmdError(f"expected {self.data_shape[0]} lanes, got {x.shape[1]}")
+        cc = None
+        if self.conditional:
+            cs = [_as_f32_2d(t, "condition") for t in c]
+            cc = cs[0] if len(cs) == 1 else torch.cat(cs, dim=1)
+            if cc.shape[1] != self.condition_length or cc.shape[0] != x.shape[0]:
+                raise HintAmdError("condition shape %s does not match dims_c / batch" % (tuple(cc.shape),))
+        eng = self.engine(x.device)
+        eng.ensure_arena()
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or (cc is not None and cc.requires_grad) or any(p.requires_grad for p in eng.params))
+        if rev:
+            if needs_grad:
+                raise NotImplementedError("autograd through rev=True is not implemented (the reference only "
+                                          "samples under no_grad: train_unconditional.py:152-153)")
+            return eng.apply(x, cc, rev=True)
+        if not needs_grad:
+            return eng.apply(x, cc, rev=False)
+        return _CouplingFn.apply(eng, x, cc, *eng.params)
+
+
+class HierarchicalAffineCouplingBlock(nn.Module):
+    """FrEIA-protocol wrapper (hint.py:104-133)."""
+
+    def __init__(self, dims_in, dims_c=[], conv=False, subnet_constructor=None, c_internal=[], clamp=4.,
+                 max_splits=-1, min_split_size=2, reshuffle=False):
+        super().__init__()
+        assert all([tuple(dims_c[i][1:]) == tuple(dims_in[0][1:]) for i in range(len(dims_c))]), \
+            "Dimensions of input and one or more conditions don't agree."
+        self.tree = HierarchicalAffineCouplingTree(tuple(dims_in[0]), dims_c=dims_c, conv=conv,
+                                                   subnet_constructor=subnet_constructor, c_internal=c_internal,
+                                                   clamp=clamp, max_splits=max_splits,
+                                                   min_split_size=min_split_size, reshuffle=reshuffle)
+        self.jac = None
+
+    def forward(self, x, c=[], rev=False):
+        x, self.jac = self.tree.forward(x[0], c, rev=rev)
+        return [x]
+
+    def jacobian(self, x, c=[], rev=False):
+        return self.jac
+
+    def output_dims(self, input_dims):
+        assert len(input_dims) == 1, "Can only use one input."
+        return input_dims

@@ -1,0 +1,92 @@
+/* hint_amd.h — C ABI of the MI355X (gfx950) implementation of HINT's recursive
+ * affine-coupling block: forward / inverse / log|det J| and the backward pass.
+ *
+ * This is the drop-in boundary.  The reference (vislearn/HINT) has no native code; the
+ * interface replaced here is the Python module protocol of
+ *     /root/reference/hint.py:104-133   HierarchicalAffineCouplingBlock
+ *         .forward(x:list, c=[], rev=False) -> [Tensor]      (hint.py:124-126)
+ *         .jacobian(x, c=[], rev=False)     -> Tensor[B]     (hint.py:128-129)
+ *     /root/reference/hint.py:21-101    HierarchicalAffineCouplingTree (the arithmetic)
+ * plus the autograd backward PyTorch derives from it when the training loop calls
+ * loss.backward() (/root/reference/train_unconditional.py:137).
+ * `hint_amd/hint.py` is the host-side mirror of that module and binds these symbols with
+ * ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success, non-zero on error
+ *     (hint_last_error() gives a thread-local message); no exceptions cross the boundary.
+ *   - all tensors are fp32, row-major, caller-allocated DEVICE memory: x,z,g_x,g_z [B,d];
+ *     c,g_c [B,dc] (all conditions concatenated, hint.py:76); J,g_J [B].
+ *   - calls are asynchronous and ordered on `stream` (a hipStream_t passed as void*).
+ *   - a plan is immutable after creation and bound to the HIP device current at creation;
+ *     it may be shared by threads.  Parameters are passed per call as ONE flat fp32 buffer
+ *     whose layout the caller described at plan creation (p_off, in floats), because the
+ *     reference loops rebind p.data / call .to() (train_unconditional.py:165-167).
+ */
+#ifndef HINT_AMD_H
+#define HINT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HINT_AMD_ABI_VERSION 1
+
+/* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
+ * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],
+ * W3 [r,h], b3 [r]; all row-major [out,in] like torch.nn.Linear.weight. */
+enum { HINT_W1 = 0, HINT_B1 = 1, HINT_W2 = 2, HINT_B2 = 3, HINT_W3 = 4, HINT_B3 = 5 };
+
+/* One node of the coupling tree (hint.py:25-54), in any order.  A node owns lanes
+ * [off, off+D); its first k = D/2 lanes condition the transform of the other r = D-k
+ * (hint.py:41,68).  depth = 0 for the root.  Nodes of equal depth own disjoint lanes. */
+typedef struct hint_node_desc {
+    int32_t off, D, k, r;
+    int32_t h;          /* hidden width of both subnets (hint.py:44-45) */
+    int32_t depth;
+    int64_t p_off[12];  /* offsets in floats into the flat parameter buffer: [net*6 + tensor] */
+} hint_node_desc;
+
+typedef struct hint_plan hint_plan;
+
+/* Build the static level schedule for one block.  d = lanes of the block, dc = total
+ * condition width (0 if unconditional), clamp as in hint.py:108 (alpha = clamp*0.636,
+ * hint.py:57,60).  Replaces HierarchicalAffineCouplingTree.__init__ (hint.py:25-54). */
+int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc,
+                     float clamp, hint_plan** out);
+void hint_plan_destroy(hint_plan* plan);
+
+/* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size). */
+int64_t hint_plan_param_floats(const hint_plan* plan);
+/* bytes of scratch hint_block_backward needs for a batch of B rows. */
+size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
+/* dynamic LDS bytes per workgroup of the forward / backward kernels (informational). */
+int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
+
+/* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0. */
+int hint_block_forward(const hint_plan* plan, const float* params, const float* x,
+                       const float* c, float* z, float* J, int32_t B, void* stream);
+/* x, J = block(z | c), rev=True: own coupling undone first, then children
+ * (hint.py:82-88); J is the NEGATED log-det like the reference returns it (hint.py:83). */
+int hint_block_inverse(const hint_plan* plan, const float* params, const float* z,
+                       const float* c, float* x, float* J, int32_t B, void* stream);
+/* Backward of hint_block_forward.  Takes the block OUTPUT z (activations are recomputed by
+ * inverting the block level by level instead of being stored), upstream g_z [B,d] and
+ * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and
+ * the flat parameter gradient g_params (same layout as params; overwritten, not
+ * accumulated).  workspace: hint_plan_workspace_bytes(plan, B) bytes of device scratch. */
+int hint_block_backward(const hint_plan* plan, const float* params, const float* z,
+                        const float* c, const float* g_z, const float* g_J, float* g_x,
+                        float* g_c, float* g_params, void* workspace, size_t workspace_bytes,
+                        int32_t B, void* stream);
+
+int hint_abi_version(void);
+const char* hint_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HINT_AMD_H */

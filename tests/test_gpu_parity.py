@@ -1,0 +1,141 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI by
+the module mirror, against (1) the golden vectors of the real reference, (2) the CPU oracle on
+fresh seeded inputs, (3) size-independent properties at the BASELINE sizes.
+
+Tolerances (fp32; north_star: log-likelihood within 1e-4 relative): z, J rtol 1e-5 / atol 1e-5
+scaled by the tensor's magnitude; gradients 1e-4 relative to the tensor's max-abs (they are
+recomputed through the block inverse)."""
+import numpy as np
+import pytest
+import torch
+
+import hint_amd
+from oracle import hint_oracle as orc
+from util import BLOCK_CASES, load_block_case, rel_err, to_torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_block(c, params=None):
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(c["d"],)], dims_c=c["dims_c"], c_internal=list(c["c_internal"]),
+                                                   clamp=c["clamp"], max_splits=c["max_splits"],
+                                                   min_split_size=c["min_split_size"])
+    if params is not None:
+        blk.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()})
+    return blk.to(DEV)
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    scale = max(1.0, float(np.abs(b).max())) if np.size(b) else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale)
+
+
+@pytest.mark.parametrize("case", BLOCK_CASES, ids=lambda c: c["name"])
+def test_block_vs_reference_golden(case):
+    c, nodes, shapes, params, x_np, conds_np, g = load_block_case(case)
+    blk = make_block(c, params)
+    x = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
+    conds = [torch.from_numpy(a).to(DEV).requires_grad_(True) for a in conds_np]
+    (z,) = blk([x], c=conds)
+    J = blk.jacobian(None)
+    close(z, g["z"])
+    close(J, g["J"])
+    L = (0.5 * torch.sum(z ** 2, dim=1) - J).mean()
+    assert abs(L.item() - float(g["L"])) <= 1e-4 * abs(float(g["L"]))     # north_star tolerance
+    L.backward()
+    assert rel_err(x.grad.cpu().numpy(), g["gx"]) < 1e-4
+    for i, cc in enumerate(conds):
+        assert rel_err(cc.grad.cpu().numpy(), g[f"gc{i}"]) < 1e-4
+    named = dict(blk.named_parameters())
+    for k in shapes:
+        assert rel_err(named[k].grad.cpu().numpy(), g["g:" + k]) < 1e-4, k
+    with torch.no_grad():
+        (xr,) = blk([z.detach()], c=[cc.detach() for cc in conds], rev=True)
+        Jr = blk.jacobian(None)
+        (xi,) = blk([x.detach()], c=[cc.detach() for cc in conds], rev=True)
+        Ji = blk.jacobian(None)
+    close(xr, g["x_rec"], rtol=1e-4, atol=2e-5)
+    close(Jr, g["J_rev"])
+    assert rel_err(xi.cpu().numpy(), g["x_inv"]) < 1e-4
+    close(Ji, g["J_inv"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("d,widths,dc,B", [
+    (6, [140, 70, 35, 17], 0, 4096),      # BASELINE config 2 (one block)
+    (8, [128, 64, 32, 16], 0, 1000),      # config 3 shape, ragged batch
+    (43, [67, 33, 16, 8], 0, 515),        # config 5 shape
+    (100, [224, 112, 56], 0, 130),        # config 4 x-lane block
+    (100, [224, 112, 56], 4, 77),         # conditional_recursive_cinn_4 style
+    (6, [200, 100, 50, 25], 0, 1),        # single row
+    (6, [200, 100, 50, 25], 0, 17),
+])
+def test_block_vs_oracle_seeded(d, widths, dc, B):
+    dims_c = [(dc,)] if dc else []
+    nodes = orc.build_nodes(d, dims_c, widths)
+    P = orc.init_params(nodes, seed=11, scale=None)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, d, generator=gen)
+    cond = [torch.randn(B, dc, generator=gen)] if dc else []
+    c = dict(d=d, dims_c=dims_c, c_internal=widths, clamp=4.0, max_splits=-1, min_split_size=2)
+    blk = make_block(c, {k: v.numpy() for k, v in P.items()})
+
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xo = x.clone().requires_grad_(True)
+    co = [t.clone().requires_grad_(True) for t in cond]
+    zo, Jo = orc.block_apply(nodes, Po, xo, co, rev=False)
+    Lo = (0.5 * torch.sum(zo ** 2, dim=1) - Jo).mean()
+    Lo.backward()
+
+    xg = x.to(DEV).requires_grad_(True)
+    cg = [t.to(DEV).requires_grad_(True) for t in cond]
+    (z,) = blk([xg], c=cg)
+    J = blk.jacobian(None)
+    L = (0.5 * torch.sum(z ** 2, dim=1) - J).mean()
+    L.backward()
+    close(z, zo.detach().numpy())
+    close(J, Jo.detach().numpy())
+    assert abs(L.item() - Lo.item()) <= 1e-4 * abs(Lo.item())
+    assert rel_err(xg.grad.cpu().numpy(), xo.grad.numpy()) < 1e-4
+    for a, b in zip(cg, co):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 1e-4
+    named = dict(blk.named_parameters())
+    for k, p in Po.items():
+        assert rel_err(named[k].grad.cpu().numpy(), p.grad.numpy()) < 2e-4, k
+
+
+@pytest.mark.parametrize("d,widths,B", [(6, [140, 70, 35, 17], 4096), (8, [128, 64, 32, 16], 8192),
+                                        (43, [67, 33, 16, 8], 4096)])
+def test_full_size_properties(d, widths, B):
+    """encode -> decode round trip, J_fwd + J_rev = 0, row independence (batch-size invariance)."""
+    torch.manual_seed(0)
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(DEV)
+    x = torch.randn(B, d, device=DEV)
+    with torch.no_grad():
+        (z,) = blk([x]); J = blk.jacobian(None)
+        (xr,) = blk([z], rev=True); Jr = blk.jacobian(None)
+        (z_small,) = blk([x[37:101]]); J_small = blk.jacobian(None)
+    assert (xr - x).abs().max().item() < 1e-4
+    assert (J + Jr).abs().max().item() < 1e-4
+    assert torch.equal(z[37:101], z_small) and torch.equal(J[37:101], J_small)
+
+
+def test_parameter_rebinding_and_empty_batch():
+    """train_unconditional.py:165-167 rebinds p.data; the arena must follow."""
+    c = dict(d=6, dims_c=[], c_internal=[32, 16], clamp=4.0, max_splits=-1, min_split_size=2)
+    blk = make_block(c)
+    x = torch.randn(64, 6, device=DEV)
+    with torch.no_grad():
+        (z0,) = blk([x])
+        for p in blk.parameters():
+            p.data = 0.005 * torch.randn_like(p.data)
+        (z1,) = blk([x])
+    assert not torch.allclose(z0, z1)
+    nodes = orc.build_nodes(6, (), [32, 16])
+    P = {k: v.cpu() for k, v in blk.state_dict().items()}
+    zo, _ = orc.block_apply(nodes, P, x.cpu(), (), rev=False)
+    close(z1, zo.numpy())
+    with torch.no_grad():
+        (ze,) = blk([torch.empty(0, 6, device=DEV)])
+    assert ze.shape == (0, 6) and blk.jacobian(None).shape == (0,)

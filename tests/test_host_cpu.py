@@ -1,0 +1,83 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the module mirror has the reference's structure and state_dict keys, and the product
+path refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import hint_amd
+from hint_amd import _lib
+from oracle import hint_oracle as orc
+from util import BLOCK_CASES, load_block_case, norm_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "hint_amd.h")).read()
+    declared = set(re.findall(r"\b(hint_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hint_abi_version() == 1
+
+
+def test_nodedesc_matches_header_layout():
+    # 6 x int32 + 12 x int64 = 120 bytes, no padding surprises
+    import ctypes as C
+    assert C.sizeof(_lib.NodeDesc) == 6 * 4 + 12 * 8
+
+
+@pytest.mark.parametrize("case", BLOCK_CASES, ids=lambda c: c["name"])
+def test_state_dict_contract(case):
+    """same keys, order and shapes as the reference module (pinned in the golden fixtures)"""
+    c, nodes, shapes, params, x, conds, g = load_block_case(case)
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(c["d"],)], dims_c=c["dims_c"], c_internal=list(c["c_internal"]),
+                                                   clamp=c["clamp"], max_splits=c["max_splits"],
+                                                   min_split_size=c["min_split_size"])
+    sd = blk.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k])
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    # flat node list agrees with the oracle's restatement of hint.py:25-54
+    flat = blk.tree._flat_nodes()
+    assert [(o, n.data_shape[0], n.split_idx, d, n.leaf) for n, o, d in flat] == \
+           [(n.off, n.D, n.k, n.depth, n.leaf) for n in nodes]
+
+
+def test_c_internal_not_mutated_and_defaults():
+    w = [12]
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(9,)], c_internal=w)
+    assert w == [12]          # the reference doubles the caller's list in place (hint.py:33-34)
+    assert blk.tree.s[0].out_features == 12 and blk.tree.upper.s[0].out_features == 12
+    assert blk.output_dims([(9,)]) == [(9,)]
+    with pytest.raises(AssertionError):
+        blk.output_dims([(9,), (9,)])
+
+
+def test_unsupported_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        hint_amd.HierarchicalAffineCouplingBlock([(6,)], conv=True)
+    with pytest.raises(NotImplementedError):
+        hint_amd.HierarchicalAffineCouplingBlock([(6,)], reshuffle=True)
+    with pytest.raises(NotImplementedError):
+        hint_amd.HierarchicalAffineCouplingBlock([(6,)], subnet_constructor=lambda a, b, c: None)
+
+
+def test_no_cpu_fallback():
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(6,)], c_internal=[8, 4])
+    with pytest.raises(hint_amd.HintAmdError):
+        blk([torch.randn(4, 6)])
+
+
+def test_product_code_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "hint_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU oracle", ""), os.path.join(dirpath, f)
