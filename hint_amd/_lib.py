@@ -33,11 +33,12 @@ _PROTOS = {
                                    C.POINTER(C.c_void_p)]),
     "hint_plan_destroy": (None, [C.c_void_p]),
     "hint_plan_param_floats": (C.c_int64, [C.c_void_p]),
+    "hint_plan_tape_floats": (C.c_int64, [C.c_void_p, C.c_int32]),
     "hint_plan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "hint_plan_lds_bytes": (C.c_int32, [C.c_void_p, C.c_int32]),
-    "hint_block_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]),
+    "hint_block_forward": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
     "hint_block_inverse": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]),
-    "hint_block_backward": (C.c_int, [C.c_void_p] * 10 + [C.c_size_t, C.c_int32, C.c_void_p]),
+    "hint_block_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_size_t, C.c_int32, C.c_void_p]),
 }
 
 

@@ -31,6 +31,8 @@ struct DGroup {
     int32_t ent_begin, ent_cnt;       // one entry per transformed lane of the group
     int32_t aw, vw, sw;               // used widths of the act / v / st buffers
     int32_t wcol0, wvcol0, wscol0;    // workspace column of this group's first node
+    int32_t level;                    // 0 = deepest tree level ... n_levels-1 = root
+    int32_t level_last;               // 1 if this is the last group of its level (forward order)
 };
 
 struct Job { int32_t node, net, tile, pad; };
@@ -49,7 +51,7 @@ struct KArgs {
     const DGroup* groups;
     const Job* jobs;
     const Ent* ents;
-    int32_t n_groups;
+    int32_t n_groups, n_levels;
     int32_t d, dc;
     int32_t xld, cld, ald, vld, sld;   // LDS row strides (floats)
     int32_t WT, VT, ST;                // workspace row widths (floats)

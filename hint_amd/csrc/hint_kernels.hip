@@ -240,7 +240,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
 template <bool REV>
 __global__ __launch_bounds__(NTHREADS) void hint_block_apply_kernel(
     KArgs a, const float* __restrict__ params, const float* __restrict__ x,
-    const float* __restrict__ c, float* __restrict__ z, float* __restrict__ J) {
+    const float* __restrict__ c, float* __restrict__ z, float* __restrict__ J,
+    float* __restrict__ tape) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* cs = xs + ROWS * a.xld;
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_apply_kernel(
                 if (sub == 0) jac[row] += part;
             }
             __syncthreads();
+            // training: keep the lane tile as it stands after each level except the root's, so
+            // that the backward pass sees bit-identical subnet inputs (tape[level][B][d])
+            if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
+                store_tile(tape + (size_t)g.level * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
         }
         store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
         if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid];
@@ -296,11 +301,12 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_apply_kernel(
 }
 
 // =======================================================================================
-// backward, part A (row parallel): from the block OUTPUT z, undo the block level by level
-// (root first, like the inverse), recompute each node's activations, back-propagate through
-// coupling and subnets to get g_x / g_c, and leave the per-layer activations and
-// pre-activation gradients in the workspace for the weight-gradient GEMMs (part B).
-//   g_t = g_l' ; g_a = g_l'*(l' - t) + g_J ; g_l = g_l'*exp(a) ; g_s = g_a*alpha/(1+s^2)
+// backward, part A (row parallel): walk the levels root first; per level reload the lane tile
+// the forward pass recorded (x for the deepest level, tape[level-1] otherwise), recompute each
+// node's activations from it (same code, same inputs -> bit-identical ReLU masks),
+// back-propagate through coupling and subnets to get g_x / g_c, and leave the per-layer
+// activations and pre-activation gradients in the workspace for the weight-gradient GEMMs.
+//   g_t = g_l' ; g_a = g_l'*exp(a)*l + g_J ; g_l = g_l'*exp(a) ; g_s = g_a*alpha/(1+s^2)
 // =======================================================================================
 __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, int dcol,
                                               const float* src, int sld, int width, int row0,
@@ -314,8 +320,9 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
 }
 
 __global__ __launch_bounds__(NTHREADS) void hint_block_bwd_kernel(
-    KArgs a, const float* __restrict__ params, const float* __restrict__ z,
-    const float* __restrict__ c, const float* __restrict__ g_z, const float* __restrict__ g_J,
+    KArgs a, const float* __restrict__ params, const float* __restrict__ x,
+    const float* __restrict__ tape, const float* __restrict__ c, const float* __restrict__ g_z,
+    const float* __restrict__ g_J,
     float* __restrict__ g_x, float* __restrict__ g_c, float* __restrict__ wsV,
     float* __restrict__ wsA1, float* __restrict__ wsA2, float* __restrict__ wsG1,
     float* __restrict__ wsG2, float* __restrict__ wsG3) {
@@ -339,7 +346,6 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_bwd_kernel(
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
-        load_tile(xs, a.xld, z, a.d, row0, a.B, tid);
         load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid);
         if (a.dc > 0) {
             load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
@@ -350,7 +356,13 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_bwd_kernel(
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
             const DGroup& g = a.groups[gi];
-            // ---- recompute s, t of every node of the group from the current lanes ----
+            // ---- the lanes as the forward pass saw them when it entered this level ----
+            if (g.level_last) {
+                const float* src = (g.level == 0) ? x : tape + (size_t)(g.level - 1) * a.B * a.d;
+                load_tile(xs, a.xld, src, a.d, row0, a.B, tid);
+                __syncthreads();
+            }
+            // ---- recompute s, t of every node of the group (bit-identical to the forward) ----
             stage_build_v(a, g, xs, cs, vb, tid);
             for (int i = tid; i < ROWS * g.sw; i += NTHREADS) {
                 const int r = i / g.sw;
@@ -366,22 +378,19 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_bwd_kernel(
             copy_rows_out(wsA2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
             stage_out(a, g, params, a2, st, wave, lane);
             __syncthreads();
-            {   // ---- coupling backward + un-transform the lower lanes ----
+            {   // ---- coupling backward ----
                 const int sub = tid & 15, row = tid >> 4;
                 const float gJr = gj[row];
                 for (int e = sub; e < g.ent_cnt; e += 16) {
                     const Ent en = a.ents[g.ent_begin + e];
                     const float s = st[row * a.sld + en.scol];
-                    const float t = st[row * a.sld + en.tcol];
                     const float aa = a.alpha * atanf(s);
                     const float ea = expf(aa);
-                    float* px = xs + row * a.xld + en.xcol;
+                    const float l = xs[row * a.xld + en.xcol];       // lower input of the node
                     float* pg = gs + row * a.xld + en.xcol;
-                    const float lp = *px, glp = *pg;
-                    const float lmt = lp - t;            // = exp(a) * l
-                    *px = lmt / ea;                       // l, the lower child's output
-                    *pg = glp * ea;                       // g_l
-                    const float ga = glp * lmt + gJr;     // g_a (a feeds both l' and J)
+                    const float glp = *pg;                            // grad wrt l' = exp(a)*l + t
+                    *pg = glp * ea;                                   // g_l
+                    const float ga = glp * ea * l + gJr;              // g_a (a feeds both l' and J)
                     gst[row * a.sld + en.scol] = ga * a.alpha / (1.f + s * s);   // g_s
                     gst[row * a.sld + en.tcol] = glp;                              // g_t
                 }
@@ -556,20 +565,21 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_dw_kernel(
 namespace hint {
 
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
-                        const float* x, const float* c, float* z, float* J, hipStream_t stream) {
+                        const float* x, const float* c, float* z, float* J, float* tape,
+                        hipStream_t stream) {
     if (rev)
-        hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params, x, c, z, J);
+        hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params, x, c, z, J, (float*)nullptr);
     else
-        hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params, x, c, z, J);
+        hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params, x, c, z, J, tape);
     return hipGetLastError();
 }
 
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params, const float* z,
-                      const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params, const float* x,
+                      const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
                       float* wsV, float* wsA1, float* wsA2, float* wsG1, float* wsG2, float* wsG3,
                       hipStream_t stream) {
     hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params,
-                       z, c, g_z, g_J, g_x, g_c, wsV, wsA1, wsA2, wsG1, wsG2, wsG3);
+                       x, tape, c, g_z, g_J, g_x, g_c, wsV, wsA1, wsA2, wsG1, wsG2, wsG3);
     return hipGetLastError();
 }
 

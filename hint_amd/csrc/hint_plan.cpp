@@ -15,9 +15,10 @@
 
 namespace hint {
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
-                        const float* x, const float* c, float* z, float* J, hipStream_t stream);
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params, const float* z,
-                      const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
+                        const float* x, const float* c, float* z, float* J, float* tape,
+                        hipStream_t stream);
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params, const float* x,
+                      const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
                       float* wsV, float* wsA1, float* wsA2, float* wsG1, float* wsG2, float* wsG3,
                       hipStream_t stream);
 hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsV, const float* wsA1,
@@ -61,7 +62,7 @@ static inline int lds_stride(int width) {
 
 struct hint_plan {
     int device = -1;
-    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_dwjobs = 0;
+    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_dwjobs = 0;
     float alpha = 0.f;
     int64_t param_floats = 0;
     int WT = 0, VT = 0, ST = 0;
@@ -116,9 +117,21 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
         for (int i = 0; i < n_nodes; ++i)
             if (nodes[i].depth == dep) order.push_back(i);
 
-    // LDS budget of the backward kernel bounds the width of a group:
-    //   2*xld + 2*cld + 2*vld + 2*ald + 2*sld + 1 rows of ROWS floats.
+    // The LDS footprint of the backward kernel bounds what one group may hold:
+    //   ROWS * (2*xld + 2*cld + 2*vld + 2*ald + 2*sld + 1) floats  <=  160 KiB.
+    // Every single node must fit (that fixes minimum strides); groups then grow up to soft
+    // caps so that shallow-but-wide and deep-but-narrow levels end up with similar footprints.
     const int WMAX = 768;
+    int min_aw = 0, min_vw = 0, min_sw = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        min_aw = std::max(min_aw, 2 * pad16(nodes[i].h));
+        min_vw = std::max(min_vw, pad16(nodes[i].k + dc));
+        min_sw = std::max(min_sw, 2 * pad16(nodes[i].r));
+    }
+    const int cap_aw = std::max(min_aw, 512), cap_vw = std::max(min_vw, 128), cap_sw = std::max(min_sw, 256);
+    auto bwd_bytes = [&](int aw_, int vw_, int sw_) {
+        return 4 * ROWS * (2 * P->xld + 2 * P->cld + 2 * lds_stride(vw_) + 2 * lds_stride(aw_) + 2 * lds_stride(sw_) + 1);
+    };
     std::vector<DNode> dn;
     std::vector<DGroup> dg;
     std::vector<Job> jobs;
@@ -142,7 +155,15 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
                 delete P;
                 return fail("hint_plan_create: hidden width %d exceeds the supported maximum %d", n.h, WMAX / 2);
             }
-            if (aw > 0 && aw + 2 * hp > WMAX) break;   // start a new group at the same depth
+            if (bwd_bytes(2 * hp, cinp, 2 * rp) > LDS_LIMIT) {
+                delete P;
+                return fail("hint_plan_create: a node with h=%d, cin=%d, r=%d does not fit the 160 KiB LDS", n.h, cin, n.r);
+            }
+            // start a new group at the same depth when this node would overflow the budget
+            if (aw > 0 && (aw + 2 * hp > cap_aw || vw + cinp > cap_vw || sw + 2 * rp > cap_sw ||
+                           bwd_bytes(std::max(min_aw, aw + 2 * hp), std::max(min_vw, vw + cinp),
+                                     std::max(min_sw, sw + 2 * rp)) > LDS_LIMIT))
+                break;
             DNode q{};
             q.off = n.off; q.k = n.k; q.r = n.r; q.h = n.h; q.cin = cin;
             q.hp = hp; q.rp = rp; q.cinp = cinp;
@@ -161,6 +182,8 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
         }
         g.node_end = (int)dn.size();
         g.aw = aw; g.vw = vw; g.sw = sw;
+        g.level = max_depth - depth;
+        g.level_last = (pos >= order.size() || nodes[order[pos]].depth != depth) ? 1 : 0;
         max_aw = std::max(max_aw, aw); max_vw = std::max(max_vw, vw); max_sw = std::max(max_sw, sw);
         // jobs: one per 16-wide output tile
         g.jobsH_begin = (int)jobs.size();
@@ -185,6 +208,7 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
         dg.push_back(g);
     }
     P->n_groups = (int)dg.size();
+    P->n_levels = max_depth + 1;
     P->WT = wcol; P->VT = std::max(wvcol, 16); P->ST = wscol;
     P->param_floats = pmax;
     P->ald = lds_stride(max_aw);
@@ -256,6 +280,11 @@ void hint_plan_destroy(hint_plan* P) {
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
 
+int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
+    if (!P || B < 0) return -1;
+    return (int64_t)(P->n_levels - 1) * B * P->d;
+}
+
 static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
@@ -272,7 +301,7 @@ int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
 static KArgs make_args(const hint_plan* P, int B) {
     KArgs a{};
     a.nodes = P->d_nodes; a.groups = P->d_groups; a.jobs = P->d_jobs; a.ents = P->d_ents;
-    a.n_groups = P->n_groups; a.d = P->d; a.dc = P->dc;
+    a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
     a.xld = P->xld; a.cld = P->cld; a.ald = P->ald; a.vld = P->vld; a.sld = P->sld;
     a.WT = P->WT; a.VT = P->VT; a.ST = P->ST;
     a.alpha = P->alpha; a.B = B;
@@ -280,31 +309,32 @@ static KArgs make_args(const hint_plan* P, int B) {
 }
 
 static int apply(const hint_plan* P, bool rev, const float* params, const float* x, const float* c,
-                 float* z, float* J, int32_t B, void* stream) {
+                 float* z, float* J, float* tape, int32_t B, void* stream) {
     if (!P || !params || !x || !z || !J) return fail("hint_block_%s: null argument", rev ? "inverse" : "forward");
     if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", rev ? "inverse" : "forward", P->dc);
     if (B < 0) return fail("negative batch");
     if (B == 0) return 0;
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, x, c, z, J, (hipStream_t)stream));
+    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, x, c, z, J, tape, (hipStream_t)stream));
     return 0;
 }
 
 int hint_block_forward(const hint_plan* P, const float* params, const float* x, const float* c, float* z,
-                       float* J, int32_t B, void* stream) {
-    return apply(P, false, params, x, c, z, J, B, stream);
+                       float* J, float* tape, int32_t B, void* stream) {
+    return apply(P, false, params, x, c, z, J, tape, B, stream);
 }
 
 int hint_block_inverse(const hint_plan* P, const float* params, const float* z, const float* c, float* x,
                        float* J, int32_t B, void* stream) {
-    return apply(P, true, params, z, c, x, J, B, stream);
+    return apply(P, true, params, z, c, x, J, nullptr, B, stream);
 }
 
-int hint_block_backward(const hint_plan* P, const float* params, const float* z, const float* c,
-                        const float* g_z, const float* g_J, float* g_x, float* g_c, float* g_params,
+int hint_block_backward(const hint_plan* P, const float* params, const float* x, const float* tape,
+                        const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c, float* g_params,
                         void* workspace, size_t workspace_bytes, int32_t B, void* stream) {
-    if (!P || !params || !z || !g_x || !g_params) return fail("hint_block_backward: null argument");
+    if (!P || !params || !x || !g_x || !g_params) return fail("hint_block_backward: null argument");
+    if (P->n_levels > 1 && !tape && B > 0) return fail("hint_block_backward: tape is NULL but the tree has %d levels", P->n_levels);
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
     if (B < 0) return fail("negative batch");
     hipStream_t s = (hipStream_t)stream;
@@ -326,7 +356,7 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* z,
 
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, z, c, g_z, g_J, g_x, g_c, wsV, wsA1,
+    HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, x, tape, c, g_z, g_J, g_x, g_c, wsV, wsA1,
                        wsA2, wsG1, wsG2, wsG3, s));
     // batch split of the weight-gradient GEMMs: enough workgroups to cover the chip ~2x,
     // each wavefront reducing at least 32 rows
@@ -339,7 +369,8 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* z,
         rows_per_wg = (int)rp;
     }
     const int splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
-    if (splits > 1) HIP_TRY(hipMemsetAsync(g_params, 0, (size_t)P->param_floats * sizeof(float), s));
+    // always clear: covers the alignment gaps of the arena and the atomics of the split case
+    HIP_TRY(hipMemsetAsync(g_params, 0, (size_t)P->param_floats * sizeof(float), s));
     HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsV, wsA1, wsA2, wsG1, wsG2, wsG3, P->WT, P->VT,
                       P->ST, (int)Bp, rows_per_wg, g_params, s));
     return 0;

@@ -131,20 +131,31 @@ class _Engine:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def apply(self, x: torch.Tensor, c: Optional[torch.Tensor], rev: bool):
+    def apply(self, x: torch.Tensor, c: Optional[torch.Tensor], rev: bool, with_tape: bool = False):
+        """-> (out, J) or, with_tape (training forward), (out, J, tape)"""
         B = x.shape[0]
         out = torch.empty_like(x)
         J = torch.empty(B, dtype=torch.float32, device=x.device)
-        if B == 0:
-            return out, J
-        fn = self.lib.hint_block_inverse if rev else self.lib.hint_block_forward
-        with torch.cuda.device(self.device):
-            st = fn(self.plan, self.arena.data_ptr(), x.data_ptr(), c.data_ptr() if c is not None else None,
-                    out.data_ptr(), J.data_ptr(), B, self._stream())
-        _lib.check(st, "hint_block_inverse" if rev else "hint_block_forward")
-        return out, J
+        tape = None
+        if with_tape:
+            tape = torch.empty(max(self.lib.hint_plan_tape_floats(self.plan, B), 1), dtype=torch.float32,
+                               device=x.device)
+        if B > 0:
+            cptr = c.data_ptr() if c is not None else None
+            with torch.cuda.device(self.device):
+                if rev:
+                    st = self.lib.hint_block_inverse(self.plan, self.arena.data_ptr(), x.data_ptr(), cptr,
+                                                     out.data_ptr(), J.data_ptr(), B, self._stream())
+                else:
+                    st = self.lib.hint_block_forward(self.plan, self.arena.data_ptr(), x.data_ptr(), cptr,
+                                                     out.data_ptr(), J.data_ptr(),
+                                                     tape.data_ptr() if tape is not None else None, B,
+                                                     self._stream())
+            _lib.check(st, "hint_block_inverse" if rev else "hint_block_forward")
+        return (out, J, tape) if with_tape else (out, J)
 
-    def backward(self, z, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None):
+    def backward(self, x, tape, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None):
+        z = x
         B = z.shape[0]
         gx = torch.empty_like(z)
         gc = torch.empty_like(c) if (c is not None and need_gc) else None
@@ -157,7 +168,8 @@ class _Engine:
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=z.device)
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_backward(
-                self.plan, self.arena.data_ptr(), z.data_ptr(), c.data_ptr() if c is not None else None,
+                self.plan, self.arena.data_ptr(), x.data_ptr(), tape.data_ptr(),
+                c.data_ptr() if c is not None else None,
                 gz.data_ptr() if gz is not None else None, gJ.data_ptr() if gJ is not None else None,
                 gx.data_ptr(), gc.data_ptr() if gc is not None else None, g_params.data_ptr(),
                 ws.data_ptr(), nbytes, B, self._stream())
@@ -166,26 +178,27 @@ class _Engine:
 
 
 class _CouplingFn(torch.autograd.Function):
-    """autograd node of one block forward; backward re-derives activations from the output."""
+    """autograd node of one block forward.  Saves the input and the (levels-1)x[B,d] lane tape;
+    the backward kernel recomputes the subnet activations from them."""
 
     @staticmethod
     def forward(ctx, engine, x, c, *params):
-        z, J = engine.apply(x, c, rev=False)
+        z, J, tape = engine.apply(x, c, rev=False, with_tape=True)
         ctx.engine = engine
         ctx.has_c = c is not None
-        ctx.save_for_backward(z, c) if c is not None else ctx.save_for_backward(z)
+        ctx.save_for_backward(x, tape, c) if c is not None else ctx.save_for_backward(x, tape)
         return z, J
 
     @staticmethod
     def backward(ctx, gz, gJ):
         engine = ctx.engine
         saved = ctx.saved_tensors
-        z = saved[0]
-        c = saved[1] if ctx.has_c else None
+        x, tape = saved[0], saved[1]
+        c = saved[2] if ctx.has_c else None
         gz = gz.contiguous() if gz is not None else None
         gJ = gJ.contiguous() if gJ is not None else None
         need_gc = ctx.has_c and ctx.needs_input_grad[2]
-        gx, gc, gflat = engine.backward(z, c, gz, gJ, need_gc)
+        gx, gc, gflat = engine.backward(x, tape, c, gz, gJ, need_gc)
         return (None, gx, gc, *engine.split_flat(gflat))
 
 

@@ -61,25 +61,31 @@ void hint_plan_destroy(hint_plan* plan);
 
 /* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size). */
 int64_t hint_plan_param_floats(const hint_plan* plan);
+/* floats of the forward "tape" for a batch of B rows: (levels-1) snapshots [B,d] of the lane
+ * tensor between tree levels, recorded by hint_block_forward and read by hint_block_backward
+ * so that the backward pass re-derives bit-identical subnet inputs (d floats per level and
+ * row instead of the ~6*h floats per node autograd keeps for hint.py:77). */
+int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
 /* bytes of scratch hint_block_backward needs for a batch of B rows. */
 size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
 /* dynamic LDS bytes per workgroup of the forward / backward kernels (informational). */
 int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
 
-/* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0. */
+/* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0.
+ * tape: NULL for inference, else hint_plan_tape_floats(plan, B) floats (training). */
 int hint_block_forward(const hint_plan* plan, const float* params, const float* x,
-                       const float* c, float* z, float* J, int32_t B, void* stream);
+                       const float* c, float* z, float* J, float* tape, int32_t B, void* stream);
 /* x, J = block(z | c), rev=True: own coupling undone first, then children
  * (hint.py:82-88); J is the NEGATED log-det like the reference returns it (hint.py:83). */
 int hint_block_inverse(const hint_plan* plan, const float* params, const float* z,
                        const float* c, float* x, float* J, int32_t B, void* stream);
-/* Backward of hint_block_forward.  Takes the block OUTPUT z (activations are recomputed by
- * inverting the block level by level instead of being stored), upstream g_z [B,d] and
+/* Backward of hint_block_forward.  Takes the block INPUT x and the tape the forward call
+ * recorded (subnet activations are recomputed from them, not stored), upstream g_z [B,d] and
  * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and
  * the flat parameter gradient g_params (same layout as params; overwritten, not
  * accumulated).  workspace: hint_plan_workspace_bytes(plan, B) bytes of device scratch. */
-int hint_block_backward(const hint_plan* plan, const float* params, const float* z,
-                        const float* c, const float* g_z, const float* g_J, float* g_x,
+int hint_block_backward(const hint_plan* plan, const float* params, const float* x,
+                        const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
                         float* g_c, float* g_params, void* workspace, size_t workspace_bytes,
                         int32_t B, void* stream);
 

@@ -56,8 +56,12 @@ def test_block_vs_reference_golden(case):
         Jr = blk.jacobian(None)
         (xi,) = blk([x.detach()], c=[cc.detach() for cc in conds], rev=True)
         Ji = blk.jacobian(None)
-    close(xr, g["x_rec"], rtol=1e-4, atol=2e-5)
-    close(Jr, g["J_rev"])
+    # the inverse of an ill-conditioned block (big_s: scales e^+-4 on |z| ~ 5e3) is noise in fp32
+    # for the reference too; bound our deviation by the reference's own round-trip error
+    ref_rt = float(np.abs(g["x_rec"] - x_np).max())
+    ref_jj = float(np.abs(g["J"] + g["J_rev"]).max())
+    close(xr, g["x_rec"], rtol=1e-4, atol=max(2e-5, 4 * ref_rt))
+    close(Jr, g["J_rev"], atol=max(1e-5, 4 * ref_jj))
     assert rel_err(xi.cpu().numpy(), g["x_inv"]) < 1e-4
     close(Ji, g["J_inv"], rtol=1e-4, atol=1e-4)
 
