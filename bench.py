@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the HINT coupling-flow training step on MI355X (BASELINE.json metric:
+training samples/s + mean NLL, UCI POWER d=6, batch 4096 per GPU, 1/2/4/8 GPUs).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = noise + forward + backward of the 8-block flow on this rank's 4096-row shard, one
+all-reduce of the flat gradient arena, fused clamp + Adam (train_unconditional.py:114-144).
+Inputs are synthetic N(0,1) rows already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: UCI POWER d=6, 8 recursive coupling blocks, batch 4096, 1 GPU
+    "power_hint_8": dict(d=6, n_blocks=8, c_internal=[140, 70, 35, 17], batch=4096),
+    "power_hint_4": dict(d=6, n_blocks=4, c_internal=[200, 100, 50, 25], batch=512),
+    "gas_hint_8": dict(d=8, n_blocks=8, c_internal=[128, 64, 32, 16], batch=8192),
+    "miniboone_hint_10": dict(d=43, n_blocks=10, c_internal=[67, 33, 16, 8], batch=4096),
+    "plus_hint_4": dict(d=100, n_blocks=4, c_internal=[224, 112, 56], batch=4096),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_sample_block(d, widths, dc=0):
+    """algorithmic forward FLOPs of one block per sample: sum over nodes of both subnets,
+    2*(cin*h + h*h + h*r) MACs each."""
+    from oracle import hint_oracle as orc   # only for the node list (bench-side bookkeeping)
+    nodes = orc.build_nodes(d, [(dc,)] if dc else [], widths)
+    return sum(2 * 2 * (n.cin * n.h + n.h * n.h + n.h * n.r) for n in nodes)
+
+
+def cpu_baseline(cfg, budget_s=12.0, max_steps=200):
+    """the reference's CPU path (oracle restatement of hint.py in plain torch CPU ops +
+    autograd + clamp + Adam), timed on this box's host cores on a bounded number of steps.
+    torch's default of one thread per core is pathological for these small matrices on a
+    many-core host, so a few thread counts are probed first (2 steps each) and the fastest
+    is used; `cores` reports the threads actually used."""
+    from oracle import hint_oracle as orc
+    ncores = os.cpu_count() or 1
+    flow = orc.OracleFlow(cfg["d"], cfg["n_blocks"], cfg["c_internal"], seed=0, init_scale=0.005)
+    flow.make_optimizer()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(cfg["batch"], cfg["d"], generator=g)
+
+    def run(n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            flow.train_step(x + 0.01 * torch.randn_like(x))
+        return time.perf_counter() - t0
+
+    best_nt, best_t = None, float("inf")
+    for nt in sorted({min(ncores, v) for v in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        run(1)
+        t = run(2) / 2
+        if t < best_t:
+            best_nt, best_t = nt, t
+    torch.set_num_threads(best_nt)
+    n = int(max(3, min(max_steps, budget_s / best_t)))
+    dt = run(n)
+    return dict(value=cfg["batch"] * n / dt, unit="samples/s", cores=best_nt, kind="port",
+                sample=f"{n} training steps of {cfg['batch']} rows ({dt:.1f} s), oracle/hint_oracle.py OracleFlow "
+                       f"(torch CPU ops, best of 8/16/32/64 threads = {best_nt}; host has {ncores} cores)")
+
+
+def kernel_legs(trainer, x, reps=200):
+    """average device time of each hot kernel, HIP events on the launch stream, back to back"""
+    from hint_amd import _lib
+    lib = _lib.load()
+    eng = trainer.engines[0]
+    B = x.shape[0]
+    out = {}
+
+    def timed(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps   # us
+
+    z = torch.empty_like(x); J = torch.empty(B, device=x.device)
+    tape = torch.empty(max(lib.hint_plan_tape_floats(eng.plan, B), 1), device=x.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    P = eng.arena.data_ptr()
+    out["hint_block_apply_kernel<fwd>"] = timed(
+        lambda: lib.hint_block_forward(eng.plan, P, x.data_ptr(), None, z.data_ptr(), J.data_ptr(), tape.data_ptr(), B, stream))
+    gz = torch.randn_like(x); gJ = torch.full((B,), -1.0 / B, device=x.device)
+    gx = torch.empty_like(x); gp = torch.empty(eng.total, device=x.device)
+    nb = lib.hint_plan_workspace_bytes(eng.plan, B)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+
+    def bwd():
+        return lib.hint_block_backward(eng.plan, P, x.data_ptr(), tape.data_ptr(), None, gz.data_ptr(), gJ.data_ptr(),
+                                       gx.data_ptr(), None, gp.data_ptr(), ws.data_ptr(), nb, B, stream)
+    for mask, name in ((1, "hint_block_bwd_kernel"), (2, "hint_block_dw_kernel+memset"), (3, "backward_total")):
+        lib.hint_debug_set_backward_stages(mask)
+        out[name] = timed(bwd)
+    lib.hint_debug_set_backward_stages(3)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="power_hint_8", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import hint_amd
+    cfg = WORKLOADS[args.workload]
+    d, B = cfg["d"], cfg["batch"]
+    torch.manual_seed(0)                                     # identical weights on every rank
+    flow = hint_amd.HintFlow(d, cfg["n_blocks"], cfg["c_internal"]).to(dev)
+    with torch.no_grad():
+        gw = torch.Generator().manual_seed(0)
+        for p in flow.parameters():                          # train_unconditional.py:165-167
+            p.data = (0.005 * torch.randn(p.shape, generator=gw)).to(dev)
+    trainer = hint_amd.FlowTrainer(flow, use_graph=not args.no_graph)
+    gx = torch.Generator().manual_seed(1000 + rank)          # each rank its own shard of the global batch
+    x = torch.randn(B, d, generator=gx).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l0, l1 = trainer.step(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+    nll = trainer.nll(x)
+    loss_last = float(l0) + float(l1)
+
+    if rank == 0:
+        F = flops_per_sample_block(d, cfg["c_internal"])
+        legs = kernel_legs(trainer, x) if world == 1 else {}
+        res = {
+            "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: d={d}, {cfg['n_blocks']} recursive coupling blocks, "
+                                   f"c_internal={cfg['c_internal']}, batch {B} per GPU",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "mean_nll_nats": nll, "last_step_loss": loss_last,
+        }
+        if legs:
+            # dominant kernel = the row-parallel backward kernel: recompute (F) + dX (F) per sample
+            name = "hint_block_bwd_kernel"
+            us = legs[name]
+            flops = 2.0 * F * B
+            ach = flops / (us * 1e-6) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "avg_launch_us": us, "algorithmic_flops_per_launch": flops}
+            res["kernels_us"] = legs
+            # the element-wise view the north_star asks for: compulsory HBM bytes of one block
+            # forward, 4*(2d+1) B/sample, against 8 TB/s
+            fwd_us = legs["hint_block_apply_kernel<fwd>"]
+            hb = 4.0 * (2 * d + 1) * B / (fwd_us * 1e-6) / 1e9
+            res["hbm_view_fwd_kernel"] = {"achieved": hb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hb / PEAK_HBM_GBS,
+                                          "bytes_per_launch": 4.0 * (2 * d + 1) * B}
+            res["mfma_view_fwd_kernel_tflops"] = F * B / (fwd_us * 1e-6) / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+            # NLL of the trained GPU weights re-evaluated by the CPU oracle on the same rows
+            from oracle import hint_oracle as orc
+            nodes = orc.build_nodes(d, (), cfg["c_internal"])
+            xc = x.cpu()
+            Jt = torch.zeros(B)
+            h = xc
+            with torch.no_grad():
+                for i, blk in enumerate(flow.blocks):
+                    if flow.has_perm(i):
+                        h = h @ flow.perms[i].W.cpu()
+                    Pc = {k: v.cpu() for k, v in blk.state_dict().items()}
+                    h, Ji = orc.block_apply(nodes, Pc, h, (), rev=False)
+                    Jt = Jt + Ji
+            const = 0.5 * d * math.log(2 * math.pi)
+            nll_cpu = float(0.5 * torch.sum(h.double() ** 2, 1).mean() - Jt.double().mean()) + const
+            with torch.no_grad():
+                zg = flow(x).double().cpu()
+                Jg = flow.log_jacobian(run_forward=False).double().cpu()
+            nll_gpu = float(0.5 * torch.sum(zg ** 2, 1).mean() - Jg.mean()) + const
+            res["nll_cpu_oracle"] = nll_cpu
+            res["nll_gpu_f64_reduction"] = nll_gpu
+            res["nll_rel_err"] = abs(nll_gpu - nll_cpu) / abs(nll_cpu)
+            res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,4 +6,7 @@ hint_amd/csrc behind the C ABI of include/hint_amd.h.
 from .hint import (HierarchicalAffineCouplingBlock, HierarchicalAffineCouplingTree,  # noqa: F401
                    HintAmdError, linear_subnet_constructor)
 
+from .flow import FixedOrthogonal, HintFlow  # noqa: F401,E402
+from .train import FlowTrainer  # noqa: F401,E402
+
 __version__ = "0.1.0"

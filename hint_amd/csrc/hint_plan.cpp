@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -26,6 +27,9 @@ hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsV
                      int WT, int VT, int ST, int Bp, int rows_per_wg, float* gparams,
                      hipStream_t stream);
 hipError_t set_max_lds(int fwd_bytes, int bwd_bytes);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+                       float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int num_cu,
+                       hipStream_t stream);
 }  // namespace hint
 
 using namespace hint;
@@ -77,6 +81,7 @@ struct hint_plan {
 };
 
 static constexpr int LDS_LIMIT = 160 * 1024;
+static int g_bwd_stages = 3;   // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 static constexpr int WS_SLACK = 64;   // floats of slack at the end of every workspace array
 
 extern "C" {
@@ -356,8 +361,10 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* x,
 
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, x, tape, c, g_z, g_J, g_x, g_c, wsV, wsA1,
-                       wsA2, wsG1, wsG2, wsG3, s));
+    if (g_bwd_stages & 1)
+        HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, x, tape, c, g_z, g_J, g_x, g_c, wsV, wsA1,
+                           wsA2, wsG1, wsG2, wsG3, s));
+    if (!(g_bwd_stages & 2)) return 0;
     // batch split of the weight-gradient GEMMs: enough workgroups to cover the chip ~2x,
     // each wavefront reducing at least 32 rows
     int rows_per_wg = 64;
@@ -373,6 +380,31 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* x,
     HIP_TRY(hipMemsetAsync(g_params, 0, (size_t)P->param_floats * sizeof(float), s));
     HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsV, wsA1, wsA2, wsG1, wsG2, wsG3, P->WT, P->VT,
                       P->ST, (int)Bp, rows_per_wg, g_params, s));
+    return 0;
+}
+
+void hint_debug_set_backward_stages(int32_t mask) { g_bwd_stages = mask & 3; }
+
+int hint_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, float grad_clamp, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail("hint_adam_step: null argument");
+    if (n < 0 || step < 1) return fail("hint_adam_step: n must be >= 0 and step >= 1");
+    if (n == 0) return 0;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
+        return fail("hint_adam_step: buffers must be 16-byte aligned");
+    // bias corrections in double like torch.optim.Adam's python scalars
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    HIP_TRY(launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, (float)((double)lr / bc1), beta1, beta2,
+                        (float)(1.0 / std::sqrt(bc2)), eps, weight_decay, grad_scale,
+                        grad_clamp > 0.f ? grad_clamp : 3.0e38f, num_cu, (hipStream_t)stream));
     return 0;
 }
 

@@ -1,0 +1,137 @@
+"""Fast training step for a HintFlow on MI355X: no autograd graph, no per-parameter ops.
+
+Reproduces one iteration of /root/reference/train_unconditional.py:114-144:
+    x += 0.01*randn_like(x)                          (:121)
+    z = model(x); J = model.log_jacobian(...)        (:124-125)
+    loss = 0.5*sum(z^2,1).mean() - J.mean()          (:128-132)
+    loss.backward(); clamp grads to +-5; Adam.step() (:137-144)
+with the whole forward + backward chain as direct C-ABI kernel launches into model-wide flat
+arenas (parameters / gradients / Adam moments), captured once in a hipGraph and replayed, then
+ONE all-reduce of the gradient arena (hint_amd/dp.py) and ONE fused clamp+Adam launch.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib, dp
+from .flow import HintFlow
+from .hint import HintAmdError
+
+
+class FlowTrainer:
+    def __init__(self, flow: HintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
+                 weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01,
+                 use_graph: bool = True, group=None):
+        self.lib = _lib.load()
+        self.flow = flow
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.grad_clamp, self.noise = grad_clamp, noise
+        self.use_graph = use_graph
+        self.group = group
+        self.step_count = 0
+        dev = next(flow.parameters()).device
+        if dev.type != "cuda":
+            raise HintAmdError("FlowTrainer needs the flow on a GPU (no CPU path)")
+        self.device = dev
+        # model-wide arenas; every block's engine is bound to its slice
+        self.engines = [blk.tree.engine(dev) for blk in flow.blocks]
+        self.slices = []
+        cursor = 0
+        for e in self.engines:
+            self.slices.append((cursor, cursor + e.total))
+            cursor += e.total
+        self.n_floats = cursor
+        self.P = torch.zeros(cursor, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(cursor, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(cursor, dtype=torch.float32, device=dev)
+        self.V = torch.zeros(cursor, dtype=torch.float32, device=dev)
+        for e, (a, b) in zip(self.engines, self.slices):
+            e.bind_external_arena(self.P[a:b])
+            e.ensure_arena()
+        self._graph = None
+        self._static = None
+
+    # ---- the un-captured step body ----------------------------------------------------
+    def _fwd_bwd(self, x: torch.Tensor, c: Optional[torch.Tensor]):
+        flow, B = self.flow, x.shape[0]
+        if self.noise > 0:
+            x = x + self.noise * torch.randn_like(x)
+        inputs, tapes = [], []
+        h, Jtot = x, None
+        for i, eng in enumerate(self.engines):
+            if flow.has_perm(i):
+                h = h @ flow.perms[i].W
+            inputs.append(h)
+            h, J, tape = eng.apply(h, c, rev=False, with_tape=True)
+            tapes.append(tape)
+            Jtot = J if Jtot is None else Jtot + J
+        z = h
+        l0 = 0.5 * torch.sum(z * z, dim=1).mean()
+        l1 = -Jtot.mean()
+        gz = z * (1.0 / B)
+        gJ = torch.full((B,), -1.0 / B, dtype=torch.float32, device=x.device)
+        for i in reversed(range(len(self.engines))):
+            a, b = self.slices[i]
+            gz, _, _ = self.engines[i].backward(inputs[i], tapes[i], c, gz, gJ, need_gc=False, g_params=self.G[a:b])
+            if flow.has_perm(i):
+                gz = gz @ flow.perms[i].W.t()
+        return l0, l1
+
+    def _check_arenas(self):
+        for e in self.engines:
+            e.ensure_arena()
+
+    def _optimizer(self, grad_scale: float):
+        self.step_count += 1
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_adam_step(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                         self.n_floats, self.step_count, self.lr, self.betas[0], self.betas[1],
+                                         self.eps, self.wd, grad_scale, self.grad_clamp,
+                                         torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(st, "hint_adam_step")
+
+    def step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
+        """one training iteration on this rank's shard; returns device scalars (l0, l1) =
+        ('-log p(z)', '-log |det J|') of the LOCAL shard (train_unconditional.py:162)"""
+        if not self.use_graph:
+            self._check_arenas()
+            l0, l1 = self._fwd_bwd(x, c)
+        else:
+            if self._graph is None or self._static["x"].shape != x.shape:
+                self._capture(x, c)
+            self._static["x"].copy_(x)
+            if c is not None:
+                self._static["c"].copy_(c)
+            self._graph.replay()
+            l0, l1 = self._static["l0"], self._static["l1"]
+        scale = dp.allreduce_sum_(self.G, self.group)
+        self._optimizer(scale)
+        return l0, l1
+
+    def _capture(self, x, c):
+        self._check_arenas()
+        sx = x.clone()
+        sc = c.clone() if c is not None else None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):          # warm-up on a side stream (allocator, plan LDS attrs)
+            for _ in range(2):
+                self._fwd_bwd(sx, sc)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            l0, l1 = self._fwd_bwd(sx, sc)
+        self._graph = g
+        self._static = dict(x=sx, c=sc, l0=l0, l1=l1)
+
+    @torch.no_grad()
+    def nll(self, x: torch.Tensor, c: Optional[torch.Tensor] = None) -> float:
+        """mean negative log-likelihood in nats incl. the Gaussian constant
+        (run_uci_experiments.py:71-72)"""
+        z = self.flow(x, c=c)
+        J = self.flow.log_jacobian(run_forward=False)
+        return float(0.5 * torch.sum(z * z, dim=1).mean() - J.mean()) + 0.5 * self.flow.ndim_x * math.log(2 * math.pi)

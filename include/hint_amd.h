@@ -89,6 +89,22 @@ int hint_block_backward(const hint_plan* plan, const float* params, const float*
                         float* g_c, float* g_params, void* workspace, size_t workspace_bytes,
                         int32_t B, void* stream);
 
+/* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces
+ *   for p in params: p.grad.data.clamp_(-5, 5)        (train_unconditional.py:140-141)
+ *   torch.optim.Adam(..., eps, weight_decay).step()    (train_unconditional.py:144,174-176)
+ * g' = clamp(grads*grad_scale, +-grad_clamp) + weight_decay*p, then the standard Adam update
+ * with bias correction for the 1-based `step`.  grad_scale = 1/world_size turns the summed
+ * all-reduce into the mean BEFORE the clamp; grad_clamp <= 0 disables clamping.  `grads` is
+ * not modified.  All four buffers must be 16-byte aligned. */
+int hint_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, float grad_clamp, void* stream);
+
+/* Profiling aid (process-global, not for production use): restrict hint_block_backward to its
+ * row-parallel kernel (mask 1), its weight-gradient kernel (mask 2, reuses whatever the
+ * workspace holds) or both (3, the default), so each can be timed on its own. */
+void hint_debug_set_backward_stages(int32_t mask);
+
 int hint_abi_version(void);
 const char* hint_last_error(void);
 
