@@ -99,18 +99,19 @@ def kernel_legs(trainer, x, reps=200):
     z = torch.empty_like(x); J = torch.empty(B, device=x.device)
     tape = torch.empty(max(lib.hint_plan_tape_floats(eng.plan, B), 1), device=x.device)
     stream = torch.cuda.current_stream().cuda_stream
-    P = eng.arena.data_ptr()
+    P, PK = eng.arena.data_ptr(), eng.packed.data_ptr()
+    out["hint_pack_kernel"] = timed(lambda: lib.hint_block_pack(eng.plan, P, PK, stream))
     out["hint_block_apply_kernel<fwd>"] = timed(
-        lambda: lib.hint_block_forward(eng.plan, P, x.data_ptr(), None, z.data_ptr(), J.data_ptr(), tape.data_ptr(), B, stream))
+        lambda: lib.hint_block_forward(eng.plan, P, PK, x.data_ptr(), None, z.data_ptr(), J.data_ptr(), tape.data_ptr(), B, stream))
     gz = torch.randn_like(x); gJ = torch.full((B,), -1.0 / B, device=x.device)
     gx = torch.empty_like(x); gp = torch.empty(eng.total, device=x.device)
     nb = lib.hint_plan_workspace_bytes(eng.plan, B)
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
 
     def bwd():
-        return lib.hint_block_backward(eng.plan, P, x.data_ptr(), tape.data_ptr(), None, gz.data_ptr(), gJ.data_ptr(),
-                                       gx.data_ptr(), None, gp.data_ptr(), ws.data_ptr(), nb, B, stream)
-    for mask, name in ((1, "hint_block_bwd_kernel"), (2, "hint_block_dw_kernel+memset"), (3, "backward_total")):
+        return lib.hint_block_backward(eng.plan, P, PK, x.data_ptr(), tape.data_ptr(), None, gz.data_ptr(), gJ.data_ptr(),
+                                       gx.data_ptr(), None, gp.data_ptr(), 1, ws.data_ptr(), nb, B, stream)
+    for mask, name in ((1, "hint_block_bwd_kernel"), (2, "hint_block_dw_kernel"), (3, "backward_total")):
         lib.hint_debug_set_backward_stages(mask)
         out[name] = timed(bwd)
     lib.hint_debug_set_backward_stages(3)

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhint_amd.so")
+LIB_PATH = os.environ.get("HINT_AMD_LIB") or os.path.join(_HERE, "lib", "libhint_amd.so")
 ABI_VERSION = 1
 
 
@@ -33,14 +33,19 @@ _PROTOS = {
                                    C.POINTER(C.c_void_p)]),
     "hint_plan_destroy": (None, [C.c_void_p]),
     "hint_plan_param_floats": (C.c_int64, [C.c_void_p]),
+    "hint_plan_packed_floats": (C.c_int64, [C.c_void_p]),
     "hint_plan_tape_floats": (C.c_int64, [C.c_void_p, C.c_int32]),
     "hint_plan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "hint_plan_lds_bytes": (C.c_int32, [C.c_void_p, C.c_int32]),
-    "hint_block_forward": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
-    "hint_block_inverse": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]),
-    "hint_block_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_size_t, C.c_int32, C.c_void_p]),
+    "hint_block_pack": (C.c_int, [C.c_void_p] * 4),
+    "hint_block_forward": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]),
+    "hint_block_inverse": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
+    "hint_block_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_int32,
+                                                          C.c_void_p]),
     "hint_debug_set_backward_stages": (None, [C.c_int32]),
-    "hint_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32] + [C.c_float] * 7 + [C.c_void_p]),
+    "hint_debug_set_stamp_buffer": (C.c_int, [C.c_void_p]),
+    "hint_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32] + [C.c_float] * 7 + [C.c_int32,
+                                                                                                 C.c_void_p]),
 }
 
 

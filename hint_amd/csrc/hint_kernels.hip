@@ -10,133 +10,329 @@
 // rows (= one M-tile of v_mfma_f32_16x16x4_f32) and carries it through ALL tree levels of
 // the block inside one launch; the lane tile, the conditioning input, both hidden
 // activations and s/t live in LDS for the whole pass, HBM sees x once in and z, J once out.
-// The four wavefronts split the hidden units (N-tiles) of the s- and t-subnets of every node
-// of a level; weights stream straight from L2 into MFMA B-fragments (each weight is used
-// once per row tile, so staging them in LDS would buy nothing).  fp32 MFMA is an exact
-// fp32 FMA chain, so results differ from the CPU reference only by summation order.
+// The eight wavefronts split the 16-wide output tiles of the s- and t-subnets of every node
+// of a level; weights stream from L2 as pre-packed MFMA B-fragments (one coalesced 1 KiB load
+// per 16x16 tile), one chunk of four tiles ahead of the MFMAs that consume them.  fp32 MFMA
+// is an exact fp32 FMA chain, so results differ from the CPU reference only by summation
+// order.
 #include <hip/hip_runtime.h>
 #include "hint_dev.h"
 
 using namespace hint;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Explicit LDS (address space 3) pointers for the tables staged in LDS.  A pointer that loses
+// its address space is read with flat_load, and a flat access forces `s_waitcnt vmcnt(0)
+// lgkmcnt(0)`, i.e. drains the whole packed-weight prefetch queue on every table read.
+#define LDS_AS __attribute__((address_space(3)))
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const LDS_AS GJob* lds_jobs_t;
+__device__ __forceinline__ int lds_int(const LDS_AS int32_t* p) { return __builtin_amdgcn_readfirstlane(*p); }
+#define GF(G, FIELD) lds_int(&(G)->FIELD)     // wave-uniform read of a DGroup field from LDS
+
+// Diagnostic build only (-DHINT_STAMPS): shader-clock stamps of workgroup 0 at stage boundaries,
+// written to a buffer nothing else reads (cdna_hip_programming.md §7 "In-kernel stamps").
+#ifdef HINT_STAMPS
+__device__ unsigned long long* g_hint_stamps = nullptr;
+#define STAMP(ID)                                                                              \
+    if (g_hint_stamps != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {               \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        g_hint_stamps[(threadIdx.x >> 6) * 128 + (ID)] = t_;                                    \
+    }
+#else
+#define STAMP(ID)
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0)
+// first, which would retire the packed-weight prefetch of the next stage at every stage
+// boundary; here only LDS operations (lgkmcnt) are waited for, global loads stay in flight
+// across the barrier (cdna_hip_programming.md §5 "Pipelining across barriers").  Global
+// stores issued before it are never read back inside the kernel.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#ifdef HINT_ABLATE_MFMA     // diagnostic: keep operands alive, skip the matrix pipe
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
-// ---------------------------------------------------------------------------------------
-// 16x16 output tile, A from LDS (16 rows, row stride lda, columns [acol, acol+pad16(K)) zero
-// padded), B from global weights.  MFMA lane map (16x16x4 f32): lane l supplies
-// A[m = l&15][kslot = l>>4] and B[kslot][n = l&15]; result reg i = C[4*(l>>4)+i][l&15].
-// The reduction index is permuted consistently on both operands (slot kq of step i of a
-// 16-wide block is k = kb + 4*kq + i) so that each lane fetches 4 consecutive k with one
-// 128-bit access.
-//
-// gemm_nt:  C[b][n] = sum_k A[b][k] * W[n][k]     W row-major [N][K]  (torch Linear.weight)
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 gemm_nt(const float* As, int lda, int acol,
-                                         const float* __restrict__ W, int ldw, int n0, int N,
-                                         int K, int lane) {
-    const int nl = lane & 15, kq = lane >> 4;
-    const int n = n0 + nl;
-    const float* wrow = W + (size_t)(n < N ? n : N - 1) * ldw + 4 * kq;
-    const float* arow = As + nl * lda + acol + 4 * kq;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int Kfull = K & ~15;
-    int kb = 0;
-    for (; kb + 32 <= Kfull; kb += 32) {
-        const f32x4 a0 = *(const f32x4*)(arow + kb);
-        const f32x4 a1 = *(const f32x4*)(arow + kb + 16);
-        const f32x4 b0 = *(const f32x4u*)(wrow + kb);
-        const f32x4 b1 = *(const f32x4u*)(wrow + kb + 16);
-        acc0 = mfma4(a0.x, b0.x, acc0);
-        acc1 = mfma4(a1.x, b1.x, acc1);
-        acc0 = mfma4(a0.y, b0.y, acc0);
-        acc1 = mfma4(a1.y, b1.y, acc1);
-        acc0 = mfma4(a0.z, b0.z, acc0);
-        acc1 = mfma4(a1.z, b1.z, acc1);
-        acc0 = mfma4(a0.w, b0.w, acc0);
-        acc1 = mfma4(a1.w, b1.w, acc1);
+// =======================================================================================
+// weight packing: flat torch-layout parameters -> MFMA fragment order (see hint_dev.h)
+// =======================================================================================
+__global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restrict__ segs,
+                                                        const int2* __restrict__ ptiles, int n_tiles,
+                                                        const int32_t* __restrict__ bmap, int n_bias,
+                                                        long bias_off, const float* __restrict__ P,
+                                                        float* __restrict__ packed) {
+    if ((int)blockIdx.x >= n_tiles) {
+        // trailing workgroups: biases laid out per group in LDS column order (zero for padding)
+        const int i = ((int)blockIdx.x - n_tiles) * 256 + (int)threadIdx.x;
+        if (i < n_bias) { const int off = bmap[i]; packed[bias_off + i] = off >= 0 ? P[off] : 0.f; }
+        return;
     }
-    if (kb < Kfull) {
-        const f32x4 a0 = *(const f32x4*)(arow + kb);
-        const f32x4 b0 = *(const f32x4u*)(wrow + kb);
-        acc0 = mfma4(a0.x, b0.x, acc0);
-        acc0 = mfma4(a0.y, b0.y, acc0);
-        acc0 = mfma4(a0.z, b0.z, acc0);
-        acc0 = mfma4(a0.w, b0.w, acc0);
-        kb += 16;
+    const int2 pt = ptiles[blockIdx.x];
+    const PackSeg sg = segs[pt.x];
+    const int nt = pt.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = nt * 16 + (lane & 15), kq = lane >> 4;
+    for (int kb = wave; kb < sg.NB; kb += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = kb * 16 + 4 * kq + i;
+            float val = 0.f;
+            if (n < sg.N && k < sg.K) {
+                if (sg.mode == 0) val = P[sg.src0 + (int64_t)n * sg.ld + k];
+                else if (sg.mode == 1) val = P[sg.src0 + (int64_t)k * sg.ld + n];
+                else {
+                    const int net = k / sg.hp, k2 = k - net * sg.hp;
+                    if (k2 < sg.h) val = P[(net ? sg.src1 : sg.src0) + (int64_t)k2 * sg.ld + n];
+                }
+            }
+            v[i] = val;
+        }
+        ((f32x4*)(packed + sg.dst + ((int64_t)nt * sg.NB + kb) * 256))[lane] = v;
     }
-    if (kb < K) {   // ragged tail: guard every element (A side is zero padded in LDS)
-        const f32x4 a0 = *(const f32x4*)(arow + kb);
-        const int kk = kb + 4 * kq;
-        f32x4 b0;
-        b0.x = (kk + 0 < K) ? wrow[kb + 0] : 0.f;
-        b0.y = (kk + 1 < K) ? wrow[kb + 1] : 0.f;
-        b0.z = (kk + 2 < K) ? wrow[kb + 2] : 0.f;
-        b0.w = (kk + 3 < K) ? wrow[kb + 3] : 0.f;
-        acc1 = mfma4(a0.x, b0.x, acc1);
-        acc1 = mfma4(a0.y, b0.y, acc1);
-        acc1 = mfma4(a0.z, b0.z, acc1);
-        acc1 = mfma4(a0.w, b0.w, acc1);
-    }
-    return acc0 + acc1;
 }
 
-// gemm_nn:  C[b][n] = sum_kk A[b][kk] * W[kk][n]    W row-major [K][N] (ld = ldw): the
-// transposed product of the backward pass (dX = g * W).
-__device__ __forceinline__ f32x4 gemm_nn(const float* As, int lda, int acol,
-                                         const float* __restrict__ W, int ldw, int n0, int N,
-                                         int K, int lane) {
-    const int nl = lane & 15, kq = lane >> 4;
-    const int n = n0 + nl;
-    const float* wcol = W + (n < N ? n : N - 1) + (size_t)(4 * kq) * ldw;
-    const float* arow = As + nl * lda + acol + 4 * kq;
+__global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, long n4, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) ((f32x4*)p)[i] = z;
+    const long t = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = 0.f;
+}
+
+// =======================================================================================
+// Generic GEMM stage.  Every wavefront walks its jobs (16-column output tiles, wave-strided)
+// as one stream of chunks of <= 4 k-blocks.  Three register sets rotate so that the packed B
+// fragments of the next two chunks are in flight while the MFMAs of the current one issue
+// (loads are unconditional so the compiler can count them exactly), across job boundaries and,
+// through stage_begin(), across the workgroup barrier in front of the stage: weights do not
+// depend on the previous stage, only the A operand in LDS does.
+//   MFMA lane map (16x16x4 f32): lane l supplies A[m = l&15][kslot = l>>4] and
+//   B[kslot][n = l&15]; result reg i = C[4*(l>>4)+i][l&15].  Slot kq of step i of a 16-wide
+//   k-block is k = 16*kb + 4*kq + i on both operands, so each lane reads 4 consecutive k with
+//   one 128-bit access (LDS for A, global for packed B).
+// Job descriptors live in LDS (staged per group, one group ahead): a global or scalar load
+// in front of every job would put an L2 round trip (~700 cycles here) on the critical path.
+// =======================================================================================
+enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_MASK = 2, EPI_PLAIN = 3 };
+
+struct JobU { int wtile, acol, ocol, nblk, nvalid, slab; };
+
+__device__ __forceinline__ JobU load_job(lds_jobs_t jl, int idx) {
+    const i32x4 raw = *(const LDS_AS i32x4*)(jl + idx);    // one ds_read_b128 at a wave-uniform address
+    JobU u;
+    u.wtile = __builtin_amdgcn_readfirstlane(raw.x);
+    const unsigned z = (unsigned)__builtin_amdgcn_readfirstlane(raw.z);
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(raw.w);
+    u.acol = (int)(z & 0xffffu);
+    u.ocol = (int)(z >> 16);
+    u.nblk = (int)(w & 0xffu);
+    u.nvalid = (int)((w >> 8) & 0xffu);
+    u.slab = (int)((w >> 16) & 0xffu);
+    return u;
+}
+
+struct Stage {
+    lds_jobs_t jl;
+    int njobs, rot;
+    bool active;
+    int pi, pkb;            // prefetch cursor: logical job index, k-block
+    JobU pjb;
+    int ci, ckb;            // compute cursor
+    JobU cjb;
+    f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+};
+
+#ifdef HINT_ABLATE_WLOAD    // diagnostic: every weight fetch hits the same 4 KiB (L1-resident)
+#define HINT_WTILE(T) ((size_t)((T) & 3))
+#else
+#define HINT_WTILE(T) ((size_t)(T))
+#endif
+#define HINT_JIDX(S, I) (((I) + (S).rot) >= (S).njobs ? ((I) + (S).rot) - (S).njobs : ((I) + (S).rot))
+
+#define HINT_FETCH(S, R0, R1, R2, R3)                                                              \
+    {                                                                                              \
+        const f32x4* wp_ = (const f32x4*)packed + HINT_WTILE((S).pjb.wtile) * 64 + lane;           \
+        const int last_ = (S).pjb.nblk > 0 ? (S).pjb.nblk - 1 : 0;                                 \
+        R0 = wp_[((S).pkb + 0 < last_ ? (S).pkb + 0 : last_) * 64];                                \
+        R1 = wp_[((S).pkb + 1 < last_ ? (S).pkb + 1 : last_) * 64];                                \
+        R2 = wp_[((S).pkb + 2 < last_ ? (S).pkb + 2 : last_) * 64];                                \
+        R3 = wp_[((S).pkb + 3 < last_ ? (S).pkb + 3 : last_) * 64];                                \
+        (S).pkb += 4;                                                                              \
+        if ((S).pkb >= (S).pjb.nblk) {                                                             \
+            if ((S).pi + NWAVES < (S).njobs) {                                                     \
+                (S).pi += NWAVES;                                                                  \
+                (S).pjb = load_job((S).jl, HINT_JIDX(S, (S).pi));                                  \
+                (S).pkb = 0;                                                                       \
+            } else (S).pkb -= 4; /* end of stream: harmlessly re-fetch the last chunk */           \
+        }                                                                                          \
+    }
+
+// Issue everything of a stage that does not depend on the preceding barrier: first job
+// descriptor, biases, the first two chunks of packed weights.
+__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t jl, int njobs,
+                                            const float* __restrict__ packed, int wave, int lane) {
+    S.jl = jl;
+    S.njobs = njobs;
+    S.active = wave < njobs;
+    if (!S.active) return;
+    // Workgroups run in near lock-step; rotate the job order per workgroup so that the CUs of
+    // an XCD do not all ask the same L2 channel for the same tile at the same moment.
+    S.rot = (int)((blockIdx.x * 5u) % (unsigned)njobs);
+    S.pi = wave;
+    S.pkb = 0;
+    S.pjb = load_job(jl, HINT_JIDX(S, wave));
+    S.ci = wave;
+    S.ckb = 0;
+    S.cjb = S.pjb;
+    HINT_FETCH(S, S.a0, S.a1, S.a2, S.a3)
+    HINT_FETCH(S, S.b0, S.b1, S.b2, S.b3)
+}
+
+template <int EPI>
+__device__ __forceinline__ void stage_epilogue(const JobU& jb, f32x4 acc, const float* bias_lds, float* O,
+                                               int ldo, int slab_stride, int lane) {
+    const int nl = lane & 15;
+    const bool ok = nl < jb.nvalid;
+    // biases of the group sit in LDS in output-column order (zero in the padding columns);
+    // only slab 0 of a K-split stage adds them
+    float bias = 0.f;
+    if ((EPI == EPI_RELU || EPI == EPI_LINEAR) && jb.slab == 0) bias = bias_lds[jb.ocol + nl];
+    float* o = O + jb.slab * slab_stride + (4 * (lane >> 4)) * ldo + jb.ocol + nl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v;
+        if (EPI == EPI_RELU) v = ok ? fmaxf(acc[i] + bias, 0.f) : 0.f;
+        else if (EPI == EPI_LINEAR) v = ok ? acc[i] + bias : 0.f;
+        else if (EPI == EPI_MASK) v = (ok && o[i * ldo] > 0.f) ? acc[i] : 0.f;
+        else v = ok ? acc[i] : 0.f;
+        o[i * ldo] = v;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void stage_run(Stage& S, const float* __restrict__ packed,
+                                          const float* bias_lds, const float* A, int lda, float* O, int ldo,
+                                          int slab_stride, int lane) {
+    if (!S.active) return;
+    const int nl = lane & 15;
+    const float* arow = A + nl * lda + 4 * (lane >> 4);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int Kfull = K & ~15;
-    int kb = 0;
-    for (; kb + 32 <= Kfull; kb += 32) {
-        const f32x4 a0 = *(const f32x4*)(arow + kb);
-        const f32x4 a1 = *(const f32x4*)(arow + kb + 16);
-        const float* w0 = wcol + (size_t)kb * ldw;
-        const float* w1 = w0 + (size_t)16 * ldw;
-        const float b00 = w0[0], b01 = w0[ldw], b02 = w0[2 * ldw], b03 = w0[3 * ldw];
-        const float b10 = w1[0], b11 = w1[ldw], b12 = w1[2 * ldw], b13 = w1[3 * ldw];
-        acc0 = mfma4(a0.x, b00, acc0);
-        acc1 = mfma4(a1.x, b10, acc1);
-        acc0 = mfma4(a0.y, b01, acc0);
-        acc1 = mfma4(a1.y, b11, acc1);
-        acc0 = mfma4(a0.z, b02, acc0);
-        acc1 = mfma4(a1.z, b12, acc1);
-        acc0 = mfma4(a0.w, b03, acc0);
-        acc1 = mfma4(a1.w, b13, acc1);
+    f32x4 c0, c1, c2, c3;
+
+#define HINT_MMA1(R, I, ACC)                                                                       \
+    if (S.ckb + I < S.cjb.nblk) {                                                                  \
+        const f32x4 a_ = *(const f32x4*)(ap_ + I * 16);                                            \
+        ACC = mfma4(a_.x, R.x, ACC);                                                               \
+        ACC = mfma4(a_.y, R.y, ACC);                                                               \
+        ACC = mfma4(a_.z, R.z, ACC);                                                               \
+        ACC = mfma4(a_.w, R.w, ACC);                                                               \
     }
-    if (kb < Kfull) {
-        const f32x4 a0 = *(const f32x4*)(arow + kb);
-        const float* w0 = wcol + (size_t)kb * ldw;
-        const float b00 = w0[0], b01 = w0[ldw], b02 = w0[2 * ldw], b03 = w0[3 * ldw];
-        acc0 = mfma4(a0.x, b00, acc0);
-        acc0 = mfma4(a0.y, b01, acc0);
-        acc0 = mfma4(a0.z, b02, acc0);
-        acc0 = mfma4(a0.w, b03, acc0);
-        kb += 16;
+#define HINT_COMPUTE(R0, R1, R2, R3, DONE)                                                         \
+    {                                                                                              \
+        const float* ap_ = arow + S.cjb.acol + S.ckb * 16;                                         \
+        HINT_MMA1(R0, 0, acc0) HINT_MMA1(R1, 1, acc1) HINT_MMA1(R2, 2, acc0) HINT_MMA1(R3, 3, acc1) \
+        S.ckb += 4;                                                                                \
+        if (S.ckb >= S.cjb.nblk) {                                                                 \
+            stage_epilogue<EPI>(S.cjb, acc0 + acc1, bias_lds, O, ldo, slab_stride, lane);          \
+            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+            S.ci += NWAVES;                                                                        \
+            if (S.ci >= S.njobs) { DONE = true; }                                                  \
+            else {                                                                                 \
+                S.cjb = load_job(S.jl, HINT_JIDX(S, S.ci));                                        \
+                S.ckb = 0;                                                                         \
+            }                                                                                      \
+        }                                                                                          \
     }
-    if (kb < K) {
-        const f32x4 a0 = *(const f32x4*)(arow + kb);
-        const float* w0 = wcol + (size_t)kb * ldw;
-        const int kk = kb + 4 * kq;
-        const float b00 = (kk + 0 < K) ? w0[0] : 0.f;
-        const float b01 = (kk + 1 < K) ? w0[ldw] : 0.f;
-        const float b02 = (kk + 2 < K) ? w0[2 * ldw] : 0.f;
-        const float b03 = (kk + 3 < K) ? w0[3 * ldw] : 0.f;
-        acc1 = mfma4(a0.x, b00, acc1);
-        acc1 = mfma4(a0.y, b01, acc1);
-        acc1 = mfma4(a0.z, b02, acc1);
-        acc1 = mfma4(a0.w, b03, acc1);
+
+    bool done = false;
+    while (true) {
+        HINT_FETCH(S, c0, c1, c2, c3)
+        HINT_COMPUTE(S.a0, S.a1, S.a2, S.a3, done)
+        if (done) break;
+        HINT_FETCH(S, S.a0, S.a1, S.a2, S.a3)
+        HINT_COMPUTE(S.b0, S.b1, S.b2, S.b3, done)
+        if (done) break;
+        HINT_FETCH(S, S.b0, S.b1, S.b2, S.b3)
+        HINT_COMPUTE(c0, c1, c2, c3, done)
+        if (done) break;
     }
-    return acc0 + acc1;
+#undef HINT_MMA1
+#undef HINT_COMPUTE
+}
+
+// Small outer-product tiles done inside the backward kernel (dW1, dW3): the reduction runs
+// over the 16 rows of the tile, results go to the flat gradient buffer with float atomics.
+__device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const float* Abuf, int lda,
+                                          const float* Bbuf, int ldb, float* __restrict__ g, int wave,
+                                          int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+    for (int j = wave; j < njobs; j += NWAVES) {
+        const i32x4 raw = *(const LDS_AS i32x4*)(jobs + j);
+        const int goff = __builtin_amdgcn_readfirstlane(raw.x);
+        const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane(raw.y);
+        const unsigned zz = (unsigned)__builtin_amdgcn_readfirstlane(raw.z);
+        const int acol = (int)(y & 0xffffu), bcol = (int)(y >> 16);
+        const int ldg = (int)(zz & 0xffffu), mvalid = (int)((zz >> 16) & 0xffu), nvalid = (int)(zz >> 24);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = kq + 4 * i;
+            acc = mfma4(Abuf[row * lda + acol + nl], Bbuf[row * ldb + bcol + nl], acc);
+        }
+        if (nl < nvalid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 4 * kq + i;
+                if (m < mvalid) atomicAdd(g + goff + (int64_t)m * ldg + nl, acc[i]);
+            }
+        }
+    }
+}
+
+// bias gradients: column sums over the 16 rows of an LDS buffer, one thread per column
+__device__ __forceinline__ void colsum_atomic(const int32_t* __restrict__ map, int ncols, const float* buf,
+                                              int ld, float* __restrict__ g, int tid) {
+    for (int col = tid; col < ncols; col += NTHREADS) {
+        const int off = map[col];
+        if (off < 0) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s += buf[r * ld + col];
+        atomicAdd(g + off, s);
+    }
+}
+
+struct VNodeU { int off, k, cin, cinp, vcol; };
+__device__ __forceinline__ VNodeU load_vnode(const LDS_AS VNode* vnodes, int ni) {
+    const LDS_AS int32_t* p = (const LDS_AS int32_t*)(vnodes + ni);       // 12 bytes = 3 dwords, wave-uniform
+    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane(p[0]);
+    const unsigned w1 = (unsigned)__builtin_amdgcn_readfirstlane(p[1]);
+    const unsigned w2 = (unsigned)__builtin_amdgcn_readfirstlane(p[2]);
+    VNodeU u;
+    u.off = (int)(w0 & 0xffffu); u.k = (int)(w0 >> 16);
+    u.cin = (int)(w1 & 0xffffu); u.cinp = (int)(w1 >> 16);
+    u.vcol = (int)(w2 & 0xffffu);
+    return u;
+}
+struct EntU { int xcol, scol, tcol; };
+__device__ __forceinline__ EntU load_ent(const LDS_AS Ent* ents, int e) {
+    const LDS_AS int32_t* p = (const LDS_AS int32_t*)(ents + e);           // 8 bytes, per-lane address
+    const unsigned w0 = (unsigned)p[0], w1 = (unsigned)p[1];
+    EntU u;
+    u.xcol = (int)(w0 & 0xffffu); u.scol = (int)(w0 >> 16); u.tcol = (int)(w1 & 0xffffu);
+    return u;
 }
 
 __device__ __forceinline__ float row16_sum(float v) {
@@ -148,13 +344,12 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// ---- stage helpers shared by forward / inverse / backward ------------------------------
-
 // v = [u | c] for every node of the group (hint.py:76), zero padded to cinp columns.
-__device__ __forceinline__ void stage_build_v(const KArgs& a, const DGroup& g, const float* xs,
-                                              const float* cs, float* vb, int tid) {
-    for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-        const DNode& nd = a.nodes[ni];
+__device__ __forceinline__ void stage_build_v(const KArgs& a, int node_begin, int node_end,
+                                              const LDS_AS VNode* vnodes, const float* xs, const float* cs,
+                                              float* vb, int tid) {
+    for (int ni = node_begin; ni < node_end; ++ni) {
+        const VNodeU nd = load_vnode(vnodes, ni);
         const int cinp = nd.cinp, k = nd.k, cin = nd.cin, off = nd.off, vcol = nd.vcol;
         for (int i = tid; i < ROWS * cinp; i += NTHREADS) {
             const int r = i / cinp, j = i - r * cinp;
@@ -163,49 +358,6 @@ __device__ __forceinline__ void stage_build_v(const KArgs& a, const DGroup& g, c
             else if (j < cin) v = cs[r * a.cld + (j - k)];
             vb[r * a.vld + vcol + j] = v;
         }
-    }
-}
-
-// hidden layer: out = relu(A * W^T + b); LAYER 1 reads v (K = cin), LAYER 2 reads a1 (K = h)
-template <int LAYER>
-__device__ __forceinline__ void stage_hidden(const KArgs& a, const DGroup& g,
-                                             const float* __restrict__ params, const float* Ain,
-                                             float* Aout, int wave, int lane) {
-    for (int j = wave; j < g.jobsH_cnt; j += NWAVES) {
-        const Job job = a.jobs[g.jobsH_begin + j];
-        const DNode& nd = a.nodes[job.node];
-        const int h = nd.h, n0 = job.tile * TILE;
-        const float* W = params + nd.p[job.net * 6 + (LAYER == 1 ? 0 : 2)];
-        const float* bvec = params + nd.p[job.net * 6 + (LAYER == 1 ? 1 : 3)];
-        f32x4 acc;
-        if (LAYER == 1) acc = gemm_nt(Ain, a.vld, nd.vcol, W, nd.cin, n0, h, nd.cin, lane);
-        else            acc = gemm_nt(Ain, a.ald, nd.acol + job.net * nd.hp, W, h, n0, h, h, lane);
-        const int n = n0 + (lane & 15);
-        const bool ok = n < h;
-        const float bias = ok ? bvec[n] : 0.f;
-        float* o = Aout + (4 * (lane >> 4)) * a.ald + nd.acol + job.net * nd.hp + n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i * a.ald] = ok ? fmaxf(acc[i] + bias, 0.f) : 0.f;
-    }
-}
-
-// output layer: st = a2 * W3^T + b3  (no activation)
-__device__ __forceinline__ void stage_out(const KArgs& a, const DGroup& g,
-                                          const float* __restrict__ params, const float* a2,
-                                          float* st, int wave, int lane) {
-    for (int j = wave; j < g.jobsR_cnt; j += NWAVES) {
-        const Job job = a.jobs[g.jobsR_begin + j];
-        const DNode& nd = a.nodes[job.node];
-        const int h = nd.h, r = nd.r, n0 = job.tile * TILE;
-        const float* W = params + nd.p[job.net * 6 + 4];
-        const float* bvec = params + nd.p[job.net * 6 + 5];
-        const f32x4 acc = gemm_nt(a2, a.ald, nd.acol + job.net * nd.hp, W, h, n0, r, h, lane);
-        const int n = n0 + (lane & 15);
-        const bool ok = n < r;
-        const float bias = ok ? bvec[n] : 0.f;
-        float* o = st + (4 * (lane >> 4)) * a.sld + nd.scol + job.net * nd.rp + n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i * a.sld] = ok ? acc[i] + bias : 0.f;
     }
 }
 
@@ -234,78 +386,170 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
     }
 }
 
+// The job list of the NEXT group travels global -> registers at the start of a group and
+// registers -> LDS near its end, so its L2 latency hides behind the group's GEMM stages.
+// (The group's biases, a few KiB, ride along: [b1 | b2 | b3] in LDS column order.)
+struct JobPrefetch { i32x4 r0, r1; f32x4 b0; int count, nbias4; };
+
+__device__ __forceinline__ void jobs_issue(JobPrefetch& jp, const GJob* __restrict__ gjobs, int jl_begin,
+                                           int jl_count, const float* __restrict__ bias_src, int nbias,
+                                           int tid) {
+    jp.count = jl_count;
+    jp.nbias4 = nbias >> 2;                       // bias blocks are multiples of 16 floats, <= 4*NTHREADS
+    const i32x4* src = (const i32x4*)(gjobs + jl_begin);
+    if (tid < jp.count) jp.r0 = src[tid];
+    if (tid + NTHREADS < jp.count) jp.r1 = src[tid + NTHREADS];
+    if (tid < jp.nbias4) jp.b0 = ((const f32x4*)bias_src)[tid];
+}
+__device__ __forceinline__ void jobs_commit(const JobPrefetch& jp, LDS_AS GJob* jbuf, float* bias_dst, int tid) {
+    if (tid < jp.count) ((LDS_AS i32x4*)jbuf)[tid] = jp.r0;
+    if (tid + NTHREADS < jp.count) ((LDS_AS i32x4*)jbuf)[tid + NTHREADS] = jp.r1;
+    if (tid < jp.nbias4) ((f32x4*)bias_dst)[tid] = jp.b0;
+}
+
+// LDS carve-up shared by both block kernels: [meta | job buffer 0 | job buffer 1 | floats...]
+__device__ __forceinline__ void lds_copy_meta(const KArgs& a, LDS_AS char* mbase, int tid) {
+    const int n16 = a.meta_bytes >> 4;
+    for (int i = tid; i < n16; i += NTHREADS) ((LDS_AS i32x4*)mbase)[i] = ((const i32x4*)a.meta)[i];
+}
+
 // =======================================================================================
 // forward (REV=false) / inverse (REV=true): x, J -> z   — one launch per block
 // =======================================================================================
+#define HINT_LDS_TABLES()                                                                          \
+    LDS_AS char* mbase = (LDS_AS char*)lds;                                                        \
+    const LDS_AS DGroup* groups = (const LDS_AS DGroup*)mbase;                                     \
+    const LDS_AS VNode* vnodes = (const LDS_AS VNode*)(mbase + a.vnodes_off);                      \
+    const LDS_AS Ent* ents = (const LDS_AS Ent*)(mbase + a.ents_off);                              \
+    LDS_AS GJob* jbuf0 = (LDS_AS GJob*)(mbase + a.meta_bytes);                                     \
+    float* bias0 = lds + ((a.meta_bytes + 2 * a.jmax * (int)sizeof(GJob)) >> 2);                   \
+    float* fbase = bias0 + 2 * a.bmax;                                                             \
+    lds_copy_meta(a, mbase, tid);
+
 template <bool REV>
-__global__ __launch_bounds__(NTHREADS) void hint_block_apply_kernel(
-    KArgs a, const float* __restrict__ params, const float* __restrict__ x,
-    const float* __restrict__ c, float* __restrict__ z, float* __restrict__ J,
-    float* __restrict__ tape) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_block_apply_kernel(
+    KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
+    const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
+    float* __restrict__ J, float* __restrict__ tape) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    STAMP(0)
+    HINT_LDS_TABLES()
+    float* xs = fbase;
     float* cs = xs + ROWS * a.xld;
     float* vb = cs + ROWS * a.cld;
     float* a1 = vb + ROWS * a.vld;
     float* a2 = a1 + ROWS * a.ald;
-    float* st = a2 + ROWS * a.ald;
-    float* jac = st + ROWS * a.sld;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* st = a2 + ROWS * a.ald;           // [s3][ROWS][sld]
+    float* jac = st + a.s3 * ROWS * a.sld;
+    const int sstride = ROWS * a.sld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
+    __syncthreads();                          // meta visible
 
+    int jb = 0;
+    Stage S, N;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
+        const bool first_tile = (tile == (int)blockIdx.x);
+        const LDS_AS DGroup* gfirst = groups + (REV ? a.n_groups - 1 : 0);
+        if (first_tile) {                     // later tiles get the first group's jobs through the prefetch below
+            JobPrefetch jp0;
+            jobs_issue(jp0, a.jobs, GF(gfirst, jl_begin), GF(gfirst, jl_count), packed + a.bias_off + GF(gfirst, bmap_begin),
+                       2 * GF(gfirst, aw) + GF(gfirst, sw), tid);
+            jobs_commit(jp0, jbuf0 + jb * a.jmax, bias0 + jb * a.bmax, tid);
+        }
         load_tile(xs, a.xld, x, a.d, row0, a.B, tid);
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
         if (tid < ROWS) jac[tid] = 0.f;
         __syncthreads();
+        STAMP(1)
+        if (first_tile)
+            stage_begin(S, jbuf0 + jb * a.jmax + GF(gfirst, l1_off), GF(gfirst, l1_cnt), packed, wave, lane);
 
         for (int gi = 0; gi < a.n_groups; ++gi) {
-            const DGroup& g = a.groups[REV ? (a.n_groups - 1 - gi) : gi];
-            stage_build_v(a, g, xs, cs, vb, tid);
-            __syncthreads();
-            stage_hidden<1>(a, g, params, vb, a1, wave, lane);
-            __syncthreads();
-            stage_hidden<2>(a, g, params, a1, a2, wave, lane);
-            __syncthreads();
-            stage_out(a, g, params, a2, st, wave, lane);
-            __syncthreads();
+            const LDS_AS DGroup* g = groups + (REV ? (a.n_groups - 1 - gi) : gi);
+            const bool more_tiles = tile + (int)gridDim.x < ntiles;
+            const bool has_next = (gi + 1 < a.n_groups) || more_tiles;
+            const int gnext = (gi + 1 < a.n_groups) ? gi + 1 : 0;
+            const LDS_AS DGroup* gn = groups + (REV ? (a.n_groups - 1 - gnext) : gnext);
+            JobPrefetch jp;
+            jp.count = 0;
+            jp.nbias4 = 0;
+            if (has_next)
+                jobs_issue(jp, a.jobs, GF(gn, jl_begin), GF(gn, jl_count), packed + a.bias_off + GF(gn, bmap_begin),
+                           2 * GF(gn, aw) + GF(gn, sw), tid);
+            lds_jobs_t jl = jbuf0 + jb * a.jmax;
+            LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
+            const int l3_slabs = GF(g, l3_slabs), ent_begin = GF(g, ent_begin), ent_cnt = GF(g, ent_cnt);
+            const int g_aw = GF(g, aw);
+            const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
+
+            stage_build_v(a, GF(g, node_begin), GF(g, node_end), vnodes, xs, cs, vb, tid);
+            STAMP(2 + 12 * gi)
+            lds_barrier();
+            STAMP(3 + 12 * gi)
+            stage_begin(N, jl + GF(g, l2_off), GF(g, l2_cnt), packed, wave, lane);
+            stage_run<EPI_RELU>(S, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            STAMP(4 + 12 * gi)
+            lds_barrier();
+            STAMP(5 + 12 * gi)
+            stage_begin(S, jl + GF(g, l3_off), GF(g, l3_cnt), packed, wave, lane);
+            stage_run<EPI_RELU>(N, packed, bias_g + g_aw, a1, a.ald, a2, a.ald, 0, lane);
+            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
+            STAMP(6 + 12 * gi)
+            lds_barrier();
+            STAMP(7 + 12 * gi)
+            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g_aw, a2, a.ald, st, a.sld, sstride, lane);
+            STAMP(8 + 12 * gi)
+            lds_barrier();
+            STAMP(9 + 12 * gi)
+            if (has_next) stage_begin(S, jl_next + GF(gn, l1_off), GF(gn, l1_cnt), packed, wave, lane);
             {   // element-wise affine coupling + log-det partial sums (hint.py:79-83)
                 const int sub = tid & 15, row = tid >> 4;
                 float part = 0.f;
-                for (int e = sub; e < g.ent_cnt; e += 16) {
-                    const Ent en = a.ents[g.ent_begin + e];
-                    const float s = st[row * a.sld + en.scol];
-                    const float t = st[row * a.sld + en.tcol];
-                    const float aa = a.alpha * atanf(s);
-                    float* px = xs + row * a.xld + en.xcol;
-                    if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
-                    else      { *px = ((*px) - t) / expf(aa); part -= aa; }
+                if (row < ROWS) {
+                    for (int e = sub; e < ent_cnt; e += 16) {
+                        const EntU en = load_ent(ents, ent_begin + e);
+                        float s = 0.f, t = 0.f;
+                        for (int sl = 0; sl < l3_slabs; ++sl) {
+                            s += st[sl * sstride + row * a.sld + en.scol];
+                            t += st[sl * sstride + row * a.sld + en.tcol];
+                        }
+                        const float aa = a.alpha * atanf(s);
+                        float* px = xs + row * a.xld + en.xcol;
+                        if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
+                        else      { *px = ((*px) - t) / expf(aa); part -= aa; }
+                    }
                 }
                 part = row16_sum(part);
-                if (sub == 0) jac[row] += part;
+                if (sub == 0 && row < ROWS) jac[row] += part;
             }
-            __syncthreads();
+            STAMP(10 + 12 * gi)
+            lds_barrier();
+            STAMP(11 + 12 * gi)
             // training: keep the lane tile as it stands after each level except the root's, so
             // that the backward pass sees bit-identical subnet inputs (tape[level][B][d])
-            if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
-                store_tile(tape + (size_t)g.level * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
+            if (!REV && tape != nullptr && GF(g, level_last) && GF(g, level) < a.n_levels - 1)
+                store_tile(tape + (size_t)GF(g, level) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
+            jb ^= 1;
         }
         store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
         if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid];
-        __syncthreads();
+        STAMP(120)
+        lds_barrier();
     }
 }
 
 // =======================================================================================
 // backward, part A (row parallel): walk the levels root first; per level reload the lane tile
 // the forward pass recorded (x for the deepest level, tape[level-1] otherwise), recompute each
-// node's activations from it (same code, same inputs -> bit-identical ReLU masks),
-// back-propagate through coupling and subnets to get g_x / g_c, and leave the per-layer
-// activations and pre-activation gradients in the workspace for the weight-gradient GEMMs.
+// node's activations from it (same code, same inputs -> bit-identical ReLU masks), and
+// back-propagate through coupling and subnets to get g_x / g_c.  The thin weight gradients
+// (dW1, dW3, all biases: O(h) floats per node) are reduced over the 16 rows here and added to
+// the flat gradient buffer with float atomics; only a1 and g2, the operands of the h x h
+// gradient dW2 = g2^T a1, go to the workspace for part B.
 //   g_t = g_l' ; g_a = g_l'*exp(a)*l + g_J ; g_l = g_l'*exp(a) ; g_s = g_a*alpha/(1+s^2)
 // =======================================================================================
 __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, int dcol,
@@ -319,33 +563,45 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
     }
 }
 
-__global__ __launch_bounds__(NTHREADS) void hint_block_bwd_kernel(
-    KArgs a, const float* __restrict__ params, const float* __restrict__ x,
-    const float* __restrict__ tape, const float* __restrict__ c, const float* __restrict__ g_z,
-    const float* __restrict__ g_J,
-    float* __restrict__ g_x, float* __restrict__ g_c, float* __restrict__ wsV,
-    float* __restrict__ wsA1, float* __restrict__ wsA2, float* __restrict__ wsG1,
-    float* __restrict__ wsG2, float* __restrict__ wsG3) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_block_bwd_kernel(
+    KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
+    const float* __restrict__ x, const float* __restrict__ tape, const float* __restrict__ c,
+    const float* __restrict__ g_z, const float* __restrict__ g_J, float* __restrict__ g_x,
+    float* __restrict__ g_c, float* __restrict__ gparams, float* __restrict__ wsA1,
+    float* __restrict__ wsG2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    STAMP(0)
+    HINT_LDS_TABLES()
+    float* xs = fbase;
     float* gs = xs + ROWS * a.xld;
     float* cs = gs + ROWS * a.xld;
     float* gcs = cs + ROWS * a.cld;
     float* vb = gcs + ROWS * a.cld;
-    float* gv = vb + ROWS * a.vld;
-    float* a1 = gv + ROWS * a.vld;
+    float* gv = vb + ROWS * a.vld;           // [sv][ROWS][vld]
+    float* a1 = gv + a.sv * ROWS * a.vld;
     float* a2 = a1 + ROWS * a.ald;
-    float* st = a2 + ROWS * a.ald;
-    float* gst = st + ROWS * a.sld;
+    float* st = a2 + ROWS * a.ald;           // [s3][ROWS][sld]
+    float* gst = st + a.s3 * ROWS * a.sld;
     float* gj = gst + ROWS * a.sld;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sstride = ROWS * a.sld, vstride = ROWS * a.vld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
+    __syncthreads();                          // meta visible
 
+    int jb = 0;
+    Stage S, N;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
+        const bool first_tile = (tile == (int)blockIdx.x);
+        const LDS_AS DGroup* gfirst = groups + (a.n_groups - 1);
+        if (first_tile) {
+            JobPrefetch jp0;
+            jobs_issue(jp0, a.jobs, GF(gfirst, jl_begin), GF(gfirst, jl_count), packed + a.bias_off + GF(gfirst, bmap_begin),
+                       2 * GF(gfirst, aw) + GF(gfirst, sw), tid);
+            jobs_commit(jp0, jbuf0 + jb * a.jmax, bias0 + jb * a.bmax, tid);
+        }
         load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid);
         if (a.dc > 0) {
             load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
@@ -353,210 +609,258 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_bwd_kernel(
         }
         if (tid < ROWS) gj[tid] = (g_J != nullptr && row0 + tid < a.B) ? g_J[row0 + tid] : 0.f;
         __syncthreads();
+        STAMP(1)
+        if (first_tile)
+            stage_begin(S, jbuf0 + jb * a.jmax + GF(gfirst, l1_off), GF(gfirst, l1_cnt), packed, wave, lane);
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
-            const DGroup& g = a.groups[gi];
+            const LDS_AS DGroup* g = groups + gi;
+            const bool more_tiles = tile + (int)gridDim.x < ntiles;
+            const bool has_next = (gi > 0) || more_tiles;
+            const LDS_AS DGroup* gn = groups + (gi > 0 ? gi - 1 : a.n_groups - 1);
+            JobPrefetch jp;
+            jp.count = 0;
+            jp.nbias4 = 0;
+            if (has_next)
+                jobs_issue(jp, a.jobs, GF(gn, jl_begin), GF(gn, jl_count), packed + a.bias_off + GF(gn, bmap_begin),
+                           2 * GF(gn, aw) + GF(gn, sw), tid);
+            lds_jobs_t jl = jbuf0 + jb * a.jmax;
+            LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
+            const int sbase = 2 + 20 * (a.n_groups - 1 - gi);
+            (void)sbase;
+            const int g_aw = GF(g, aw), g_sw = GF(g, sw), g_wcol0 = GF(g, wcol0);
+            const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
+            const int node_begin = GF(g, node_begin), node_end = GF(g, node_end);
+            const int l3_slabs = GF(g, l3_slabs), dv_slabs = GF(g, dv_slabs);
+            const int ent_begin = GF(g, ent_begin), ent_cnt = GF(g, ent_cnt);
+            const int bmap_begin = GF(g, bmap_begin), bmap3_begin = GF(g, bmap3_begin);
+
             // ---- the lanes as the forward pass saw them when it entered this level ----
-            if (g.level_last) {
-                const float* src = (g.level == 0) ? x : tape + (size_t)(g.level - 1) * a.B * a.d;
+            if (GF(g, level_last)) {
+                const int level = GF(g, level);
+                const float* src = (level == 0) ? x : tape + (size_t)(level - 1) * a.B * a.d;
                 load_tile(xs, a.xld, src, a.d, row0, a.B, tid);
-                __syncthreads();
+                lds_barrier();
             }
             // ---- recompute s, t of every node of the group (bit-identical to the forward) ----
-            stage_build_v(a, g, xs, cs, vb, tid);
-            for (int i = tid; i < ROWS * g.sw; i += NTHREADS) {
-                const int r = i / g.sw;
-                gst[r * a.sld + (i - r * g.sw)] = 0.f;
+            stage_build_v(a, node_begin, node_end, vnodes, xs, cs, vb, tid);
+            for (int i = tid; i < ROWS * g_sw; i += NTHREADS) {
+                const int r = i / g_sw;
+                gst[r * a.sld + (i - r * g_sw)] = 0.f;
             }
-            __syncthreads();
-            if (g.vw > 0) copy_rows_out(wsV, a.VT, g.wvcol0, vb, a.vld, g.vw, row0, tid);
-            stage_hidden<1>(a, g, params, vb, a1, wave, lane);
-            __syncthreads();
-            copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            stage_hidden<2>(a, g, params, a1, a2, wave, lane);
-            __syncthreads();
-            copy_rows_out(wsA2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
-            stage_out(a, g, params, a2, st, wave, lane);
-            __syncthreads();
+            STAMP(sbase + 0)
+            lds_barrier();
+            STAMP(sbase + 1)
+            stage_begin(N, jl + GF(g, l2_off), GF(g, l2_cnt), packed, wave, lane);
+            stage_run<EPI_RELU>(S, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            STAMP(sbase + 2)
+            lds_barrier();
+            STAMP(sbase + 3)
+            stage_begin(S, jl + GF(g, l3_off), GF(g, l3_cnt), packed, wave, lane);
+            copy_rows_out(wsA1, a.WT, g_wcol0, a1, a.ald, g_aw, row0, tid);
+            stage_run<EPI_RELU>(N, packed, bias_g + g_aw, a1, a.ald, a2, a.ald, 0, lane);
+            STAMP(sbase + 4)
+            lds_barrier();
+            STAMP(sbase + 5)
+            stage_begin(N, jl + GF(g, g2_off), GF(g, g2_cnt), packed, wave, lane);
+            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g_aw, a2, a.ald, st, a.sld, sstride, lane);
+            STAMP(sbase + 6)
+            lds_barrier();
+            STAMP(sbase + 7)
             {   // ---- coupling backward ----
                 const int sub = tid & 15, row = tid >> 4;
-                const float gJr = gj[row];
-                for (int e = sub; e < g.ent_cnt; e += 16) {
-                    const Ent en = a.ents[g.ent_begin + e];
-                    const float s = st[row * a.sld + en.scol];
-                    const float aa = a.alpha * atanf(s);
-                    const float ea = expf(aa);
-                    const float l = xs[row * a.xld + en.xcol];       // lower input of the node
-                    float* pg = gs + row * a.xld + en.xcol;
-                    const float glp = *pg;                            // grad wrt l' = exp(a)*l + t
-                    *pg = glp * ea;                                   // g_l
-                    const float ga = glp * ea * l + gJr;              // g_a (a feeds both l' and J)
-                    gst[row * a.sld + en.scol] = ga * a.alpha / (1.f + s * s);   // g_s
-                    gst[row * a.sld + en.tcol] = glp;                              // g_t
+                if (row < ROWS) {
+                    const float gJr = gj[row];
+                    for (int e = sub; e < ent_cnt; e += 16) {
+                        const EntU en = load_ent(ents, ent_begin + e);
+                        float s = 0.f;
+                        for (int sl = 0; sl < l3_slabs; ++sl) s += st[sl * sstride + row * a.sld + en.scol];
+                        const float aa = a.alpha * atanf(s);
+                        const float ea = expf(aa);
+                        const float l = xs[row * a.xld + en.xcol];       // lower input of the node
+                        float* pg = gs + row * a.xld + en.xcol;
+                        const float glp = *pg;                            // grad wrt l' = exp(a)*l + t
+                        *pg = glp * ea;                                   // g_l
+                        const float ga = glp * ea * l + gJr;              // g_a (a feeds both l' and J)
+                        gst[row * a.sld + en.scol] = ga * a.alpha / (1.f + s * s);   // g_s
+                        gst[row * a.sld + en.tcol] = glp;                              // g_t
+                    }
                 }
             }
-            __syncthreads();
-            // ---- g2 = (g3 * W3) .* relu'(a2), in place over a2 ----
-            copy_rows_out(wsG3, a.ST, g.wscol0, gst, a.sld, g.sw, row0, tid);
-            for (int j = wave; j < g.jobsH_cnt; j += NWAVES) {
-                const Job job = a.jobs[g.jobsH_begin + j];
-                const DNode& nd = a.nodes[job.node];
-                const int h = nd.h, n0 = job.tile * TILE;
-                const float* W3 = params + nd.p[job.net * 6 + 4];
-                const f32x4 acc = gemm_nn(gst, a.sld, nd.scol + job.net * nd.rp, W3, h, n0, h, nd.r, lane);
-                const int n = n0 + (lane & 15);
-                float* o = a2 + (4 * (lane >> 4)) * a.ald + nd.acol + job.net * nd.hp + n;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i * a.ald] = (n < h && o[i * a.ald] > 0.f) ? acc[i] : 0.f;
-            }
-            __syncthreads();
-            // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1 ----
-            copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
-            for (int j = wave; j < g.jobsH_cnt; j += NWAVES) {
-                const Job job = a.jobs[g.jobsH_begin + j];
-                const DNode& nd = a.nodes[job.node];
-                const int h = nd.h, n0 = job.tile * TILE;
-                const float* W2 = params + nd.p[job.net * 6 + 2];
-                const f32x4 acc = gemm_nn(a2, a.ald, nd.acol + job.net * nd.hp, W2, h, n0, h, h, lane);
-                const int n = n0 + (lane & 15);
-                float* o = a1 + (4 * (lane >> 4)) * a.ald + nd.acol + job.net * nd.hp + n;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i * a.ald] = (n < h && o[i * a.ald] > 0.f) ? acc[i] : 0.f;
-            }
-            __syncthreads();
-            // ---- g_v = g1_s * W1_s + g1_t * W1_t  (both nets feed the same v) ----
-            copy_rows_out(wsG1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            for (int j = wave; j < g.jobsC_cnt; j += NWAVES) {
-                const Job job = a.jobs[g.jobsC_begin + j];   // net field unused: one job sums s and t
-                const DNode& nd = a.nodes[job.node];
-                const int h = nd.h, cin = nd.cin, n0 = job.tile * TILE;
-                const f32x4 accs = gemm_nn(a1, a.ald, nd.acol, params + nd.p[0], cin, n0, cin, h, lane);
-                const f32x4 acct = gemm_nn(a1, a.ald, nd.acol + nd.hp, params + nd.p[6], cin, n0, cin, h, lane);
-                const int n = n0 + (lane & 15);
-                float* o = gv + (4 * (lane >> 4)) * a.vld + nd.vcol + n;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i * a.vld] = (n < cin) ? accs[i] + acct[i] : 0.f;
-            }
-            __syncthreads();
+            STAMP(sbase + 8)
+            lds_barrier();
+            STAMP(sbase + 9)
+            // ---- dW3 += g_st^T a2, db3 += colsum(g_st)  (a2 still holds the activations) ----
+            run_ojobs(jl + GF(g, o3_off), GF(g, o3_cnt), gst, a.sld, a2, a.ald, gparams, wave, lane);
+            colsum_atomic(a.bmap + bmap3_begin, g_sw, gst, a.sld, gparams, tid);
+            STAMP(sbase + 10)
+            lds_barrier();
+            STAMP(sbase + 11)
+            // ---- g2 = (g_st * W3) .* relu'(a2), in place over a2 ----
+            stage_begin(S, jl + GF(g, g1_off), GF(g, g1_cnt), packed, wave, lane);
+            stage_run<EPI_MASK>(N, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
+            STAMP(sbase + 12)
+            lds_barrier();
+            STAMP(sbase + 13)
+            // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1;  db2 += colsum(g2) ----
+            stage_begin(N, jl + GF(g, dv_off), GF(g, dv_cnt), packed, wave, lane);
+            copy_rows_out(wsG2, a.WT, g_wcol0, a2, a.ald, g_aw, row0, tid);
+            colsum_atomic(a.bmap + bmap_begin + g_aw, g_aw, a2, a.ald, gparams, tid);
+            stage_run<EPI_MASK>(S, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
+            STAMP(sbase + 14)
+            lds_barrier();
+            STAMP(sbase + 15)
+            // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
+            stage_run<EPI_PLAIN>(N, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
+            run_ojobs(jl + GF(g, o1_off), GF(g, o1_cnt), a1, a.ald, vb, a.vld, gparams, wave, lane);
+            colsum_atomic(a.bmap + bmap_begin, g_aw, a1, a.ald, gparams, tid);
+            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
+            STAMP(sbase + 16)
+            lds_barrier();
+            STAMP(sbase + 17)
+            if (has_next) stage_begin(S, jl_next + GF(gn, l1_off), GF(gn, l1_cnt), packed, wave, lane);
             // ---- scatter g_v: first k columns to the upper lanes, the rest to g_c ----
-            for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-                const DNode& nd = a.nodes[ni];
+            for (int ni = node_begin; ni < node_end; ++ni) {
+                const VNodeU nd = load_vnode(vnodes, ni);
                 const int k = nd.k;
                 for (int i = tid; i < ROWS * k; i += NTHREADS) {
                     const int r = i / k, j = i - r * k;
-                    gs[r * a.xld + nd.off + j] += gv[r * a.vld + nd.vcol + j];
+                    float acc = gs[r * a.xld + nd.off + j];
+                    for (int sl = 0; sl < dv_slabs; ++sl) acc += gv[sl * vstride + r * a.vld + nd.vcol + j];
+                    gs[r * a.xld + nd.off + j] = acc;
                 }
             }
             if (a.dc > 0) {
                 for (int i = tid; i < ROWS * a.dc; i += NTHREADS) {
                     const int r = i / a.dc, j = i - r * a.dc;
                     float acc = gcs[r * a.cld + j];
-                    for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-                        const DNode& nd = a.nodes[ni];
-                        acc += gv[r * a.vld + nd.vcol + nd.k + j];
+                    for (int ni = node_begin; ni < node_end; ++ni) {
+                        const VNodeU nd = load_vnode(vnodes, ni);
+                        for (int sl = 0; sl < dv_slabs; ++sl) acc += gv[sl * vstride + r * a.vld + nd.vcol + nd.k + j];
                     }
                     gcs[r * a.cld + j] = acc;
                 }
             }
-            __syncthreads();
+            STAMP(sbase + 18)
+            lds_barrier();
+            STAMP(sbase + 19)
+            jb ^= 1;
         }
         store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid);
         if (a.dc > 0 && g_c != nullptr) store_tile(g_c, gcs, a.cld, a.dc, row0, a.B, tid);
-        __syncthreads();
+        STAMP(120)
+        lds_barrier();
     }
 }
 
 // =======================================================================================
-// backward, part B: weight gradients.  dW[m][n] = sum_b G[b][gcol+m] * X[b][xcol+n] is a
-// GEMM whose reduction runs over the batch, so here the OUTPUT is tiled (48x48 per
-// workgroup) and the batch is split over blockIdx.y and over the 4 wavefronts of a
-// workgroup; wavefront partials are combined in LDS, workgroup partials with float atomics.
-// The bias gradient (column sums of G) rides along as one extra MFMA against a ones vector.
+// backward, part B: dW2[m][n] = sum_b G2[b][col+m] * A1[b][col+n] for every (node, net): a
+// GEMM whose reduction runs over the batch, so the OUTPUT is tiled (48x48 per workgroup) and
+// the batch is split over `splits` workgroups and the 8 wavefronts of each; wavefront partials
+// are combined in LDS, workgroup partials with float atomics.  Block ids are mapped so that
+// all tiles of one batch split run on the same XCD (blocks b, b+8, .. share an XCD): the
+// G2/A1 rows of a split are fetched from HBM / Infinity Cache once and re-read from that
+// XCD's L2 by the tiles that share them.
 // =======================================================================================
-__global__ __launch_bounds__(NTHREADS) void hint_block_dw_kernel(
-    const DWJob* __restrict__ jobs, const float* __restrict__ wsV, const float* __restrict__ wsA1,
-    const float* __restrict__ wsA2, const float* __restrict__ wsG1, const float* __restrict__ wsG2,
-    const float* __restrict__ wsG3, int WT, int VT, int ST, int Bp, int rows_per_wg,
-    int use_atomics, float* __restrict__ gparams) {
-    __shared__ float red[NWAVES][12][64][4];   // 48 KB
+constexpr int DW_WAVES = 8;
 
-    const DWJob job = jobs[blockIdx.x];
+__global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
+    const DWJob* __restrict__ jobs, int n_jobs, int splits, const float* __restrict__ wsA1,
+    const float* __restrict__ wsG2, int WT, int Bp, int rows_per_wg, float* __restrict__ gparams) {
+    __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
+
+    int jidx, split;
+    {
+        const int id = blockIdx.x;
+        if ((splits & 7) == 0) {          // XCD-aware: split s lives on XCD s % 8
+            const int xcd = id & 7, t = id >> 3;
+            split = xcd + 8 * (t / n_jobs);
+            jidx = t % n_jobs;
+        } else {
+            split = id / n_jobs;
+            jidx = id % n_jobs;
+        }
+    }
+    const DWJob job = jobs[jidx];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 15, kq = lane >> 4;
 
-    const float* G; int gld;
-    if (job.gsel == 0) { G = wsG1; gld = WT; } else if (job.gsel == 1) { G = wsG2; gld = WT; } else { G = wsG3; gld = ST; }
-    const float* X; int xld;
-    if (job.xsel == 0) { X = wsV; xld = VT; } else if (job.xsel == 1) { X = wsA1; xld = WT; } else { X = wsA2; xld = WT; }
-
-    const int ntm = min(3, (job.M - job.m0 + 15) >> 4);
-    const int ntn = min(3, (job.N - job.n0 + 15) >> 4);
-    const bool bias = (job.n0 == 0);
-
-    const int b_begin = blockIdx.y * rows_per_wg;
+    const int ntm = min(3, (job.H - job.m0 + 15) >> 4);
+    const int ntn = min(3, (job.H - job.n0 + 15) >> 4);
+    const int b_begin = split * rows_per_wg;
     const int b_end = min(Bp, b_begin + rows_per_wg);
 
-    f32x4 acc[3][3], accb[3];
+    f32x4 acc[3][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // columns beyond the (node, net)'s padded extent are clamped to a valid tile; their
+    // products are discarded below, this only keeps every load in bounds and unconditional
+    const float* gp[3];
+    const float* xp[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        gp[t] = wsG2 + job.col + job.m0 + 16 * (t < ntm ? t : 0) + nl;
+        xp[t] = wsA1 + job.col + job.n0 + 16 * (t < ntn ? t : 0) + nl;
     }
 
-    const float* gp = G + job.gcol + job.m0 + nl;
-    const float* xp = X + job.xcol + job.n0 + nl;
-    for (int bb = b_begin + wave * 16; bb < b_end; bb += 16 * NWAVES) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t row = (size_t)(bb + 4 * i + kq);
-            float av[3], bv[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                av[t] = (t < ntm) ? gp[row * gld + 16 * t] : 0.f;
-                bv[t] = (t < ntn) ? xp[row * xld + 16 * t] : 0.f;
-            }
-#pragma unroll
-            for (int tm = 0; tm < 3; ++tm) {
-                if (tm < ntm) {
-#pragma unroll
-                    for (int tn = 0; tn < 3; ++tn)
-                        if (tn < ntn) acc[tm][tn] = mfma4(av[tm], bv[tn], acc[tm][tn]);
-                    if (bias) accb[tm] = mfma4(av[tm], 1.0f, accb[tm]);
-                }
-            }
+    float av[2][4][3], bv[2][4][3];
+#define DW_LOAD(BUF, BB)                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                           \
+        const size_t row_ = (size_t)((BB) + 4 * i + kq) * WT;                 \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                       \
+            av[BUF][i][t] = gp[t][row_];                                      \
+            bv[BUF][i][t] = xp[t][row_];                                      \
+        }                                                                     \
+    }
+#define DW_MMA(BUF)                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                             \
+        _Pragma("unroll") for (int tm = 0; tm < 3; ++tm)                      \
+            _Pragma("unroll") for (int tn = 0; tn < 3; ++tn)                  \
+                acc[tm][tn] = mfma4(av[BUF][i][tm], bv[BUF][i][tn], acc[tm][tn]);
+
+    const int step = 16 * DW_WAVES;
+    int bb = b_begin + wave * 16;
+    if (bb < b_end) {
+        DW_LOAD(0, bb)
+        while (true) {
+            const int nb1 = bb + step;
+            const int l1 = nb1 < b_end ? nb1 : bb;      // clamp: re-load the same rows at the end
+            DW_LOAD(1, l1)
+            DW_MMA(0)
+            if (nb1 >= b_end) break;
+            const int nb2 = nb1 + step;
+            const int l2 = nb2 < b_end ? nb2 : nb1;
+            DW_LOAD(0, l2)
+            DW_MMA(1)
+            if (nb2 >= b_end) break;
+            bb = nb2;
         }
     }
-    // combine the four wavefronts
+#undef DW_LOAD
+#undef DW_MMA
+    // combine the wavefronts
 #pragma unroll
-    for (int tm = 0; tm < 3; ++tm) {
+    for (int tm = 0; tm < 3; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 3; ++tn) *(f32x4*)&red[wave][tm * 3 + tn][lane][0] = acc[tm][tn];
-        *(f32x4*)&red[wave][9 + tm][lane][0] = accb[tm];
-    }
     __syncthreads();
-    for (int idx = tid; idx < 12 * 64; idx += NTHREADS) {
+    for (int idx = tid; idx < 9 * 64; idx += DW_WAVES * 64) {
         const int t = idx >> 6, l = idx & 63;
-        const int tm = (t < 9) ? t / 3 : t - 9;
-        const int tn = (t < 9) ? t - 3 * tm : 0;
-        if (tm >= ntm || (t < 9 && tn >= ntn) || (t >= 9 && !bias)) continue;
-        const f32x4 v = *(f32x4*)&red[0][t][l][0] + *(f32x4*)&red[1][t][l][0] +
-                        *(f32x4*)&red[2][t][l][0] + *(f32x4*)&red[3][t][l][0];
+        const int tm = t / 3, tn = t - 3 * tm;
+        if (tm >= ntm || tn >= ntn) continue;
+        f32x4 v = *(f32x4*)&red[0][t][l][0];
+#pragma unroll
+        for (int w = 1; w < DW_WAVES; ++w) v += *(f32x4*)&red[w][t][l][0];
         const int n = job.n0 + 16 * tn + (l & 15);
+        if (n >= job.H) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = job.m0 + 16 * tm + 4 * (l >> 4) + i;
-            if (m >= job.M) continue;
-            if (t < 9) {
-                if (n < job.N) {
-                    float* dst = gparams + job.wofs + (size_t)m * job.N + n;
-                    if (use_atomics) atomicAdd(dst, v[i]); else *dst = v[i];
-                }
-            } else if ((l & 15) == 0) {
-                float* dst = gparams + job.bofs + m;
-                if (use_atomics) atomicAdd(dst, v[i]); else *dst = v[i];
-            }
+            if (m < job.H) atomicAdd(gparams + job.wofs + (size_t)m * job.H + n, v[i]);
         }
     }
 }
@@ -564,33 +868,59 @@ __global__ __launch_bounds__(NTHREADS) void hint_block_dw_kernel(
 // ---- launchers (called from hint_plan.cpp) ----------------------------------------------
 namespace hint {
 
+hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
+                       long bias_off, const float* params, float* packed, hipStream_t stream) {
+    const int grid = n_tiles + (n_bias + 255) / 256;
+    if (grid > 0)
+        hipLaunchKernelGGL(hint_pack_kernel, dim3(grid), dim3(256), 0, stream, segs, ptiles, n_tiles, bmap, n_bias,
+                           bias_off, params, packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream) {
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > (long)num_cu * 4 ? (long)num_cu * 4 : blocks);
+    hipLaunchKernelGGL(hint_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n4, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
-                        const float* x, const float* c, float* z, float* J, float* tape,
-                        hipStream_t stream) {
+                        const float* packed, const float* x, const float* c, float* z, float* J,
+                        float* tape, hipStream_t stream) {
     if (rev)
-        hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params, x, c, z, J, (float*)nullptr);
+        hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a,
+                           params, packed, x, c, z, J, (float*)nullptr);
     else
-        hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params, x, c, z, J, tape);
+        hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a,
+                           params, packed, x, c, z, J, tape);
     return hipGetLastError();
 }
 
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params, const float* x,
-                      const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
-                      float* wsV, float* wsA1, float* wsA2, float* wsG1, float* wsG2, float* wsG3,
-                      hipStream_t stream) {
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
+                      const float* packed, const float* x, const float* tape, const float* c,
+                      const float* g_z, const float* g_J, float* g_x, float* g_c, float* gparams,
+                      float* wsA1, float* wsG2, hipStream_t stream) {
     hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params,
-                       x, tape, c, g_z, g_J, g_x, g_c, wsV, wsA1, wsA2, wsG1, wsG2, wsG3);
+                       packed, x, tape, c, g_z, g_J, g_x, g_c, gparams, wsA1, wsG2);
     return hipGetLastError();
 }
 
-hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsV, const float* wsA1,
-                     const float* wsA2, const float* wsG1, const float* wsG2, const float* wsG3,
-                     int WT, int VT, int ST, int Bp, int rows_per_wg, float* gparams,
-                     hipStream_t stream) {
-    hipLaunchKernelGGL(hint_block_dw_kernel, dim3(n_jobs, splits), dim3(NTHREADS), 0, stream, jobs, wsV,
-                       wsA1, wsA2, wsG1, wsG2, wsG3, WT, VT, ST, Bp, rows_per_wg, splits > 1 ? 1 : 0,
-                       gparams);
+hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
+                     int Bp, int rows_per_wg, float* gparams, hipStream_t stream) {
+    if (n_jobs > 0)
+        hipLaunchKernelGGL(hint_block_dw_kernel, dim3(n_jobs * splits), dim3(DW_WAVES * 64), 0, stream, jobs,
+                           n_jobs, splits, wsA1, wsG2, WT, Bp, rows_per_wg, gparams);
     return hipGetLastError();
+}
+
+hipError_t set_stamp_buffer(unsigned long long* p) {
+#ifdef HINT_STAMPS
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_hint_stamps), &p, sizeof(p));
+#else
+    (void)p;
+    return hipErrorNotSupported;
+#endif
 }
 
 hipError_t set_max_lds(int fwd_bytes, int bwd_bytes) {

@@ -9,19 +9,21 @@
 //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // `gscale` carries the 1/world_size of the data-parallel all-reduce (sum -> mean), applied
 // BEFORE the clamp because the reference clamps the final, averaged gradient.
-// Pure HBM streaming: 16 B/lane loads and stores, 4 arrays read + 3 written = 28 B/param.
+// With zero_grads the kernel also clears the gradient arena it has just consumed, so the next
+// step's backward kernels can accumulate into it without a separate memset.
+// Pure HBM streaming: 16 B/lane loads and stores, 4 arrays read + 3 (4) written = 28-32 B/param.
 #include <hip/hip_runtime.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         long n4, long n, float lr_t, float b1, float b2,
                                                         float inv_sqrt_bc2, float eps, float wd,
-                                                        float gscale, float gclamp) {
+                                                        float gscale, float gclamp, int zero_grads) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        f32x4 pp = ((f32x4*)p)[i], gg = ((f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float gj = gg[j] * gscale;
@@ -33,6 +35,7 @@ __global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, c
             pp[j] = pp[j] - lr_t * (mm[j] / denom);
         }
         ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        if (zero_grads) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // ragged tail (n not a multiple of 4)
     const long tail0 = n4 * 4;
@@ -45,19 +48,20 @@ __global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, c
         const float vj = b2 * v[t] + (1.f - b2) * gj * gj;
         m[t] = mj; v[t] = vj;
         p[t] = p[t] - lr_t * (mj / (sqrtf(vj) * inv_sqrt_bc2 + eps));
+        if (zero_grads) g[t] = 0.f;
     }
 }
 
 namespace hint {
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
-                       float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int num_cu,
+hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+                       float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads, int num_cu,
                        hipStream_t stream) {
     const long n4 = n / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > (long)num_cu * 8) blocks = (long)num_cu * 8;
     hipLaunchKernelGGL(hint_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n4, n, lr_t,
-                       b1, b2, inv_sqrt_bc2, eps, wd, gscale, gclamp);
+                       b1, b2, inv_sqrt_bc2, eps, wd, gscale, gclamp, zero_grads);
     return hipGetLastError();
 }
 }  // namespace hint

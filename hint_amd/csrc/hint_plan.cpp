@@ -1,6 +1,6 @@
 // Host side of the C ABI (include/hint_amd.h): turns the node list of one coupling tree
 // (the structure /root/reference/hint.py:25-54 builds recursively) into a static level
-// schedule in device memory, and launches the kernels of hint_kernels.hip.
+// schedule in device memory, and launches the kernels of hint_kernels.hip / hint_optim.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -9,27 +9,30 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/hint_amd.h"
 #include "hint_dev.h"
 
 namespace hint {
+hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
+                       long bias_off, const float* params, float* packed, hipStream_t stream);
+hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
-                        const float* x, const float* c, float* z, float* J, float* tape,
-                        hipStream_t stream);
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params, const float* x,
-                      const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
-                      float* wsV, float* wsA1, float* wsA2, float* wsG1, float* wsG2, float* wsG3,
-                      hipStream_t stream);
-hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsV, const float* wsA1,
-                     const float* wsA2, const float* wsG1, const float* wsG2, const float* wsG3,
-                     int WT, int VT, int ST, int Bp, int rows_per_wg, float* gparams,
-                     hipStream_t stream);
+                        const float* packed, const float* x, const float* c, float* z, float* J,
+                        float* tape, hipStream_t stream);
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
+                      const float* packed, const float* x, const float* tape, const float* c,
+                      const float* g_z, const float* g_J, float* g_x, float* g_c, float* gparams,
+                      float* wsA1, float* wsG2, hipStream_t stream);
+hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
+                     int Bp, int rows_per_wg, float* gparams, hipStream_t stream);
 hipError_t set_max_lds(int fwd_bytes, int bwd_bytes);
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
-                       float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int num_cu,
-                       hipStream_t stream);
+hipError_t set_stamp_buffer(unsigned long long* p);
+hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
+                       float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads,
+                       int num_cu, hipStream_t stream);
 }  // namespace hint
 
 using namespace hint;
@@ -66,52 +69,55 @@ static inline int lds_stride(int width) {
 
 struct hint_plan {
     int device = -1;
-    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_dwjobs = 0;
+    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_dwjobs = 0, n_ptiles = 0;
     float alpha = 0.f;
-    int64_t param_floats = 0;
-    int WT = 0, VT = 0, ST = 0;
+    int64_t param_floats = 0, packed_floats = 0;
+    int WT = 0;
     int xld = 0, cld = 0, ald = 0, vld = 0, sld = 0;
+    int s3 = 1, sv = 1;   // max K-split slabs of the layer-3 / dv stages
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
-    DNode* d_nodes = nullptr;
-    DGroup* d_groups = nullptr;
-    Job* d_jobs = nullptr;
-    Ent* d_ents = nullptr;
+    int meta_bytes = 0, vnodes_off = 0, ents_off = 0, jmax = 0, bmax = 0, n_bias = 0;
+    void* d_meta = nullptr;      // [groups | vnodes | ents]
+    GJob* d_jobs = nullptr;      // per-group job lists (GJob and OJob records, 16 bytes each)
+    int32_t* d_bmap = nullptr;
     DWJob* d_dwjobs = nullptr;
+    PackSeg* d_segs = nullptr;
+    int2* d_ptiles = nullptr;
 };
 
 static constexpr int LDS_LIMIT = 160 * 1024;
-static int g_bwd_stages = 3;   // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 static constexpr int WS_SLACK = 64;   // floats of slack at the end of every workspace array
+static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 
-extern "C" {
+static int fwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3) {
+    return 4 * ROWS * (xld + cld + vld + 2 * ald + s3 * sld + 1);
+}
+static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, int sv) {
+    return 4 * ROWS * (2 * xld + 2 * cld + (1 + sv) * vld + 2 * ald + (s3 + 1) * sld + 1);
+}
+static constexpr int JOBS_PER_GROUP_MAX = 2 * NTHREADS;   // what the in-kernel job prefetch moves
 
-int hint_abi_version(void) { return HINT_AMD_ABI_VERSION; }
-const char* hint_last_error(void) { return g_err.c_str(); }
+// how many K-split slabs a thin stage gets: enough jobs to occupy the 8 wavefronts, each slab
+// at least 2 k-blocks deep
+static int pick_slabs(int n_tile_jobs, int min_nblk, int max_slabs) {
+    if (n_tile_jobs <= 0) return 1;
+    int s = NWAVES / n_tile_jobs;
+    s = std::min(s, min_nblk / 2);
+    return std::max(1, std::min(s, max_slabs));
+}
 
-int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
-                     hint_plan** out) {
-    if (!nodes || n_nodes <= 0 || d <= 0 || dc < 0 || !out) return fail("hint_plan_create: bad arguments");
-    *out = nullptr;
-    // ---- validate the tree: lane ranges inside [0,d), same-depth nodes disjoint ----
+static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
+                      int max_slabs, int cap_scale, hint_plan** out, bool* retry_smaller) {
+    *retry_smaller = false;
     int max_depth = 0;
-    for (int i = 0; i < n_nodes; ++i) {
-        const hint_node_desc& n = nodes[i];
-        if (n.D < 1 || n.k != n.D / 2 || n.r != n.D - n.k || n.off < 0 || n.off + n.D > d || n.h < 1 || n.depth < 0)
-            return fail("hint_plan_create: node %d is malformed (off=%d D=%d k=%d r=%d h=%d depth=%d)", i,
-                        n.off, n.D, n.k, n.r, n.h, n.depth);
-        max_depth = std::max(max_depth, n.depth);
-    }
-    for (int i = 0; i < n_nodes; ++i)
-        for (int j = i + 1; j < n_nodes; ++j)
-            if (nodes[i].depth == nodes[j].depth && nodes[i].off < nodes[j].off + nodes[j].D &&
-                nodes[j].off < nodes[i].off + nodes[i].D)
-                return fail("hint_plan_create: nodes %d and %d of depth %d overlap", i, j, nodes[i].depth);
+    for (int i = 0; i < n_nodes; ++i) max_depth = std::max(max_depth, nodes[i].depth);
 
     hint_plan* P = new hint_plan();
     P->d = d;
     P->dc = dc;
     P->n_nodes = n_nodes;
+    P->n_levels = max_depth + 1;
     P->alpha = (float)((double)clamp * 0.636);   // hint.py:57,60 (python float product, then fp32)
     P->xld = pad16(d) + 4;
     P->cld = dc > 0 ? pad16(dc) + 4 : 0;
@@ -122,44 +128,60 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
         for (int i = 0; i < n_nodes; ++i)
             if (nodes[i].depth == dep) order.push_back(i);
 
-    // The LDS footprint of the backward kernel bounds what one group may hold:
-    //   ROWS * (2*xld + 2*cld + 2*vld + 2*ald + 2*sld + 1) floats  <=  160 KiB.
-    // Every single node must fit (that fixes minimum strides); groups then grow up to soft
-    // caps so that shallow-but-wide and deep-but-narrow levels end up with similar footprints.
-    const int WMAX = 768;
+    // Every single node must fit the 160 KiB LDS of the backward kernel (that fixes minimum
+    // strides); groups then grow up to soft caps so that shallow-but-wide and deep-but-narrow
+    // levels end up with similar footprints.
     int min_aw = 0, min_vw = 0, min_sw = 0;
     for (int i = 0; i < n_nodes; ++i) {
         min_aw = std::max(min_aw, 2 * pad16(nodes[i].h));
         min_vw = std::max(min_vw, pad16(nodes[i].k + dc));
         min_sw = std::max(min_sw, 2 * pad16(nodes[i].r));
     }
-    const int cap_aw = std::max(min_aw, 512), cap_vw = std::max(min_vw, 128), cap_sw = std::max(min_sw, 256);
+    const int cap_aw = std::max(min_aw, 512 / cap_scale), cap_vw = std::max(min_vw, 128 / cap_scale),
+              cap_sw = std::max(min_sw, 256 / cap_scale);
+    // rough size of what rides along in LDS besides the float buffers (group/node/lane tables)
+    const int meta_guess = 16 * n_nodes + 8 * d + 160 * (max_depth + 2);
     auto bwd_bytes = [&](int aw_, int vw_, int sw_) {
-        return 4 * ROWS * (2 * P->xld + 2 * P->cld + 2 * lds_stride(vw_) + 2 * lds_stride(aw_) + 2 * lds_stride(sw_) + 1);
+        return meta_guess + bwd_lds_bytes(P->xld, P->cld, lds_stride(vw_), lds_stride(aw_), lds_stride(sw_), 1, 1);
+    };
+
+    struct DNode {            // host-side working copy of a node
+        int off, k, r, h, cin, hp, rp, cinp, acol, vcol, scol, wcol;
     };
     std::vector<DNode> dn;
+    std::vector<const hint_node_desc*> src;   // parallel to dn
     std::vector<DGroup> dg;
-    std::vector<Job> jobs;
+    std::vector<GJob> jobs;                   // all groups' job lists (GJob and OJob records)
     std::vector<Ent> ents;
+    std::vector<int32_t> bmap;
     std::vector<DWJob> dwj;
-    int wcol = 0, wvcol = 0, wscol = 0;
+    std::vector<PackSeg> segs;
+    std::vector<int2> ptiles;
+    int wcol = 0;
     int max_aw = 0, max_vw = 0, max_sw = 0;
-    int64_t pmax = 0;
+    int64_t pmax = 0, packed = 0;
+
+    auto add_seg = [&](int N, int K, int NB, int ld, int mode, int64_t s0, int64_t s1, int hp, int h) -> int64_t {
+        PackSeg sg{};
+        sg.dst = packed; sg.src0 = s0; sg.src1 = s1; sg.N = N; sg.K = K; sg.NB = NB; sg.ld = ld; sg.mode = mode;
+        sg.hp = hp; sg.h = h; sg.tile_begin = (int)ptiles.size();
+        const int NT = (N + 15) / 16;
+        for (int nt = 0; nt < NT; ++nt) ptiles.push_back(int2{(int)segs.size(), nt});
+        segs.push_back(sg);
+        packed += (int64_t)NT * NB * 256;
+        return sg.dst;
+    };
 
     size_t pos = 0;
     while (pos < order.size()) {
         DGroup g{};
         g.node_begin = (int)dn.size();
-        g.wcol0 = wcol; g.wvcol0 = wvcol; g.wscol0 = wscol;
+        g.wcol0 = wcol;
         int aw = 0, vw = 0, sw = 0;
         const int depth = nodes[order[pos]].depth;
         while (pos < order.size() && nodes[order[pos]].depth == depth) {
             const hint_node_desc& n = nodes[order[pos]];
             const int hp = pad16(n.h), rp = pad16(n.r), cin = n.k + dc, cinp = pad16(cin);
-            if (2 * hp > WMAX) {
-                delete P;
-                return fail("hint_plan_create: hidden width %d exceeds the supported maximum %d", n.h, WMAX / 2);
-            }
             if (bwd_bytes(2 * hp, cinp, 2 * rp) > LDS_LIMIT) {
                 delete P;
                 return fail("hint_plan_create: a node with h=%d, cin=%d, r=%d does not fit the 160 KiB LDS", n.h, cin, n.r);
@@ -172,17 +194,12 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
             DNode q{};
             q.off = n.off; q.k = n.k; q.r = n.r; q.h = n.h; q.cin = cin;
             q.hp = hp; q.rp = rp; q.cinp = cinp;
-            q.acol = aw; q.vcol = vw; q.scol = sw;
-            q.wcol = wcol; q.wvcol = wvcol; q.wscol = wscol;
+            q.acol = aw; q.vcol = vw; q.scol = sw; q.wcol = wcol;
             const int64_t sizes[6] = {(int64_t)n.h * cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
-            for (int t = 0; t < 12; ++t) {
-                q.p[t] = n.p_off[t];
-                if (n.p_off[t] < 0) { delete P; return fail("hint_plan_create: negative parameter offset"); }
-                pmax = std::max(pmax, n.p_off[t] + sizes[t % 6]);
-            }
-            aw += 2 * hp; vw += cinp; sw += 2 * rp;
-            wcol += 2 * hp; wvcol += cinp; wscol += 2 * rp;
+            for (int t = 0; t < 12; ++t) pmax = std::max(pmax, n.p_off[t] + sizes[t % 6]);
+            aw += 2 * hp; vw += cinp; sw += 2 * rp; wcol += 2 * hp;
             dn.push_back(q);
+            src.push_back(&n);
             ++pos;
         }
         g.node_end = (int)dn.size();
@@ -190,80 +207,216 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
         g.level = max_depth - depth;
         g.level_last = (pos >= order.size() || nodes[order[pos]].depth != depth) ? 1 : 0;
         max_aw = std::max(max_aw, aw); max_vw = std::max(max_vw, vw); max_sw = std::max(max_sw, sw);
-        // jobs: one per 16-wide output tile
-        g.jobsH_begin = (int)jobs.size();
+
+        // ---- K-split factors of the thin stages of this group ----
+        int l3_tiles = 0, dv_tiles = 0, min_hb = 1 << 30;
+        for (int ni = g.node_begin; ni < g.node_end; ++ni) {
+            l3_tiles += 2 * (dn[ni].rp / 16);
+            dv_tiles += dn[ni].cinp / 16;
+            min_hb = std::min(min_hb, dn[ni].hp / 16);
+        }
+        g.l3_slabs = pick_slabs(l3_tiles, min_hb, max_slabs);
+        g.dv_slabs = pick_slabs(dv_tiles, 2 * min_hb, max_slabs);
+        P->s3 = std::max(P->s3, g.l3_slabs);
+        P->sv = std::max(P->sv, g.dv_slabs);
+
+        // ---- packed weight segments + GEMM tile jobs ----
+        struct NodePack { int64_t f1[2], f2[2], f3[2], b3[2], b2[2], bdv; };
+        std::vector<NodePack> np(g.node_end - g.node_begin);
+        for (int ni = g.node_begin; ni < g.node_end; ++ni) {
+            const DNode& q = dn[ni];
+            const hint_node_desc& n = *src[ni];
+            NodePack& k = np[ni - g.node_begin];
+            for (int net = 0; net < 2; ++net) {
+                const int64_t* po = n.p_off + net * 6;
+                k.f1[net] = add_seg(q.h, q.cin, q.cinp / 16, q.cin, 0, po[0], 0, q.hp, q.h);   // v  -> a1
+                k.f2[net] = add_seg(q.h, q.h, q.hp / 16, q.h, 0, po[2], 0, q.hp, q.h);         // a1 -> a2
+                k.f3[net] = add_seg(q.r, q.h, q.hp / 16, q.h, 0, po[4], 0, q.hp, q.h);         // a2 -> s|t
+                k.b3[net] = add_seg(q.h, q.r, q.rp / 16, q.h, 1, po[4], 0, q.hp, q.h);         // g_st -> g2
+                k.b2[net] = add_seg(q.h, q.h, q.hp / 16, q.h, 1, po[2], 0, q.hp, q.h);         // g2 -> g1
+            }
+            k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
+        }
+        auto tile_jobs = [&](int which) {
+            // which: 1 = L1, 2 = L2, 3 = L3, 4 = g2, 5 = g1, 6 = dv
+            const int begin = (int)jobs.size() - g.jl_begin;
+            const int slabs = which == 3 ? g.l3_slabs : (which == 6 ? g.dv_slabs : 1);
+            for (int sl = 0; sl < slabs; ++sl)
+                for (int ni = g.node_begin; ni < g.node_end; ++ni) {
+                    const DNode& q = dn[ni];
+                    const hint_node_desc& n = *src[ni];
+                    const NodePack& k = np[ni - g.node_begin];
+                    const int nets = which == 6 ? 1 : 2;
+                    for (int net = 0; net < nets; ++net) {
+                        int N, NB, acol, ocol0; int64_t wbase, boff;
+                        switch (which) {
+                            case 1: N = q.h; NB = q.cinp / 16; acol = q.vcol; ocol0 = q.acol + net * q.hp; wbase = k.f1[net]; boff = n.p_off[net * 6 + 1]; break;
+                            case 2: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.f2[net]; boff = n.p_off[net * 6 + 3]; break;
+                            case 3: N = q.r; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.scol + net * q.rp; wbase = k.f3[net]; boff = n.p_off[net * 6 + 5]; break;
+                            case 4: N = q.h; NB = q.rp / 16; acol = q.scol + net * q.rp; ocol0 = q.acol + net * q.hp; wbase = k.b3[net]; boff = -1; break;
+                            case 5: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.b2[net]; boff = -1; break;
+                            default: N = q.cin; NB = 2 * q.hp / 16; acol = q.acol; ocol0 = q.vcol; wbase = k.bdv; boff = -1; break;
+                        }
+                        // this slab's share of the k-blocks
+                        const int kb0 = (int)((int64_t)NB * sl / slabs), kb1 = (int)((int64_t)NB * (sl + 1) / slabs);
+                        const int NT = (N + 15) / 16;
+                        for (int nt = 0; nt < NT; ++nt) {
+                            GJob jb{};
+                            if (kb1 > kb0) {
+                                jb.wtile = (int32_t)(wbase / 256 + (int64_t)nt * NB + kb0);
+                                jb.nblk = (uint8_t)(kb1 - kb0);
+                                jb.acol = (uint16_t)(acol + kb0 * 16);
+                            } else {            // K = 0 (cin = 0 with min_split_size 1) or empty slab
+                                jb.wtile = 0; jb.nblk = 0; jb.acol = 0;
+                            }
+                            jb.ocol = (uint16_t)(ocol0 + nt * 16);
+                            jb.boff = (sl == 0 && boff >= 0) ? (int32_t)(boff + nt * 16) : -1;
+                            jb.nvalid = (uint8_t)std::min(16, N - nt * 16);
+                            jb.slab = (uint8_t)sl;
+                            jobs.push_back(jb);
+                        }
+                    }
+                }
+            return std::make_pair(begin, (int)jobs.size() - g.jl_begin - begin);
+        };
+        g.jl_begin = (int)jobs.size();
+        std::tie(g.l1_off, g.l1_cnt) = tile_jobs(1);
+        std::tie(g.l2_off, g.l2_cnt) = tile_jobs(2);
+        std::tie(g.l3_off, g.l3_cnt) = tile_jobs(3);
+        std::tie(g.g2_off, g.g2_cnt) = tile_jobs(4);
+        std::tie(g.g1_off, g.g1_cnt) = tile_jobs(5);
+        std::tie(g.dv_off, g.dv_cnt) = tile_jobs(6);
+        auto push_ojob = [&](const OJob& o) {
+            GJob raw;
+            static_assert(sizeof(OJob) == sizeof(GJob), "job records share one 16-byte array");
+            std::memcpy(&raw, &o, sizeof raw);
+            jobs.push_back(raw);
+        };
+
+        // ---- in-kernel outer-product jobs (dW3 = g_st^T a2, dW1 = g1^T v) + bias maps ----
+        g.o3_off = (int)jobs.size() - g.jl_begin;
+        for (int ni = g.node_begin; ni < g.node_end; ++ni)
+            for (int net = 0; net < 2; ++net) {
+                const DNode& q = dn[ni];
+                for (int mt = 0; mt < q.rp / 16; ++mt)
+                    for (int nt = 0; nt < q.hp / 16; ++nt) {
+                        OJob o{};
+                        o.acol = (uint16_t)(q.scol + net * q.rp + mt * 16); o.bcol = (uint16_t)(q.acol + net * q.hp + nt * 16);
+                        const int mv = std::min(16, q.r - mt * 16), nv = std::min(16, q.h - nt * 16);
+                        o.mvalid = (uint8_t)std::max(mv, 0); o.nvalid = (uint8_t)std::max(nv, 0);
+                        o.ldg = (uint16_t)q.h; o.goff = (int32_t)(src[ni]->p_off[net * 6 + 4] + (int64_t)mt * 16 * q.h + nt * 16);
+                        if (mv > 0 && nv > 0) push_ojob(o);
+                    }
+            }
+        g.o3_cnt = (int)jobs.size() - g.jl_begin - g.o3_off;
+        g.o1_off = (int)jobs.size() - g.jl_begin;
+        for (int ni = g.node_begin; ni < g.node_end; ++ni)
+            for (int net = 0; net < 2; ++net) {
+                const DNode& q = dn[ni];
+                for (int mt = 0; mt < q.hp / 16; ++mt)
+                    for (int nt = 0; nt < q.cinp / 16; ++nt) {
+                        OJob o{};
+                        o.acol = (uint16_t)(q.acol + net * q.hp + mt * 16); o.bcol = (uint16_t)(q.vcol + nt * 16);
+                        const int mv = std::min(16, q.h - mt * 16), nv = std::min(16, q.cin - nt * 16);
+                        o.mvalid = (uint8_t)std::max(mv, 0); o.nvalid = (uint8_t)std::max(nv, 0);
+                        o.ldg = (uint16_t)q.cin; o.goff = (int32_t)(src[ni]->p_off[net * 6 + 0] + (int64_t)mt * 16 * q.cin + nt * 16);
+                        if (mv > 0 && nv > 0) push_ojob(o);
+                    }
+            }
+        g.o1_cnt = (int)jobs.size() - g.jl_begin - g.o1_off;
+        g.jl_count = (int)jobs.size() - g.jl_begin;
+        if (g.jl_count > JOBS_PER_GROUP_MAX) {
+            delete P;
+            if (cap_scale < 16) { *retry_smaller = true; return 1; }
+            return fail("hint_plan_create: a group needs %d tile jobs (max %d)", g.jl_count, JOBS_PER_GROUP_MAX);
+        }
+        P->jmax = std::max(P->jmax, g.jl_count);
+        P->bmax = std::max(P->bmax, 2 * aw + sw);
+        g.bmap_begin = (int)bmap.size();
+        for (int layer = 0; layer < 2; ++layer)          // b1 map, then b2 map, aw entries each
+            for (int ni = g.node_begin; ni < g.node_end; ++ni)
+                for (int net = 0; net < 2; ++net)
+                    for (int j = 0; j < dn[ni].hp; ++j)
+                        bmap.push_back(j < dn[ni].h ? (int32_t)(src[ni]->p_off[net * 6 + (layer ? 3 : 1)] + j) : -1);
+        g.bmap3_begin = (int)bmap.size();
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net)
-                for (int t = 0; t < dn[ni].hp / 16; ++t) jobs.push_back(Job{ni, net, t, 0});
-        g.jobsH_cnt = (int)jobs.size() - g.jobsH_begin;
-        g.jobsR_begin = (int)jobs.size();
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net)
-                for (int t = 0; t < dn[ni].rp / 16; ++t) jobs.push_back(Job{ni, net, t, 0});
-        g.jobsR_cnt = (int)jobs.size() - g.jobsR_begin;
-        g.jobsC_begin = (int)jobs.size();
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int t = 0; t < dn[ni].cinp / 16; ++t) jobs.push_back(Job{ni, 0, t, 0});
-        g.jobsC_cnt = (int)jobs.size() - g.jobsC_begin;
+                for (int j = 0; j < dn[ni].rp; ++j)
+                    bmap.push_back(j < dn[ni].r ? (int32_t)(src[ni]->p_off[net * 6 + 5] + j) : -1);
+
         g.ent_begin = (int)ents.size();
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int j = 0; j < dn[ni].r; ++j)
-                ents.push_back(Ent{dn[ni].off + dn[ni].k + j, dn[ni].scol + j, dn[ni].scol + dn[ni].rp + j, ni});
+                ents.push_back(Ent{(int16_t)(dn[ni].off + dn[ni].k + j), (int16_t)(dn[ni].scol + j),
+                                   (int16_t)(dn[ni].scol + dn[ni].rp + j), 0});
         g.ent_cnt = (int)ents.size() - g.ent_begin;
         dg.push_back(g);
     }
+    if (pmax >= (int64_t)1 << 31 || packed >= (int64_t)1 << 31) {
+        delete P;
+        return fail("hint_plan_create: block too large (parameter offsets must fit 31 bits)");
+    }
     P->n_groups = (int)dg.size();
-    P->n_levels = max_depth + 1;
-    P->WT = wcol; P->VT = std::max(wvcol, 16); P->ST = wscol;
+    P->WT = wcol;
     P->param_floats = pmax;
+    P->packed_floats = packed;
     P->ald = lds_stride(max_aw);
     P->vld = lds_stride(max_vw);
     P->sld = lds_stride(max_sw);
-    P->lds_fwd = 4 * ROWS * (P->xld + P->cld + P->vld + 2 * P->ald + P->sld + 1);
-    P->lds_bwd = 4 * ROWS * (2 * P->xld + 2 * P->cld + 2 * P->vld + 2 * P->ald + 2 * P->sld + 1);
-    if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT) {
-        int need = P->lds_bwd;
+    // ---- meta blob staged in LDS by the kernels: [groups | vnodes | ents] ----
+    std::vector<VNode> vn(dn.size());
+    for (size_t i = 0; i < dn.size(); ++i)
+        vn[i] = VNode{(int16_t)dn[i].off, (int16_t)dn[i].k, (int16_t)dn[i].cin, (int16_t)dn[i].cinp, (int16_t)dn[i].vcol, 0};
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t groups_bytes = up16(dg.size() * sizeof(DGroup));
+    const size_t vnodes_bytes = up16(vn.size() * sizeof(VNode));
+    const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
+    P->vnodes_off = (int)groups_bytes;
+    P->ents_off = (int)(groups_bytes + vnodes_bytes);
+    P->meta_bytes = (int)(groups_bytes + vnodes_bytes + ents_bytes);
+    std::vector<char> meta(P->meta_bytes, 0);
+    std::memcpy(meta.data(), dg.data(), dg.size() * sizeof(DGroup));
+    std::memcpy(meta.data() + P->vnodes_off, vn.data(), vn.size() * sizeof(VNode));
+    std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
+    P->n_bias = (int)bmap.size();
+    const int fixed = P->meta_bytes + 2 * P->jmax * (int)sizeof(GJob) + 2 * P->bmax * 4;
+    P->lds_fwd = fixed + fwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3);
+    P->lds_bwd = fixed + bwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3, P->sv);
+    if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT || d + 16 > 32000 || max_aw > 60000 ||
+        P->bmax > 4 * NTHREADS) {
+        const int need = std::max(P->lds_bwd, P->lds_fwd);
+        const bool can_retry = max_slabs > 1 || cap_scale < 16;
         delete P;
+        if (can_retry) { *retry_smaller = true; return 1; }   // rebuild with fewer slabs / smaller groups
         return fail("hint_plan_create: block needs %d bytes of LDS (> %d); d/dc/h too large", need, LDS_LIMIT);
     }
 
-    // ---- weight-gradient jobs: 48x48 output tiles of dW1, dW2, dW3 of every (node, net) ----
-    for (size_t ni = 0; ni < dn.size(); ++ni) {
-        const DNode& q = dn[ni];
-        for (int net = 0; net < 2; ++net) {
-            struct L { int gsel, gcol, M, xsel, xcol, N; int64_t wofs, bofs; } ls[3] = {
-                {0, q.wcol + net * q.hp, q.h, 0, q.wvcol, q.cin, q.p[net * 6 + 0], q.p[net * 6 + 1]},
-                {1, q.wcol + net * q.hp, q.h, 1, q.wcol + net * q.hp, q.h, q.p[net * 6 + 2], q.p[net * 6 + 3]},
-                {2, q.wscol + net * q.rp, q.r, 2, q.wcol + net * q.hp, q.h, q.p[net * 6 + 4], q.p[net * 6 + 5]},
-            };
-            for (const L& l : ls)
-                for (int m0 = 0; m0 < l.M; m0 += 48) {
-                    int n0 = 0;
-                    do {
-                        dwj.push_back(DWJob{l.gsel, l.gcol, l.M, l.xsel, l.xcol, l.N, m0, n0, l.wofs, l.bofs});
-                        n0 += 48;
-                    } while (n0 < l.N);
-                }
-        }
-    }
+    // ---- weight-gradient jobs: 48x48 output tiles of dW2 of every (node, net) ----
+    for (size_t ni = 0; ni < dn.size(); ++ni)
+        for (int net = 0; net < 2; ++net)
+            for (int m0 = 0; m0 < dn[ni].h; m0 += 48)
+                for (int n0 = 0; n0 < dn[ni].h; n0 += 48)
+                    dwj.push_back(DWJob{dn[ni].wcol + net * dn[ni].hp, dn[ni].h, m0, n0, src[ni]->p_off[net * 6 + 2]});
     P->n_dwjobs = (int)dwj.size();
+    P->n_ptiles = (int)ptiles.size();
 
     // ---- upload ----
     HIP_TRY(hipGetDevice(&P->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, P->device));
     P->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    auto upload = [](void** dst, const void* src, size_t bytes) -> hipError_t {
+    auto upload = [](void** dst, const void* srcp, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
         if (e != hipSuccess) return e;
-        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+        return bytes ? hipMemcpy(*dst, srcp, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = upload((void**)&P->d_nodes, dn.data(), dn.size() * sizeof(DNode));
-    if (e == hipSuccess) e = upload((void**)&P->d_groups, dg.data(), dg.size() * sizeof(DGroup));
-    if (e == hipSuccess) e = upload((void**)&P->d_jobs, jobs.data(), jobs.size() * sizeof(Job));
-    if (e == hipSuccess) e = upload((void**)&P->d_ents, ents.data(), ents.size() * sizeof(Ent));
+    if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
+    if (e == hipSuccess) e = upload((void**)&P->d_jobs, jobs.data(), jobs.size() * sizeof(GJob));
+    if (e == hipSuccess) e = upload((void**)&P->d_bmap, bmap.data(), bmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_dwjobs, dwj.data(), dwj.size() * sizeof(DWJob));
+    if (e == hipSuccess) e = upload((void**)&P->d_segs, segs.data(), segs.size() * sizeof(PackSeg));
+    if (e == hipSuccess) e = upload((void**)&P->d_ptiles, ptiles.data(), ptiles.size() * sizeof(int2));
     if (e == hipSuccess) e = set_max_lds(P->lds_fwd, P->lds_bwd);
     if (e != hipSuccess) {
         hint_plan_destroy(P);
@@ -273,17 +426,54 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
     return 0;
 }
 
+extern "C" {
+
+int hint_abi_version(void) { return HINT_AMD_ABI_VERSION; }
+const char* hint_last_error(void) { return g_err.c_str(); }
+
+int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
+                     hint_plan** out) {
+    if (!nodes || n_nodes <= 0 || d <= 0 || dc < 0 || !out) return fail("hint_plan_create: bad arguments");
+    *out = nullptr;
+    // ---- validate the tree: lane ranges inside [0,d), same-depth nodes disjoint ----
+    for (int i = 0; i < n_nodes; ++i) {
+        const hint_node_desc& n = nodes[i];
+        if (n.D < 1 || n.k != n.D / 2 || n.r != n.D - n.k || n.off < 0 || n.off + n.D > d || n.h < 1 || n.depth < 0)
+            return fail("hint_plan_create: node %d is malformed (off=%d D=%d k=%d r=%d h=%d depth=%d)", i,
+                        n.off, n.D, n.k, n.r, n.h, n.depth);
+        for (int t = 0; t < 12; ++t)
+            if (n.p_off[t] < 0) return fail("hint_plan_create: negative parameter offset");
+    }
+    for (int i = 0; i < n_nodes; ++i)
+        for (int j = i + 1; j < n_nodes; ++j)
+            if (nodes[i].depth == nodes[j].depth && nodes[i].off < nodes[j].off + nodes[j].D &&
+                nodes[j].off < nodes[i].off + nodes[i].D)
+                return fail("hint_plan_create: nodes %d and %d of depth %d overlap", i, j, nodes[i].depth);
+    // first choice: full K-split and large groups; fall back to fewer slabs, then smaller groups
+    for (int cap_scale = 1; cap_scale <= 16; cap_scale *= 2)
+        for (int max_slabs = MAX_SLABS; max_slabs >= 1; max_slabs /= 2) {
+            bool retry = false;
+            const int st = build_plan(nodes, n_nodes, d, dc, clamp, max_slabs, cap_scale, out, &retry);
+            if (st == 0 || !retry) return st;
+        }
+    return fail("hint_plan_create: could not fit the block into LDS");
+}
+
 void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
-    (void)hipFree(P->d_nodes);
-    (void)hipFree(P->d_groups);
+    (void)hipFree(P->d_meta);
     (void)hipFree(P->d_jobs);
-    (void)hipFree(P->d_ents);
+    (void)hipFree(P->d_bmap);
     (void)hipFree(P->d_dwjobs);
+    (void)hipFree(P->d_segs);
+    (void)hipFree(P->d_ptiles);
     delete P;
 }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
+// +1 KiB of slack: the chunk prefetcher of the GEMM stages never reads past a job's last
+// k-block, but keeping a margin makes that robust against future tuning
+int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 256 : -1; }
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
@@ -295,7 +485,7 @@ static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
     if (!P || B <= 0) return 0;
     const size_t Bp = rows_padded(B);
-    const size_t floats = Bp * ((size_t)4 * P->WT + P->VT + P->ST) + 6 * WS_SLACK;
+    const size_t floats = 2 * (Bp * (size_t)P->WT + WS_SLACK);
     return floats * sizeof(float);
 }
 
@@ -305,89 +495,95 @@ int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
 
 static KArgs make_args(const hint_plan* P, int B) {
     KArgs a{};
-    a.nodes = P->d_nodes; a.groups = P->d_groups; a.jobs = P->d_jobs; a.ents = P->d_ents;
+    a.meta = P->d_meta; a.jobs = P->d_jobs; a.bmap = P->d_bmap;
+    a.meta_bytes = P->meta_bytes; a.vnodes_off = P->vnodes_off; a.ents_off = P->ents_off; a.jmax = P->jmax;
+    a.bmax = P->bmax; a.bias_off = P->packed_floats;
+    a.s3 = P->s3; a.sv = P->sv;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
     a.xld = P->xld; a.cld = P->cld; a.ald = P->ald; a.vld = P->vld; a.sld = P->sld;
-    a.WT = P->WT; a.VT = P->VT; a.ST = P->ST;
+    a.WT = P->WT;
     a.alpha = P->alpha; a.B = B;
     return a;
 }
 
-static int apply(const hint_plan* P, bool rev, const float* params, const float* x, const float* c,
-                 float* z, float* J, float* tape, int32_t B, void* stream) {
-    if (!P || !params || !x || !z || !J) return fail("hint_block_%s: null argument", rev ? "inverse" : "forward");
-    if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", rev ? "inverse" : "forward", P->dc);
+int hint_block_pack(const hint_plan* P, const float* params, float* packed, void* stream) {
+    if (!P || !params || !packed) return fail("hint_block_pack: null argument");
+    HIP_TRY(launch_pack(P->d_segs, P->d_ptiles, P->n_ptiles, P->d_bmap, P->n_bias, (long)P->packed_floats, params,
+                        packed, (hipStream_t)stream));
+    return 0;
+}
+
+static int apply(const hint_plan* P, bool rev, const float* params, const float* packed, const float* x,
+                 const float* c, float* z, float* J, float* tape, int32_t B, void* stream) {
+    const char* what = rev ? "inverse" : "forward";
+    if (!P || !params || !packed || !x || !z || !J) return fail("hint_block_%s: null argument", what);
+    if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", what, P->dc);
     if (B < 0) return fail("negative batch");
     if (B == 0) return 0;
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, x, c, z, J, tape, (hipStream_t)stream));
+    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, packed, x, c, z, J, tape,
+                         (hipStream_t)stream));
     return 0;
 }
 
-int hint_block_forward(const hint_plan* P, const float* params, const float* x, const float* c, float* z,
-                       float* J, float* tape, int32_t B, void* stream) {
-    return apply(P, false, params, x, c, z, J, tape, B, stream);
+int hint_block_forward(const hint_plan* P, const float* params, const float* packed, const float* x,
+                       const float* c, float* z, float* J, float* tape, int32_t B, void* stream) {
+    return apply(P, false, params, packed, x, c, z, J, tape, B, stream);
 }
 
-int hint_block_inverse(const hint_plan* P, const float* params, const float* z, const float* c, float* x,
-                       float* J, int32_t B, void* stream) {
-    return apply(P, true, params, z, c, x, J, nullptr, B, stream);
+int hint_block_inverse(const hint_plan* P, const float* params, const float* packed, const float* z,
+                       const float* c, float* x, float* J, int32_t B, void* stream) {
+    return apply(P, true, params, packed, z, c, x, J, nullptr, B, stream);
 }
 
-int hint_block_backward(const hint_plan* P, const float* params, const float* x, const float* tape,
-                        const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c, float* g_params,
-                        void* workspace, size_t workspace_bytes, int32_t B, void* stream) {
-    if (!P || !params || !x || !g_x || !g_params) return fail("hint_block_backward: null argument");
-    if (P->n_levels > 1 && !tape && B > 0) return fail("hint_block_backward: tape is NULL but the tree has %d levels", P->n_levels);
+int hint_block_backward(const hint_plan* P, const float* params, const float* packed, const float* x,
+                        const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
+                        float* g_c, float* g_params, int32_t accumulate, void* workspace,
+                        size_t workspace_bytes, int32_t B, void* stream) {
+    if (!P || !params || !packed || !x || !g_x || !g_params) return fail("hint_block_backward: null argument");
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
+    if (P->n_levels > 1 && !tape && B > 0) return fail("hint_block_backward: tape is NULL but the tree has %d levels", P->n_levels);
     if (B < 0) return fail("negative batch");
     hipStream_t s = (hipStream_t)stream;
-    if (B == 0) {
-        HIP_TRY(hipMemsetAsync(g_params, 0, (size_t)P->param_floats * sizeof(float), s));
-        return 0;
-    }
+    if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
+    if (B == 0) return 0;
     if (!workspace || workspace_bytes < hint_plan_workspace_bytes(P, B))
         return fail("hint_block_backward: workspace too small (%zu < %zu)", workspace_bytes,
                     hint_plan_workspace_bytes(P, B));
+    if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_backward: workspace must be 16-byte aligned");
     const size_t Bp = rows_padded(B);
-    float* w = (float*)workspace;
-    float* wsA1 = w; w += Bp * P->WT + WS_SLACK;
-    float* wsA2 = w; w += Bp * P->WT + WS_SLACK;
-    float* wsG1 = w; w += Bp * P->WT + WS_SLACK;
-    float* wsG2 = w; w += Bp * P->WT + WS_SLACK;
-    float* wsV = w;  w += Bp * P->VT + WS_SLACK;
-    float* wsG3 = w;
+    float* wsA1 = (float*)workspace;
+    float* wsG2 = wsA1 + Bp * P->WT + WS_SLACK;
 
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
     if (g_bwd_stages & 1)
-        HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, x, tape, c, g_z, g_J, g_x, g_c, wsV, wsA1,
-                           wsA2, wsG1, wsG2, wsG3, s));
+        HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, packed, x, tape, c, g_z, g_J,
+                           g_x, g_c, g_params, wsA1, wsG2, s));
     if (!(g_bwd_stages & 2)) return 0;
-    // batch split of the weight-gradient GEMMs: enough workgroups to cover the chip ~2x,
-    // each wavefront reducing at least 32 rows
-    int rows_per_wg = 64;
-    {
-        const long target_wgs = 2L * P->num_cu;
-        long splits = std::max<long>(1, target_wgs / std::max(1, P->n_dwjobs));
-        long rp = ((long)Bp + splits - 1) / splits;
-        rp = std::max<long>(128, (rp + 63) / 64 * 64);
-        rows_per_wg = (int)rp;
-    }
-    const int splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
-    // always clear: covers the alignment gaps of the arena and the atomics of the split case
-    HIP_TRY(hipMemsetAsync(g_params, 0, (size_t)P->param_floats * sizeof(float), s));
-    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsV, wsA1, wsA2, wsG1, wsG2, wsG3, P->WT, P->VT,
-                      P->ST, (int)Bp, rows_per_wg, g_params, s));
+    // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
+    // to cover the chip, every workgroup reducing at least 128 rows
+    int splits = 8;
+    while ((long)splits * P->n_dwjobs < (long)P->num_cu && (long)Bp / (splits * 2) >= 128) splits *= 2;
+    int rows_per_wg = (int)(((long)Bp + splits - 1) / splits);
+    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+    if ((long)rows_per_wg * (splits - 1) >= (long)Bp)   // tiny batches: fewer, non-empty splits
+        splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
+    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsA1, wsG2, P->WT, (int)Bp, rows_per_wg, g_params, s));
     return 0;
 }
 
 void hint_debug_set_backward_stages(int32_t mask) { g_bwd_stages = mask & 3; }
 
-int hint_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                   int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                   float grad_scale, float grad_clamp, void* stream) {
+int hint_debug_set_stamp_buffer(void* device_buffer) {
+    HIP_TRY(set_stamp_buffer((unsigned long long*)device_buffer));
+    return 0;
+}
+
+int hint_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                   float grad_clamp, int32_t zero_grads, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq) return fail("hint_adam_step: null argument");
     if (n < 0 || step < 1) return fail("hint_adam_step: n must be >= 0 and step >= 1");
     if (n == 0) return 0;
@@ -404,7 +600,7 @@ int hint_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     }
     HIP_TRY(launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, (float)((double)lr / bc1), beta1, beta2,
                         (float)(1.0 / std::sqrt(bc2)), eps, weight_decay, grad_scale,
-                        grad_clamp > 0.f ? grad_clamp : 3.0e38f, num_cu, (hipStream_t)stream));
+                        grad_clamp > 0.f ? grad_clamp : 3.0e38f, zero_grads ? 1 : 0, num_cu, (hipStream_t)stream));
     return 0;
 }
 

@@ -79,8 +79,10 @@ class _Engine:
                                                  C.byref(handle)), "hint_plan_create")
         self.plan = handle
         self.arena: Optional[torch.Tensor] = None
+        self.packed: Optional[torch.Tensor] = None
         self._ext_arena: Optional[torch.Tensor] = None
         self._ptrs: List[int] = []
+        self._regathered = False
 
     def __del__(self):
         try:
@@ -111,6 +113,7 @@ class _Engine:
                     view.copy_(p.data.to(self.device))
                     p.data = view
         self.arena = arena
+        self._regathered = True
         base = arena.data_ptr()
         self._ptrs = [base + 4 * off for off in self.offsets]
 
@@ -131,6 +134,17 @@ class _Engine:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def pack(self):
+        """(re)build the MFMA-fragment-order copy of the weights the kernels read.  Cheap (one
+        small launch), so the module path calls it on every forward; FlowTrainer calls it once
+        per optimizer step."""
+        if self.packed is None or self.packed.device != self.device:
+            self.packed = torch.empty(self.lib.hint_plan_packed_floats(self.plan), dtype=torch.float32,
+                                      device=self.device)
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_block_pack(self.plan, self.arena.data_ptr(), self.packed.data_ptr(), self._stream())
+        _lib.check(st, "hint_block_pack")
+
     def apply(self, x: torch.Tensor, c: Optional[torch.Tensor], rev: bool, with_tape: bool = False):
         """-> (out, J) or, with_tape (training forward), (out, J, tape)"""
         B = x.shape[0]
@@ -144,35 +158,38 @@ class _Engine:
             cptr = c.data_ptr() if c is not None else None
             with torch.cuda.device(self.device):
                 if rev:
-                    st = self.lib.hint_block_inverse(self.plan, self.arena.data_ptr(), x.data_ptr(), cptr,
-                                                     out.data_ptr(), J.data_ptr(), B, self._stream())
+                    st = self.lib.hint_block_inverse(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
+                                                     x.data_ptr(), cptr, out.data_ptr(), J.data_ptr(), B,
+                                                     self._stream())
                 else:
-                    st = self.lib.hint_block_forward(self.plan, self.arena.data_ptr(), x.data_ptr(), cptr,
-                                                     out.data_ptr(), J.data_ptr(),
+                    st = self.lib.hint_block_forward(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
+                                                     x.data_ptr(), cptr, out.data_ptr(), J.data_ptr(),
                                                      tape.data_ptr() if tape is not None else None, B,
                                                      self._stream())
             _lib.check(st, "hint_block_inverse" if rev else "hint_block_forward")
         return (out, J, tape) if with_tape else (out, J)
 
-    def backward(self, x, tape, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None):
-        z = x
-        B = z.shape[0]
-        gx = torch.empty_like(z)
+    def backward(self, x, tape, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None,
+                 accumulate: bool = False):
+        B = x.shape[0]
+        gx = torch.empty_like(x)
         gc = torch.empty_like(c) if (c is not None and need_gc) else None
         if g_params is None:
-            g_params = torch.empty(self.total, dtype=torch.float32, device=z.device)
+            g_params = torch.empty(self.total, dtype=torch.float32, device=x.device)
+            accumulate = False
         if B == 0:
-            g_params.zero_()
+            if not accumulate:
+                g_params.zero_()
             return gx, gc, g_params
         nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
-        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=z.device)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_backward(
-                self.plan, self.arena.data_ptr(), x.data_ptr(), tape.data_ptr(),
-                c.data_ptr() if c is not None else None,
+                self.plan, self.arena.data_ptr(), self.packed.data_ptr(), x.data_ptr(),
+                tape.data_ptr() if tape is not None else None, c.data_ptr() if c is not None else None,
                 gz.data_ptr() if gz is not None else None, gJ.data_ptr() if gJ is not None else None,
                 gx.data_ptr(), gc.data_ptr() if gc is not None else None, g_params.data_ptr(),
-                ws.data_ptr(), nbytes, B, self._stream())
+                1 if accumulate else 0, ws.data_ptr(), nbytes, B, self._stream())
         _lib.check(st, "hint_block_backward")
         return gx, gc, g_params
 
@@ -292,6 +309,7 @@ class HierarchicalAffineCouplingTree(nn.Module):
                 raise HintAmdError("condition shape %s does not match dims_c / batch" % (tuple(cc.shape),))
         eng = self.engine(x.device)
         eng.ensure_arena()
+        eng.pack()
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or (cc is not None and cc.requires_grad) or any(p.requires_grad for p in eng.params))
         if rev:

@@ -51,6 +51,7 @@ class FlowTrainer:
         for e, (a, b) in zip(self.engines, self.slices):
             e.bind_external_arena(self.P[a:b])
             e.ensure_arena()
+            e.pack()
         self._graph = None
         self._static = None
 
@@ -75,23 +76,38 @@ class FlowTrainer:
         gJ = torch.full((B,), -1.0 / B, dtype=torch.float32, device=x.device)
         for i in reversed(range(len(self.engines))):
             a, b = self.slices[i]
-            gz, _, _ = self.engines[i].backward(inputs[i], tapes[i], c, gz, gJ, need_gc=False, g_params=self.G[a:b])
+            gz, _, _ = self.engines[i].backward(inputs[i], tapes[i], c, gz, gJ, need_gc=False, g_params=self.G[a:b],
+                                                accumulate=True)   # G is cleared by the optimizer kernel
             if flow.has_perm(i):
                 gz = gz @ flow.perms[i].W.t()
         return l0, l1
 
     def _check_arenas(self):
+        """parameters rebound from outside (p.data = ..., load_state_dict into new storage)
+        are pulled back into the arena and re-packed"""
+        for e in self.engines:
+            before = e.arena
+            e.ensure_arena()
+            if e.arena is not before or e._regathered:
+                e._regathered = False
+                e.pack()
+
+    def repack(self):
+        """call after changing parameters in place from outside the trainer"""
         for e in self.engines:
             e.ensure_arena()
+            e.pack()
 
     def _optimizer(self, grad_scale: float):
         self.step_count += 1
         with torch.cuda.device(self.device):
             st = self.lib.hint_adam_step(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                          self.n_floats, self.step_count, self.lr, self.betas[0], self.betas[1],
-                                         self.eps, self.wd, grad_scale, self.grad_clamp,
+                                         self.eps, self.wd, grad_scale, self.grad_clamp, 1,
                                          torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(st, "hint_adam_step")
+        for e in self.engines:      # the new weights in MFMA fragment order for the next step
+            e.pack()
 
     def step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
         """one training iteration on this rank's shard; returns device scalars (l0, l1) =
@@ -121,6 +137,7 @@ class FlowTrainer:
             for _ in range(2):
                 self._fwd_bwd(sx, sc)
         torch.cuda.current_stream(self.device).wait_stream(side)
+        self.G.zero_()                         # the warm-up runs accumulated into the gradient arena
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

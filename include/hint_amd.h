@@ -61,6 +61,9 @@ void hint_plan_destroy(hint_plan* plan);
 
 /* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size). */
 int64_t hint_plan_param_floats(const hint_plan* plan);
+/* floats of the packed-weight buffer (both subnets of every node, forward and transposed
+ * copies, in MFMA fragment order, zero padded). */
+int64_t hint_plan_packed_floats(const hint_plan* plan);
 /* floats of the forward "tape" for a batch of B rows: (levels-1) snapshots [B,d] of the lane
  * tensor between tree levels, recorded by hint_block_forward and read by hint_block_backward
  * so that the backward pass re-derives bit-identical subnet inputs (d floats per level and
@@ -71,39 +74,55 @@ size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
 /* dynamic LDS bytes per workgroup of the forward / backward kernels (informational). */
 int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
 
+/* Re-pack the flat parameters into `packed` (hint_plan_packed_floats floats).  Must be called
+ * after every change of the parameters and before the next forward / inverse / backward that
+ * should see it; one small launch (the weights of a block are a few hundred KiB). */
+int hint_block_pack(const hint_plan* plan, const float* params, float* packed, void* stream);
+
 /* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0.
+ * params: flat parameters (biases are read from here); packed: output of hint_block_pack.
  * tape: NULL for inference, else hint_plan_tape_floats(plan, B) floats (training). */
-int hint_block_forward(const hint_plan* plan, const float* params, const float* x,
-                       const float* c, float* z, float* J, float* tape, int32_t B, void* stream);
+int hint_block_forward(const hint_plan* plan, const float* params, const float* packed,
+                       const float* x, const float* c, float* z, float* J, float* tape, int32_t B,
+                       void* stream);
 /* x, J = block(z | c), rev=True: own coupling undone first, then children
  * (hint.py:82-88); J is the NEGATED log-det like the reference returns it (hint.py:83). */
-int hint_block_inverse(const hint_plan* plan, const float* params, const float* z,
-                       const float* c, float* x, float* J, int32_t B, void* stream);
+int hint_block_inverse(const hint_plan* plan, const float* params, const float* packed,
+                       const float* z, const float* c, float* x, float* J, int32_t B, void* stream);
 /* Backward of hint_block_forward.  Takes the block INPUT x and the tape the forward call
  * recorded (subnet activations are recomputed from them, not stored), upstream g_z [B,d] and
- * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and
- * the flat parameter gradient g_params (same layout as params; overwritten, not
- * accumulated).  workspace: hint_plan_workspace_bytes(plan, B) bytes of device scratch. */
-int hint_block_backward(const hint_plan* plan, const float* params, const float* x,
-                        const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
-                        float* g_c, float* g_params, void* workspace, size_t workspace_bytes,
-                        int32_t B, void* stream);
+ * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and the
+ * flat parameter gradient g_params (same layout as params): overwritten when accumulate == 0,
+ * added to when accumulate != 0 (the caller then owns zeroing, e.g. hint_adam_step's
+ * zero_grads).  Parameter gradients are reduced with float atomics, so their last bits can
+ * differ from run to run.  workspace: hint_plan_workspace_bytes(plan, B) bytes, 16-byte
+ * aligned device scratch. */
+int hint_block_backward(const hint_plan* plan, const float* params, const float* packed,
+                        const float* x, const float* tape, const float* c, const float* g_z,
+                        const float* g_J, float* g_x, float* g_c, float* g_params,
+                        int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t B,
+                        void* stream);
 
 /* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces
  *   for p in params: p.grad.data.clamp_(-5, 5)        (train_unconditional.py:140-141)
  *   torch.optim.Adam(..., eps, weight_decay).step()    (train_unconditional.py:144,174-176)
  * g' = clamp(grads*grad_scale, +-grad_clamp) + weight_decay*p, then the standard Adam update
  * with bias correction for the 1-based `step`.  grad_scale = 1/world_size turns the summed
- * all-reduce into the mean BEFORE the clamp; grad_clamp <= 0 disables clamping.  `grads` is
- * not modified.  All four buffers must be 16-byte aligned. */
-int hint_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+ * all-reduce into the mean BEFORE the clamp; grad_clamp <= 0 disables clamping.  With
+ * zero_grads != 0 the gradient arena is cleared after it has been consumed.  All four buffers
+ * must be 16-byte aligned. */
+int hint_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                    int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                   float grad_scale, float grad_clamp, void* stream);
+                   float grad_scale, float grad_clamp, int32_t zero_grads, void* stream);
 
 /* Profiling aid (process-global, not for production use): restrict hint_block_backward to its
  * row-parallel kernel (mask 1), its weight-gradient kernel (mask 2, reuses whatever the
  * workspace holds) or both (3, the default), so each can be timed on its own. */
 void hint_debug_set_backward_stages(int32_t mask);
+/* Diagnostic builds only (-DHINT_STAMPS): workgroup 0 of the block kernels writes shader-clock
+ * stamps of its stage boundaries into device_buffer (8 waves x 128 uint64).  Returns non-zero
+ * in a normal build. */
+int hint_debug_set_stamp_buffer(void* device_buffer);
 
 int hint_abi_version(void);
 const char* hint_last_error(void);

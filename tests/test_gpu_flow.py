@@ -67,6 +67,7 @@ def test_autograd_path_equals_fast_path():
     (0.5 * (z ** 2).sum(1).mean() - J.mean()).backward()
     ref = {n: p.grad.clone() for n, p in flow.named_parameters()}
     tr._check_arenas()
+    tr.G.zero_()
     tr._fwd_bwd(x, None)
     for (a, b), eng, blk_i in zip(tr.slices, tr.engines, range(3)):
         for p, g in zip(eng.params, eng.split_flat(tr.G[a:b])):
@@ -88,7 +89,7 @@ def test_adam_kernel_matches_torch():
         p_ref.grad = (g * 0.5).clamp(-5, 5)
         opt.step()
         st = lib.hint_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, step, 3e-4, 0.9, 0.95,
-                                1e-4, 1.86e-5, 0.5, 5.0, torch.cuda.current_stream().cuda_stream)
+                                1e-4, 1.86e-5, 0.5, 5.0, 0, torch.cuda.current_stream().cuda_stream)
         assert st == 0
     torch.cuda.synchronize()
     np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
