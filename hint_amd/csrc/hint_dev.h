@@ -31,19 +31,27 @@ struct PackSeg {
     int32_t tile_begin; // index of this segment's first n-tile in the global n-tile list
 };
 
-// One 16-column output tile of a GEMM stage:  out[16 rows][16 cols] (+)= A[16][K] * Wlog^T.
-// 16 bytes: the job lists of a group are staged in LDS and read with one ds_read_b128.
-struct GJob {
-    int32_t wtile;      // packed offset, in 256-float tiles, of the first k-block this job reads
-    int32_t boff;       // (unused by the kernels: biases are staged in LDS per group)
-    uint16_t acol;      // first A column (floats) in the stage's LDS input buffer
-    uint16_t ocol;      // first output column in the stage's LDS output buffer
-    uint8_t nblk;       // number of 16-wide k-blocks
-    uint8_t nvalid;     // valid output columns of this tile (others are written as 0)
+// One chunk (<= 4 consecutive 16-wide k-blocks) of one 16-column output tile of a GEMM stage:
+//   out[16 rows][16 cols] (+)= A[16][K] * Wlog^T.
+// The host cuts every tile job into chunks, deals the jobs to the 8 wavefronts (longest first)
+// and lays the chunks out per wavefront, so that the device loop is a plain walk over 16-byte
+// records read from LDS with one ds_read_b128 each.
+struct Chunk {
+    int32_t wtile;      // packed offset, in 256-float tiles, of the chunk's first k-block
+    uint16_t acol;      // A column (floats) of the chunk's first k-block in the stage's LDS input
+    uint16_t ocol;      // first output column of the tile in the stage's LDS output
+    uint8_t nv;         // valid k-blocks in this chunk (0 only for K = 0 jobs)
+    uint8_t last;       // 1: last chunk of its tile job -> epilogue
+    uint8_t nvalid;     // valid output columns of the tile (others are written as 0)
     uint8_t slab;       // K-split slab the partial result goes to
-    uint8_t pad;
+    int32_t pad;
 };
-static_assert(sizeof(GJob) == 16, "GJob must be 16 bytes");
+static_assert(sizeof(Chunk) == 16, "Chunk must be 16 bytes");
+typedef Chunk GJob;     // the per-group lists hold Chunk, stage-header and OJob records, 16 B each
+
+// A stage's list starts with a 32-byte header: uint16 first[9] = first chunk of wavefront w
+// (relative to the end of the header), first[8] = total; then the chunks, wavefront by wavefront.
+constexpr int STAGE_HDR_RECORDS = 2;
 
 // Small weight-gradient tile done inside the row-parallel backward kernel:
 //   g[goff + m*ldg + n] += sum_rows A[row][acol+m] * B[row][bcol+n]   (atomic)
@@ -57,26 +65,21 @@ struct OJob {
 static_assert(sizeof(OJob) == 16, "OJob must be 16 bytes");
 
 struct Ent { int16_t xcol, scol, tcol, pad; };                  // one transformed lane of a group
-struct VNode { int16_t off, k, cin, cinp, vcol, pad; };          // what build_v / scatter need
 
-// A group = a set of same-depth nodes processed together by one workgroup pass.
-// All *_off fields index the group's job list (16-byte units from jl_begin).
+// A group = a set of same-depth nodes processed together by one workgroup pass.  28 int32
+// fields = 7 x 16 bytes, read from LDS in one burst (see load_group()).  All *_off fields index
+// the group's job list (16-byte records from jl_begin); the six GEMM stages point at their
+// stage header.
 struct DGroup {
-    int32_t node_begin, node_end;
-    int32_t jl_begin, jl_count;     // this group's job list in the global job array
-    int32_t l1_off, l1_cnt, l2_off, l2_cnt, l3_off, l3_cnt;      // GJob stages
-    int32_t g2_off, g2_cnt, g1_off, g1_cnt, dv_off, dv_cnt;
-    int32_t o3_off, o3_cnt, o1_off, o1_cnt;                      // OJob lists (dW3, dW1)
-    int32_t ent_begin, ent_cnt;
-    int32_t bmap_begin;             // per activation column: offsets of b1 / b2 (aw entries each)
-    int32_t bmap3_begin;            // per s/t column: offset of b3 (sw entries)
-    int32_t aw, vw, sw;
-    int32_t l3_slabs, dv_slabs;
-    int32_t wcol0;
-    int32_t level, level_last;
-    int32_t pad0, pad1, pad2, pad3;
+    int32_t node_begin, node_end, jl_begin, jl_count;
+    int32_t l1_off, l2_off, l3_off, g2_off;
+    int32_t g1_off, dv_off, o3_off, o3_cnt;
+    int32_t o1_off, o1_cnt, ent_begin, ent_cnt;
+    int32_t bmap_begin, bmap3_begin, aw, vw;
+    int32_t sw, l3_slabs, dv_slabs, wcol0;
+    int32_t level, level_last, vmap_begin, pad;
 };
-static_assert(sizeof(DGroup) % 16 == 0, "DGroup must be a multiple of 16 bytes");
+static_assert(sizeof(DGroup) == 112, "DGroup must be 7 x 16 bytes");
 
 // dW2 tile job of the weight-gradient kernel: C[m][n] = sum_b G2[b][col+m] * A1[b][col+n]
 struct DWJob {
@@ -86,11 +89,13 @@ struct DWJob {
 };
 
 struct KArgs {
-    const void* meta;              // [groups | vnodes | ents] contiguous, copied to LDS at kernel start
+    const void* meta;              // [groups | vmap | ents] contiguous, copied to LDS at kernel start
     const GJob* jobs;              // all groups' job lists (GJob / OJob, 16 bytes each)
-    const int32_t* bmap;
+    const int32_t* bmap;           // per LDS column: compact thin-gradient index of its bias, or -1
+    int32_t thin_total;            // floats of one row tile's thin-gradient slab
     int32_t meta_bytes;            // multiple of 16
-    int32_t vnodes_off, ents_off;  // byte offsets inside meta
+    int32_t vmap_off, ents_off;    // byte offsets inside meta (vmap: int16 per v column)
+    int32_t first[2][4];           // {jl_begin, jl_count, bmap_begin, nbias} of the first group: [0] forward order, [1] reverse
     int32_t jmax;                  // capacity (jobs) of one LDS job buffer
     int32_t bmax;                  // capacity (floats) of one LDS bias buffer
     int64_t bias_off;              // float offset of the bias region inside the packed buffer

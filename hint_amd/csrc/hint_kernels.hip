@@ -111,46 +111,48 @@ __global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, l
 }
 
 // =======================================================================================
-// Generic GEMM stage.  Every wavefront walks its jobs (16-column output tiles, wave-strided)
-// as one stream of chunks of <= 4 k-blocks.  Three register sets rotate so that the packed B
-// fragments of the next two chunks are in flight while the MFMAs of the current one issue
-// (loads are unconditional so the compiler can count them exactly), across job boundaries and,
-// through stage_begin(), across the workgroup barrier in front of the stage: weights do not
-// depend on the previous stage, only the A operand in LDS does.
+// Generic GEMM stage.  The host has cut every 16-column output tile of the stage into chunks
+// of <= 4 k-blocks and dealt them to the 8 wavefronts; a wavefront walks its chunk list with a
+// three-deep software pipeline:
+//     step i :  global fetch of the packed B tiles of chunk i+2      (3 register sets rotate)
+//               LDS read of the A fragments of chunk i+1
+//               16 MFMAs of chunk i  (+ epilogue when the chunk ends its tile)
+// Every chunk issues exactly four tile loads with immediate offsets (a short chunk over-reads
+// into the following tiles, which only costs a little L2 bandwidth) so the compiler can count
+// outstanding loads exactly; the stream crosses tile boundaries and, through stage_begin(), the
+// workgroup barrier in front of the stage: weights do not depend on the previous stage, only
+// the A operand in LDS does.
 //   MFMA lane map (16x16x4 f32): lane l supplies A[m = l&15][kslot = l>>4] and
 //   B[kslot][n = l&15]; result reg i = C[4*(l>>4)+i][l&15].  Slot kq of step i of a 16-wide
 //   k-block is k = 16*kb + 4*kq + i on both operands, so each lane reads 4 consecutive k with
 //   one 128-bit access (LDS for A, global for packed B).
-// Job descriptors live in LDS (staged per group, one group ahead): a global or scalar load
-// in front of every job would put an L2 round trip (~700 cycles here) on the critical path.
+// Chunk records and biases live in LDS (staged per group, one group ahead): a global or
+// scalar load in front of every tile would put an L2 round trip on the critical path, and
+// per-chunk bookkeeping instructions, not MFMAs, were what bounded the first versions.
 // =======================================================================================
 enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_MASK = 2, EPI_PLAIN = 3 };
 
-struct JobU { int wtile, acol, ocol, nblk, nvalid, slab; };
+struct ChunkU { int wtile, acol, ocol, nv, last, nvalid, slab; };
 
-__device__ __forceinline__ JobU load_job(lds_jobs_t jl, int idx) {
-    const i32x4 raw = *(const LDS_AS i32x4*)(jl + idx);    // one ds_read_b128 at a wave-uniform address
-    JobU u;
+__device__ __forceinline__ ChunkU decode_chunk(i32x4 raw) {
+    ChunkU u;
     u.wtile = __builtin_amdgcn_readfirstlane(raw.x);
+    const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane(raw.y);
     const unsigned z = (unsigned)__builtin_amdgcn_readfirstlane(raw.z);
-    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(raw.w);
-    u.acol = (int)(z & 0xffffu);
-    u.ocol = (int)(z >> 16);
-    u.nblk = (int)(w & 0xffu);
-    u.nvalid = (int)((w >> 8) & 0xffu);
-    u.slab = (int)((w >> 16) & 0xffu);
+    u.acol = (int)(y & 0xffffu);
+    u.ocol = (int)(y >> 16);
+    u.nv = (int)(z & 0xffu);
+    u.last = (int)((z >> 8) & 0xffu);
+    u.nvalid = (int)((z >> 16) & 0xffu);
+    u.slab = (int)(z >> 24);
     return u;
 }
 
 struct Stage {
-    lds_jobs_t jl;
-    int njobs, rot;
-    bool active;
-    int pi, pkb;            // prefetch cursor: logical job index, k-block
-    JobU pjb;
-    int ci, ckb;            // compute cursor
-    JobU cjb;
-    f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+    lds_jobs_t cl;      // this wavefront's chunk list (LDS)
+    int n;              // its length
+    ChunkU d0, d1, d2;
+    f32x4 b00, b01, b02, b03, b10, b11, b12, b13, b20, b21, b22, b23;
 };
 
 #ifdef HINT_ABLATE_WLOAD    // diagnostic: every weight fetch hits the same 4 KiB (L1-resident)
@@ -158,49 +160,36 @@ struct Stage {
 #else
 #define HINT_WTILE(T) ((size_t)(T))
 #endif
-#define HINT_JIDX(S, I) (((I) + (S).rot) >= (S).njobs ? ((I) + (S).rot) - (S).njobs : ((I) + (S).rot))
 
-#define HINT_FETCH(S, R0, R1, R2, R3)                                                              \
+#define HINT_CHUNK_AT(S, I) decode_chunk(*(const LDS_AS i32x4*)((S).cl + ((I) < (S).n ? (I) : (S).n - 1)))
+#define HINT_FETCH(D, R0, R1, R2, R3)                                                              \
     {                                                                                              \
-        const f32x4* wp_ = (const f32x4*)packed + HINT_WTILE((S).pjb.wtile) * 64 + lane;           \
-        const int last_ = (S).pjb.nblk > 0 ? (S).pjb.nblk - 1 : 0;                                 \
-        R0 = wp_[((S).pkb + 0 < last_ ? (S).pkb + 0 : last_) * 64];                                \
-        R1 = wp_[((S).pkb + 1 < last_ ? (S).pkb + 1 : last_) * 64];                                \
-        R2 = wp_[((S).pkb + 2 < last_ ? (S).pkb + 2 : last_) * 64];                                \
-        R3 = wp_[((S).pkb + 3 < last_ ? (S).pkb + 3 : last_) * 64];                                \
-        (S).pkb += 4;                                                                              \
-        if ((S).pkb >= (S).pjb.nblk) {                                                             \
-            if ((S).pi + NWAVES < (S).njobs) {                                                     \
-                (S).pi += NWAVES;                                                                  \
-                (S).pjb = load_job((S).jl, HINT_JIDX(S, (S).pi));                                  \
-                (S).pkb = 0;                                                                       \
-            } else (S).pkb -= 4; /* end of stream: harmlessly re-fetch the last chunk */           \
-        }                                                                                          \
+        const f32x4* wp_ = (const f32x4*)packed + HINT_WTILE((D).wtile) * 64 + lane;               \
+        R0 = wp_[0]; R1 = wp_[64]; R2 = wp_[128]; R3 = wp_[192];                                   \
     }
 
-// Issue everything of a stage that does not depend on the preceding barrier: first job
-// descriptor, biases, the first two chunks of packed weights.
-__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t jl, int njobs,
-                                            const float* __restrict__ packed, int wave, int lane) {
-    S.jl = jl;
-    S.njobs = njobs;
-    S.active = wave < njobs;
-    if (!S.active) return;
-    // Workgroups run in near lock-step; rotate the job order per workgroup so that the CUs of
-    // an XCD do not all ask the same L2 channel for the same tile at the same moment.
-    S.rot = (int)((blockIdx.x * 5u) % (unsigned)njobs);
-    S.pi = wave;
-    S.pkb = 0;
-    S.pjb = load_job(jl, HINT_JIDX(S, wave));
-    S.ci = wave;
-    S.ckb = 0;
-    S.cjb = S.pjb;
-    HINT_FETCH(S, S.a0, S.a1, S.a2, S.a3)
-    HINT_FETCH(S, S.b0, S.b1, S.b2, S.b3)
+// Issue everything of a stage that does not depend on the preceding barrier: the first two
+// chunk records and their packed weights.
+__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t hdr, const float* __restrict__ packed,
+                                            int wave, int lane) {
+#ifdef HINT_SKIP_GEMM          // diagnostic: no GEMM stage work at all
+    S.n = 0;
+    return;
+#endif
+    const LDS_AS uint16_t* first = (const LDS_AS uint16_t*)hdr;
+    const int b = __builtin_amdgcn_readfirstlane((int)first[wave]);
+    const int e = __builtin_amdgcn_readfirstlane((int)first[wave + 1]);
+    S.n = e - b;
+    S.cl = hdr + STAGE_HDR_RECORDS + b;
+    if (S.n <= 0) return;
+    S.d0 = HINT_CHUNK_AT(S, 0);
+    HINT_FETCH(S.d0, S.b00, S.b01, S.b02, S.b03)
+    S.d1 = HINT_CHUNK_AT(S, 1);
+    HINT_FETCH(S.d1, S.b10, S.b11, S.b12, S.b13)
 }
 
 template <int EPI>
-__device__ __forceinline__ void stage_epilogue(const JobU& jb, f32x4 acc, const float* bias_lds, float* O,
+__device__ __forceinline__ void stage_epilogue(const ChunkU& jb, f32x4 acc, const float* bias_lds, float* O,
                                                int ldo, int slab_stride, int lane) {
     const int nl = lane & 15;
     const bool ok = nl < jb.nvalid;
@@ -223,57 +212,90 @@ __device__ __forceinline__ void stage_epilogue(const JobU& jb, f32x4 acc, const 
 template <int EPI>
 __device__ __forceinline__ void stage_run(Stage& S, const float* __restrict__ packed,
                                           const float* bias_lds, const float* A, int lda, float* O, int ldo,
-                                          int slab_stride, int lane) {
-    if (!S.active) return;
-    const int nl = lane & 15;
-    const float* arow = A + nl * lda + 4 * (lane >> 4);
+                                          int slab_stride, int lane, int stamp_base = -1) {
+    if (S.n <= 0) return;
+    int sk_ = 0;
+    (void)sk_;
+#ifdef HINT_STAMPS
+#define SSTAMP() if (stamp_base >= 0 && sk_ < 60) { STAMP(stamp_base + sk_) ++sk_; }
+#else
+#define SSTAMP()
+#endif
+    const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 c0, c1, c2, c3;
+    f32x4 a00, a01, a02, a03, a10, a11, a12, a13, a20, a21, a22, a23;
 
-#define HINT_MMA1(R, I, ACC)                                                                       \
-    if (S.ckb + I < S.cjb.nblk) {                                                                  \
-        const f32x4 a_ = *(const f32x4*)(ap_ + I * 16);                                            \
-        ACC = mfma4(a_.x, R.x, ACC);                                                               \
-        ACC = mfma4(a_.y, R.y, ACC);                                                               \
-        ACC = mfma4(a_.z, R.z, ACC);                                                               \
-        ACC = mfma4(a_.w, R.w, ACC);                                                               \
-    }
-#define HINT_COMPUTE(R0, R1, R2, R3, DONE)                                                         \
+    // A fragments of one chunk: four 128-bit LDS reads with immediate offsets (a short chunk
+    // reads past its last block; those registers are never used)
+#define HINT_AREAD(D, R0, R1, R2, R3)                                                              \
     {                                                                                              \
-        const float* ap_ = arow + S.cjb.acol + S.ckb * 16;                                         \
-        HINT_MMA1(R0, 0, acc0) HINT_MMA1(R1, 1, acc1) HINT_MMA1(R2, 2, acc0) HINT_MMA1(R3, 3, acc1) \
-        S.ckb += 4;                                                                                \
-        if (S.ckb >= S.cjb.nblk) {                                                                 \
-            stage_epilogue<EPI>(S.cjb, acc0 + acc1, bias_lds, O, ldo, slab_stride, lane);          \
+        const float* ap_ = arow + (D).acol;                                                        \
+        R0 = *(const f32x4*)(ap_);       R1 = *(const f32x4*)(ap_ + 16);                           \
+        R2 = *(const f32x4*)(ap_ + 32);  R3 = *(const f32x4*)(ap_ + 48);                           \
+    }
+#define HINT_MMA_BLK(AR, BR, ACC)                                                                  \
+    ACC = mfma4(AR.x, BR.x, ACC); ACC = mfma4(AR.y, BR.y, ACC);                                    \
+    ACC = mfma4(AR.z, BR.z, ACC); ACC = mfma4(AR.w, BR.w, ACC);
+    // the MFMAs of one chunk; two accumulators alternate so that no MFMA waits on its predecessor
+#define HINT_MMA(D, AR0, AR1, AR2, AR3, BR0, BR1, BR2, BR3)                                        \
+    {                                                                                              \
+        if ((D).nv >= 4) {                                                                         \
+            acc0 = mfma4(AR0.x, BR0.x, acc0); acc1 = mfma4(AR1.x, BR1.x, acc1);                    \
+            acc0 = mfma4(AR0.y, BR0.y, acc0); acc1 = mfma4(AR1.y, BR1.y, acc1);                    \
+            acc0 = mfma4(AR0.z, BR0.z, acc0); acc1 = mfma4(AR1.z, BR1.z, acc1);                    \
+            acc0 = mfma4(AR0.w, BR0.w, acc0); acc1 = mfma4(AR1.w, BR1.w, acc1);                    \
+            acc0 = mfma4(AR2.x, BR2.x, acc0); acc1 = mfma4(AR3.x, BR3.x, acc1);                    \
+            acc0 = mfma4(AR2.y, BR2.y, acc0); acc1 = mfma4(AR3.y, BR3.y, acc1);                    \
+            acc0 = mfma4(AR2.z, BR2.z, acc0); acc1 = mfma4(AR3.z, BR3.z, acc1);                    \
+            acc0 = mfma4(AR2.w, BR2.w, acc0); acc1 = mfma4(AR3.w, BR3.w, acc1);                    \
+        } else {                                                                                   \
+            if ((D).nv >= 1) { HINT_MMA_BLK(AR0, BR0, acc0) }                                      \
+            if ((D).nv >= 2) { HINT_MMA_BLK(AR1, BR1, acc1) }                                      \
+            if ((D).nv >= 3) { HINT_MMA_BLK(AR2, BR2, acc0) }                                      \
+        }                                                                                          \
+        if ((D).last) {                                                                            \
+            stage_epilogue<EPI>(D, acc0 + acc1, bias_lds, O, ldo, slab_stride, lane);              \
             acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
-            S.ci += NWAVES;                                                                        \
-            if (S.ci >= S.njobs) { DONE = true; }                                                  \
-            else {                                                                                 \
-                S.cjb = load_job(S.jl, HINT_JIDX(S, S.ci));                                        \
-                S.ckb = 0;                                                                         \
-            }                                                                                      \
         }                                                                                          \
     }
 
-    bool done = false;
+    HINT_AREAD(S.d0, a00, a01, a02, a03)
+    int ci = 0;   // chunk held in (d0, a0*, b0*) at the top of the loop
     while (true) {
-        HINT_FETCH(S, c0, c1, c2, c3)
-        HINT_COMPUTE(S.a0, S.a1, S.a2, S.a3, done)
-        if (done) break;
-        HINT_FETCH(S, S.a0, S.a1, S.a2, S.a3)
-        HINT_COMPUTE(S.b0, S.b1, S.b2, S.b3, done)
-        if (done) break;
-        HINT_FETCH(S, S.b0, S.b1, S.b2, S.b3)
-        HINT_COMPUTE(c0, c1, c2, c3, done)
-        if (done) break;
+        SSTAMP()
+        S.d2 = HINT_CHUNK_AT(S, ci + 2);
+        SSTAMP()
+        HINT_FETCH(S.d2, S.b20, S.b21, S.b22, S.b23)
+        SSTAMP()
+        HINT_AREAD(S.d1, a10, a11, a12, a13)
+        SSTAMP()
+        HINT_MMA(S.d0, a00, a01, a02, a03, S.b00, S.b01, S.b02, S.b03)
+        SSTAMP()
+        if (ci + 1 >= S.n) break;
+        S.d0 = HINT_CHUNK_AT(S, ci + 3);
+        HINT_FETCH(S.d0, S.b00, S.b01, S.b02, S.b03)
+        HINT_AREAD(S.d2, a20, a21, a22, a23)
+        HINT_MMA(S.d1, a10, a11, a12, a13, S.b10, S.b11, S.b12, S.b13)
+        if (ci + 2 >= S.n) break;
+        S.d1 = HINT_CHUNK_AT(S, ci + 4);
+        HINT_FETCH(S.d1, S.b10, S.b11, S.b12, S.b13)
+        HINT_AREAD(S.d0, a00, a01, a02, a03)
+        HINT_MMA(S.d2, a20, a21, a22, a23, S.b20, S.b21, S.b22, S.b23)
+        if (ci + 3 >= S.n) break;
+        ci += 3;
     }
-#undef HINT_MMA1
-#undef HINT_COMPUTE
+#undef HINT_AREAD
+#undef HINT_MMA_BLK
+#undef HINT_MMA
+#undef SSTAMP
 }
 
 // Small outer-product tiles done inside the backward kernel (dW1, dW3): the reduction runs
-// over the 16 rows of the tile, results go to the flat gradient buffer with float atomics.
+// over the 16 rows of the tile; the partial goes to this row tile's own slab of the workspace
+// with plain stores (every slab element is written exactly once) and part B sums the slabs.
+// Atomics straight into the gradient buffer would have all 256 workgroups hammer the same few
+// KiB at once: measured 65 us of a 115 us kernel.
 __device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const float* Abuf, int lda,
                                           const float* Bbuf, int ldb, float* __restrict__ g, int wave,
                                           int lane) {
@@ -295,14 +317,14 @@ __device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const floa
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = 4 * kq + i;
-                if (m < mvalid) atomicAdd(g + goff + (int64_t)m * ldg + nl, acc[i]);
+                if (m < mvalid) g[goff + m * ldg + nl] = acc[i];
             }
         }
     }
 }
 
 // bias gradients: column sums over the 16 rows of an LDS buffer, one thread per column
-__device__ __forceinline__ void colsum_atomic(const int32_t* __restrict__ map, int ncols, const float* buf,
+__device__ __forceinline__ void colsum_store(const int32_t* __restrict__ map, int ncols, const float* buf,
                                               int ld, float* __restrict__ g, int tid) {
     for (int col = tid; col < ncols; col += NTHREADS) {
         const int off = map[col];
@@ -310,28 +332,38 @@ __device__ __forceinline__ void colsum_atomic(const int32_t* __restrict__ map, i
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) s += buf[r * ld + col];
-        atomicAdd(g + off, s);
+        g[off] = s;
     }
 }
 
-struct VNodeU { int off, k, cin, cinp, vcol; };
-__device__ __forceinline__ VNodeU load_vnode(const LDS_AS VNode* vnodes, int ni) {
-    const LDS_AS int32_t* p = (const LDS_AS int32_t*)(vnodes + ni);       // 12 bytes = 3 dwords, wave-uniform
-    const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane(p[0]);
-    const unsigned w1 = (unsigned)__builtin_amdgcn_readfirstlane(p[1]);
-    const unsigned w2 = (unsigned)__builtin_amdgcn_readfirstlane(p[2]);
-    VNodeU u;
-    u.off = (int)(w0 & 0xffffu); u.k = (int)(w0 >> 16);
-    u.cin = (int)(w1 & 0xffffu); u.cinp = (int)(w1 >> 16);
-    u.vcol = (int)(w2 & 0xffffu);
-    return u;
-}
 struct EntU { int xcol, scol, tcol; };
 __device__ __forceinline__ EntU load_ent(const LDS_AS Ent* ents, int e) {
     const LDS_AS int32_t* p = (const LDS_AS int32_t*)(ents + e);           // 8 bytes, per-lane address
     const unsigned w0 = (unsigned)p[0], w1 = (unsigned)p[1];
     EntU u;
     u.xcol = (int)(w0 & 0xffffu); u.scol = (int)(w0 >> 16); u.tcol = (int)(w1 & 0xffffu);
+    return u;
+}
+
+// All fields of a group descriptor in one burst of seven 128-bit LDS reads (wave-uniform).
+struct GroupU {
+    int node_begin, node_end, jl_begin, jl_count, l1_off, l2_off, l3_off, g2_off, g1_off, dv_off, o3_off, o3_cnt,
+        o1_off, o1_cnt, ent_begin, ent_cnt, bmap_begin, bmap3_begin, aw, vw, sw, l3_slabs, dv_slabs, wcol0, level,
+        level_last, vmap_begin;
+};
+__device__ __forceinline__ GroupU load_group(const LDS_AS DGroup* g) {
+    const LDS_AS i32x4* p = (const LDS_AS i32x4*)g;
+    const i32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
+#define RFL(V) __builtin_amdgcn_readfirstlane(V)
+    GroupU u;
+    u.node_begin = RFL(q0.x); u.node_end = RFL(q0.y); u.jl_begin = RFL(q0.z); u.jl_count = RFL(q0.w);
+    u.l1_off = RFL(q1.x); u.l2_off = RFL(q1.y); u.l3_off = RFL(q1.z); u.g2_off = RFL(q1.w);
+    u.g1_off = RFL(q2.x); u.dv_off = RFL(q2.y); u.o3_off = RFL(q2.z); u.o3_cnt = RFL(q2.w);
+    u.o1_off = RFL(q3.x); u.o1_cnt = RFL(q3.y); u.ent_begin = RFL(q3.z); u.ent_cnt = RFL(q3.w);
+    u.bmap_begin = RFL(q4.x); u.bmap3_begin = RFL(q4.y); u.aw = RFL(q4.z); u.vw = RFL(q4.w);
+    u.sw = RFL(q5.x); u.l3_slabs = RFL(q5.y); u.dv_slabs = RFL(q5.z); u.wcol0 = RFL(q5.w);
+    u.level = RFL(q6.x); u.level_last = RFL(q6.y); u.vmap_begin = RFL(q6.z);
+#undef RFL
     return u;
 }
 
@@ -344,20 +376,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// v = [u | c] for every node of the group (hint.py:76), zero padded to cinp columns.
-__device__ __forceinline__ void stage_build_v(const KArgs& a, int node_begin, int node_end,
-                                              const LDS_AS VNode* vnodes, const float* xs, const float* cs,
-                                              float* vb, int tid) {
-    for (int ni = node_begin; ni < node_end; ++ni) {
-        const VNodeU nd = load_vnode(vnodes, ni);
-        const int cinp = nd.cinp, k = nd.k, cin = nd.cin, off = nd.off, vcol = nd.vcol;
-        for (int i = tid; i < ROWS * cinp; i += NTHREADS) {
-            const int r = i / cinp, j = i - r * cinp;
-            float v = 0.f;
-            if (j < k) v = xs[r * a.xld + off + j];
-            else if (j < cin) v = cs[r * a.cld + (j - k)];
-            vb[r * a.vld + vcol + j] = v;
-        }
+// v = [u | c] for every node of the group (hint.py:76), zero padded: one pass over the group's
+// v columns through a per-column source map (>= 0: lane column, -1: zero, <= -2: condition column)
+__device__ __forceinline__ void stage_build_v(const KArgs& a, const LDS_AS int16_t* vmap, int vw,
+                                              const float* xs, const float* cs, float* vb, int tid) {
+    for (int i = tid; i < ROWS * vw; i += NTHREADS) {
+        const int r = i / vw, j = i - r * vw;
+        const int m = vmap[j];
+        float v = 0.f;
+        if (m >= 0) v = xs[r * a.xld + m];
+        else if (m <= -2) v = cs[r * a.cld + (-2 - m)];
+        vb[r * a.vld + j] = v;
     }
 }
 
@@ -407,25 +436,25 @@ __device__ __forceinline__ void jobs_commit(const JobPrefetch& jp, LDS_AS GJob* 
     if (tid < jp.nbias4) ((f32x4*)bias_dst)[tid] = jp.b0;
 }
 
-// LDS carve-up shared by both block kernels: [meta | job buffer 0 | job buffer 1 | floats...]
+// LDS carve-up shared by both block kernels:
+//   [meta: groups | vmap | ents][job buffer 0 | 1][bias buffer 0 | 1][float buffers ...]
 __device__ __forceinline__ void lds_copy_meta(const KArgs& a, LDS_AS char* mbase, int tid) {
     const int n16 = a.meta_bytes >> 4;
     for (int i = tid; i < n16; i += NTHREADS) ((LDS_AS i32x4*)mbase)[i] = ((const i32x4*)a.meta)[i];
 }
-
-// =======================================================================================
-// forward (REV=false) / inverse (REV=true): x, J -> z   — one launch per block
-// =======================================================================================
 #define HINT_LDS_TABLES()                                                                          \
     LDS_AS char* mbase = (LDS_AS char*)lds;                                                        \
     const LDS_AS DGroup* groups = (const LDS_AS DGroup*)mbase;                                     \
-    const LDS_AS VNode* vnodes = (const LDS_AS VNode*)(mbase + a.vnodes_off);                      \
+    const LDS_AS int16_t* vmap = (const LDS_AS int16_t*)(mbase + a.vmap_off);                      \
     const LDS_AS Ent* ents = (const LDS_AS Ent*)(mbase + a.ents_off);                              \
     LDS_AS GJob* jbuf0 = (LDS_AS GJob*)(mbase + a.meta_bytes);                                     \
     float* bias0 = lds + ((a.meta_bytes + 2 * a.jmax * (int)sizeof(GJob)) >> 2);                   \
     float* fbase = bias0 + 2 * a.bmax;                                                             \
     lds_copy_meta(a, mbase, tid);
 
+// =======================================================================================
+// forward (REV=false) / inverse (REV=true): x, J -> z   — one launch per block
+// =======================================================================================
 template <bool REV>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_block_apply_kernel(
     KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
@@ -446,74 +475,73 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* jac = st + a.s3 * ROWS * a.sld;
     const int sstride = ROWS * a.sld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
-    __syncthreads();                          // meta visible
+    const int fo = REV ? 1 : 0;               // which "first group" record of the kernel arguments
+    {   // the first group's chunk lists and biases: issued together with the meta copy
+        JobPrefetch jp0;
+        jobs_issue(jp0, a.jobs, a.first[fo][0], a.first[fo][1], packed + a.bias_off + a.first[fo][2], a.first[fo][3], tid);
+        jobs_commit(jp0, jbuf0, bias0, tid);
+    }
 
     int jb = 0;
     Stage S, N;
+    bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
-        const bool first_tile = (tile == (int)blockIdx.x);
-        const LDS_AS DGroup* gfirst = groups + (REV ? a.n_groups - 1 : 0);
-        if (first_tile) {                     // later tiles get the first group's jobs through the prefetch below
-            JobPrefetch jp0;
-            jobs_issue(jp0, a.jobs, GF(gfirst, jl_begin), GF(gfirst, jl_count), packed + a.bias_off + GF(gfirst, bmap_begin),
-                       2 * GF(gfirst, aw) + GF(gfirst, sw), tid);
-            jobs_commit(jp0, jbuf0 + jb * a.jmax, bias0 + jb * a.bmax, tid);
-        }
         load_tile(xs, a.xld, x, a.d, row0, a.B, tid);
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
         if (tid < ROWS) jac[tid] = 0.f;
-        __syncthreads();
+        __syncthreads();                      // meta, first chunk lists and the lane tile visible
         STAMP(1)
-        if (first_tile)
-            stage_begin(S, jbuf0 + jb * a.jmax + GF(gfirst, l1_off), GF(gfirst, l1_cnt), packed, wave, lane);
+        GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
+        if (first_tile) stage_begin(S, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
+        first_tile = false;
 
         for (int gi = 0; gi < a.n_groups; ++gi) {
-            const LDS_AS DGroup* g = groups + (REV ? (a.n_groups - 1 - gi) : gi);
             const bool more_tiles = tile + (int)gridDim.x < ntiles;
             const bool has_next = (gi + 1 < a.n_groups) || more_tiles;
             const int gnext = (gi + 1 < a.n_groups) ? gi + 1 : 0;
-            const LDS_AS DGroup* gn = groups + (REV ? (a.n_groups - 1 - gnext) : gnext);
+            const GroupU gn = load_group(groups + (REV ? (a.n_groups - 1 - gnext) : gnext));
             JobPrefetch jp;
             jp.count = 0;
             jp.nbias4 = 0;
             if (has_next)
-                jobs_issue(jp, a.jobs, GF(gn, jl_begin), GF(gn, jl_count), packed + a.bias_off + GF(gn, bmap_begin),
-                           2 * GF(gn, aw) + GF(gn, sw), tid);
+                jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
             lds_jobs_t jl = jbuf0 + jb * a.jmax;
             LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
-            const int l3_slabs = GF(g, l3_slabs), ent_begin = GF(g, ent_begin), ent_cnt = GF(g, ent_cnt);
-            const int g_aw = GF(g, aw);
             const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
 
-            stage_build_v(a, GF(g, node_begin), GF(g, node_end), vnodes, xs, cs, vb, tid);
+            stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
             STAMP(2 + 12 * gi)
             lds_barrier();
             STAMP(3 + 12 * gi)
-            stage_begin(N, jl + GF(g, l2_off), GF(g, l2_cnt), packed, wave, lane);
+            stage_begin(N, jl + g.l2_off, packed, wave, lane);
             stage_run<EPI_RELU>(S, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
             STAMP(4 + 12 * gi)
             lds_barrier();
             STAMP(5 + 12 * gi)
-            stage_begin(S, jl + GF(g, l3_off), GF(g, l3_cnt), packed, wave, lane);
-            stage_run<EPI_RELU>(N, packed, bias_g + g_aw, a1, a.ald, a2, a.ald, 0, lane);
+            stage_begin(S, jl + g.l3_off, packed, wave, lane);
+            stage_run<EPI_RELU>(N, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane, gi == a.n_groups - 1 ? 60 : -1);
             if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(6 + 12 * gi)
             lds_barrier();
             STAMP(7 + 12 * gi)
-            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g_aw, a2, a.ald, st, a.sld, sstride, lane);
+            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
             STAMP(8 + 12 * gi)
             lds_barrier();
             STAMP(9 + 12 * gi)
-            if (has_next) stage_begin(S, jl_next + GF(gn, l1_off), GF(gn, l1_cnt), packed, wave, lane);
+            if (has_next) stage_begin(S, jl_next + gn.l1_off, packed, wave, lane);
             {   // element-wise affine coupling + log-det partial sums (hint.py:79-83)
                 const int sub = tid & 15, row = tid >> 4;
                 float part = 0.f;
+#ifdef HINT_SKIP_COUPLE
+                if (false) {
+#else
                 if (row < ROWS) {
-                    for (int e = sub; e < ent_cnt; e += 16) {
-                        const EntU en = load_ent(ents, ent_begin + e);
+#endif
+                    for (int e = sub; e < g.ent_cnt; e += 16) {
+                        const EntU en = load_ent(ents, g.ent_begin + e);
                         float s = 0.f, t = 0.f;
-                        for (int sl = 0; sl < l3_slabs; ++sl) {
+                        for (int sl = 0; sl < g.l3_slabs; ++sl) {
                             s += st[sl * sstride + row * a.sld + en.scol];
                             t += st[sl * sstride + row * a.sld + en.tcol];
                         }
@@ -531,9 +559,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             STAMP(11 + 12 * gi)
             // training: keep the lane tile as it stands after each level except the root's, so
             // that the backward pass sees bit-identical subnet inputs (tape[level][B][d])
-            if (!REV && tape != nullptr && GF(g, level_last) && GF(g, level) < a.n_levels - 1)
-                store_tile(tape + (size_t)GF(g, level) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
+            if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
+                store_tile(tape + (size_t)g.level * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
             jb ^= 1;
+            g = gn;
         }
         store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
         if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid];
@@ -557,6 +586,9 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
                                               int tid) {
     // width is a multiple of 16, dcol/dld multiples of 4 -> 128-bit rows
     const int w4 = width >> 2;
+#ifdef HINT_SKIP_WSCOPY
+    if (width > 0) return;
+#endif
     for (int i = tid; i < ROWS * w4; i += NTHREADS) {
         const int r = i / w4, j = (i - r * w4) << 2;
         *(f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j) = *(const f32x4*)(src + r * sld + j);
@@ -567,7 +599,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ tape, const float* __restrict__ c,
     const float* __restrict__ g_z, const float* __restrict__ g_J, float* __restrict__ g_x,
-    float* __restrict__ g_c, float* __restrict__ gparams, float* __restrict__ wsA1,
+    float* __restrict__ g_c, float* __restrict__ wsT, float* __restrict__ wsA1,
     float* __restrict__ wsG2) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -588,20 +620,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* gj = gst + ROWS * a.sld;
     const int sstride = ROWS * a.sld, vstride = ROWS * a.vld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
-    __syncthreads();                          // meta visible
+    {
+        JobPrefetch jp0;
+        jobs_issue(jp0, a.jobs, a.first[1][0], a.first[1][1], packed + a.bias_off + a.first[1][2], a.first[1][3], tid);
+        jobs_commit(jp0, jbuf0, bias0, tid);
+    }
 
     int jb = 0;
     Stage S, N;
+    bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
-        const bool first_tile = (tile == (int)blockIdx.x);
-        const LDS_AS DGroup* gfirst = groups + (a.n_groups - 1);
-        if (first_tile) {
-            JobPrefetch jp0;
-            jobs_issue(jp0, a.jobs, GF(gfirst, jl_begin), GF(gfirst, jl_count), packed + a.bias_off + GF(gfirst, bmap_begin),
-                       2 * GF(gfirst, aw) + GF(gfirst, sw), tid);
-            jobs_commit(jp0, jbuf0 + jb * a.jmax, bias0 + jb * a.bmax, tid);
-        }
+        float* gparams = wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
         load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid);
         if (a.dc > 0) {
             load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
@@ -610,60 +640,53 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (tid < ROWS) gj[tid] = (g_J != nullptr && row0 + tid < a.B) ? g_J[row0 + tid] : 0.f;
         __syncthreads();
         STAMP(1)
-        if (first_tile)
-            stage_begin(S, jbuf0 + jb * a.jmax + GF(gfirst, l1_off), GF(gfirst, l1_cnt), packed, wave, lane);
+        GroupU g = load_group(groups + (a.n_groups - 1));
+        if (first_tile) stage_begin(S, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
+        first_tile = false;
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
-            const LDS_AS DGroup* g = groups + gi;
             const bool more_tiles = tile + (int)gridDim.x < ntiles;
             const bool has_next = (gi > 0) || more_tiles;
-            const LDS_AS DGroup* gn = groups + (gi > 0 ? gi - 1 : a.n_groups - 1);
+            const GroupU gn = load_group(groups + (gi > 0 ? gi - 1 : a.n_groups - 1));
             JobPrefetch jp;
             jp.count = 0;
             jp.nbias4 = 0;
             if (has_next)
-                jobs_issue(jp, a.jobs, GF(gn, jl_begin), GF(gn, jl_count), packed + a.bias_off + GF(gn, bmap_begin),
-                           2 * GF(gn, aw) + GF(gn, sw), tid);
+                jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
             lds_jobs_t jl = jbuf0 + jb * a.jmax;
             LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
+            const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
             const int sbase = 2 + 20 * (a.n_groups - 1 - gi);
             (void)sbase;
-            const int g_aw = GF(g, aw), g_sw = GF(g, sw), g_wcol0 = GF(g, wcol0);
-            const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
-            const int node_begin = GF(g, node_begin), node_end = GF(g, node_end);
-            const int l3_slabs = GF(g, l3_slabs), dv_slabs = GF(g, dv_slabs);
-            const int ent_begin = GF(g, ent_begin), ent_cnt = GF(g, ent_cnt);
-            const int bmap_begin = GF(g, bmap_begin), bmap3_begin = GF(g, bmap3_begin);
 
             // ---- the lanes as the forward pass saw them when it entered this level ----
-            if (GF(g, level_last)) {
-                const int level = GF(g, level);
-                const float* src = (level == 0) ? x : tape + (size_t)(level - 1) * a.B * a.d;
+            if (g.level_last) {
+                const float* src = (g.level == 0) ? x : tape + (size_t)(g.level - 1) * a.B * a.d;
                 load_tile(xs, a.xld, src, a.d, row0, a.B, tid);
                 lds_barrier();
             }
             // ---- recompute s, t of every node of the group (bit-identical to the forward) ----
-            stage_build_v(a, node_begin, node_end, vnodes, xs, cs, vb, tid);
-            for (int i = tid; i < ROWS * g_sw; i += NTHREADS) {
-                const int r = i / g_sw;
-                gst[r * a.sld + (i - r * g_sw)] = 0.f;
+            stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
+            for (int i = tid; i < ROWS * g.sw; i += NTHREADS) {
+                const int r = i / g.sw;
+                gst[r * a.sld + (i - r * g.sw)] = 0.f;
             }
             STAMP(sbase + 0)
             lds_barrier();
             STAMP(sbase + 1)
-            stage_begin(N, jl + GF(g, l2_off), GF(g, l2_cnt), packed, wave, lane);
+            stage_begin(N, jl + g.l2_off, packed, wave, lane);
             stage_run<EPI_RELU>(S, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
             STAMP(sbase + 2)
             lds_barrier();
             STAMP(sbase + 3)
-            stage_begin(S, jl + GF(g, l3_off), GF(g, l3_cnt), packed, wave, lane);
-            copy_rows_out(wsA1, a.WT, g_wcol0, a1, a.ald, g_aw, row0, tid);
-            stage_run<EPI_RELU>(N, packed, bias_g + g_aw, a1, a.ald, a2, a.ald, 0, lane);
+            stage_begin(S, jl + g.l3_off, packed, wave, lane);
+            copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
+            stage_run<EPI_RELU>(N, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
-            stage_begin(N, jl + GF(g, g2_off), GF(g, g2_cnt), packed, wave, lane);
-            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g_aw, a2, a.ald, st, a.sld, sstride, lane);
+            stage_begin(N, jl + g.g2_off, packed, wave, lane);
+            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
             STAMP(sbase + 6)
             lds_barrier();
             STAMP(sbase + 7)
@@ -671,10 +694,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int sub = tid & 15, row = tid >> 4;
                 if (row < ROWS) {
                     const float gJr = gj[row];
-                    for (int e = sub; e < ent_cnt; e += 16) {
-                        const EntU en = load_ent(ents, ent_begin + e);
+                    for (int e = sub; e < g.ent_cnt; e += 16) {
+                        const EntU en = load_ent(ents, g.ent_begin + e);
                         float s = 0.f;
-                        for (int sl = 0; sl < l3_slabs; ++sl) s += st[sl * sstride + row * a.sld + en.scol];
+                        for (int sl = 0; sl < g.l3_slabs; ++sl) s += st[sl * sstride + row * a.sld + en.scol];
                         const float aa = a.alpha * atanf(s);
                         const float ea = expf(aa);
                         const float l = xs[row * a.xld + en.xcol];       // lower input of the node
@@ -691,60 +714,63 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             lds_barrier();
             STAMP(sbase + 9)
             // ---- dW3 += g_st^T a2, db3 += colsum(g_st)  (a2 still holds the activations) ----
-            run_ojobs(jl + GF(g, o3_off), GF(g, o3_cnt), gst, a.sld, a2, a.ald, gparams, wave, lane);
-            colsum_atomic(a.bmap + bmap3_begin, g_sw, gst, a.sld, gparams, tid);
+            run_ojobs(jl + g.o3_off, g.o3_cnt, gst, a.sld, a2, a.ald, gparams, wave, lane);
+            colsum_store(a.bmap + g.bmap3_begin, g.sw, gst, a.sld, gparams, tid);
             STAMP(sbase + 10)
             lds_barrier();
             STAMP(sbase + 11)
             // ---- g2 = (g_st * W3) .* relu'(a2), in place over a2 ----
-            stage_begin(S, jl + GF(g, g1_off), GF(g, g1_cnt), packed, wave, lane);
+            stage_begin(S, jl + g.g1_off, packed, wave, lane);
             stage_run<EPI_MASK>(N, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
             STAMP(sbase + 12)
             lds_barrier();
             STAMP(sbase + 13)
             // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1;  db2 += colsum(g2) ----
-            stage_begin(N, jl + GF(g, dv_off), GF(g, dv_cnt), packed, wave, lane);
-            copy_rows_out(wsG2, a.WT, g_wcol0, a2, a.ald, g_aw, row0, tid);
-            colsum_atomic(a.bmap + bmap_begin + g_aw, g_aw, a2, a.ald, gparams, tid);
+            stage_begin(N, jl + g.dv_off, packed, wave, lane);
+            copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
+            colsum_store(a.bmap + g.bmap_begin + g.aw, g.aw, a2, a.ald, gparams, tid);
             stage_run<EPI_MASK>(S, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
             STAMP(sbase + 14)
             lds_barrier();
             STAMP(sbase + 15)
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
             stage_run<EPI_PLAIN>(N, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
-            run_ojobs(jl + GF(g, o1_off), GF(g, o1_cnt), a1, a.ald, vb, a.vld, gparams, wave, lane);
-            colsum_atomic(a.bmap + bmap_begin, g_aw, a1, a.ald, gparams, tid);
+            run_ojobs(jl + g.o1_off, g.o1_cnt, a1, a.ald, vb, a.vld, gparams, wave, lane);
+            colsum_store(a.bmap + g.bmap_begin, g.aw, a1, a.ald, gparams, tid);
             if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)
-            if (has_next) stage_begin(S, jl_next + GF(gn, l1_off), GF(gn, l1_cnt), packed, wave, lane);
-            // ---- scatter g_v: first k columns to the upper lanes, the rest to g_c ----
-            for (int ni = node_begin; ni < node_end; ++ni) {
-                const VNodeU nd = load_vnode(vnodes, ni);
-                const int k = nd.k;
-                for (int i = tid; i < ROWS * k; i += NTHREADS) {
-                    const int r = i / k, j = i - r * k;
-                    float acc = gs[r * a.xld + nd.off + j];
-                    for (int sl = 0; sl < dv_slabs; ++sl) acc += gv[sl * vstride + r * a.vld + nd.vcol + j];
-                    gs[r * a.xld + nd.off + j] = acc;
-                }
-            }
-            if (a.dc > 0) {
-                for (int i = tid; i < ROWS * a.dc; i += NTHREADS) {
-                    const int r = i / a.dc, j = i - r * a.dc;
-                    float acc = gcs[r * a.cld + j];
-                    for (int ni = node_begin; ni < node_end; ++ni) {
-                        const VNodeU nd = load_vnode(vnodes, ni);
-                        for (int sl = 0; sl < dv_slabs; ++sl) acc += gv[sl * vstride + r * a.vld + nd.vcol + nd.k + j];
+            if (has_next) stage_begin(S, jl_next + gn.l1_off, packed, wave, lane);
+            // ---- scatter g_v: upper-lane columns to g (each lane has one v column per group),
+            //      condition columns to g_c (every node of the group contributes) ----
+            {
+                const LDS_AS int16_t* vm = vmap + g.vmap_begin;
+                for (int i = tid; i < ROWS * g.vw; i += NTHREADS) {
+                    const int r = i / g.vw, j = i - r * g.vw;
+                    const int m = vm[j];
+                    if (m >= 0) {
+                        float acc = gs[r * a.xld + m];
+                        for (int sl = 0; sl < g.dv_slabs; ++sl) acc += gv[sl * vstride + r * a.vld + j];
+                        gs[r * a.xld + m] = acc;
                     }
-                    gcs[r * a.cld + j] = acc;
+                }
+                if (a.dc > 0) {
+                    for (int i = tid; i < ROWS * a.dc; i += NTHREADS) {
+                        const int r = i / a.dc, cc = i - r * a.dc;
+                        float acc = gcs[r * a.cld + cc];
+                        for (int j = 0; j < g.vw; ++j)
+                            if (vm[j] == -2 - cc)
+                                for (int sl = 0; sl < g.dv_slabs; ++sl) acc += gv[sl * vstride + r * a.vld + j];
+                        gcs[r * a.cld + cc] = acc;
+                    }
                 }
             }
             STAMP(sbase + 18)
             lds_barrier();
             STAMP(sbase + 19)
             jb ^= 1;
+            g = gn;
         }
         store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid);
         if (a.dc > 0 && g_c != nullptr) store_tile(g_c, gcs, a.cld, a.dc, row0, a.B, tid);
@@ -766,9 +792,31 @@ constexpr int DW_WAVES = 8;
 
 __global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
     const DWJob* __restrict__ jobs, int n_jobs, int splits, const float* __restrict__ wsA1,
-    const float* __restrict__ wsG2, int WT, int Bp, int rows_per_wg, float* __restrict__ gparams) {
+    const float* __restrict__ wsG2, int WT, int Bp, int rows_per_wg, const float* __restrict__ wsT,
+    const int32_t* __restrict__ tmap, int thin_total, int ntiles, int tsplit, float* __restrict__ gparams) {
     __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
 
+    const int n_dw_blocks = n_jobs * splits;
+    if ((int)blockIdx.x >= n_dw_blocks) {
+        // ---- thin gradients (dW1, dW3, biases): sum the per-row-tile slabs part A wrote ----
+        const int id = (int)blockIdx.x - n_dw_blocks;
+        const int chunk = id / tsplit, part = id - chunk * tsplit;
+        const int idx = chunk * (DW_WAVES * 64) + (int)threadIdx.x;
+        if (idx >= thin_total) return;
+        const int per = (ntiles + tsplit - 1) / tsplit;
+        const int t0 = part * per, t1 = min(ntiles, t0 + per);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            s0 += wsT[(size_t)(t + 0) * thin_total + idx];
+            s1 += wsT[(size_t)(t + 1) * thin_total + idx];
+            s2 += wsT[(size_t)(t + 2) * thin_total + idx];
+            s3 += wsT[(size_t)(t + 3) * thin_total + idx];
+        }
+        for (; t < t1; ++t) s0 += wsT[(size_t)t * thin_total + idx];
+        if (t1 > t0) atomicAdd(gparams + tmap[idx], (s0 + s1) + (s2 + s3));
+        return;
+    }
     int jidx, split;
     {
         const int id = blockIdx.x;
@@ -899,18 +947,24 @@ hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const
 
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
                       const float* packed, const float* x, const float* tape, const float* c,
-                      const float* g_z, const float* g_J, float* g_x, float* g_c, float* gparams,
+                      const float* g_z, const float* g_J, float* g_x, float* g_c, float* wsT,
                       float* wsA1, float* wsG2, hipStream_t stream) {
     hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params,
-                       packed, x, tape, c, g_z, g_J, g_x, g_c, gparams, wsA1, wsG2);
+                       packed, x, tape, c, g_z, g_J, g_x, g_c, wsT, wsA1, wsG2);
     return hipGetLastError();
 }
 
 hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
-                     int Bp, int rows_per_wg, float* gparams, hipStream_t stream) {
-    if (n_jobs > 0)
-        hipLaunchKernelGGL(hint_block_dw_kernel, dim3(n_jobs * splits), dim3(DW_WAVES * 64), 0, stream, jobs,
-                           n_jobs, splits, wsA1, wsG2, WT, Bp, rows_per_wg, gparams);
+                     int Bp, int rows_per_wg, const float* wsT, const int32_t* tmap, int thin_total, int ntiles,
+                     float* gparams, hipStream_t stream) {
+    // thin-gradient reduction rides in the same launch: enough parts that a thread sums <= 32 slabs
+    int tsplit = (ntiles + 31) / 32;
+    if (tsplit < 1) tsplit = 1;
+    const int thin_blocks = ((thin_total + DW_WAVES * 64 - 1) / (DW_WAVES * 64)) * tsplit;
+    const int grid = n_jobs * splits + thin_blocks;
+    if (grid > 0)
+        hipLaunchKernelGGL(hint_block_dw_kernel, dim3(grid), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, splits,
+                           wsA1, wsG2, WT, Bp, rows_per_wg, wsT, tmap, thin_total, ntiles, tsplit, gparams);
     return hipGetLastError();
 }
 

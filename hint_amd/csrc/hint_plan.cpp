@@ -27,7 +27,8 @@ hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* para
                       const float* g_z, const float* g_J, float* g_x, float* g_c, float* gparams,
                       float* wsA1, float* wsG2, hipStream_t stream);
 hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
-                     int Bp, int rows_per_wg, float* gparams, hipStream_t stream);
+                     int Bp, int rows_per_wg, const float* wsT, const int32_t* tmap, int thin_total, int ntiles,
+                     float* gparams, hipStream_t stream);
 hipError_t set_max_lds(int fwd_bytes, int bwd_bytes);
 hipError_t set_stamp_buffer(unsigned long long* p);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
@@ -77,7 +78,11 @@ struct hint_plan {
     int s3 = 1, sv = 1;   // max K-split slabs of the layer-3 / dv stages
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
-    int meta_bytes = 0, vnodes_off = 0, ents_off = 0, jmax = 0, bmax = 0, n_bias = 0;
+    int meta_bytes = 0, vmap_off = 0, ents_off = 0, jmax = 0, bmax = 0, n_bias = 0;
+    int first[2][4] = {{0}};
+    int thin_total = 0;
+    int32_t* d_tmap = nullptr;
+    int32_t* d_tbmap = nullptr;
     void* d_meta = nullptr;      // [groups | vnodes | ents]
     GJob* d_jobs = nullptr;      // per-group job lists (GJob and OJob records, 16 bytes each)
     int32_t* d_bmap = nullptr;
@@ -153,6 +158,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<DGroup> dg;
     std::vector<GJob> jobs;                   // all groups' job lists (GJob and OJob records)
     std::vector<Ent> ents;
+    std::vector<int16_t> vmap;
+    std::vector<int32_t> tmap;     // compact thin-gradient index -> offset in the flat gradient buffer
+    std::vector<int32_t> tbmap;    // like bmap, but compact thin indices (bias gradients)
     std::vector<int32_t> bmap;
     std::vector<DWJob> dwj;
     std::vector<PackSeg> segs;
@@ -237,55 +245,88 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
         }
-        auto tile_jobs = [&](int which) {
+        struct TileJob { int64_t wtile; int nblk, acol, ocol, nvalid, slab; };
+        auto emit_stage = [&](int which) -> int {
             // which: 1 = L1, 2 = L2, 3 = L3, 4 = g2, 5 = g1, 6 = dv
-            const int begin = (int)jobs.size() - g.jl_begin;
+            std::vector<TileJob> tj;
             const int slabs = which == 3 ? g.l3_slabs : (which == 6 ? g.dv_slabs : 1);
             for (int sl = 0; sl < slabs; ++sl)
                 for (int ni = g.node_begin; ni < g.node_end; ++ni) {
                     const DNode& q = dn[ni];
-                    const hint_node_desc& n = *src[ni];
                     const NodePack& k = np[ni - g.node_begin];
                     const int nets = which == 6 ? 1 : 2;
                     for (int net = 0; net < nets; ++net) {
-                        int N, NB, acol, ocol0; int64_t wbase, boff;
+                        int N, NB, acol, ocol0; int64_t wbase;
                         switch (which) {
-                            case 1: N = q.h; NB = q.cinp / 16; acol = q.vcol; ocol0 = q.acol + net * q.hp; wbase = k.f1[net]; boff = n.p_off[net * 6 + 1]; break;
-                            case 2: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.f2[net]; boff = n.p_off[net * 6 + 3]; break;
-                            case 3: N = q.r; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.scol + net * q.rp; wbase = k.f3[net]; boff = n.p_off[net * 6 + 5]; break;
-                            case 4: N = q.h; NB = q.rp / 16; acol = q.scol + net * q.rp; ocol0 = q.acol + net * q.hp; wbase = k.b3[net]; boff = -1; break;
-                            case 5: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.b2[net]; boff = -1; break;
-                            default: N = q.cin; NB = 2 * q.hp / 16; acol = q.acol; ocol0 = q.vcol; wbase = k.bdv; boff = -1; break;
+                            case 1: N = q.h; NB = q.cinp / 16; acol = q.vcol; ocol0 = q.acol + net * q.hp; wbase = k.f1[net]; break;
+                            case 2: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.f2[net]; break;
+                            case 3: N = q.r; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.scol + net * q.rp; wbase = k.f3[net]; break;
+                            case 4: N = q.h; NB = q.rp / 16; acol = q.scol + net * q.rp; ocol0 = q.acol + net * q.hp; wbase = k.b3[net]; break;
+                            case 5: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.b2[net]; break;
+                            default: N = q.cin; NB = 2 * q.hp / 16; acol = q.acol; ocol0 = q.vcol; wbase = k.bdv; break;
                         }
                         // this slab's share of the k-blocks
                         const int kb0 = (int)((int64_t)NB * sl / slabs), kb1 = (int)((int64_t)NB * (sl + 1) / slabs);
                         const int NT = (N + 15) / 16;
                         for (int nt = 0; nt < NT; ++nt) {
-                            GJob jb{};
-                            if (kb1 > kb0) {
-                                jb.wtile = (int32_t)(wbase / 256 + (int64_t)nt * NB + kb0);
-                                jb.nblk = (uint8_t)(kb1 - kb0);
-                                jb.acol = (uint16_t)(acol + kb0 * 16);
-                            } else {            // K = 0 (cin = 0 with min_split_size 1) or empty slab
-                                jb.wtile = 0; jb.nblk = 0; jb.acol = 0;
-                            }
-                            jb.ocol = (uint16_t)(ocol0 + nt * 16);
-                            jb.boff = (sl == 0 && boff >= 0) ? (int32_t)(boff + nt * 16) : -1;
-                            jb.nvalid = (uint8_t)std::min(16, N - nt * 16);
-                            jb.slab = (uint8_t)sl;
-                            jobs.push_back(jb);
+                            TileJob t{};
+                            if (kb1 > kb0) { t.wtile = wbase / 256 + (int64_t)nt * NB + kb0; t.nblk = kb1 - kb0; t.acol = acol + kb0 * 16; }
+                            else { t.wtile = 0; t.nblk = 0; t.acol = 0; }   // K = 0 (cin = 0) or empty slab
+                            t.ocol = ocol0 + nt * 16;
+                            t.nvalid = std::min(16, N - nt * 16);
+                            t.slab = sl;
+                            tj.push_back(t);
                         }
                     }
                 }
-            return std::make_pair(begin, (int)jobs.size() - g.jl_begin - begin);
+            // deal the tile jobs to the wavefronts, longest first onto the least loaded wavefront
+            std::vector<int> idx(tj.size());
+            for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return tj[x].nblk > tj[y].nblk; });
+            std::vector<std::vector<int>> per_wave(NWAVES);
+            int load[NWAVES] = {0};
+            for (int i : idx) {
+                int w = 0;
+                for (int v = 1; v < NWAVES; ++v) if (load[v] < load[w]) w = v;
+                per_wave[w].push_back(i);
+                load[w] += std::max(tj[i].nblk, 1) + 1;     // +1: epilogue / tile switch cost
+            }
+            const int hdr = (int)jobs.size() - g.jl_begin;
+            uint16_t first[16] = {0};
+            std::vector<Chunk> chunks;
+            for (int w = 0; w < NWAVES; ++w) {
+                first[w] = (uint16_t)chunks.size();
+                for (int i : per_wave[w]) {
+                    const TileJob& t = tj[i];
+                    const int nch = std::max(1, (t.nblk + 3) / 4);
+                    for (int cidx = 0; cidx < nch; ++cidx) {
+                        Chunk c{};
+                        c.wtile = (int32_t)(t.wtile + 4 * cidx);
+                        c.acol = (uint16_t)(t.acol + 64 * cidx);
+                        c.ocol = (uint16_t)t.ocol;
+                        c.nv = (uint8_t)std::max(0, std::min(4, t.nblk - 4 * cidx));
+                        c.last = (uint8_t)(cidx == nch - 1);
+                        c.nvalid = (uint8_t)t.nvalid;
+                        c.slab = (uint8_t)t.slab;
+                        chunks.push_back(c);
+                    }
+                }
+            }
+            first[NWAVES] = (uint16_t)chunks.size();
+            Chunk h[STAGE_HDR_RECORDS];
+            static_assert(sizeof(h) == sizeof(first), "stage header is 16 uint16");
+            std::memcpy(h, first, sizeof h);
+            for (const Chunk& c : h) jobs.push_back(c);
+            for (const Chunk& c : chunks) jobs.push_back(c);
+            return hdr;
         };
         g.jl_begin = (int)jobs.size();
-        std::tie(g.l1_off, g.l1_cnt) = tile_jobs(1);
-        std::tie(g.l2_off, g.l2_cnt) = tile_jobs(2);
-        std::tie(g.l3_off, g.l3_cnt) = tile_jobs(3);
-        std::tie(g.g2_off, g.g2_cnt) = tile_jobs(4);
-        std::tie(g.g1_off, g.g1_cnt) = tile_jobs(5);
-        std::tie(g.dv_off, g.dv_cnt) = tile_jobs(6);
+        g.l1_off = emit_stage(1);
+        g.l2_off = emit_stage(2);
+        g.l3_off = emit_stage(3);
+        g.g2_off = emit_stage(4);
+        g.g1_off = emit_stage(5);
+        g.dv_off = emit_stage(6);
         auto push_ojob = [&](const OJob& o) {
             GJob raw;
             static_assert(sizeof(OJob) == sizeof(GJob), "job records share one 16-byte array");
@@ -294,17 +335,23 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         };
 
         // ---- in-kernel outer-product jobs (dW3 = g_st^T a2, dW1 = g1^T v) + bias maps ----
+        auto thin_alloc = [&](int64_t param_off, int count) {   // contiguous compact range mirroring a tensor
+            const int base = (int)tmap.size();
+            for (int i = 0; i < count; ++i) tmap.push_back((int32_t)(param_off + i));
+            return base;
+        };
         g.o3_off = (int)jobs.size() - g.jl_begin;
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net) {
                 const DNode& q = dn[ni];
+                const int tbase = thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h);
                 for (int mt = 0; mt < q.rp / 16; ++mt)
                     for (int nt = 0; nt < q.hp / 16; ++nt) {
                         OJob o{};
                         o.acol = (uint16_t)(q.scol + net * q.rp + mt * 16); o.bcol = (uint16_t)(q.acol + net * q.hp + nt * 16);
                         const int mv = std::min(16, q.r - mt * 16), nv = std::min(16, q.h - nt * 16);
                         o.mvalid = (uint8_t)std::max(mv, 0); o.nvalid = (uint8_t)std::max(nv, 0);
-                        o.ldg = (uint16_t)q.h; o.goff = (int32_t)(src[ni]->p_off[net * 6 + 4] + (int64_t)mt * 16 * q.h + nt * 16);
+                        o.ldg = (uint16_t)q.h; o.goff = (int32_t)(tbase + (int64_t)mt * 16 * q.h + nt * 16);
                         if (mv > 0 && nv > 0) push_ojob(o);
                     }
             }
@@ -313,13 +360,14 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net) {
                 const DNode& q = dn[ni];
+                const int tbase = thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin);
                 for (int mt = 0; mt < q.hp / 16; ++mt)
                     for (int nt = 0; nt < q.cinp / 16; ++nt) {
                         OJob o{};
                         o.acol = (uint16_t)(q.acol + net * q.hp + mt * 16); o.bcol = (uint16_t)(q.vcol + nt * 16);
                         const int mv = std::min(16, q.h - mt * 16), nv = std::min(16, q.cin - nt * 16);
                         o.mvalid = (uint8_t)std::max(mv, 0); o.nvalid = (uint8_t)std::max(nv, 0);
-                        o.ldg = (uint16_t)q.cin; o.goff = (int32_t)(src[ni]->p_off[net * 6 + 0] + (int64_t)mt * 16 * q.cin + nt * 16);
+                        o.ldg = (uint16_t)q.cin; o.goff = (int32_t)(tbase + (int64_t)mt * 16 * q.cin + nt * 16);
                         if (mv > 0 && nv > 0) push_ojob(o);
                     }
             }
@@ -336,14 +384,29 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int layer = 0; layer < 2; ++layer)          // b1 map, then b2 map, aw entries each
             for (int ni = g.node_begin; ni < g.node_end; ++ni)
                 for (int net = 0; net < 2; ++net)
-                    for (int j = 0; j < dn[ni].hp; ++j)
+                {
+                    const int tb = thin_alloc(src[ni]->p_off[net * 6 + (layer ? 3 : 1)], dn[ni].h);
+                    for (int j = 0; j < dn[ni].hp; ++j) {
                         bmap.push_back(j < dn[ni].h ? (int32_t)(src[ni]->p_off[net * 6 + (layer ? 3 : 1)] + j) : -1);
+                        tbmap.push_back(j < dn[ni].h ? tb + j : -1);
+                    }
+                }
         g.bmap3_begin = (int)bmap.size();
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net)
-                for (int j = 0; j < dn[ni].rp; ++j)
+            {
+                const int tb = thin_alloc(src[ni]->p_off[net * 6 + 5], dn[ni].r);
+                for (int j = 0; j < dn[ni].rp; ++j) {
                     bmap.push_back(j < dn[ni].r ? (int32_t)(src[ni]->p_off[net * 6 + 5] + j) : -1);
+                    tbmap.push_back(j < dn[ni].r ? tb + j : -1);
+                }
+            }
 
+        g.vmap_begin = (int)vmap.size();
+        for (int ni = g.node_begin; ni < g.node_end; ++ni)
+            for (int j = 0; j < dn[ni].cinp; ++j)
+                vmap.push_back(j < dn[ni].k ? (int16_t)(dn[ni].off + j)
+                                             : (j < dn[ni].cin ? (int16_t)(-2 - (j - dn[ni].k)) : (int16_t)-1));
         g.ent_begin = (int)ents.size();
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int j = 0; j < dn[ni].r; ++j)
@@ -363,21 +426,23 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->ald = lds_stride(max_aw);
     P->vld = lds_stride(max_vw);
     P->sld = lds_stride(max_sw);
-    // ---- meta blob staged in LDS by the kernels: [groups | vnodes | ents] ----
-    std::vector<VNode> vn(dn.size());
-    for (size_t i = 0; i < dn.size(); ++i)
-        vn[i] = VNode{(int16_t)dn[i].off, (int16_t)dn[i].k, (int16_t)dn[i].cin, (int16_t)dn[i].cinp, (int16_t)dn[i].vcol, 0};
+    // ---- meta blob staged in LDS by the kernels: [groups | vmap | ents] ----
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t groups_bytes = up16(dg.size() * sizeof(DGroup));
-    const size_t vnodes_bytes = up16(vn.size() * sizeof(VNode));
+    const size_t vmap_bytes = up16(vmap.size() * sizeof(int16_t));
     const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
-    P->vnodes_off = (int)groups_bytes;
-    P->ents_off = (int)(groups_bytes + vnodes_bytes);
-    P->meta_bytes = (int)(groups_bytes + vnodes_bytes + ents_bytes);
+    P->vmap_off = (int)groups_bytes;
+    P->ents_off = (int)(groups_bytes + vmap_bytes);
+    P->meta_bytes = (int)(groups_bytes + vmap_bytes + ents_bytes);
     std::vector<char> meta(P->meta_bytes, 0);
     std::memcpy(meta.data(), dg.data(), dg.size() * sizeof(DGroup));
-    std::memcpy(meta.data() + P->vnodes_off, vn.data(), vn.size() * sizeof(VNode));
-    std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
+    if (!vmap.empty()) std::memcpy(meta.data() + P->vmap_off, vmap.data(), vmap.size() * sizeof(int16_t));
+    if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
+    for (int o = 0; o < 2; ++o) {
+        const DGroup& fg = o == 0 ? dg.front() : dg.back();
+        P->first[o][0] = fg.jl_begin; P->first[o][1] = fg.jl_count;
+        P->first[o][2] = fg.bmap_begin; P->first[o][3] = 2 * fg.aw + fg.sw;
+    }
     P->n_bias = (int)bmap.size();
     const int fixed = P->meta_bytes + 2 * P->jmax * (int)sizeof(GJob) + 2 * P->bmax * 4;
     P->lds_fwd = fixed + fwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3);
@@ -413,6 +478,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
     if (e == hipSuccess) e = upload((void**)&P->d_jobs, jobs.data(), jobs.size() * sizeof(GJob));
+    P->thin_total = (int)tmap.size();
+    if (e == hipSuccess) e = upload((void**)&P->d_tmap, tmap.data(), tmap.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = upload((void**)&P->d_tbmap, tbmap.data(), tbmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_bmap, bmap.data(), bmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_dwjobs, dwj.data(), dwj.size() * sizeof(DWJob));
     if (e == hipSuccess) e = upload((void**)&P->d_segs, segs.data(), segs.size() * sizeof(PackSeg));
@@ -464,6 +532,8 @@ void hint_plan_destroy(hint_plan* P) {
     (void)hipFree(P->d_meta);
     (void)hipFree(P->d_jobs);
     (void)hipFree(P->d_bmap);
+    (void)hipFree(P->d_tmap);
+    (void)hipFree(P->d_tbmap);
     (void)hipFree(P->d_dwjobs);
     (void)hipFree(P->d_segs);
     (void)hipFree(P->d_ptiles);
@@ -473,7 +543,7 @@ void hint_plan_destroy(hint_plan* P) {
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
 // +1 KiB of slack: the chunk prefetcher of the GEMM stages never reads past a job's last
 // k-block, but keeping a margin makes that robust against future tuning
-int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 256 : -1; }
+int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 4 * 256 : -1; }
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
@@ -485,7 +555,7 @@ static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
     if (!P || B <= 0) return 0;
     const size_t Bp = rows_padded(B);
-    const size_t floats = 2 * (Bp * (size_t)P->WT + WS_SLACK);
+    const size_t floats = 2 * (Bp * (size_t)P->WT + WS_SLACK) + (Bp / ROWS) * (size_t)P->thin_total + WS_SLACK;
     return floats * sizeof(float);
 }
 
@@ -495,8 +565,9 @@ int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
 
 static KArgs make_args(const hint_plan* P, int B) {
     KArgs a{};
-    a.meta = P->d_meta; a.jobs = P->d_jobs; a.bmap = P->d_bmap;
-    a.meta_bytes = P->meta_bytes; a.vnodes_off = P->vnodes_off; a.ents_off = P->ents_off; a.jmax = P->jmax;
+    a.meta = P->d_meta; a.jobs = P->d_jobs; a.bmap = P->d_tbmap; a.thin_total = P->thin_total;
+    a.meta_bytes = P->meta_bytes; a.vmap_off = P->vmap_off; a.ents_off = P->ents_off; a.jmax = P->jmax;
+    std::memcpy(a.first, P->first, sizeof a.first);
     a.bmax = P->bmax; a.bias_off = P->packed_floats;
     a.s3 = P->s3; a.sv = P->sv;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
@@ -555,12 +626,13 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* pa
     const size_t Bp = rows_padded(B);
     float* wsA1 = (float*)workspace;
     float* wsG2 = wsA1 + Bp * P->WT + WS_SLACK;
+    float* wsT = wsG2 + Bp * P->WT + WS_SLACK;     // [row tile][thin_total] partial thin gradients
 
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
     if (g_bwd_stages & 1)
         HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, packed, x, tape, c, g_z, g_J,
-                           g_x, g_c, g_params, wsA1, wsG2, s));
+                           g_x, g_c, wsT, wsA1, wsG2, s));
     if (!(g_bwd_stages & 2)) return 0;
     // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
     // to cover the chip, every workgroup reducing at least 128 rows
@@ -570,7 +642,8 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* pa
     rows_per_wg = (rows_per_wg + 15) / 16 * 16;
     if ((long)rows_per_wg * (splits - 1) >= (long)Bp)   // tiny batches: fewer, non-empty splits
         splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
-    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsA1, wsG2, P->WT, (int)Bp, rows_per_wg, g_params, s));
+    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsA1, wsG2, P->WT, (int)Bp, rows_per_wg, wsT, P->d_tmap,
+                      P->thin_total, ntiles, g_params, s));
     return 0;
 }
 

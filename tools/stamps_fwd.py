@@ -25,6 +25,8 @@ for gi in range(4):
     for k, nm in enumerate(["build_v", "sync", "L1", "sync", "L2", "sync", "L3", "sync", "couple", "sync"]):
         names[2 + 12 * gi + k] = f"g{gi}:{nm}"
 names[120] = "stored"
+for k in range(60):
+    names[60 + k] = "L2root:" + ["top", "decoded", "fetched", "aread", "mma"][k % 5] + f"#{k // 5}" if k < 15 else f"L2root:s{k}"
 ids = [i for i in sorted(names) if s[0, i] != 0]
 t0 = s[:, 0].min().item()
 print("stage".ljust(16) + "".join(f"w{w}".rjust(9) for w in range(8)) + "   (cycles since start; delta of wave 0)")
