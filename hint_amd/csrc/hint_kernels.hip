@@ -459,15 +459,17 @@ template <bool REV>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_block_apply_kernel(
     KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
-    float* __restrict__ J, float* __restrict__ tape) {
+    float* __restrict__ J, float* __restrict__ tape, const float* __restrict__ perm,
+    const float* __restrict__ J_in, float* __restrict__ loss_acc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     STAMP(0)
     HINT_LDS_TABLES()
-    float* xs = fbase;
-    float* cs = xs + ROWS * a.xld;
+    float* xin = fbase;                      // the tile as loaded (only used when a permutation is fused)
+    float* xs = perm != nullptr ? xin + ROWS * a.xld : xin;
+    float* cs = xin + 2 * ROWS * a.xld;
     float* vb = cs + ROWS * a.cld;
     float* a1 = vb + ROWS * a.vld;
     float* a2 = a1 + ROWS * a.ald;
@@ -487,10 +489,27 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
-        load_tile(xs, a.xld, x, a.d, row0, a.B, tid);
+        load_tile(xin, a.xld, x, a.d, row0, a.B, tid);
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
         if (tid < ROWS) jac[tid] = 0.f;
         __syncthreads();                      // meta, first chunk lists and the lane tile visible
+        if (perm != nullptr) {
+            // fused fixed inter-block permutation (power_hint_8.py:59-62): forward x' = x W,
+            // inverse x = x' W^T is applied on the way out instead
+            if (!REV) {
+                for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                    const int r = i / a.d, j = i - r * a.d;
+                    float acc = 0.f;
+                    for (int k = 0; k < a.d; ++k) acc = fmaf(xin[r * a.xld + k], perm[k * a.d + j], acc);
+                    xs[r * a.xld + j] = acc;
+                }
+            } else {
+                for (int i = tid; i < ROWS * a.d; i += NTHREADS) { const int r = i / a.d, j = i - r * a.d; xs[r * a.xld + j] = xin[r * a.xld + j]; }
+            }
+            __syncthreads();
+            if (!REV && tape != nullptr)      // the permuted input is what the backward pass starts from
+                store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
+        }
         STAMP(1)
         GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
         if (first_tile) stage_begin(S, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
@@ -564,8 +583,37 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             jb ^= 1;
             g = gn;
         }
-        store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
-        if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid];
+        if (REV && perm != nullptr) {         // x = x' W^T
+            for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                const int r = i / a.d, j = i - r * a.d;
+                float acc = 0.f;
+                for (int k = 0; k < a.d; ++k) acc = fmaf(xs[r * a.xld + k], perm[j * a.d + k], acc);
+                xin[r * a.xld + j] = acc;
+            }
+            __syncthreads();
+            store_tile(z, xin, a.xld, a.d, row0, a.B, tid);
+        } else {
+            store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
+        }
+        if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid] + (J_in != nullptr ? J_in[row0 + tid] : 0.f);
+        if (loss_acc != nullptr) {
+            // per-workgroup partial sums of the two loss terms (train_unconditional.py:128-129):
+            // loss_acc[0] += sum_rows 0.5*|z|^2, loss_acc[1] += sum_rows J_total
+            float zz = 0.f;
+            const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS);
+            for (int i = tid; i < nvalid * a.d; i += NTHREADS) { const int r = i / a.d; const float v = xs[r * a.xld + (i - r * a.d)]; zz += v * v; }
+            for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o, 64);
+            if (lane == 0) vb[wave] = zz;      // vb is free at this point
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (int w = 0; w < NWAVES; ++w) t += vb[w];
+                float js = 0.f;
+                for (int r = 0; r < nvalid; ++r) js += jac[r] + (J_in != nullptr ? J_in[row0 + r] : 0.f);
+                atomicAdd(loss_acc, 0.5f * t);
+                atomicAdd(loss_acc + 1, js);
+            }
+        }
         STAMP(120)
         lds_barrier();
     }
@@ -600,7 +648,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float* __restrict__ x, const float* __restrict__ tape, const float* __restrict__ c,
     const float* __restrict__ g_z, const float* __restrict__ g_J, float* __restrict__ g_x,
     float* __restrict__ g_c, float* __restrict__ wsT, float* __restrict__ wsA1,
-    float* __restrict__ wsG2) {
+    float* __restrict__ wsG2, const float* __restrict__ perm, float gz_scale, float gJ_const) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -633,11 +681,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int row0 = tile * ROWS;
         float* gparams = wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
         load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid);
+        if (gz_scale != 1.f)                   // loss gradient fused: g_z = z / B given z
+            for (int i = tid; i < ROWS * a.d; i += NTHREADS) { const int r = i / a.d; gs[r * a.xld + (i - r * a.d)] *= gz_scale; }
         if (a.dc > 0) {
             load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
             load_tile(gcs, a.cld, nullptr, a.dc, row0, a.B, tid);
         }
-        if (tid < ROWS) gj[tid] = (g_J != nullptr && row0 + tid < a.B) ? g_J[row0 + tid] : 0.f;
+        if (tid < ROWS) gj[tid] = (row0 + tid < a.B) ? (g_J != nullptr ? g_J[row0 + tid] : gJ_const) : 0.f;
         __syncthreads();
         STAMP(1)
         GroupU g = load_group(groups + (a.n_groups - 1));
@@ -661,7 +711,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 
             // ---- the lanes as the forward pass saw them when it entered this level ----
             if (g.level_last) {
-                const float* src = (g.level == 0) ? x : tape + (size_t)(g.level - 1) * a.B * a.d;
+                const float* src = (g.level == 0) ? (perm != nullptr ? tape + (size_t)(a.n_levels - 1) * a.B * a.d : x)
+                                                  : tape + (size_t)(g.level - 1) * a.B * a.d;
                 load_tile(xs, a.xld, src, a.d, row0, a.B, tid);
                 lds_barrier();
             }
@@ -772,7 +823,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             jb ^= 1;
             g = gn;
         }
-        store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid);
+        if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
+            for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                const int r = i / a.d, j = i - r * a.d;
+                float acc = 0.f;
+                for (int k = 0; k < a.d; ++k) acc = fmaf(gs[r * a.xld + k], perm[j * a.d + k], acc);
+                xs[r * a.xld + j] = acc;       // xs is free after the last level
+            }
+            __syncthreads();
+            store_tile(g_x, xs, a.xld, a.d, row0, a.B, tid);
+        } else {
+            store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid);
+        }
         if (a.dc > 0 && g_c != nullptr) store_tile(g_c, gcs, a.cld, a.dc, row0, a.B, tid);
         STAMP(120)
         lds_barrier();
@@ -935,22 +997,24 @@ hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream) {
 
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
                         const float* packed, const float* x, const float* c, float* z, float* J,
-                        float* tape, hipStream_t stream) {
+                        float* tape, const float* perm, const float* J_in, float* loss_acc,
+                        hipStream_t stream) {
     if (rev)
         hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a,
-                           params, packed, x, c, z, J, (float*)nullptr);
+                           params, packed, x, c, z, J, (float*)nullptr, perm, J_in, (float*)nullptr);
     else
         hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a,
-                           params, packed, x, c, z, J, tape);
+                           params, packed, x, c, z, J, tape, perm, J_in, loss_acc);
     return hipGetLastError();
 }
 
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
                       const float* packed, const float* x, const float* tape, const float* c,
                       const float* g_z, const float* g_J, float* g_x, float* g_c, float* wsT,
-                      float* wsA1, float* wsG2, hipStream_t stream) {
+                      float* wsA1, float* wsG2, const float* perm, float gz_scale, float gJ_const,
+                      hipStream_t stream) {
     hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params,
-                       packed, x, tape, c, g_z, g_J, g_x, g_c, wsT, wsA1, wsG2);
+                       packed, x, tape, c, g_z, g_J, g_x, g_c, wsT, wsA1, wsG2, perm, gz_scale, gJ_const);
     return hipGetLastError();
 }
 

@@ -21,11 +21,13 @@ hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, con
 hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
                         const float* packed, const float* x, const float* c, float* z, float* J,
-                        float* tape, hipStream_t stream);
+                        float* tape, const float* perm, const float* J_in, float* loss_acc,
+                        hipStream_t stream);
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
                       const float* packed, const float* x, const float* tape, const float* c,
                       const float* g_z, const float* g_J, float* g_x, float* g_c, float* gparams,
-                      float* wsA1, float* wsG2, hipStream_t stream);
+                      float* wsA1, float* wsG2, const float* perm, float gz_scale, float gJ_const,
+                      hipStream_t stream);
 hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
                      int Bp, int rows_per_wg, const float* wsT, const int32_t* tmap, int thin_total, int ntiles,
                      float* gparams, hipStream_t stream);
@@ -96,7 +98,7 @@ static constexpr int WS_SLACK = 64;   // floats of slack at the end of every wor
 static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 
 static int fwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3) {
-    return 4 * ROWS * (xld + cld + vld + 2 * ald + s3 * sld + 1);
+    return 4 * ROWS * (2 * xld + cld + vld + 2 * ald + s3 * sld + 1);
 }
 static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, int sv) {
     return 4 * ROWS * (2 * xld + 2 * cld + (1 + sv) * vld + 2 * ald + (s3 + 1) * sld + 1);
@@ -547,7 +549,7 @@ int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_float
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
-    return (int64_t)(P->n_levels - 1) * B * P->d;
+    return (int64_t)P->n_levels * B * P->d;    // (levels-1) snapshots + the permuted input of the _ex form
 }
 
 static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
@@ -585,7 +587,8 @@ int hint_block_pack(const hint_plan* P, const float* params, float* packed, void
 }
 
 static int apply(const hint_plan* P, bool rev, const float* params, const float* packed, const float* x,
-                 const float* c, float* z, float* J, float* tape, int32_t B, void* stream) {
+                 const float* c, float* z, float* J, float* tape, const float* perm, const float* J_in,
+                 float* loss_acc, int32_t B, void* stream) {
     const char* what = rev ? "inverse" : "forward";
     if (!P || !params || !packed || !x || !z || !J) return fail("hint_block_%s: null argument", what);
     if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", what, P->dc);
@@ -593,26 +596,48 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     if (B == 0) return 0;
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, packed, x, c, z, J, tape,
-                         (hipStream_t)stream));
+    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, packed, x, c, z, J, tape, perm, J_in,
+                         loss_acc, (hipStream_t)stream));
     return 0;
 }
 
 int hint_block_forward(const hint_plan* P, const float* params, const float* packed, const float* x,
                        const float* c, float* z, float* J, float* tape, int32_t B, void* stream) {
-    return apply(P, false, params, packed, x, c, z, J, tape, B, stream);
+    return apply(P, false, params, packed, x, c, z, J, tape, nullptr, nullptr, nullptr, B, stream);
+}
+
+int hint_block_forward_ex(const hint_plan* P, const float* params, const float* packed, const float* x,
+                          const float* c, float* z, float* J, float* tape, const float* perm,
+                          const float* J_in, float* loss_acc, int32_t B, void* stream) {
+    return apply(P, false, params, packed, x, c, z, J, tape, perm, J_in, loss_acc, B, stream);
 }
 
 int hint_block_inverse(const hint_plan* P, const float* params, const float* packed, const float* z,
                        const float* c, float* x, float* J, int32_t B, void* stream) {
-    return apply(P, true, params, packed, z, c, x, J, nullptr, B, stream);
+    return apply(P, true, params, packed, z, c, x, J, nullptr, nullptr, nullptr, nullptr, B, stream);
+}
+
+int hint_block_inverse_ex(const hint_plan* P, const float* params, const float* packed, const float* z,
+                          const float* c, float* x, float* J, const float* perm, const float* J_in,
+                          int32_t B, void* stream) {
+    return apply(P, true, params, packed, z, c, x, J, nullptr, perm, J_in, nullptr, B, stream);
 }
 
 int hint_block_backward(const hint_plan* P, const float* params, const float* packed, const float* x,
                         const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
                         float* g_c, float* g_params, int32_t accumulate, void* workspace,
                         size_t workspace_bytes, int32_t B, void* stream) {
-    if (!P || !params || !packed || !x || !g_x || !g_params) return fail("hint_block_backward: null argument");
+    return hint_block_backward_ex(P, params, packed, x, tape, c, g_z, g_J, g_x, g_c, g_params, accumulate,
+                                  workspace, workspace_bytes, nullptr, 1.0f, 0.0f, B, stream);
+}
+
+int hint_block_backward_ex(const hint_plan* P, const float* params, const float* packed, const float* x,
+                           const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
+                           float* g_c, float* g_params, int32_t accumulate, void* workspace,
+                           size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
+                           int32_t B, void* stream) {
+    if (!P || !params || !packed || (!x && !perm) || !g_x || !g_params) return fail("hint_block_backward: null argument");
+    if (perm && !tape) return fail("hint_block_backward_ex: a fused permutation needs the tape of hint_block_forward_ex");
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
     if (P->n_levels > 1 && !tape && B > 0) return fail("hint_block_backward: tape is NULL but the tree has %d levels", P->n_levels);
     if (B < 0) return fail("negative batch");
@@ -632,7 +657,7 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* pa
     const int grid = std::min(ntiles, P->num_cu * 8);
     if (g_bwd_stages & 1)
         HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, packed, x, tape, c, g_z, g_J,
-                           g_x, g_c, wsT, wsA1, wsG2, s));
+                           g_x, g_c, wsT, wsA1, wsG2, perm, gz_scale, gJ_const, s));
     if (!(g_bwd_stages & 2)) return 0;
     // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
     // to cover the chip, every workgroup reducing at least 128 rows

@@ -23,7 +23,8 @@ from .hint import HierarchicalAffineCouplingBlock, HintAmdError
 def random_orthogonal(d: int, seed: int) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     q, r = torch.linalg.qr(torch.randn(d, d, generator=g, dtype=torch.float64))
-    return (q * torch.sign(torch.diagonal(r))).to(torch.float32)
+    # QR returns column-major storage; the kernels read W through its raw pointer as row-major
+    return (q * torch.sign(torch.diagonal(r))).to(torch.float32).contiguous()
 
 
 class FixedOrthogonal(nn.Module):
@@ -32,7 +33,7 @@ class FixedOrthogonal(nn.Module):
     def __init__(self, dims_in, dims_c=[], seed: int = 0, W: Optional[torch.Tensor] = None):
         super().__init__()
         d = dims_in[0][0]
-        self.register_buffer("W", random_orthogonal(d, seed) if W is None else W.clone().to(torch.float32))
+        self.register_buffer("W", random_orthogonal(d, seed) if W is None else W.clone().to(torch.float32).contiguous())
 
     def forward(self, x, c=[], rev=False):
         return [x[0] @ (self.W.t() if rev else self.W)]

@@ -169,6 +169,40 @@ class _Engine:
             _lib.check(st, "hint_block_inverse" if rev else "hint_block_forward")
         return (out, J, tape) if with_tape else (out, J)
 
+    # ---- chained forms (flow container / trainer): permutation, J accumulation, loss fused ----
+    def forward_chain(self, x, c, perm, J_in, loss_acc, with_tape: bool):
+        B = x.shape[0]
+        out = torch.empty_like(x)
+        J = torch.empty(B, dtype=torch.float32, device=x.device)
+        tape = None
+        if with_tape:
+            tape = torch.empty(max(self.lib.hint_plan_tape_floats(self.plan, B), 1), dtype=torch.float32,
+                               device=x.device)
+        if B > 0:
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            with torch.cuda.device(self.device):
+                st = self.lib.hint_block_forward_ex(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
+                                                    x.data_ptr(), ptr(c), out.data_ptr(), J.data_ptr(), ptr(tape),
+                                                    ptr(perm), ptr(J_in), ptr(loss_acc), B, self._stream())
+            _lib.check(st, "hint_block_forward_ex")
+        return out, J, tape
+
+    def backward_chain(self, x, tape, c, gz, gz_scale, gJ_const, perm, g_params, accumulate=True):
+        B = gz.shape[0]
+        gx = torch.empty_like(gz)
+        if B == 0:
+            return gx
+        nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gz.device)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_block_backward_ex(
+                self.plan, self.arena.data_ptr(), self.packed.data_ptr(), ptr(x), ptr(tape), ptr(c), gz.data_ptr(),
+                None, gx.data_ptr(), None, g_params.data_ptr(), 1 if accumulate else 0, ws.data_ptr(), nbytes,
+                ptr(perm), float(gz_scale), float(gJ_const), B, self._stream())
+        _lib.check(st, "hint_block_backward_ex")
+        return gx
+
     def backward(self, x, tape, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None,
                  accumulate: bool = False):
         B = x.shape[0]

@@ -52,34 +52,42 @@ class FlowTrainer:
             e.bind_external_arena(self.P[a:b])
             e.ensure_arena()
             e.pack()
+        self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        for i in range(flow.n_blocks):          # the kernels read W through its raw pointer (row-major)
+            if flow.has_perm(i) and not flow.perms[i].W.is_contiguous():
+                flow.perms[i].W = flow.perms[i].W.contiguous()
         self._graph = None
         self._static = None
 
     # ---- the un-captured step body ----------------------------------------------------
     def _fwd_bwd(self, x: torch.Tensor, c: Optional[torch.Tensor]):
+        """pack -> forward chain -> backward chain, every piece a direct C-ABI launch: the fixed
+        permutations, the running log-det, the two loss sums and the loss gradient are folded
+        into the block kernels (hint_block_*_ex)."""
         flow, B = self.flow, x.shape[0]
+        for e in self.engines:               # weights of the previous optimizer step, MFMA order
+            e.pack()
         if self.noise > 0:
-            x = x + self.noise * torch.randn_like(x)
+            x = x.add(torch.randn_like(x), alpha=self.noise)
+        self.loss_acc.zero_()
         inputs, tapes = [], []
-        h, Jtot = x, None
+        h, J = x, None
+        n = len(self.engines)
         for i, eng in enumerate(self.engines):
-            if flow.has_perm(i):
-                h = h @ flow.perms[i].W
-            inputs.append(h)
-            h, J, tape = eng.apply(h, c, rev=False, with_tape=True)
+            perm = flow.perms[i].W if flow.has_perm(i) else None
+            inputs.append(h if perm is None else None)
+            h, J, tape = eng.forward_chain(h, c, perm, J, self.loss_acc if i == n - 1 else None, with_tape=True)
             tapes.append(tape)
-            Jtot = J if Jtot is None else Jtot + J
         z = h
-        l0 = 0.5 * torch.sum(z * z, dim=1).mean()
-        l1 = -Jtot.mean()
-        gz = z * (1.0 / B)
-        gJ = torch.full((B,), -1.0 / B, dtype=torch.float32, device=x.device)
-        for i in reversed(range(len(self.engines))):
+        g = z                                  # dL/dz = z / B : the scale is applied inside the kernel
+        for i in reversed(range(n)):
             a, b = self.slices[i]
-            gz, _, _ = self.engines[i].backward(inputs[i], tapes[i], c, gz, gJ, need_gc=False, g_params=self.G[a:b],
-                                                accumulate=True)   # G is cleared by the optimizer kernel
-            if flow.has_perm(i):
-                gz = gz @ flow.perms[i].W.t()
+            perm = flow.perms[i].W if flow.has_perm(i) else None
+            g = self.engines[i].backward_chain(inputs[i], tapes[i], c, g, (1.0 / B) if i == n - 1 else 1.0,
+                                               -1.0 / B, perm, self.G[a:b], accumulate=True)
+        # loss terms as the reference logs them ('-log p(z)', '-log |det J|'), lazily scaled views
+        l0 = self.loss_acc[0] / B
+        l1 = -self.loss_acc[1] / B
         return l0, l1
 
     def _check_arenas(self):
@@ -106,8 +114,6 @@ class FlowTrainer:
                                          self.eps, self.wd, grad_scale, self.grad_clamp, 1,
                                          torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(st, "hint_adam_step")
-        for e in self.engines:      # the new weights in MFMA fragment order for the next step
-            e.pack()
 
     def step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
         """one training iteration on this rank's shard; returns device scalars (l0, l1) =

@@ -65,7 +65,7 @@ int64_t hint_plan_param_floats(const hint_plan* plan);
  * copies, in MFMA fragment order, zero padded). */
 int64_t hint_plan_packed_floats(const hint_plan* plan);
 /* floats of the forward "tape" for a batch of B rows: (levels-1) snapshots [B,d] of the lane
- * tensor between tree levels, recorded by hint_block_forward and read by hint_block_backward
+ * tensor between tree levels (+ one [B,d] slice for the permuted input of the _ex forms), recorded by hint_block_forward and read by hint_block_backward
  * so that the backward pass re-derives bit-identical subnet inputs (d floats per level and
  * row instead of the ~6*h floats per node autograd keeps for hint.py:77). */
 int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
@@ -102,6 +102,33 @@ int hint_block_backward(const hint_plan* plan, const float* params, const float*
                         const float* g_J, float* g_x, float* g_c, float* g_params,
                         int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t B,
                         void* stream);
+
+/* Chained forms used by the flow container / trainer (hint_amd/flow.py, hint_amd/train.py): the
+ * work FrEIA's graph does between two blocks is folded into the block kernels.
+ *   perm     [d,d] row-major fixed orthogonal matrix of the permutation node in front of the
+ *            block (power_hint_8.py:59-62): forward computes block(x @ perm), inverse returns
+ *            block^-1(z) @ perm^T, backward returns g_x @ perm^T.  NULL = none.  With perm the
+ *            forward stores the permuted input in the last [B,d] slice of the tape and backward
+ *            reads it from there (x may be NULL).
+ *   J_in     [B] log-det accumulated by the preceding blocks, added to this block's J
+ *            (ReversibleGraphNet.log_jacobian sums the nodes); NULL = 0.
+ *   loss_acc float[2], accumulated atomically: [0] += sum_rows 0.5*|z|^2, [1] += sum_rows J
+ *            (the two loss terms of train_unconditional.py:128-129 before the .mean()); NULL = skip.
+ *   gz_scale multiplies g_z on load (pass z and 1/B for the first term's gradient);
+ *   gJ_const used for every row when g_J is NULL (-1/B for the second term). */
+int hint_block_forward_ex(const hint_plan* plan, const float* params, const float* packed,
+                          const float* x, const float* c, float* z, float* J, float* tape,
+                          const float* perm, const float* J_in, float* loss_acc, int32_t B,
+                          void* stream);
+int hint_block_inverse_ex(const hint_plan* plan, const float* params, const float* packed,
+                          const float* z, const float* c, float* x, float* J, const float* perm,
+                          const float* J_in, int32_t B, void* stream);
+int hint_block_backward_ex(const hint_plan* plan, const float* params, const float* packed,
+                           const float* x, const float* tape, const float* c, const float* g_z,
+                           const float* g_J, float* g_x, float* g_c, float* g_params,
+                           int32_t accumulate, void* workspace, size_t workspace_bytes,
+                           const float* perm, float gz_scale, float gJ_const, int32_t B,
+                           void* stream);
 
 /* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces
  *   for p in params: p.grad.data.clamp_(-5, 5)        (train_unconditional.py:140-141)

@@ -16,7 +16,7 @@ def build_flow(case, params, perms):
     for i, blk in enumerate(flow.blocks):
         blk.load_state_dict({k: torch.from_numpy(v) for k, v in params[i].items()})
         if perms[i] is not None:
-            flow.perms[i].W.copy_(torch.from_numpy(perms[i]))
+            flow.perms[i].W.copy_(torch.from_numpy(np.ascontiguousarray(perms[i])))
     return flow.to(DEV)
 
 
