@@ -5,9 +5,21 @@
 
 namespace hint {
 
+// Tuning knobs (compile-time; the plan builder and the kernels must agree):
+//   HINT_NWAVES  wavefronts per workgroup (8 or 16): with one 16-row tile per CU at B = 4096 the
+//                only latency hiding is between the wavefronts of the one resident workgroup
+//   HINT_CHB     k-blocks per chunk of the GEMM stage pipeline (register sets are 3 x CHB x 4 VGPRs
+//                for B plus the same for A)
+#ifndef HINT_NWAVES
+#define HINT_NWAVES 8
+#endif
+#ifndef HINT_CHB
+#define HINT_CHB 2      // 2: three Stage objects + A sets stay inside 256 VGPRs without scratch; 4 measured no faster
+#endif
 constexpr int ROWS = 16;        // batch rows per workgroup tile = one MFMA M-tile
-constexpr int NTHREADS = 512;   // 8 wavefronts of 64: two per SIMD, so one wave's weight loads
-constexpr int NWAVES = 8;       //   land while its SIMD partner issues MFMAs
+constexpr int NWAVES = HINT_NWAVES;
+constexpr int NTHREADS = 64 * NWAVES;
+constexpr int CHB = HINT_CHB;
 constexpr int TILE = 16;        // MFMA 16x16x4 f32 tile edge
 constexpr int MAX_SLABS = 4;    // K-split partial-sum slabs of the thin (N <= 16) layers
 
@@ -31,7 +43,7 @@ struct PackSeg {
     int32_t tile_begin; // index of this segment's first n-tile in the global n-tile list
 };
 
-// One chunk (<= 4 consecutive 16-wide k-blocks) of one 16-column output tile of a GEMM stage:
+// One chunk (<= CHB consecutive 16-wide k-blocks) of one 16-column output tile of a GEMM stage:
 //   out[16 rows][16 cols] (+)= A[16][K] * Wlog^T.
 // The host cuts every tile job into chunks, deals the jobs to the 8 wavefronts (longest first)
 // and lays the chunks out per wavefront, so that the device loop is a plain walk over 16-byte
@@ -49,9 +61,10 @@ struct Chunk {
 static_assert(sizeof(Chunk) == 16, "Chunk must be 16 bytes");
 typedef Chunk GJob;     // the per-group lists hold Chunk, stage-header and OJob records, 16 B each
 
-// A stage's list starts with a 32-byte header: uint16 first[9] = first chunk of wavefront w
-// (relative to the end of the header), first[8] = total; then the chunks, wavefront by wavefront.
-constexpr int STAGE_HDR_RECORDS = 2;
+// A stage's list starts with a header of uint16 first[NWAVES+1] (padded to whole records):
+// first[w] = first chunk of wavefront w relative to the end of the header, first[NWAVES] = total;
+// then the chunks, wavefront by wavefront.
+constexpr int STAGE_HDR_RECORDS = (NWAVES + 1 + 7) / 8;   // 8 uint16 per 16-byte record
 
 // Small weight-gradient tile done inside the row-parallel backward kernel:
 //   g[goff + m*ldg + n] += sum_rows A[row][acol+m] * B[row][bcol+n]   (atomic)

@@ -41,8 +41,15 @@ __device__ unsigned long long* g_hint_stamps = nullptr;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
         g_hint_stamps[(threadIdx.x >> 6) * 128 + (ID)] = t_;                                    \
     }
+// per-section cycle sums of one wavefront (wave 0 of workgroup 0), kept in registers
+#define TSEC_DECL unsigned long long tsec_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast_ = 0; (void)tsec_; (void)tlast_;
+#define TSEC_START() { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast_)::"memory"); }
+#define TSEC(K) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tsec_[K] += t_ - tlast_; tlast_ = t_; }
 #else
 #define STAMP(ID)
+#define TSEC_DECL
+#define TSEC_START()
+#define TSEC(K)
 #endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0)
@@ -51,7 +58,11 @@ __device__ unsigned long long* g_hint_stamps = nullptr;
 // across the barrier (cdna_hip_programming.md §5 "Pipelining across barriers").  Global
 // stores issued before it are never read back inside the kernel.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef HINT_NO_BARRIER      // diagnostic only (results are wrong): how much do the stage barriers cost?
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -150,26 +161,28 @@ __device__ __forceinline__ ChunkU decode_chunk(i32x4 raw) {
 
 struct Stage {
     lds_jobs_t cl;      // this wavefront's chunk list (LDS)
-    int n;              // its length
+    int n;              // its length (>= 1: the host gives idle wavefronts one empty chunk)
     ChunkU d0, d1, d2;
-    f32x4 b00, b01, b02, b03, b10, b11, b12, b13, b20, b21, b22, b23;
+    i32x4 raw;          // record of the next chunk to decode, read from LDS one step ahead
+    f32x4 b0[CHB], b1[CHB], b2[CHB];    // three rotating sets of packed B tiles
 };
 
-#ifdef HINT_ABLATE_WLOAD    // diagnostic: every weight fetch hits the same 4 KiB (L1-resident)
+#ifdef HINT_ABLATE_WLOAD    // diagnostic: every weight fetch hits the same few KiB (L1-resident)
 #define HINT_WTILE(T) ((size_t)((T) & 3))
 #else
 #define HINT_WTILE(T) ((size_t)(T))
 #endif
 
-#define HINT_CHUNK_AT(S, I) decode_chunk(*(const LDS_AS i32x4*)((S).cl + ((I) < (S).n ? (I) : (S).n - 1)))
-#define HINT_FETCH(D, R0, R1, R2, R3)                                                              \
-    {                                                                                              \
-        const f32x4* wp_ = (const f32x4*)packed + HINT_WTILE((D).wtile) * 64 + lane;               \
-        R0 = wp_[0]; R1 = wp_[64]; R2 = wp_[128]; R3 = wp_[192];                                   \
-    }
+#define HINT_RAW_AT(S, I) (*(const LDS_AS i32x4*)((S).cl + ((I) < (S).n ? (I) : (S).n - 1)))
+
+__device__ __forceinline__ void fetch_b(f32x4 (&R)[CHB], const ChunkU& d, const float* __restrict__ packed, int lane) {
+    const f32x4* wp = (const f32x4*)packed + HINT_WTILE(d.wtile) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) R[i] = wp[64 * i];
+}
 
 // Issue everything of a stage that does not depend on the preceding barrier: the first two
-// chunk records and their packed weights.
+// chunk records, their packed weights, and the read of the third record.
 __device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t hdr, const float* __restrict__ packed,
                                             int wave, int lane) {
 #ifdef HINT_SKIP_GEMM          // diagnostic: no GEMM stage work at all
@@ -181,22 +194,19 @@ __device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t hdr, const floa
     const int e = __builtin_amdgcn_readfirstlane((int)first[wave + 1]);
     S.n = e - b;
     S.cl = hdr + STAGE_HDR_RECORDS + b;
-    if (S.n <= 0) return;
-    S.d0 = HINT_CHUNK_AT(S, 0);
-    HINT_FETCH(S.d0, S.b00, S.b01, S.b02, S.b03)
-    S.d1 = HINT_CHUNK_AT(S, 1);
-    HINT_FETCH(S.d1, S.b10, S.b11, S.b12, S.b13)
+    const i32x4 r0 = HINT_RAW_AT(S, 0), r1 = HINT_RAW_AT(S, 1);
+    S.raw = HINT_RAW_AT(S, 2);
+    S.d0 = decode_chunk(r0);
+    fetch_b(S.b0, S.d0, packed, lane);
+    S.d1 = decode_chunk(r1);
+    fetch_b(S.b1, S.d1, packed, lane);
 }
 
 template <int EPI>
-__device__ __forceinline__ void stage_epilogue(const ChunkU& jb, f32x4 acc, const float* bias_lds, float* O,
-                                               int ldo, int slab_stride, int lane) {
+__device__ __forceinline__ void stage_epilogue(const ChunkU& jb, f32x4 acc, float bias, float* O, int ldo,
+                                               int slab_stride, int lane) {
     const int nl = lane & 15;
     const bool ok = nl < jb.nvalid;
-    // biases of the group sit in LDS in output-column order (zero in the padding columns);
-    // only slab 0 of a K-split stage adds them
-    float bias = 0.f;
-    if ((EPI == EPI_RELU || EPI == EPI_LINEAR) && jb.slab == 0) bias = bias_lds[jb.ocol + nl];
     float* o = O + jb.slab * slab_stride + (4 * (lane >> 4)) * ldo + jb.ocol + nl;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -209,86 +219,107 @@ __device__ __forceinline__ void stage_epilogue(const ChunkU& jb, f32x4 acc, cons
     }
 }
 
+// A fragments of one chunk: CHB 128-bit LDS reads with immediate offsets (a short chunk reads
+// past its last block; those registers are never used).  The bias of the chunk's tile rides
+// along (biases of the group sit in LDS in output-column order, zero in the padding columns;
+// only slab 0 of a K-split stage adds them), so the epilogue never waits for it.
+template <int EPI>
+__device__ __forceinline__ void read_a(f32x4 (&R)[CHB], float& bias, const ChunkU& d, const float* arow,
+                                       const float* bias_lds, int lane) {
+    const float* ap = arow + d.acol;
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) R[i] = *(const f32x4*)(ap + 16 * i);
+    bias = 0.f;
+    if (EPI == EPI_RELU || EPI == EPI_LINEAR) bias = bias_lds[d.ocol + (lane & 15)];
+}
+
+// the MFMAs of one chunk; two accumulators alternate so that no MFMA waits on its predecessor
+template <int EPI>
+__device__ __forceinline__ void mma_chunk(const ChunkU& d, const f32x4 (&A)[CHB], const f32x4 (&Bt)[CHB], float bias,
+                                          f32x4& acc0, f32x4& acc1, float* O, int ldo, int slab_stride, int lane) {
+    if (d.nv >= CHB) {
+#pragma unroll
+        for (int p = 0; p + 1 < CHB; p += 2) {
+            acc0 = mfma4(A[p].x, Bt[p].x, acc0); acc1 = mfma4(A[p + 1].x, Bt[p + 1].x, acc1);
+            acc0 = mfma4(A[p].y, Bt[p].y, acc0); acc1 = mfma4(A[p + 1].y, Bt[p + 1].y, acc1);
+            acc0 = mfma4(A[p].z, Bt[p].z, acc0); acc1 = mfma4(A[p + 1].z, Bt[p + 1].z, acc1);
+            acc0 = mfma4(A[p].w, Bt[p].w, acc0); acc1 = mfma4(A[p + 1].w, Bt[p + 1].w, acc1);
+        }
+        if (CHB & 1) {
+            acc0 = mfma4(A[CHB - 1].x, Bt[CHB - 1].x, acc0); acc1 = mfma4(A[CHB - 1].y, Bt[CHB - 1].y, acc1);
+            acc0 = mfma4(A[CHB - 1].z, Bt[CHB - 1].z, acc0); acc1 = mfma4(A[CHB - 1].w, Bt[CHB - 1].w, acc1);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < CHB - 1; ++p)
+            if (d.nv > p) {
+                acc0 = mfma4(A[p].x, Bt[p].x, acc0); acc1 = mfma4(A[p].y, Bt[p].y, acc1);
+                acc0 = mfma4(A[p].z, Bt[p].z, acc0); acc1 = mfma4(A[p].w, Bt[p].w, acc1);
+            }
+    }
+    if (d.last) {
+        stage_epilogue<EPI>(d, acc0 + acc1, d.slab == 0 ? bias : 0.f, O, ldo, slab_stride, lane);
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 template <int EPI>
 __device__ __forceinline__ void stage_run(Stage& S, const float* __restrict__ packed,
                                           const float* bias_lds, const float* A, int lda, float* O, int ldo,
-                                          int slab_stride, int lane, int stamp_base = -1) {
-    if (S.n <= 0) return;
-    int sk_ = 0;
-    (void)sk_;
-#ifdef HINT_STAMPS
-#define SSTAMP() if (stamp_base >= 0 && sk_ < 60) { STAMP(stamp_base + sk_) ++sk_; }
-#else
-#define SSTAMP()
+                                          int slab_stride, int lane) {
+#ifdef HINT_SKIP_GEMM
+    return;
 #endif
     const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a00, a01, a02, a03, a10, a11, a12, a13, a20, a21, a22, a23;
+    f32x4 a0[CHB], a1[CHB], a2[CHB];
+    float bi0, bi1, bi2;
 
-    // A fragments of one chunk: four 128-bit LDS reads with immediate offsets (a short chunk
-    // reads past its last block; those registers are never used)
-#define HINT_AREAD(D, R0, R1, R2, R3)                                                              \
-    {                                                                                              \
-        const float* ap_ = arow + (D).acol;                                                        \
-        R0 = *(const f32x4*)(ap_);       R1 = *(const f32x4*)(ap_ + 16);                           \
-        R2 = *(const f32x4*)(ap_ + 32);  R3 = *(const f32x4*)(ap_ + 48);                           \
-    }
-#define HINT_MMA_BLK(AR, BR, ACC)                                                                  \
-    ACC = mfma4(AR.x, BR.x, ACC); ACC = mfma4(AR.y, BR.y, ACC);                                    \
-    ACC = mfma4(AR.z, BR.z, ACC); ACC = mfma4(AR.w, BR.w, ACC);
-    // the MFMAs of one chunk; two accumulators alternate so that no MFMA waits on its predecessor
-#define HINT_MMA(D, AR0, AR1, AR2, AR3, BR0, BR1, BR2, BR3)                                        \
-    {                                                                                              \
-        if ((D).nv >= 4) {                                                                         \
-            acc0 = mfma4(AR0.x, BR0.x, acc0); acc1 = mfma4(AR1.x, BR1.x, acc1);                    \
-            acc0 = mfma4(AR0.y, BR0.y, acc0); acc1 = mfma4(AR1.y, BR1.y, acc1);                    \
-            acc0 = mfma4(AR0.z, BR0.z, acc0); acc1 = mfma4(AR1.z, BR1.z, acc1);                    \
-            acc0 = mfma4(AR0.w, BR0.w, acc0); acc1 = mfma4(AR1.w, BR1.w, acc1);                    \
-            acc0 = mfma4(AR2.x, BR2.x, acc0); acc1 = mfma4(AR3.x, BR3.x, acc1);                    \
-            acc0 = mfma4(AR2.y, BR2.y, acc0); acc1 = mfma4(AR3.y, BR3.y, acc1);                    \
-            acc0 = mfma4(AR2.z, BR2.z, acc0); acc1 = mfma4(AR3.z, BR3.z, acc1);                    \
-            acc0 = mfma4(AR2.w, BR2.w, acc0); acc1 = mfma4(AR3.w, BR3.w, acc1);                    \
-        } else {                                                                                   \
-            if ((D).nv >= 1) { HINT_MMA_BLK(AR0, BR0, acc0) }                                      \
-            if ((D).nv >= 2) { HINT_MMA_BLK(AR1, BR1, acc1) }                                      \
-            if ((D).nv >= 3) { HINT_MMA_BLK(AR2, BR2, acc0) }                                      \
-        }                                                                                          \
-        if ((D).last) {                                                                            \
-            stage_epilogue<EPI>(D, acc0 + acc1, bias_lds, O, ldo, slab_stride, lane);              \
-            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
-            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
-        }                                                                                          \
-    }
-
-    HINT_AREAD(S.d0, a00, a01, a02, a03)
-    int ci = 0;   // chunk held in (d0, a0*, b0*) at the top of the loop
+    TSEC_DECL
+    TSEC_START()
+    read_a<EPI>(a0, bi0, S.d0, arow, bias_lds, lane);
+    TSEC(0)
+    int ci = 0;   // chunk held in (d0, a0, b0) at the top of the loop
     while (true) {
-        SSTAMP()
-        S.d2 = HINT_CHUNK_AT(S, ci + 2);
-        SSTAMP()
-        HINT_FETCH(S.d2, S.b20, S.b21, S.b22, S.b23)
-        SSTAMP()
-        HINT_AREAD(S.d1, a10, a11, a12, a13)
-        SSTAMP()
-        HINT_MMA(S.d0, a00, a01, a02, a03, S.b00, S.b01, S.b02, S.b03)
-        SSTAMP()
+        S.d2 = decode_chunk(S.raw);
+        S.raw = HINT_RAW_AT(S, ci + 3);
+        TSEC(1)
+        fetch_b(S.b2, S.d2, packed, lane);
+        TSEC(2)
+        read_a<EPI>(a1, bi1, S.d1, arow, bias_lds, lane);
+        TSEC(3)
+        mma_chunk<EPI>(S.d0, a0, S.b0, bi0, acc0, acc1, O, ldo, slab_stride, lane);
+        TSEC(4)
         if (ci + 1 >= S.n) break;
-        S.d0 = HINT_CHUNK_AT(S, ci + 3);
-        HINT_FETCH(S.d0, S.b00, S.b01, S.b02, S.b03)
-        HINT_AREAD(S.d2, a20, a21, a22, a23)
-        HINT_MMA(S.d1, a10, a11, a12, a13, S.b10, S.b11, S.b12, S.b13)
+        S.d0 = decode_chunk(S.raw);
+        S.raw = HINT_RAW_AT(S, ci + 4);
+        TSEC(1)
+        fetch_b(S.b0, S.d0, packed, lane);
+        TSEC(2)
+        read_a<EPI>(a2, bi2, S.d2, arow, bias_lds, lane);
+        TSEC(3)
+        mma_chunk<EPI>(S.d1, a1, S.b1, bi1, acc0, acc1, O, ldo, slab_stride, lane);
+        TSEC(4)
         if (ci + 2 >= S.n) break;
-        S.d1 = HINT_CHUNK_AT(S, ci + 4);
-        HINT_FETCH(S.d1, S.b10, S.b11, S.b12, S.b13)
-        HINT_AREAD(S.d0, a00, a01, a02, a03)
-        HINT_MMA(S.d2, a20, a21, a22, a23, S.b20, S.b21, S.b22, S.b23)
+        S.d1 = decode_chunk(S.raw);
+        S.raw = HINT_RAW_AT(S, ci + 5);
+        TSEC(1)
+        fetch_b(S.b1, S.d1, packed, lane);
+        TSEC(2)
+        read_a<EPI>(a0, bi0, S.d0, arow, bias_lds, lane);
+        TSEC(3)
+        mma_chunk<EPI>(S.d2, a2, S.b2, bi2, acc0, acc1, O, ldo, slab_stride, lane);
+        TSEC(4)
         if (ci + 3 >= S.n) break;
         ci += 3;
     }
-#undef HINT_AREAD
-#undef HINT_MMA_BLK
-#undef HINT_MMA
-#undef SSTAMP
+#ifdef HINT_STAMPS
+    if (g_hint_stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 5; ++k) g_hint_stamps[1024 + k] += tsec_[k];
+        g_hint_stamps[1024 + 5] += 1;      // stage_run calls
+    }
+#endif
 }
 
 // Small outer-product tiles done inside the backward kernel (dW1, dW3): the reduction runs
@@ -456,7 +487,7 @@ __device__ __forceinline__ void lds_copy_meta(const KArgs& a, LDS_AS char* mbase
 // forward (REV=false) / inverse (REV=true): x, J -> z   — one launch per block
 // =======================================================================================
 template <bool REV>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_block_apply_kernel(
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void hint_block_apply_kernel(
     KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
     float* __restrict__ J, float* __restrict__ tape, const float* __restrict__ perm,
@@ -484,8 +515,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         jobs_commit(jp0, jbuf0, bias0, tid);
     }
 
+    // Weight prefetch runs TWO GEMM stages ahead: the stage_begin() of stage k+2 is issued right
+    // after stage k has issued its last fetch.  One stage ahead is not enough (a stage is often
+    // shorter than the ~1500-cycle L2 latency under load), and issuing it earlier would put the
+    // loads in front of stage k's own fetches in the in-order vmcnt queue.  L1, L2, L3 each own
+    // one Stage object, so nothing has to be copied.
     int jb = 0;
-    Stage S, N;
+    Stage SA, SB, SC;     // L1, L2, L3
     bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
@@ -512,7 +548,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         STAMP(1)
         GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
-        if (first_tile) stage_begin(S, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
+        if (first_tile) {
+            stage_begin(SA, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
+            stage_begin(SB, jbuf0 + jb * a.jmax + g.l2_off, packed, wave, lane);
+        }
         first_tile = false;
 
         for (int gi = 0; gi < a.n_groups; ++gi) {
@@ -533,22 +572,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             STAMP(2 + 12 * gi)
             lds_barrier();
             STAMP(3 + 12 * gi)
-            stage_begin(N, jl + g.l2_off, packed, wave, lane);
-            stage_run<EPI_RELU>(S, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            stage_begin(SC, jl + g.l3_off, packed, wave, lane);
+            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(4 + 12 * gi)
             lds_barrier();
             STAMP(5 + 12 * gi)
-            stage_begin(S, jl + g.l3_off, packed, wave, lane);
-            stage_run<EPI_RELU>(N, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane, gi == a.n_groups - 1 ? 60 : -1);
-            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
+            stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
+            if (has_next) stage_begin(SA, jl_next + gn.l1_off, packed, wave, lane);
             STAMP(6 + 12 * gi)
             lds_barrier();
             STAMP(7 + 12 * gi)
-            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+            stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+            if (has_next) stage_begin(SB, jl_next + gn.l2_off, packed, wave, lane);
             STAMP(8 + 12 * gi)
             lds_barrier();
             STAMP(9 + 12 * gi)
-            if (has_next) stage_begin(S, jl_next + gn.l1_off, packed, wave, lane);
             {   // element-wise affine coupling + log-det partial sums (hint.py:79-83)
                 const int sub = tid & 15, row = tid >> 4;
                 float part = 0.f;
@@ -643,7 +682,7 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
     }
 }
 
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_block_bwd_kernel(
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void hint_block_bwd_kernel(
     KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
     const float* __restrict__ x, const float* __restrict__ tape, const float* __restrict__ c,
     const float* __restrict__ g_z, const float* __restrict__ g_J, float* __restrict__ g_x,
@@ -675,7 +714,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 
     int jb = 0;
-    Stage S, N;
+    Stage SA, SB, SC;     // rotate over the six GEMM stages: L1, L2, L3, g2, g1, dv (prefetch two ahead)
     bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
@@ -691,7 +730,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         STAMP(1)
         GroupU g = load_group(groups + (a.n_groups - 1));
-        if (first_tile) stage_begin(S, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
+        if (first_tile) {
+            stage_begin(SA, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
+            stage_begin(SB, jbuf0 + jb * a.jmax + g.l2_off, packed, wave, lane);
+        }
         first_tile = false;
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
@@ -725,19 +767,20 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             STAMP(sbase + 0)
             lds_barrier();
             STAMP(sbase + 1)
-            stage_begin(N, jl + g.l2_off, packed, wave, lane);
-            stage_run<EPI_RELU>(S, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            stage_begin(SC, jl + g.l3_off, packed, wave, lane);
             STAMP(sbase + 2)
             lds_barrier();
             STAMP(sbase + 3)
-            stage_begin(S, jl + g.l3_off, packed, wave, lane);
             copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            stage_run<EPI_RELU>(N, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
+            stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
+            stage_begin(SA, jl + g.g2_off, packed, wave, lane);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
-            stage_begin(N, jl + g.g2_off, packed, wave, lane);
-            stage_run<EPI_LINEAR>(S, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+            stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+            stage_begin(SB, jl + g.g1_off, packed, wave, lane);
+            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(sbase + 6)
             lds_barrier();
             STAMP(sbase + 7)
@@ -771,28 +814,27 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
             lds_barrier();
             STAMP(sbase + 11)
             // ---- g2 = (g_st * W3) .* relu'(a2), in place over a2 ----
-            stage_begin(S, jl + g.g1_off, packed, wave, lane);
-            stage_run<EPI_MASK>(N, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
+            stage_run<EPI_MASK>(SA, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
+            stage_begin(SC, jl + g.dv_off, packed, wave, lane);
             STAMP(sbase + 12)
             lds_barrier();
             STAMP(sbase + 13)
             // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1;  db2 += colsum(g2) ----
-            stage_begin(N, jl + g.dv_off, packed, wave, lane);
             copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
             colsum_store(a.bmap + g.bmap_begin + g.aw, g.aw, a2, a.ald, gparams, tid);
-            stage_run<EPI_MASK>(S, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
+            stage_run<EPI_MASK>(SB, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
+            if (has_next) stage_begin(SA, jl_next + gn.l1_off, packed, wave, lane);
             STAMP(sbase + 14)
             lds_barrier();
             STAMP(sbase + 15)
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
-            stage_run<EPI_PLAIN>(N, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
+            stage_run<EPI_PLAIN>(SC, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
+            if (has_next) stage_begin(SB, jl_next + gn.l2_off, packed, wave, lane);
             run_ojobs(jl + g.o1_off, g.o1_cnt, a1, a.ald, vb, a.vld, gparams, wave, lane);
             colsum_store(a.bmap + g.bmap_begin, g.aw, a1, a.ald, gparams, tid);
-            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)
-            if (has_next) stage_begin(S, jl_next + gn.l1_off, packed, wave, lane);
             // ---- scatter g_v: upper-lane columns to g (each lane has one v column per group),
             //      condition columns to g_c (every node of the group contributes) ----
             {

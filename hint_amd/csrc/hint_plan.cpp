@@ -294,19 +294,27 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 load[w] += std::max(tj[i].nblk, 1) + 1;     // +1: epilogue / tile switch cost
             }
             const int hdr = (int)jobs.size() - g.jl_begin;
-            uint16_t first[16] = {0};
+            uint16_t first[16 * STAGE_HDR_RECORDS / 2] = {0};
             std::vector<Chunk> chunks;
             for (int w = 0; w < NWAVES; ++w) {
                 first[w] = (uint16_t)chunks.size();
+                if (per_wave[w].empty()) {
+                    // an idle wavefront still walks one empty chunk: every wavefront then issues the
+                    // same, unconditional sequence of loads per stage, which lets the compiler keep
+                    // exact vmcnt counts (a conditional prefetch forces conservative full drains)
+                    Chunk c{};
+                    c.wtile = 0; c.acol = 0; c.ocol = 0; c.nv = 0; c.last = 0; c.nvalid = 0; c.slab = 0;
+                    chunks.push_back(c);
+                }
                 for (int i : per_wave[w]) {
                     const TileJob& t = tj[i];
-                    const int nch = std::max(1, (t.nblk + 3) / 4);
+                    const int nch = std::max(1, (t.nblk + CHB - 1) / CHB);
                     for (int cidx = 0; cidx < nch; ++cidx) {
                         Chunk c{};
-                        c.wtile = (int32_t)(t.wtile + 4 * cidx);
-                        c.acol = (uint16_t)(t.acol + 64 * cidx);
+                        c.wtile = (int32_t)(t.wtile + CHB * cidx);
+                        c.acol = (uint16_t)(t.acol + 16 * CHB * cidx);
                         c.ocol = (uint16_t)t.ocol;
-                        c.nv = (uint8_t)std::max(0, std::min(4, t.nblk - 4 * cidx));
+                        c.nv = (uint8_t)std::max(0, std::min(CHB, t.nblk - CHB * cidx));
                         c.last = (uint8_t)(cidx == nch - 1);
                         c.nvalid = (uint8_t)t.nvalid;
                         c.slab = (uint8_t)t.slab;
@@ -545,7 +553,7 @@ void hint_plan_destroy(hint_plan* P) {
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
 // +1 KiB of slack: the chunk prefetcher of the GEMM stages never reads past a job's last
 // k-block, but keeping a margin makes that robust against future tuning
-int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 4 * 256 : -1; }
+int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + (CHB + 1) * 256 : -1; }
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;

@@ -13,21 +13,24 @@ dev = "cuda:0"
 lib = _lib.load()
 blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(dev)
 x = torch.randn(B, d, device=dev)
-buf = torch.zeros(8 * 128, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 128 + 64, dtype=torch.int64, device=dev)
 assert lib.hint_debug_set_stamp_buffer(buf.data_ptr()) == 0, "not a stamps build"
 with torch.no_grad():
     for _ in range(20):
         blk([x])
 torch.cuda.synchronize()
-s = buf.cpu().view(8, 128)
+sec = buf.cpu()[1024:1032].tolist()
+s = buf.cpu()[:1024].view(8, 128)
 names = {0: "start", 1: "x loaded+sync"}
 for gi in range(4):
     for k, nm in enumerate(["build_v", "sync", "L1", "sync", "L2", "sync", "L3", "sync", "couple", "sync"]):
         names[2 + 12 * gi + k] = f"g{gi}:{nm}"
 names[120] = "stored"
+for gi in range(4):
+    names[100 + 2 * gi] = f"g{gi}:L1 begun(L2)"; names[101 + 2 * gi] = f"g{gi}:L2 begun(L3)"; names[110 + gi] = f"g{gi}:L2 run done"
 for k in range(60):
     names[60 + k] = "L2root:" + ["top", "decoded", "fetched", "aread", "mma"][k % 5] + f"#{k // 5}" if k < 15 else f"L2root:s{k}"
-ids = [i for i in sorted(names) if s[0, i] != 0]
+ids = sorted([i for i in names if s[0, i] != 0], key=lambda i: s[0, i].item())
 t0 = s[:, 0].min().item()
 print("stage".ljust(16) + "".join(f"w{w}".rjust(9) for w in range(8)) + "   (cycles since start; delta of wave 0)")
 prev = None
@@ -36,3 +39,8 @@ for i in ids:
     dl = "" if prev is None else f"  +{row[0]-prev}"
     prev = row[0]
     print(names[i].ljust(16) + "".join(f"{v:9d}" for v in row) + dl)
+
+calls = max(sec[5], 1)
+print("stage_run sections, wave 0 of WG 0, summed over", calls, "stage_run calls (", calls // 6, "kernel launches ):")
+for k, nm in enumerate(["first read_a", "decode+raw", "fetch_b", "read_a", "mma+epilogue"]):
+    print(f"   {nm:14s} {sec[k] / (calls / 6):10.0f} cycles per launch")
