@@ -95,9 +95,13 @@ struct DGroup {
 static_assert(sizeof(DGroup) == 112, "DGroup must be 7 x 16 bytes");
 
 // dW2 tile job of the weight-gradient kernel: C[m][n] = sum_b G2[b][col+m] * A1[b][col+n]
+// The tile spans mw x nw "virtual" 16x16 MFMA tiles (1..3 each way): lane l of virtual tile j
+// holds column m0 + mw*(l&15) + j, so one dwordx3 load per operand and k-step feeds up to three
+// MFMA tiles (the permutation of columns inside the 48-wide group is undone at write-out).
 struct DWJob {
     int32_t col, H;     // workspace column of this (node, net); H = valid extent (h)
-    int32_t m0, n0;     // 48x48 output tile origin
+    int32_t m0, n0;     // output tile origin
+    int32_t mw, nw;     // virtual tiles (= floats per lane and load) along m and n
     int64_t wofs;       // offset of dW2 in the flat gradient buffer (row stride H)
 };
 

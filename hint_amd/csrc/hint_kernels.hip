@@ -938,8 +938,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 15, kq = lane >> 4;
 
-    const int ntm = min(3, (job.H - job.m0 + 15) >> 4);
-    const int ntn = min(3, (job.H - job.n0 + 15) >> 4);
+    const int ntm = job.mw, ntn = job.nw;
     const int b_begin = split * rows_per_wg;
     const int b_end = min(Bp, b_begin + rows_per_wg);
 
@@ -949,30 +948,27 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // columns beyond the (node, net)'s padded extent are clamped to a valid tile; their
-    // products are discarded below, this only keeps every load in bounds and unconditional
-    const float* gp[3];
-    const float* xp[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        gp[t] = wsG2 + job.col + job.m0 + 16 * (t < ntm ? t : 0) + nl;
-        xp[t] = wsA1 + job.col + job.n0 + 16 * (t < ntn ? t : 0) + nl;
-    }
+    // one 12-byte load per operand and k-step: lane nl holds columns m0 + mw*nl + {0,1,2}
+    // (a narrower group over-reads into the following columns; those products are never used)
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    const float* gp = wsG2 + job.col + job.m0 + ntm * nl;
+    const float* xp = wsA1 + job.col + job.n0 + ntn * nl;
 
-    float av[2][4][3], bv[2][4][3];
+    // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs
+    // of block j (issuing four blocks up front measured slower: no load/MFMA overlap)
+    f32x3u av[2][4], bv[2][4];
 #define DW_LOAD(BUF, BB)                                                     \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                           \
         const size_t row_ = (size_t)((BB) + 4 * i + kq) * WT;                 \
-        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                       \
-            av[BUF][i][t] = gp[t][row_];                                      \
-            bv[BUF][i][t] = xp[t][row_];                                      \
-        }                                                                     \
+        av[BUF][i] = *(const f32x3u*)(gp + row_);                             \
+        bv[BUF][i] = *(const f32x3u*)(xp + row_);                             \
     }
 #define DW_MMA(BUF)                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                             \
         _Pragma("unroll") for (int tm = 0; tm < 3; ++tm)                      \
-            _Pragma("unroll") for (int tn = 0; tn < 3; ++tn)                  \
-                acc[tm][tn] = mfma4(av[BUF][i][tm], bv[BUF][i][tn], acc[tm][tn]);
+            if (tm < ntm)                                                     \
+                _Pragma("unroll") for (int tn = 0; tn < 3; ++tn)              \
+                    if (tn < ntn) acc[tm][tn] = mfma4(av[BUF][i][tm], bv[BUF][i][tn], acc[tm][tn]);
 
     const int step = 16 * DW_WAVES;
     int bb = b_begin + wave * 16;
@@ -1007,11 +1003,11 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
         f32x4 v = *(f32x4*)&red[0][t][l][0];
 #pragma unroll
         for (int w = 1; w < DW_WAVES; ++w) v += *(f32x4*)&red[w][t][l][0];
-        const int n = job.n0 + 16 * tn + (l & 15);
+        const int n = job.n0 + ntn * (l & 15) + tn;          // undo the column permutation of the loads
         if (n >= job.H) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = job.m0 + 16 * tm + 4 * (l >> 4) + i;
+            const int m = job.m0 + ntm * (4 * (l >> 4) + i) + tm;
             if (m < job.H) atomicAdd(gparams + job.wofs + (size_t)m * job.H + n, v[i]);
         }
     }

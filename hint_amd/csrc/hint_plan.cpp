@@ -468,10 +468,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
 
     // ---- weight-gradient jobs: 48x48 output tiles of dW2 of every (node, net) ----
     for (size_t ni = 0; ni < dn.size(); ++ni)
-        for (int net = 0; net < 2; ++net)
-            for (int m0 = 0; m0 < dn[ni].h; m0 += 48)
-                for (int n0 = 0; n0 < dn[ni].h; n0 += 48)
-                    dwj.push_back(DWJob{dn[ni].wcol + net * dn[ni].hp, dn[ni].h, m0, n0, src[ni]->p_off[net * 6 + 2]});
+        for (int net = 0; net < 2; ++net) {
+            const int T = dn[ni].hp / 16;          // padded extent in 16-wide tiles, cut into groups of <= 3
+            for (int mt = 0; mt < T; mt += 3)
+                for (int nt = 0; nt < T; nt += 3)
+                    dwj.push_back(DWJob{dn[ni].wcol + net * dn[ni].hp, dn[ni].h, mt * 16, nt * 16, std::min(3, T - mt),
+                                        std::min(3, T - nt), src[ni]->p_off[net * 6 + 2]});
+        }
     P->n_dwjobs = (int)dwj.size();
     P->n_ptiles = (int)ptiles.size();
 
