@@ -56,23 +56,27 @@ struct Chunk {
     uint8_t last;       // 1: last chunk of its tile job -> epilogue
     uint8_t nvalid;     // valid output columns of the tile (others are written as 0)
     uint8_t slab;       // K-split slab the partial result goes to
-    int32_t pad;
+    int32_t count;      // in the FIRST record of a wavefront's list: number of chunks in the list
 };
 static_assert(sizeof(Chunk) == 16, "Chunk must be 16 bytes");
 typedef Chunk GJob;     // the per-group lists hold Chunk, stage-header and OJob records, 16 B each
 
-// A stage's list starts with a header of uint16 first[NWAVES+1] (padded to whole records):
-// first[w] = first chunk of wavefront w relative to the end of the header, first[NWAVES] = total;
-// then the chunks, wavefront by wavefront.
-constexpr int STAGE_HDR_RECORDS = (NWAVES + 1 + 7) / 8;   // 8 uint16 per 16-byte record
+// A stage's lists sit at a fixed stride: wavefront w's list starts at record w*stride (the stage
+// descriptor packs offset and stride into one int, see STAGE_DESC) and is padded with empty
+// chunks (nv = 0, last = 0) up to the stride, which is at least 3 longer than the longest list:
+// the device loop may then read three records ahead without clamping, and stage_begin() needs
+// no header round trip (the length rides in the first record).
+constexpr int STAGE_TAIL = 3;
+#define STAGE_DESC(OFF, STRIDE) (((OFF) & 0xffff) | ((STRIDE) << 16))
 
-// Small weight-gradient tile done inside the row-parallel backward kernel:
-//   g[goff + m*ldg + n] += sum_rows A[row][acol+m] * B[row][bcol+n]   (atomic)
+// Thin weight gradient of one (node, net) done inside the row-parallel backward kernel: a grid
+// of 16x16 outer-product tiles  T[m][n] = sum_rows A[row][acol+m] * B[row][bcol+n],  M x N valid,
+// stored at slab[goff + m*N + n] (row stride N).  One record per (node, net); the wavefronts
+// share the grid's tiles round-robin.
 struct OJob {
     int32_t goff;
     uint16_t acol, bcol;
-    uint16_t ldg;
-    uint8_t mvalid, nvalid;
+    uint16_t M, N;
     int32_t pad;
 };
 static_assert(sizeof(OJob) == 16, "OJob must be 16 bytes");

@@ -173,7 +173,7 @@ struct Stage {
 #define HINT_WTILE(T) ((size_t)(T))
 #endif
 
-#define HINT_RAW_AT(S, I) (*(const LDS_AS i32x4*)((S).cl + ((I) < (S).n ? (I) : (S).n - 1)))
+#define HINT_RAW_AT(S, I) (*(const LDS_AS i32x4*)((S).cl + (I)))     /* lists are padded: no clamp needed */
 
 __device__ __forceinline__ void fetch_b(f32x4 (&R)[CHB], const ChunkU& d, const float* __restrict__ packed, int lane) {
     const f32x4* wp = (const f32x4*)packed + HINT_WTILE(d.wtile) * 64 + lane;
@@ -183,19 +183,17 @@ __device__ __forceinline__ void fetch_b(f32x4 (&R)[CHB], const ChunkU& d, const 
 
 // Issue everything of a stage that does not depend on the preceding barrier: the first two
 // chunk records, their packed weights, and the read of the third record.
-__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t hdr, const float* __restrict__ packed,
+__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t jl, int desc, const float* __restrict__ packed,
                                             int wave, int lane) {
 #ifdef HINT_SKIP_GEMM          // diagnostic: no GEMM stage work at all
     S.n = 0;
     return;
 #endif
-    const LDS_AS uint16_t* first = (const LDS_AS uint16_t*)hdr;
-    const int b = __builtin_amdgcn_readfirstlane((int)first[wave]);
-    const int e = __builtin_amdgcn_readfirstlane((int)first[wave + 1]);
-    S.n = e - b;
-    S.cl = hdr + STAGE_HDR_RECORDS + b;
+    // desc = offset | stride << 16: wavefront w's padded list starts at jl + offset + w*stride
+    S.cl = jl + (desc & 0xffff) + wave * (desc >> 16);
     const i32x4 r0 = HINT_RAW_AT(S, 0), r1 = HINT_RAW_AT(S, 1);
     S.raw = HINT_RAW_AT(S, 2);
+    S.n = __builtin_amdgcn_readfirstlane(r0.w);      // list length rides in the first record
     S.d0 = decode_chunk(r0);
     fetch_b(S.b0, S.d0, packed, lane);
     S.d1 = decode_chunk(r1);
@@ -331,26 +329,34 @@ __device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const floa
                                           const float* Bbuf, int ldb, float* __restrict__ g, int wave,
                                           int lane) {
     const int nl = lane & 15, kq = lane >> 4;
-    for (int j = wave; j < njobs; j += NWAVES) {
+    int t0 = wave;                                   // round-robin over the tiles of all grids
+    for (int j = 0; j < njobs; ++j) {
         const i32x4 raw = *(const LDS_AS i32x4*)(jobs + j);
         const int goff = __builtin_amdgcn_readfirstlane(raw.x);
         const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane(raw.y);
         const unsigned zz = (unsigned)__builtin_amdgcn_readfirstlane(raw.z);
         const int acol = (int)(y & 0xffffu), bcol = (int)(y >> 16);
-        const int ldg = (int)(zz & 0xffffu), mvalid = (int)((zz >> 16) & 0xffu), nvalid = (int)(zz >> 24);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = kq + 4 * i;
-            acc = mfma4(Abuf[row * lda + acol + nl], Bbuf[row * ldb + bcol + nl], acc);
-        }
-        if (nl < nvalid) {
+        const int M = (int)(zz & 0xffffu), N = (int)(zz >> 16);
+        const int mtiles = (M + 15) >> 4, ntiles = (N + 15) >> 4, tiles = mtiles * ntiles;
+        int t = t0;
+        for (; t < tiles; t += NWAVES) {
+            const int mt = t / ntiles, nt = t - mt * ntiles;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = 4 * kq + i;
-                if (m < mvalid) g[goff + m * ldg + nl] = acc[i];
+                const int row = kq + 4 * i;
+                acc = mfma4(Abuf[row * lda + acol + 16 * mt + nl], Bbuf[row * ldb + bcol + 16 * nt + nl], acc);
+            }
+            const int n = 16 * nt + nl;
+            if (n < N) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = 16 * mt + 4 * kq + i;
+                    if (m < M) g[goff + m * N + n] = acc[i];
+                }
             }
         }
+        t0 = t - tiles;                              // keep the round-robin phase across grids
     }
 }
 
@@ -469,9 +475,19 @@ __device__ __forceinline__ void jobs_commit(const JobPrefetch& jp, LDS_AS GJob* 
 
 // LDS carve-up shared by both block kernels:
 //   [meta: groups | vmap | ents][job buffer 0 | 1][bias buffer 0 | 1][float buffers ...]
-__device__ __forceinline__ void lds_copy_meta(const KArgs& a, LDS_AS char* mbase, int tid) {
+// The meta copy is split into issue (global -> registers) and commit (registers -> LDS) so
+// that it shares ONE memory round trip with the first chunk lists and the first lane tile.
+struct MetaPrefetch { i32x4 r0, r1; };
+__device__ __forceinline__ void meta_issue(MetaPrefetch& mp, const KArgs& a, int tid) {
     const int n16 = a.meta_bytes >> 4;
-    for (int i = tid; i < n16; i += NTHREADS) ((LDS_AS i32x4*)mbase)[i] = ((const i32x4*)a.meta)[i];
+    if (tid < n16) mp.r0 = ((const i32x4*)a.meta)[tid];
+    if (tid + NTHREADS < n16) mp.r1 = ((const i32x4*)a.meta)[tid + NTHREADS];
+}
+__device__ __forceinline__ void meta_commit(const MetaPrefetch& mp, const KArgs& a, LDS_AS char* mbase, int tid) {
+    const int n16 = a.meta_bytes >> 4;
+    if (tid < n16) ((LDS_AS i32x4*)mbase)[tid] = mp.r0;
+    if (tid + NTHREADS < n16) ((LDS_AS i32x4*)mbase)[tid + NTHREADS] = mp.r1;
+    for (int i = tid + 2 * NTHREADS; i < n16; i += NTHREADS) ((LDS_AS i32x4*)mbase)[i] = ((const i32x4*)a.meta)[i];
 }
 #define HINT_LDS_TABLES()                                                                          \
     LDS_AS char* mbase = (LDS_AS char*)lds;                                                        \
@@ -481,7 +497,8 @@ __device__ __forceinline__ void lds_copy_meta(const KArgs& a, LDS_AS char* mbase
     LDS_AS GJob* jbuf0 = (LDS_AS GJob*)(mbase + a.meta_bytes);                                     \
     float* bias0 = lds + ((a.meta_bytes + 2 * a.jmax * (int)sizeof(GJob)) >> 2);                   \
     float* fbase = bias0 + 2 * a.bmax;                                                             \
-    lds_copy_meta(a, mbase, tid);
+    MetaPrefetch mp_;                                                                              \
+    meta_issue(mp_, a, tid);
 
 // =======================================================================================
 // forward (REV=false) / inverse (REV=true): x, J -> z   — one launch per block
@@ -512,6 +529,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     {   // the first group's chunk lists and biases: issued together with the meta copy
         JobPrefetch jp0;
         jobs_issue(jp0, a.jobs, a.first[fo][0], a.first[fo][1], packed + a.bias_off + a.first[fo][2], a.first[fo][3], tid);
+        meta_commit(mp_, a, mbase, tid);
         jobs_commit(jp0, jbuf0, bias0, tid);
     }
 
@@ -549,8 +567,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         STAMP(1)
         GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
         if (first_tile) {
-            stage_begin(SA, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
-            stage_begin(SB, jbuf0 + jb * a.jmax + g.l2_off, packed, wave, lane);
+            stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
+            stage_begin(SB, jbuf0 + jb * a.jmax, g.l2_off, packed, wave, lane);
         }
         first_tile = false;
 
@@ -573,18 +591,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             lds_barrier();
             STAMP(3 + 12 * gi)
             stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
-            stage_begin(SC, jl + g.l3_off, packed, wave, lane);
+            stage_begin(SC, jl, g.l3_off, packed, wave, lane);
             if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(4 + 12 * gi)
             lds_barrier();
             STAMP(5 + 12 * gi)
             stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
-            if (has_next) stage_begin(SA, jl_next + gn.l1_off, packed, wave, lane);
+            if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed, wave, lane);
             STAMP(6 + 12 * gi)
             lds_barrier();
             STAMP(7 + 12 * gi)
             stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
-            if (has_next) stage_begin(SB, jl_next + gn.l2_off, packed, wave, lane);
+            if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed, wave, lane);
             STAMP(8 + 12 * gi)
             lds_barrier();
             STAMP(9 + 12 * gi)
@@ -710,6 +728,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     {
         JobPrefetch jp0;
         jobs_issue(jp0, a.jobs, a.first[1][0], a.first[1][1], packed + a.bias_off + a.first[1][2], a.first[1][3], tid);
+        meta_commit(mp_, a, mbase, tid);
         jobs_commit(jp0, jbuf0, bias0, tid);
     }
 
@@ -731,8 +750,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         STAMP(1)
         GroupU g = load_group(groups + (a.n_groups - 1));
         if (first_tile) {
-            stage_begin(SA, jbuf0 + jb * a.jmax + g.l1_off, packed, wave, lane);
-            stage_begin(SB, jbuf0 + jb * a.jmax + g.l2_off, packed, wave, lane);
+            stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
+            stage_begin(SB, jbuf0 + jb * a.jmax, g.l2_off, packed, wave, lane);
         }
         first_tile = false;
 
@@ -768,18 +787,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             lds_barrier();
             STAMP(sbase + 1)
             stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
-            stage_begin(SC, jl + g.l3_off, packed, wave, lane);
+            stage_begin(SC, jl, g.l3_off, packed, wave, lane);
             STAMP(sbase + 2)
             lds_barrier();
             STAMP(sbase + 3)
             copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
             stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
-            stage_begin(SA, jl + g.g2_off, packed, wave, lane);
+            stage_begin(SA, jl, g.g2_off, packed, wave, lane);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
             stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
-            stage_begin(SB, jl + g.g1_off, packed, wave, lane);
+            stage_begin(SB, jl, g.g1_off, packed, wave, lane);
             if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
             STAMP(sbase + 6)
             lds_barrier();
@@ -815,7 +834,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 11)
             // ---- g2 = (g_st * W3) .* relu'(a2), in place over a2 ----
             stage_run<EPI_MASK>(SA, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
-            stage_begin(SC, jl + g.dv_off, packed, wave, lane);
+            stage_begin(SC, jl, g.dv_off, packed, wave, lane);
             STAMP(sbase + 12)
             lds_barrier();
             STAMP(sbase + 13)
@@ -823,13 +842,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
             colsum_store(a.bmap + g.bmap_begin + g.aw, g.aw, a2, a.ald, gparams, tid);
             stage_run<EPI_MASK>(SB, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
-            if (has_next) stage_begin(SA, jl_next + gn.l1_off, packed, wave, lane);
+            if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed, wave, lane);
             STAMP(sbase + 14)
             lds_barrier();
             STAMP(sbase + 15)
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
             stage_run<EPI_PLAIN>(SC, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
-            if (has_next) stage_begin(SB, jl_next + gn.l2_off, packed, wave, lane);
+            if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed, wave, lane);
             run_ojobs(jl + g.o1_off, g.o1_cnt, a1, a.ald, vb, a.vld, gparams, wave, lane);
             colsum_store(a.bmap + g.bmap_begin, g.aw, a1, a.ald, gparams, tid);
             STAMP(sbase + 16)

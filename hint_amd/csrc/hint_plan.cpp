@@ -294,18 +294,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 load[w] += std::max(tj[i].nblk, 1) + 1;     // +1: epilogue / tile switch cost
             }
             const int hdr = (int)jobs.size() - g.jl_begin;
-            uint16_t first[16 * STAGE_HDR_RECORDS / 2] = {0};
-            std::vector<Chunk> chunks;
+            std::vector<std::vector<Chunk>> lists(NWAVES);
+            size_t longest = 1;
             for (int w = 0; w < NWAVES; ++w) {
-                first[w] = (uint16_t)chunks.size();
-                if (per_wave[w].empty()) {
-                    // an idle wavefront still walks one empty chunk: every wavefront then issues the
-                    // same, unconditional sequence of loads per stage, which lets the compiler keep
-                    // exact vmcnt counts (a conditional prefetch forces conservative full drains)
-                    Chunk c{};
-                    c.wtile = 0; c.acol = 0; c.ocol = 0; c.nv = 0; c.last = 0; c.nvalid = 0; c.slab = 0;
-                    chunks.push_back(c);
-                }
                 for (int i : per_wave[w]) {
                     const TileJob& t = tj[i];
                     const int nch = std::max(1, (t.nblk + CHB - 1) / CHB);
@@ -318,17 +309,22 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                         c.last = (uint8_t)(cidx == nch - 1);
                         c.nvalid = (uint8_t)t.nvalid;
                         c.slab = (uint8_t)t.slab;
-                        chunks.push_back(c);
+                        lists[w].push_back(c);
                     }
                 }
+                // an idle wavefront still walks one empty chunk: every wavefront issues the same,
+                // unconditional sequence of loads per stage (exact vmcnt counts for the compiler)
+                if (lists[w].empty()) lists[w].push_back(Chunk{});
+                longest = std::max(longest, lists[w].size());
             }
-            first[NWAVES] = (uint16_t)chunks.size();
-            Chunk h[STAGE_HDR_RECORDS];
-            static_assert(sizeof(h) == sizeof(first), "stage header is 16 uint16");
-            std::memcpy(h, first, sizeof h);
-            for (const Chunk& c : h) jobs.push_back(c);
-            for (const Chunk& c : chunks) jobs.push_back(c);
-            return hdr;
+            const int stride = (int)longest + STAGE_TAIL;
+            for (int w = 0; w < NWAVES; ++w) {
+                lists[w][0].count = (int32_t)lists[w].size();
+                lists[w].resize(stride, Chunk{});      // empty tail: nv = 0, last = 0, tile 0
+                for (const Chunk& c : lists[w]) jobs.push_back(c);
+            }
+            if (hdr > 0xffff || stride > 0x7fff) return -1;
+            return STAGE_DESC(hdr, stride);
         };
         g.jl_begin = (int)jobs.size();
         g.l1_off = emit_stage(1);
@@ -337,6 +333,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         g.g2_off = emit_stage(4);
         g.g1_off = emit_stage(5);
         g.dv_off = emit_stage(6);
+        if (g.l1_off < 0 || g.l2_off < 0 || g.l3_off < 0 || g.g2_off < 0 || g.g1_off < 0 || g.dv_off < 0) {
+            delete P;
+            if (cap_scale < 16) { *retry_smaller = true; return 1; }
+            return fail("hint_plan_create: a group's chunk lists exceed the 16-bit stage descriptor");
+        }
         auto push_ojob = [&](const OJob& o) {
             GJob raw;
             static_assert(sizeof(OJob) == sizeof(GJob), "job records share one 16-byte array");
@@ -352,34 +353,25 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         };
         g.o3_off = (int)jobs.size() - g.jl_begin;
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net) {
+            for (int net = 0; net < 2; ++net) {            // dW3[r][h] = g_st^T a2
                 const DNode& q = dn[ni];
-                const int tbase = thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h);
-                for (int mt = 0; mt < q.rp / 16; ++mt)
-                    for (int nt = 0; nt < q.hp / 16; ++nt) {
-                        OJob o{};
-                        o.acol = (uint16_t)(q.scol + net * q.rp + mt * 16); o.bcol = (uint16_t)(q.acol + net * q.hp + nt * 16);
-                        const int mv = std::min(16, q.r - mt * 16), nv = std::min(16, q.h - nt * 16);
-                        o.mvalid = (uint8_t)std::max(mv, 0); o.nvalid = (uint8_t)std::max(nv, 0);
-                        o.ldg = (uint16_t)q.h; o.goff = (int32_t)(tbase + (int64_t)mt * 16 * q.h + nt * 16);
-                        if (mv > 0 && nv > 0) push_ojob(o);
-                    }
+                OJob o{};
+                o.goff = thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h);
+                o.acol = (uint16_t)(q.scol + net * q.rp); o.bcol = (uint16_t)(q.acol + net * q.hp);
+                o.M = (uint16_t)q.r; o.N = (uint16_t)q.h;
+                push_ojob(o);
             }
         g.o3_cnt = (int)jobs.size() - g.jl_begin - g.o3_off;
         g.o1_off = (int)jobs.size() - g.jl_begin;
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net) {
+            for (int net = 0; net < 2; ++net) {            // dW1[h][cin] = g1^T v
                 const DNode& q = dn[ni];
-                const int tbase = thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin);
-                for (int mt = 0; mt < q.hp / 16; ++mt)
-                    for (int nt = 0; nt < q.cinp / 16; ++nt) {
-                        OJob o{};
-                        o.acol = (uint16_t)(q.acol + net * q.hp + mt * 16); o.bcol = (uint16_t)(q.vcol + nt * 16);
-                        const int mv = std::min(16, q.h - mt * 16), nv = std::min(16, q.cin - nt * 16);
-                        o.mvalid = (uint8_t)std::max(mv, 0); o.nvalid = (uint8_t)std::max(nv, 0);
-                        o.ldg = (uint16_t)q.cin; o.goff = (int32_t)(tbase + (int64_t)mt * 16 * q.cin + nt * 16);
-                        if (mv > 0 && nv > 0) push_ojob(o);
-                    }
+                if (q.cin == 0) continue;
+                OJob o{};
+                o.goff = thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin);
+                o.acol = (uint16_t)(q.acol + net * q.hp); o.bcol = (uint16_t)q.vcol;
+                o.M = (uint16_t)q.h; o.N = (uint16_t)q.cin;
+                push_ojob(o);
             }
         g.o1_cnt = (int)jobs.size() - g.jl_begin - g.o1_off;
         g.jl_count = (int)jobs.size() - g.jl_begin;

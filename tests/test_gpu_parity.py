@@ -143,3 +143,31 @@ def test_parameter_rebinding_and_empty_batch():
     with torch.no_grad():
         (ze,) = blk([torch.empty(0, 6, device=DEV)])
     assert ze.shape == (0, 6) and blk.jacobian(None).shape == (0,)
+
+
+def test_persistent_tile_loop_large_batch():
+    """more row tiles than the launch has workgroups (grid is capped at 8 per CU): the kernels
+    loop over tiles, re-using the LDS tables and prefetching the first group's lists again"""
+    torch.manual_seed(1)
+    d, widths, B = 6, [24, 12], 16 * 2048 + 16 * 300 + 5
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(DEV)
+    x = torch.randn(B, d, device=DEV)
+    nodes = orc.build_nodes(d, (), widths)
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xo = x.cpu().clone().requires_grad_(True)
+    zo, Jo = orc.block_apply(nodes, P, xo, (), rev=False)
+    Lo = (0.5 * (zo ** 2).sum(1) - Jo).mean()
+    Lo.backward()
+    xg = x.clone().requires_grad_(True)
+    (z,) = blk([xg]); J = blk.jacobian(None)
+    L = (0.5 * (z ** 2).sum(1) - J).mean()
+    L.backward()
+    close(z, zo.detach().numpy())
+    close(J, Jo.detach().numpy())
+    assert rel_err(xg.grad.cpu().numpy(), xo.grad.numpy()) < 1e-4
+    named = dict(blk.named_parameters())
+    for k, p in P.items():
+        assert rel_err(named[k].grad.cpu().numpy(), p.grad.numpy()) < 2e-4, k
+    with torch.no_grad():
+        (xr,) = blk([z.detach()], rev=True)
+    assert (xr - x).abs().max().item() < 1e-4
