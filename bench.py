@@ -138,8 +138,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("HINT_FORCE_DIST") == "1"   # the latter: exercise RCCL on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import hint_amd
@@ -156,7 +158,7 @@ def main():
     x = torch.randn(B, d, generator=gx).to(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,7 +170,7 @@ def main():
         l0, l1 = trainer.step(x)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -240,7 +242,7 @@ def main():
             res["nll_rel_err"] = abs(nll_gpu - nll_cpu) / abs(nll_cpu)
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> float:
     """one collective over the whole flat gradient bucket; returns the scale (1/world) that
     turns the sum into the mean (applied later, fused into the optimizer kernel)"""
     rank, world = world_info(group)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
 
