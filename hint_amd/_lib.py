@@ -38,6 +38,10 @@ _PROTOS = {
     "hint_plan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "hint_plan_lds_bytes": (C.c_int32, [C.c_void_p, C.c_int32]),
     "hint_block_pack": (C.c_int, [C.c_void_p] * 4),
+    "hint_pack_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.c_int32, C.POINTER(C.c_void_p)]),
+    "hint_pack_group_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hint_pack_group_destroy": (None, [C.c_void_p]),
     "hint_block_forward": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]),
     "hint_block_inverse": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
     "hint_block_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_int32,

@@ -43,6 +43,18 @@ struct PackSeg {
     int32_t tile_begin; // index of this segment's first n-tile in the global n-tile list
 };
 
+// one block's share of a multi-block pack launch (hint_pack_group_*)
+struct PackItem {
+    const PackSeg* segs;
+    const void* ptiles;       // int2[n_tiles]
+    const int32_t* bmap;
+    const float* params;
+    float* packed;
+    int64_t bias_off;
+    int32_t n_tiles, n_bias;
+    int32_t grid_begin, pad;
+};
+
 // One chunk (<= CHB consecutive 16-wide k-blocks) of one 16-column output tile of a GEMM stage:
 //   out[16 rows][16 cols] (+)= A[16][K] * Wlog^T.
 // The host cuts every tile job into chunks, deals the jobs to the 8 wavefronts (longest first)

@@ -77,18 +77,17 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // =======================================================================================
 // weight packing: flat torch-layout parameters -> MFMA fragment order (see hint_dev.h)
 // =======================================================================================
-__global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restrict__ segs,
-                                                        const int2* __restrict__ ptiles, int n_tiles,
-                                                        const int32_t* __restrict__ bmap, int n_bias,
-                                                        long bias_off, const float* __restrict__ P,
-                                                        float* __restrict__ packed) {
-    if ((int)blockIdx.x >= n_tiles) {
+__device__ __forceinline__ void pack_body(int bid, const PackSeg* __restrict__ segs,
+                                          const int2* __restrict__ ptiles, int n_tiles,
+                                          const int32_t* __restrict__ bmap, int n_bias, long bias_off,
+                                          const float* __restrict__ P, float* __restrict__ packed) {
+    if (bid >= n_tiles) {
         // trailing workgroups: biases laid out per group in LDS column order (zero for padding)
-        const int i = ((int)blockIdx.x - n_tiles) * 256 + (int)threadIdx.x;
+        const int i = (bid - n_tiles) * 256 + (int)threadIdx.x;
         if (i < n_bias) { const int off = bmap[i]; packed[bias_off + i] = off >= 0 ? P[off] : 0.f; }
         return;
     }
-    const int2 pt = ptiles[blockIdx.x];
+    const int2 pt = ptiles[bid];
     const PackSeg sg = segs[pt.x];
     const int nt = pt.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,6 +110,23 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restric
         }
         ((f32x4*)(packed + sg.dst + ((int64_t)nt * sg.NB + kb) * 256))[lane] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restrict__ segs,
+                                                        const int2* __restrict__ ptiles, int n_tiles,
+                                                        const int32_t* __restrict__ bmap, int n_bias,
+                                                        long bias_off, const float* __restrict__ P,
+                                                        float* __restrict__ packed) {
+    pack_body((int)blockIdx.x, segs, ptiles, n_tiles, bmap, n_bias, bias_off, P, packed);
+}
+
+// all blocks of a flow in ONE launch (the trainer re-packs every block after each optimizer step)
+__global__ __launch_bounds__(256) void hint_pack_many_kernel(const PackItem* __restrict__ items, int n_items) {
+    int it = 0;
+    while (it + 1 < n_items && (int)blockIdx.x >= items[it + 1].grid_begin) ++it;
+    const PackItem q = items[it];
+    pack_body((int)blockIdx.x - q.grid_begin, q.segs, (const int2*)q.ptiles, q.n_tiles, q.bmap, q.n_bias, q.bias_off, q.params,
+              q.packed);
 }
 
 __global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, long n4, long n) {
@@ -1041,6 +1057,11 @@ hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, con
     if (grid > 0)
         hipLaunchKernelGGL(hint_pack_kernel, dim3(grid), dim3(256), 0, stream, segs, ptiles, n_tiles, bmap, n_bias,
                            bias_off, params, packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, hipStream_t stream) {
+    if (grid > 0) hipLaunchKernelGGL(hint_pack_many_kernel, dim3(grid), dim3(256), 0, stream, items, n_items);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 namespace hint {
 hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
                        long bias_off, const float* params, float* packed, hipStream_t stream);
+hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, hipStream_t stream);
 hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
                         const float* packed, const float* x, const float* c, float* z, float* J,
@@ -587,6 +588,45 @@ int hint_block_pack(const hint_plan* P, const float* params, float* packed, void
     HIP_TRY(launch_pack(P->d_segs, P->d_ptiles, P->n_ptiles, P->d_bmap, P->n_bias, (long)P->packed_floats, params,
                         packed, (hipStream_t)stream));
     return 0;
+}
+
+struct hint_pack_group {
+    PackItem* d_items = nullptr;
+    int n = 0, grid = 0;
+};
+
+int hint_pack_group_create(const hint_plan* const* plans, const float* const* params, float* const* packed,
+                           int32_t n, hint_pack_group** out) {
+    if (!plans || !params || !packed || n <= 0 || !out) return fail("hint_pack_group_create: bad arguments");
+    std::vector<PackItem> items(n);
+    int grid = 0;
+    for (int i = 0; i < n; ++i) {
+        const hint_plan* P = plans[i];
+        if (!P || !params[i] || !packed[i]) return fail("hint_pack_group_create: null entry %d", i);
+        PackItem& q = items[i];
+        q.segs = P->d_segs; q.ptiles = P->d_ptiles; q.bmap = P->d_bmap; q.params = params[i]; q.packed = packed[i];
+        q.bias_off = P->packed_floats; q.n_tiles = P->n_ptiles; q.n_bias = P->n_bias; q.grid_begin = grid; q.pad = 0;
+        grid += P->n_ptiles + (P->n_bias + 255) / 256;
+    }
+    hint_pack_group* G = new hint_pack_group();
+    G->n = n; G->grid = grid;
+    hipError_t e = hipMalloc((void**)&G->d_items, items.size() * sizeof(PackItem));
+    if (e == hipSuccess) e = hipMemcpy(G->d_items, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(G->d_items); delete G; return fail("hint_pack_group_create: %s", hipGetErrorString(e)); }
+    *out = G;
+    return 0;
+}
+
+int hint_pack_group_run(const hint_pack_group* G, void* stream) {
+    if (!G) return fail("hint_pack_group_run: null group");
+    HIP_TRY(launch_pack_many(G->d_items, G->n, G->grid, (hipStream_t)stream));
+    return 0;
+}
+
+void hint_pack_group_destroy(hint_pack_group* G) {
+    if (!G) return;
+    (void)hipFree(G->d_items);
+    delete G;
 }
 
 static int apply(const hint_plan* P, bool rev, const float* params, const float* packed, const float* x,

@@ -53,6 +53,7 @@ class FlowTrainer:
             e.ensure_arena()
             e.pack()
         self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._pack_group, self._pack_key = None, None
         for i in range(flow.n_blocks):          # the kernels read W through its raw pointer (row-major)
             if flow.has_perm(i) and not flow.perms[i].W.is_contiguous():
                 flow.perms[i].W = flow.perms[i].W.contiguous()
@@ -65,8 +66,7 @@ class FlowTrainer:
         permutations, the running log-det, the two loss sums and the loss gradient are folded
         into the block kernels (hint_block_*_ex)."""
         flow, B = self.flow, x.shape[0]
-        for e in self.engines:               # weights of the previous optimizer step, MFMA order
-            e.pack()
+        self._pack_all()                     # weights of the previous optimizer step, MFMA order
         if self.noise > 0:
             x = x.add(torch.randn_like(x), alpha=self.noise)
         self.loss_acc.zero_()
@@ -89,6 +89,27 @@ class FlowTrainer:
         l0 = self.loss_acc[0] / B
         l1 = -self.loss_acc[1] / B
         return l0, l1
+
+    def _pack_all(self):
+        """one launch re-packs every block (hint_pack_group_*); the group is rebuilt whenever an
+        arena or packed buffer moved"""
+        import ctypes as C
+        key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines)
+        if self._pack_key != key:
+            if self._pack_group:
+                self.lib.hint_pack_group_destroy(self._pack_group)
+            n = len(self.engines)
+            plans = (C.c_void_p * n)(*[e.plan.value for e in self.engines])
+            params = (C.c_void_p * n)(*[e.arena.data_ptr() for e in self.engines])
+            packed = (C.c_void_p * n)(*[e.packed.data_ptr() for e in self.engines])
+            handle = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.hint_pack_group_create(plans, params, packed, n, C.byref(handle)),
+                           "hint_pack_group_create")
+            self._pack_group, self._pack_key = handle, key
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_pack_group_run(self._pack_group, torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(st, "hint_pack_group_run")
 
     def _check_arenas(self):
         """parameters rebound from outside (p.data = ..., load_state_dict into new storage)

@@ -79,6 +79,14 @@ int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
  * should see it; one small launch (the weights of a block are a few hundred KiB). */
 int hint_block_pack(const hint_plan* plan, const float* params, float* packed, void* stream);
 
+/* The same for several blocks in ONE launch (a trainer re-packs every block of the flow after
+ * each optimizer step): the group records plan / params / packed pointers of n blocks once. */
+typedef struct hint_pack_group hint_pack_group;
+int hint_pack_group_create(const hint_plan* const* plans, const float* const* params,
+                           float* const* packed, int32_t n, hint_pack_group** out);
+int hint_pack_group_run(const hint_pack_group* group, void* stream);
+void hint_pack_group_destroy(hint_pack_group* group);
+
 /* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0.
  * params: flat parameters (biases are read from here); packed: output of hint_block_pack.
  * tape: NULL for inference, else hint_plan_tape_floats(plan, B) floats (training). */
