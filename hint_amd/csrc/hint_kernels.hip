@@ -458,6 +458,28 @@ __device__ __forceinline__ void load_tile(float* dst, int ld, const float* __res
     }
 }
 
+// A [16, width] tile held in registers between its global load and its LDS commit, so that the
+// load latency hides behind other work (width <= TILE_REGS * NTHREADS / 16 floats per row).
+constexpr int TILE_REGS = 4;
+struct TilePrefetch { float r[TILE_REGS]; };
+__device__ __forceinline__ void tile_issue(TilePrefetch& tp, const float* __restrict__ src, int width, int row0,
+                                           int B, int tid) {
+    const float* p = src + (size_t)row0 * width;
+    const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
+#pragma unroll
+    for (int k = 0; k < TILE_REGS; ++k) {
+        const int i = tid + k * NTHREADS;
+        tp.r[k] = (i < nvalid) ? p[i] : 0.f;
+    }
+}
+__device__ __forceinline__ void tile_commit(const TilePrefetch& tp, float* dst, int ld, int width, int tid) {
+#pragma unroll
+    for (int k = 0; k < TILE_REGS; ++k) {
+        const int i = tid + k * NTHREADS;
+        if (i < ROWS * width) { const int r = i / width; dst[r * ld + (i - r * width)] = tp.r[k]; }
+    }
+}
+
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* src, int ld,
                                            int width, int row0, int B, int tid) {
     float* p = dst + (size_t)row0 * width;
@@ -762,6 +784,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             load_tile(gcs, a.cld, nullptr, a.dc, row0, a.B, tid);
         }
         if (tid < ROWS) gj[tid] = (row0 + tid < a.B) ? (g_J != nullptr ? g_J[row0 + tid] : gJ_const) : 0.f;
+        // lane tile of the first (root) level: same memory round trip as everything above
+#define LEVEL_SRC(LV) ((LV) == 0 ? (perm != nullptr ? tape + (size_t)(a.n_levels - 1) * a.B * a.d : x) \
+                                  : tape + (size_t)((LV) - 1) * a.B * a.d)
+        load_tile(xs, a.xld, LEVEL_SRC(a.n_levels - 1), a.d, row0, a.B, tid);
         __syncthreads();
         STAMP(1)
         GroupU g = load_group(groups + (a.n_groups - 1));
@@ -786,13 +812,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             const int sbase = 2 + 20 * (a.n_groups - 1 - gi);
             (void)sbase;
 
-            // ---- the lanes as the forward pass saw them when it entered this level ----
-            if (g.level_last) {
-                const float* src = (g.level == 0) ? (perm != nullptr ? tape + (size_t)(a.n_levels - 1) * a.B * a.d : x)
-                                                  : tape + (size_t)(g.level - 1) * a.B * a.d;
-                load_tile(xs, a.xld, src, a.d, row0, a.B, tid);
-                lds_barrier();
-            }
+            // ---- the lanes as the forward pass saw them when it entered the NEXT level: fetched
+            //      into registers now, committed to LDS once this group no longer reads xs ----
+            const bool level_switch = (gi > 0) && (gn.level != g.level);
+            TilePrefetch xnext;
+            if (level_switch) tile_issue(xnext, LEVEL_SRC(gn.level), a.d, row0, a.B, tid);
             // ---- recompute s, t of every node of the group (bit-identical to the forward) ----
             stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
             for (int i = tid; i < ROWS * g.sw; i += NTHREADS) {
@@ -870,6 +894,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)
+            if (level_switch) tile_commit(xnext, xs, a.xld, a.d, tid);
             // ---- scatter g_v: upper-lane columns to g (each lane has one v column per group),
             //      condition columns to g_c (every node of the group contributes) ----
             {

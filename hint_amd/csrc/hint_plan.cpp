@@ -509,6 +509,8 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
                      hint_plan** out) {
     if (!nodes || n_nodes <= 0 || d <= 0 || dc < 0 || !out) return fail("hint_plan_create: bad arguments");
     *out = nullptr;
+    if (d > 4 * NTHREADS / ROWS)      // TilePrefetch of the backward kernel holds 4 floats per thread
+        return fail("hint_plan_create: d = %d lanes exceeds the supported maximum %d", d, 4 * NTHREADS / ROWS);
     // ---- validate the tree: lane ranges inside [0,d), same-depth nodes disjoint ----
     for (int i = 0; i < n_nodes; ++i) {
         const hint_node_desc& n = nodes[i];

@@ -1,0 +1,39 @@
+"""Per-stage cycle breakdown of the backward kernel, part A (diagnostic build with -DHINT_STAMPS)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hint_amd
+from hint_amd import _lib
+d, widths, B = 6, [140, 70, 35, 17], 4096
+if len(sys.argv) > 1:
+    d = int(sys.argv[1]); widths = [int(v) for v in sys.argv[2].split(",")]; B = int(sys.argv[3])
+dev = "cuda:0"
+lib = _lib.load()
+blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(dev)
+x = torch.randn(B, d, device=dev, requires_grad=True)
+buf = torch.zeros(8 * 128 + 64, dtype=torch.int64, device=dev)
+(z,) = blk([x]); J = blk.jacobian(None)
+L = (0.5 * (z ** 2).sum(1) - J).mean()
+for _ in range(5):
+    L.backward(retain_graph=True)
+torch.cuda.synchronize()
+assert lib.hint_debug_set_stamp_buffer(buf.data_ptr()) == 0, "not a stamps build"
+lib.hint_debug_set_backward_stages(1)
+L.backward(retain_graph=True)
+torch.cuda.synchronize()
+lib.hint_debug_set_backward_stages(3)
+s = buf.cpu()[:1024].view(8, 128)
+names = {0: "start", 1: "loaded+sync", 120: "stored"}
+stages = ["build_v", "sync", "L1(+begin L3)", "sync", "L2(+copy a1,begin g2)", "sync", "L3(+begin g1)", "sync", "couple", "sync",
+          "o3+colsum", "sync", "g2(+begin dv)", "sync", "g1(+copy g2,colsum)", "sync", "dv+o1+colsum", "sync", "scatter", "sync"]
+for gi in range(5):
+    for k, nm in enumerate(stages):
+        names[2 + 20 * gi + k] = f"g{gi}:{nm}"
+ids = sorted([i for i in names if s[0, i] != 0], key=lambda i: s[0, i].item())
+t0 = s[:, 0].min().item()
+prev = None
+for i in ids:
+    row = [(s[w, i].item() - t0) for w in range(8)]
+    dl = "" if prev is None else f"  +{row[0]-prev}"
+    prev = row[0]
+    print(names[i].ljust(28) + f"{row[0]:9d} {max(row):9d}" + dl)
