@@ -167,7 +167,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        l0, l1 = trainer.step(x)
+        trainer.step(x)                      # loss terms are accumulated on the device, read once below
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -177,8 +177,9 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
-    nll = trainer.nll(x)
+    l0, l1 = trainer.last_losses()
     loss_last = float(l0) + float(l1)
+    nll = trainer.nll(x)
 
     if rank == 0:
         F = flops_per_sample_block(d, cfg["c_internal"])

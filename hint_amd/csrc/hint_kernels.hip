@@ -705,8 +705,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 for (int w = 0; w < NWAVES; ++w) t += vb[w];
                 float js = 0.f;
                 for (int r = 0; r < nvalid; ++r) js += jac[r] + (J_in != nullptr ? J_in[row0 + r] : 0.f);
-                atomicAdd(loss_acc, 0.5f * t);
-                atomicAdd(loss_acc + 1, js);
+                // 64 slots of {sum 0.5|z|^2, sum J}: spreads the atomics of the 256 workgroups
+                float* slot = loss_acc + 2 * (blockIdx.x & 63);
+                atomicAdd(slot, 0.5f * t);
+                atomicAdd(slot + 1, js);
             }
         }
         STAMP(120)

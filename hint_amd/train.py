@@ -21,6 +21,17 @@ from .flow import HintFlow
 from .hint import HintAmdError
 
 
+class _LossPair:
+    """what step() returns: unpacks to the two loss terms, evaluated lazily so that no kernel
+    is launched for them unless somebody looks"""
+
+    def __init__(self, trainer):
+        self._t = trainer
+
+    def __iter__(self):
+        return iter(self._t.last_losses())
+
+
 class FlowTrainer:
     def __init__(self, flow: HintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
                  weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01,
@@ -52,7 +63,7 @@ class FlowTrainer:
             e.bind_external_arena(self.P[a:b])
             e.ensure_arena()
             e.pack()
-        self.loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)   # per-slot partial loss sums
         self._pack_group, self._pack_key = None, None
         for i in range(flow.n_blocks):          # the kernels read W through its raw pointer (row-major)
             if flow.has_perm(i) and not flow.perms[i].W.is_contiguous():
@@ -85,10 +96,7 @@ class FlowTrainer:
             perm = flow.perms[i].W if flow.has_perm(i) else None
             g = self.engines[i].backward_chain(inputs[i], tapes[i], c, g, (1.0 / B) if i == n - 1 else 1.0,
                                                -1.0 / B, perm, self.G[a:b], accumulate=True)
-        # loss terms as the reference logs them ('-log p(z)', '-log |det J|'), lazily scaled views
-        l0 = self.loss_acc[0] / B
-        l1 = -self.loss_acc[1] / B
-        return l0, l1
+        return B
 
     def _pack_all(self):
         """one launch re-packs every block (hint_pack_group_*); the group is rebuilt whenever an
@@ -141,7 +149,7 @@ class FlowTrainer:
         ('-log p(z)', '-log |det J|') of the LOCAL shard (train_unconditional.py:162)"""
         if not self.use_graph:
             self._check_arenas()
-            l0, l1 = self._fwd_bwd(x, c)
+            self._fwd_bwd(x, c)
         else:
             if self._graph is None or self._static["x"].shape != x.shape:
                 self._capture(x, c)
@@ -149,10 +157,10 @@ class FlowTrainer:
             if c is not None:
                 self._static["c"].copy_(c)
             self._graph.replay()
-            l0, l1 = self._static["l0"], self._static["l1"]
+        self._last_B = x.shape[0]
         scale = dp.allreduce_sum_(self.G, self.group)
         self._optimizer(scale)
-        return l0, l1
+        return _LossPair(self)
 
     def _capture(self, x, c):
         self._check_arenas()
@@ -168,9 +176,16 @@ class FlowTrainer:
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            l0, l1 = self._fwd_bwd(sx, sc)
+            self._fwd_bwd(sx, sc)
         self._graph = g
-        self._static = dict(x=sx, c=sc, l0=l0, l1=l1)
+        self._static = dict(x=sx, c=sc)
+
+    def last_losses(self):
+        """(-log p(z), -log|det J|) of the most recent step's local shard as device scalars
+        (train_unconditional.py:162 labels).  The sums live in a buffer the next step overwrites:
+        read them before stepping again."""
+        s = self.loss_acc.sum(dim=0)
+        return s[0] / self._last_B, -s[1] / self._last_B
 
     @torch.no_grad()
     def nll(self, x: torch.Tensor, c: Optional[torch.Tensor] = None) -> float:

@@ -120,8 +120,9 @@ int hint_block_backward(const hint_plan* plan, const float* params, const float*
  *            reads it from there (x may be NULL).
  *   J_in     [B] log-det accumulated by the preceding blocks, added to this block's J
  *            (ReversibleGraphNet.log_jacobian sums the nodes); NULL = 0.
- *   loss_acc float[2], accumulated atomically: [0] += sum_rows 0.5*|z|^2, [1] += sum_rows J
- *            (the two loss terms of train_unconditional.py:128-129 before the .mean()); NULL = skip.
+ *   loss_acc float[64][2], accumulated atomically (workgroup b adds to slot b % 64, the caller
+ *            sums the slots): [.][0] += sum_rows 0.5*|z|^2, [.][1] += sum_rows J (the two loss
+ *            terms of train_unconditional.py:128-129 before the .mean()); NULL = skip.
  *   gz_scale multiplies g_z on load (pass z and 1/B for the first term's gradient);
  *   gJ_const used for every row when g_J is NULL (-1/B for the second term). */
 int hint_block_forward_ex(const hint_plan* plan, const float* params, const float* packed,
