@@ -50,6 +50,12 @@ _PROTOS = {
     "hint_block_inverse_ex": (C.c_int, [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
     "hint_block_backward_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
                                                              C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "hint_chain_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "hint_chain_set_block": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
+    "hint_chain_commit": (C.c_int, [C.c_void_p]),
+    "hint_chain_forward": (C.c_int, [C.c_void_p] * 8),
+    "hint_chain_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "hint_chain_destroy": (None, [C.c_void_p]),
     "hint_debug_set_backward_stages": (None, [C.c_int32]),
     "hint_debug_set_stamp_buffer": (C.c_int, [C.c_void_p]),
     "hint_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32] + [C.c_float] * 7 + [C.c_int32,

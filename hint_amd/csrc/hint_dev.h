@@ -43,6 +43,20 @@ struct PackSeg {
     int32_t tile_begin; // index of this segment's first n-tile in the global n-tile list
 };
 
+// Per-block pointers of a chained launch (hint_chain_*): all blocks of a flow share one plan
+// shape, so the kernels loop over the blocks with the lane tile (forward) or the gradient tile
+// (backward) staying in LDS between blocks.
+struct ChainBlock {
+    const float* params;
+    const float* packed;
+    const float* perm;     // [d,d] permutation in front of the block, or nullptr
+    float* tape;           // forward tape of this block (or nullptr)
+    float* wsA1;           // backward workspace of this block
+    float* wsG2;
+    float* wsT;
+    float* gparams;        // flat parameter gradient of this block (part B)
+};
+
 // one block's share of a multi-block pack launch (hint_pack_group_*)
 struct PackItem {
     const PackSeg* segs;

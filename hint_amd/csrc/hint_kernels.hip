@@ -541,21 +541,48 @@ __device__ __forceinline__ void meta_commit(const MetaPrefetch& mp, const KArgs&
 // =======================================================================================
 // forward (REV=false) / inverse (REV=true): x, J -> z   — one launch per block
 // =======================================================================================
+// Pointers that reach a kernel inside a by-value struct or a device table are generic ("flat") to
+// the compiler; a flat load counts against vmcnt AND lgkmcnt and so serialises with the LDS
+// traffic.  Laundering them through address space 1 tells it they are global memory.
+#define GLOBAL_AS __attribute__((address_space(1)))
+struct GBlock {      // ChainBlock with the pointers typed as global memory
+    const GLOBAL_AS float* params;
+    const GLOBAL_AS float* packed;
+    const GLOBAL_AS float* perm;
+    GLOBAL_AS float* tape;
+    GLOBAL_AS float* wsA1;
+    GLOBAL_AS float* wsG2;
+    GLOBAL_AS float* wsT;
+    GLOBAL_AS float* gparams;
+};
+__device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ chain, const ChainBlock& one, int i) {
+    const ChainBlock b = (chain != nullptr) ? chain[i] : one;
+    GBlock g;
+    g.params = (const GLOBAL_AS float*)b.params;
+    g.packed = (const GLOBAL_AS float*)b.packed;
+    g.perm = (const GLOBAL_AS float*)b.perm;
+    g.tape = (GLOBAL_AS float*)b.tape;
+    g.wsA1 = (GLOBAL_AS float*)b.wsA1;
+    g.wsG2 = (GLOBAL_AS float*)b.wsG2;
+    g.wsT = (GLOBAL_AS float*)b.wsT;
+    g.gparams = (GLOBAL_AS float*)b.gparams;
+    return g;
+}
+
 template <bool REV>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void hint_block_apply_kernel(
-    KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
+    KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
-    float* __restrict__ J, float* __restrict__ tape, const float* __restrict__ perm,
-    const float* __restrict__ J_in, float* __restrict__ loss_acc) {
+    float* __restrict__ J, const float* __restrict__ J_in, float* __restrict__ loss_acc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     STAMP(0)
     HINT_LDS_TABLES()
-    float* xin = fbase;                      // the tile as loaded (only used when a permutation is fused)
-    float* xs = perm != nullptr ? xin + ROWS * a.xld : xin;
-    float* cs = xin + 2 * ROWS * a.xld;
+    float* t0 = fbase;                        // two lane tiles: a fused permutation ping-pongs between them
+    float* t1 = t0 + ROWS * a.xld;
+    float* cs = t0 + 2 * ROWS * a.xld;
     float* vb = cs + ROWS * a.cld;
     float* a1 = vb + ROWS * a.vld;
     float* a2 = a1 + ROWS * a.ald;
@@ -564,9 +591,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     const int sstride = ROWS * a.sld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
     const int fo = REV ? 1 : 0;               // which "first group" record of the kernel arguments
+#define HINT_CB(I) chain_block(chain, one, I)
+    GBlock blk = HINT_CB(0);
     {   // the first group's chunk lists and biases: issued together with the meta copy
         JobPrefetch jp0;
-        jobs_issue(jp0, a.jobs, a.first[fo][0], a.first[fo][1], packed + a.bias_off + a.first[fo][2], a.first[fo][3], tid);
+        jobs_issue(jp0, a.jobs, a.first[fo][0], a.first[fo][1], (const float*)blk.packed + a.bias_off + a.first[fo][2], a.first[fo][3], tid);
         meta_commit(mp_, a, mbase, tid);
         jobs_commit(jp0, jbuf0, bias0, tid);
     }
@@ -578,122 +607,139 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     // one Stage object, so nothing has to be copied.
     int jb = 0;
     Stage SA, SB, SC;     // L1, L2, L3
-    bool first_tile = true;
+    bool first = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
-        load_tile(xin, a.xld, x, a.d, row0, a.B, tid);
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
+        // the current lane tile is t0 + xcur (an integer offset, not a swapped pointer: the
+        // compiler must keep seeing LDS addresses or it falls back to flat loads)
+        int xcur = 0;
+        const int xflip = ROWS * a.xld;
+        (void)t1;
+#define xs (t0 + xcur)
+#define xo (t0 + (xflip - xcur))
+        load_tile(xs, a.xld, x, a.d, row0, a.B, tid);
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
         if (tid < ROWS) jac[tid] = 0.f;
         __syncthreads();                      // meta, first chunk lists and the lane tile visible
-        if (perm != nullptr) {
-            // fused fixed inter-block permutation (power_hint_8.py:59-62): forward x' = x W,
-            // inverse x = x' W^T is applied on the way out instead
-            if (!REV) {
+        STAMP(1)
+
+        // ---- the blocks of the chain (one for the plain per-block entry points): the lane tile
+        //      stays in LDS from block to block ----
+        for (int cb = 0; cb < n_chain; ++cb) {
+            const GBlock nblk = HINT_CB(cb + 1 < n_chain ? cb + 1 : 0);   // whose weights get prefetched next
+            const float* packed = (const float*)blk.packed;
+            const float* perm = (const float*)blk.perm;
+            float* tape = (float*)blk.tape;
+            if (!REV && perm != nullptr) {
+                // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
                 for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
                     const int r = i / a.d, j = i - r * a.d;
                     float acc = 0.f;
-                    for (int k = 0; k < a.d; ++k) acc = fmaf(xin[r * a.xld + k], perm[k * a.d + j], acc);
-                    xs[r * a.xld + j] = acc;
+                    for (int k = 0; k < a.d; ++k) acc = fmaf(xs[r * a.xld + k], perm[k * a.d + j], acc);
+                    xo[r * a.xld + j] = acc;
                 }
-            } else {
-                for (int i = tid; i < ROWS * a.d; i += NTHREADS) { const int r = i / a.d, j = i - r * a.d; xs[r * a.xld + j] = xin[r * a.xld + j]; }
-            }
-            __syncthreads();
-            if (!REV && tape != nullptr)      // the permuted input is what the backward pass starts from
+                xcur = xflip - xcur;
+                __syncthreads();
+                if (tape != nullptr)      // the permuted input is what the backward pass starts from
+                    store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
+            } else if (!REV && cb > 0 && tape != nullptr) {
+                // inner block of a chain without a permutation: its input exists nowhere else
                 store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
-        }
-        STAMP(1)
-        GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
-        if (first_tile) {
-            stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
-            stage_begin(SB, jbuf0 + jb * a.jmax, g.l2_off, packed, wave, lane);
-        }
-        first_tile = false;
+            }
+            GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
+            if (first) {
+                stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
+                stage_begin(SB, jbuf0 + jb * a.jmax, g.l2_off, packed, wave, lane);
+            }
+            first = false;
 
-        for (int gi = 0; gi < a.n_groups; ++gi) {
-            const bool more_tiles = tile + (int)gridDim.x < ntiles;
-            const bool has_next = (gi + 1 < a.n_groups) || more_tiles;
-            const int gnext = (gi + 1 < a.n_groups) ? gi + 1 : 0;
-            const GroupU gn = load_group(groups + (REV ? (a.n_groups - 1 - gnext) : gnext));
-            JobPrefetch jp;
-            jp.count = 0;
-            jp.nbias4 = 0;
-            if (has_next)
-                jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
-            lds_jobs_t jl = jbuf0 + jb * a.jmax;
-            LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
-            const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
+            for (int gi = 0; gi < a.n_groups; ++gi) {
+                const bool last_group = gi + 1 >= a.n_groups;
+                const bool has_next = !last_group || (cb + 1 < n_chain) || more_tiles;
+                const float* packed_n = last_group ? (const float*)nblk.packed : packed;     // weights of the next group
+                const int gnext = last_group ? 0 : gi + 1;
+                const GroupU gn = load_group(groups + (REV ? (a.n_groups - 1 - gnext) : gnext));
+                JobPrefetch jp;
+                jp.count = 0;
+                jp.nbias4 = 0;
+                if (has_next)
+                    jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed_n + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
+                lds_jobs_t jl = jbuf0 + jb * a.jmax;
+                LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
+                const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
 
-            stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
-            STAMP(2 + 12 * gi)
-            lds_barrier();
-            STAMP(3 + 12 * gi)
-            stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
-            stage_begin(SC, jl, g.l3_off, packed, wave, lane);
-            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
-            STAMP(4 + 12 * gi)
-            lds_barrier();
-            STAMP(5 + 12 * gi)
-            stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
-            if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed, wave, lane);
-            STAMP(6 + 12 * gi)
-            lds_barrier();
-            STAMP(7 + 12 * gi)
-            stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
-            if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed, wave, lane);
-            STAMP(8 + 12 * gi)
-            lds_barrier();
-            STAMP(9 + 12 * gi)
-            {   // element-wise affine coupling + log-det partial sums (hint.py:79-83)
-                const int sub = tid & 15, row = tid >> 4;
-                float part = 0.f;
+                stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
+                STAMP(2 + 12 * gi)
+                lds_barrier();
+                STAMP(3 + 12 * gi)
+                stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+                stage_begin(SC, jl, g.l3_off, packed, wave, lane);
+                if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
+                STAMP(4 + 12 * gi)
+                lds_barrier();
+                STAMP(5 + 12 * gi)
+                stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
+                if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed_n, wave, lane);
+                STAMP(6 + 12 * gi)
+                lds_barrier();
+                STAMP(7 + 12 * gi)
+                stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+                if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed_n, wave, lane);
+                STAMP(8 + 12 * gi)
+                lds_barrier();
+                STAMP(9 + 12 * gi)
+                {   // element-wise affine coupling + log-det partial sums (hint.py:79-83)
+                    const int sub = tid & 15, row = tid >> 4;
+                    float part = 0.f;
 #ifdef HINT_SKIP_COUPLE
-                if (false) {
+                    if (false) {
 #else
-                if (row < ROWS) {
+                    if (row < ROWS) {
 #endif
-                    for (int e = sub; e < g.ent_cnt; e += 16) {
-                        const EntU en = load_ent(ents, g.ent_begin + e);
-                        float s = 0.f, t = 0.f;
-                        for (int sl = 0; sl < g.l3_slabs; ++sl) {
-                            s += st[sl * sstride + row * a.sld + en.scol];
-                            t += st[sl * sstride + row * a.sld + en.tcol];
+                        for (int e = sub; e < g.ent_cnt; e += 16) {
+                            const EntU en = load_ent(ents, g.ent_begin + e);
+                            float s = 0.f, t = 0.f;
+                            for (int sl = 0; sl < g.l3_slabs; ++sl) {
+                                s += st[sl * sstride + row * a.sld + en.scol];
+                                t += st[sl * sstride + row * a.sld + en.tcol];
+                            }
+                            const float aa = a.alpha * atanf(s);
+                            float* px = xs + row * a.xld + en.xcol;
+                            if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
+                            else      { *px = ((*px) - t) / expf(aa); part -= aa; }
                         }
-                        const float aa = a.alpha * atanf(s);
-                        float* px = xs + row * a.xld + en.xcol;
-                        if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
-                        else      { *px = ((*px) - t) / expf(aa); part -= aa; }
                     }
+                    part = row16_sum(part);
+                    if (sub == 0 && row < ROWS) jac[row] += part;
                 }
-                part = row16_sum(part);
-                if (sub == 0 && row < ROWS) jac[row] += part;
+                STAMP(10 + 12 * gi)
+                lds_barrier();
+                STAMP(11 + 12 * gi)
+                // training: keep the lane tile as it stands after each level except the root's, so
+                // that the backward pass sees bit-identical subnet inputs (tape[level][B][d])
+                if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
+                    store_tile(tape + (size_t)g.level * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
+                jb ^= 1;
+                g = gn;
             }
-            STAMP(10 + 12 * gi)
-            lds_barrier();
-            STAMP(11 + 12 * gi)
-            // training: keep the lane tile as it stands after each level except the root's, so
-            // that the backward pass sees bit-identical subnet inputs (tape[level][B][d])
-            if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
-                store_tile(tape + (size_t)g.level * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
-            jb ^= 1;
-            g = gn;
-        }
-        if (REV && perm != nullptr) {         // x = x' W^T
-            for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
-                const int r = i / a.d, j = i - r * a.d;
-                float acc = 0.f;
-                for (int k = 0; k < a.d; ++k) acc = fmaf(xs[r * a.xld + k], perm[j * a.d + k], acc);
-                xin[r * a.xld + j] = acc;
+            if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
+                for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                    const int r = i / a.d, j = i - r * a.d;
+                    float acc = 0.f;
+                    for (int k = 0; k < a.d; ++k) acc = fmaf(xs[r * a.xld + k], perm[j * a.d + k], acc);
+                    xo[r * a.xld + j] = acc;
+                }
+                xcur = xflip - xcur;
+                __syncthreads();
             }
-            __syncthreads();
-            store_tile(z, xin, a.xld, a.d, row0, a.B, tid);
-        } else {
-            store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
+            blk = nblk;
         }
+        store_tile(z, xs, a.xld, a.d, row0, a.B, tid);
         if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid] + (J_in != nullptr ? J_in[row0 + tid] : 0.f);
         if (loss_acc != nullptr) {
             // per-workgroup partial sums of the two loss terms (train_unconditional.py:128-129):
-            // loss_acc[0] += sum_rows 0.5*|z|^2, loss_acc[1] += sum_rows J_total
+            // slot[0] += sum_rows 0.5*|z|^2, slot[1] += sum_rows J_total
             float zz = 0.f;
             const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS);
             for (int i = tid; i < nvalid * a.d; i += NTHREADS) { const int r = i / a.d; const float v = xs[r * a.xld + (i - r * a.d)]; zz += v * v; }
@@ -713,7 +759,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         }
         STAMP(120)
         lds_barrier();
+#undef xs
+#undef xo
     }
+#undef HINT_CB
 }
 
 // =======================================================================================
@@ -741,11 +790,10 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
 }
 
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void hint_block_bwd_kernel(
-    KArgs a, const float* __restrict__ params, const float* __restrict__ packed,
-    const float* __restrict__ x, const float* __restrict__ tape, const float* __restrict__ c,
+    KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
+    const float* __restrict__ x, const float* __restrict__ c,
     const float* __restrict__ g_z, const float* __restrict__ g_J, float* __restrict__ g_x,
-    float* __restrict__ g_c, float* __restrict__ wsT, float* __restrict__ wsA1,
-    float* __restrict__ wsG2, const float* __restrict__ perm, float gz_scale, float gJ_const) {
+    float* __restrict__ g_c, float gz_scale, float gJ_const) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -765,9 +813,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     float* gj = gst + ROWS * a.sld;
     const int sstride = ROWS * a.sld, vstride = ROWS * a.vld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
+#define HINT_CB(I) chain_block(chain, one, I)
+    GBlock blk = HINT_CB(n_chain - 1);         // the chain is walked from its last block to its first
     {
         JobPrefetch jp0;
-        jobs_issue(jp0, a.jobs, a.first[1][0], a.first[1][1], packed + a.bias_off + a.first[1][2], a.first[1][3], tid);
+        jobs_issue(jp0, a.jobs, a.first[1][0], a.first[1][1], (const float*)blk.packed + a.bias_off + a.first[1][2], a.first[1][3], tid);
         meta_commit(mp_, a, mbase, tid);
         jobs_commit(jp0, jbuf0, bias0, tid);
     }
@@ -777,7 +827,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
-        float* gparams = wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
+        const bool more_tiles = tile + (int)gridDim.x < ntiles;
         load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid);
         if (gz_scale != 1.f)                   // loss gradient fused: g_z = z / B given z
             for (int i = tid; i < ROWS * a.d; i += NTHREADS) { const int r = i / a.d; gs[r * a.xld + (i - r * a.d)] *= gz_scale; }
@@ -786,12 +836,28 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             load_tile(gcs, a.cld, nullptr, a.dc, row0, a.B, tid);
         }
         if (tid < ROWS) gj[tid] = (row0 + tid < a.B) ? (g_J != nullptr ? g_J[row0 + tid] : gJ_const) : 0.f;
-        // lane tile of the first (root) level: same memory round trip as everything above
-#define LEVEL_SRC(LV) ((LV) == 0 ? (perm != nullptr ? tape + (size_t)(a.n_levels - 1) * a.B * a.d : x) \
-                                  : tape + (size_t)((LV) - 1) * a.B * a.d)
-        load_tile(xs, a.xld, LEVEL_SRC(a.n_levels - 1), a.d, row0, a.B, tid);
+        // lane tile of the first (root) level: same memory round trip as everything above.  The
+        // input of a block is x for the first block of a call without a fused permutation, and the
+        // top tape slot otherwise (hint_block_apply_kernel stored it there).
+#define BLOCK_LEVEL_SRC(TAPE, TOP, LV) ((LV) == 0 ? ((TOP) ? (TAPE) + (size_t)(a.n_levels - 1) * a.B * a.d : x) \
+                                                  : (TAPE) + (size_t)((LV) - 1) * a.B * a.d)
+#define LEVEL_SRC(LV) BLOCK_LEVEL_SRC(tape, (perm != nullptr || cb > 0), LV)
+        {
+            const float* tape = (const float*)blk.tape;
+            const float* perm = (const float*)blk.perm;
+            const int cb = n_chain - 1;
+            load_tile(xs, a.xld, LEVEL_SRC(a.n_levels - 1), a.d, row0, a.B, tid);
+        }
         __syncthreads();
         STAMP(1)
+      for (int cb = n_chain - 1; cb >= 0; --cb) {
+        const GBlock nblk = HINT_CB(cb > 0 ? cb - 1 : n_chain - 1);    // the block worked on after this one
+        const float* packed = (const float*)blk.packed;
+        const float* perm = (const float*)blk.perm;
+        const float* tape = (const float*)blk.tape;
+        float* wsA1 = (float*)blk.wsA1;
+        float* wsG2 = (float*)blk.wsG2;
+        float* gparams = (float*)blk.wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
         GroupU g = load_group(groups + (a.n_groups - 1));
         if (first_tile) {
             stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
@@ -800,14 +866,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         first_tile = false;
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
-            const bool more_tiles = tile + (int)gridDim.x < ntiles;
-            const bool has_next = (gi > 0) || more_tiles;
+            const bool has_next = (gi > 0) || (cb > 0) || more_tiles;
+            const float* packed_n = (gi > 0) ? packed : (const float*)nblk.packed;   // weights of the next group
             const GroupU gn = load_group(groups + (gi > 0 ? gi - 1 : a.n_groups - 1));
             JobPrefetch jp;
             jp.count = 0;
             jp.nbias4 = 0;
             if (has_next)
-                jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
+                jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed_n + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
             lds_jobs_t jl = jbuf0 + jb * a.jmax;
             LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
             const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
@@ -816,9 +882,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 
             // ---- the lanes as the forward pass saw them when it entered the NEXT level: fetched
             //      into registers now, committed to LDS once this group no longer reads xs ----
-            const bool level_switch = (gi > 0) && (gn.level != g.level);
+            const bool block_switch = (gi == 0) && (cb > 0);       // next: the root level of the block before
+            const bool level_switch = ((gi > 0) && (gn.level != g.level)) || block_switch;
             TilePrefetch xnext;
-            if (level_switch) tile_issue(xnext, LEVEL_SRC(gn.level), a.d, row0, a.B, tid);
+            if (level_switch) {
+                const float* src = block_switch
+                    ? BLOCK_LEVEL_SRC((const float*)nblk.tape, (nblk.perm != nullptr || cb > 1), a.n_levels - 1)
+                    : LEVEL_SRC(gn.level);
+                tile_issue(xnext, src, a.d, row0, a.B, tid);
+            }
             // ---- recompute s, t of every node of the group (bit-identical to the forward) ----
             stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
             for (int i = tid; i < ROWS * g.sw; i += NTHREADS) {
@@ -884,13 +956,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
             colsum_store(a.bmap + g.bmap_begin + g.aw, g.aw, a2, a.ald, gparams, tid);
             stage_run<EPI_MASK>(SB, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
-            if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed, wave, lane);
+            if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed_n, wave, lane);
             STAMP(sbase + 14)
             lds_barrier();
             STAMP(sbase + 15)
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
             stage_run<EPI_PLAIN>(SC, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
-            if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed, wave, lane);
+            if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed_n, wave, lane);
             run_ojobs(jl + g.o1_off, g.o1_cnt, a1, a.ald, vb, a.vld, gparams, wave, lane);
             colsum_store(a.bmap + g.bmap_begin, g.aw, a1, a.ald, gparams, tid);
             STAMP(sbase + 16)
@@ -928,21 +1000,35 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             g = gn;
         }
         if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
-            for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
-                const int r = i / a.d, j = i - r * a.d;
+            // d <= 128 (plan check): at most four elements per thread, held in registers across
+            // the barrier so that the product can go back into gs
+            float pacc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + q * NTHREADS;
                 float acc = 0.f;
-                for (int k = 0; k < a.d; ++k) acc = fmaf(gs[r * a.xld + k], perm[j * a.d + k], acc);
-                xs[r * a.xld + j] = acc;       // xs is free after the last level
+                if (i < ROWS * a.d) {
+                    const int r = i / a.d, j = i - r * a.d;
+                    for (int k = 0; k < a.d; ++k) acc = fmaf(gs[r * a.xld + k], perm[j * a.d + k], acc);
+                }
+                pacc[q] = acc;
             }
             __syncthreads();
-            store_tile(g_x, xs, a.xld, a.d, row0, a.B, tid);
-        } else {
-            store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + q * NTHREADS;
+                if (i < ROWS * a.d) { const int r = i / a.d; gs[r * a.xld + (i - r * a.d)] = pacc[q]; }
+            }
+            __syncthreads();
         }
+        blk = nblk;
+      }
+        store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid);
         if (a.dc > 0 && g_c != nullptr) store_tile(g_c, gcs, a.cld, a.dc, row0, a.B, tid);
         STAMP(120)
         lds_barrier();
     }
+#undef HINT_CB
 }
 
 // =======================================================================================
@@ -957,15 +1043,26 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 constexpr int DW_WAVES = 8;
 
 __global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
-    const DWJob* __restrict__ jobs, int n_jobs, int splits, const float* __restrict__ wsA1,
-    const float* __restrict__ wsG2, int WT, int Bp, int rows_per_wg, const float* __restrict__ wsT,
-    const int32_t* __restrict__ tmap, int thin_total, int ntiles, int tsplit, float* __restrict__ gparams) {
+    const DWJob* __restrict__ jobs, int n_jobs, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
+    int grid_pb, int grid_used, int WT, int Bp, int rows_per_wg,
+    const int32_t* __restrict__ tmap, int thin_total, int ntiles, int tsplit) {
     __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
 
+    // a chained launch holds grid_pb (a multiple of 8, so that the XCD mapping below holds for
+    // every block) workgroups per block of the chain, of which the first grid_used have work
+    const int cbi = (int)blockIdx.x / grid_pb;
+    const int bid = (int)blockIdx.x - cbi * grid_pb;
+    if (bid >= grid_used) return;
+    const GBlock blk = chain_block(chain, one, cbi);
+    const float* wsA1 = (const float*)blk.wsA1;
+    const float* wsG2 = (const float*)blk.wsG2;
+    const float* wsT = (const float*)blk.wsT;
+    float* gparams = (float*)blk.gparams;
+
     const int n_dw_blocks = n_jobs * splits;
-    if ((int)blockIdx.x >= n_dw_blocks) {
+    if (bid >= n_dw_blocks) {
         // ---- thin gradients (dW1, dW3, biases): sum the per-row-tile slabs part A wrote ----
-        const int id = (int)blockIdx.x - n_dw_blocks;
+        const int id = bid - n_dw_blocks;
         const int chunk = id / tsplit, part = id - chunk * tsplit;
         const int idx = chunk * (DW_WAVES * 64) + (int)threadIdx.x;
         if (idx >= thin_total) return;
@@ -985,7 +1082,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_block_dw_kernel(
     }
     int jidx, split;
     {
-        const int id = blockIdx.x;
+        const int id = bid;
         if ((splits & 7) == 0) {          // XCD-aware: split s lives on XCD s % 8
             const int xcd = id & 7, t = id >> 3;
             split = xcd + 8 * (t / n_jobs);
@@ -1100,40 +1197,39 @@ hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
-                        const float* packed, const float* x, const float* c, float* z, float* J,
-                        float* tape, const float* perm, const float* J_in, float* loss_acc,
-                        hipStream_t stream) {
+hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
+                        const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
+                        const float* J_in, float* loss_acc, hipStream_t stream) {
     if (rev)
-        hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a,
-                           params, packed, x, c, z, J, (float*)nullptr, perm, J_in, (float*)nullptr);
+        hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one,
+                           chain, n_chain, x, c, z, J, J_in, (float*)nullptr);
     else
-        hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a,
-                           params, packed, x, c, z, J, tape, perm, J_in, loss_acc);
+        hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one,
+                           chain, n_chain, x, c, z, J, J_in, loss_acc);
     return hipGetLastError();
 }
 
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
-                      const float* packed, const float* x, const float* tape, const float* c,
-                      const float* g_z, const float* g_J, float* g_x, float* g_c, float* wsT,
-                      float* wsA1, float* wsG2, const float* perm, float gz_scale, float gJ_const,
-                      hipStream_t stream) {
-    hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, params,
-                       packed, x, tape, c, g_z, g_J, g_x, g_c, wsT, wsA1, wsG2, perm, gz_scale, gJ_const);
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
+                      int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
+                      float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream) {
+    hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one, chain,
+                       n_chain, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const);
     return hipGetLastError();
 }
 
-hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
-                     int Bp, int rows_per_wg, const float* wsT, const int32_t* tmap, int thin_total, int ntiles,
-                     float* gparams, hipStream_t stream) {
+hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
+                     int n_chain, int WT, int Bp, int rows_per_wg, const int32_t* tmap, int thin_total, int ntiles,
+                     hipStream_t stream) {
     // thin-gradient reduction rides in the same launch: enough parts that a thread sums <= 32 slabs
     int tsplit = (ntiles + 31) / 32;
     if (tsplit < 1) tsplit = 1;
     const int thin_blocks = ((thin_total + DW_WAVES * 64 - 1) / (DW_WAVES * 64)) * tsplit;
-    const int grid = n_jobs * splits + thin_blocks;
-    if (grid > 0)
-        hipLaunchKernelGGL(hint_block_dw_kernel, dim3(grid), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, splits,
-                           wsA1, wsG2, WT, Bp, rows_per_wg, wsT, tmap, thin_total, ntiles, tsplit, gparams);
+    const int used = n_jobs * splits + thin_blocks;
+    const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
+    if (used > 0)
+        hipLaunchKernelGGL(hint_block_dw_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs,
+                           n_jobs, splits, one, chain, grid_pb, used, WT, Bp, rows_per_wg, tmap, thin_total, ntiles,
+                           tsplit);
     return hipGetLastError();
 }
 

@@ -20,18 +20,15 @@ hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, con
                        long bias_off, const float* params, float* packed, hipStream_t stream);
 hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, hipStream_t stream);
 hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
-hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const float* params,
-                        const float* packed, const float* x, const float* c, float* z, float* J,
-                        float* tape, const float* perm, const float* J_in, float* loss_acc,
-                        hipStream_t stream);
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const float* params,
-                      const float* packed, const float* x, const float* tape, const float* c,
-                      const float* g_z, const float* g_J, float* g_x, float* g_c, float* gparams,
-                      float* wsA1, float* wsG2, const float* perm, float gz_scale, float gJ_const,
-                      hipStream_t stream);
-hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const float* wsA1, const float* wsG2, int WT,
-                     int Bp, int rows_per_wg, const float* wsT, const int32_t* tmap, int thin_total, int ntiles,
-                     float* gparams, hipStream_t stream);
+hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
+                        const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
+                        const float* J_in, float* loss_acc, hipStream_t stream);
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
+                      int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
+                      float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
+hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
+                     int n_chain, int WT, int Bp, int rows_per_wg, const int32_t* tmap, int thin_total, int ntiles,
+                     hipStream_t stream);
 hipError_t set_max_lds(int fwd_bytes, int bwd_bytes);
 hipError_t set_stamp_buffer(unsigned long long* p);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
@@ -631,6 +628,38 @@ void hint_pack_group_destroy(hint_pack_group* G) {
     delete G;
 }
 
+static void split_workspace(const hint_plan* P, int B, void* workspace, ChainBlock* b) {
+    const size_t Bp = rows_padded(B);
+    b->wsA1 = (float*)workspace;
+    b->wsG2 = b->wsA1 + Bp * P->WT + WS_SLACK;
+    b->wsT = b->wsG2 + Bp * P->WT + WS_SLACK;       // [row tile][thin_total] partial thin gradients
+}
+
+// part A (row-parallel) + part B (weight gradients) of the backward pass of one block or a chain
+static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, int n_chain,
+                        const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
+                        float gz_scale, float gJ_const, int B, hipStream_t s) {
+    const size_t Bp = rows_padded(B);
+    const int ntiles = (B + ROWS - 1) / ROWS;
+    const int grid = std::min(ntiles, P->num_cu * 8);
+    const int stages = g_bwd_stages;
+    if (stages & 1)
+        HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, one, chain, n_chain, x, c, g_z, g_J, g_x, g_c,
+                           gz_scale, gJ_const, s));
+    if (!(stages & 2)) return 0;
+    // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
+    // to cover the chip, every workgroup reducing at least 128 rows
+    int splits = 8;
+    while ((long)splits * P->n_dwjobs * n_chain < (long)P->num_cu && (long)Bp / (splits * 2) >= 128) splits *= 2;
+    int rows_per_wg = (int)(((long)Bp + splits - 1) / splits);
+    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+    if ((long)rows_per_wg * (splits - 1) >= (long)Bp)   // tiny batches: fewer, non-empty splits
+        splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
+    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, one, chain, n_chain, P->WT, (int)Bp, rows_per_wg, P->d_tmap,
+                      P->thin_total, ntiles, s));
+    return 0;
+}
+
 static int apply(const hint_plan* P, bool rev, const float* params, const float* packed, const float* x,
                  const float* c, float* z, float* J, float* tape, const float* perm, const float* J_in,
                  float* loss_acc, int32_t B, void* stream) {
@@ -641,8 +670,10 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     if (B == 0) return 0;
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, params, packed, x, c, z, J, tape, perm, J_in,
-                         loss_acc, (hipStream_t)stream));
+    ChainBlock one{};
+    one.params = params; one.packed = packed; one.perm = perm; one.tape = tape;
+    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc,
+                         (hipStream_t)stream));
     return 0;
 }
 
@@ -693,28 +724,106 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
         return fail("hint_block_backward: workspace too small (%zu < %zu)", workspace_bytes,
                     hint_plan_workspace_bytes(P, B));
     if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_backward: workspace must be 16-byte aligned");
-    const size_t Bp = rows_padded(B);
-    float* wsA1 = (float*)workspace;
-    float* wsG2 = wsA1 + Bp * P->WT + WS_SLACK;
-    float* wsT = wsG2 + Bp * P->WT + WS_SLACK;     // [row tile][thin_total] partial thin gradients
+    ChainBlock one{};
+    one.params = params; one.packed = packed; one.perm = perm; one.tape = const_cast<float*>(tape);
+    one.gparams = g_params;
+    split_workspace(P, B, workspace, &one);
+    return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, s);
+}
 
-    const int ntiles = (B + ROWS - 1) / ROWS;
-    const int grid = std::min(ntiles, P->num_cu * 8);
-    if (g_bwd_stages & 1)
-        HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, params, packed, x, tape, c, g_z, g_J,
-                           g_x, g_c, wsT, wsA1, wsG2, perm, gz_scale, gJ_const, s));
-    if (!(g_bwd_stages & 2)) return 0;
-    // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
-    // to cover the chip, every workgroup reducing at least 128 rows
-    int splits = 8;
-    while ((long)splits * P->n_dwjobs < (long)P->num_cu && (long)Bp / (splits * 2) >= 128) splits *= 2;
-    int rows_per_wg = (int)(((long)Bp + splits - 1) / splits);
-    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
-    if ((long)rows_per_wg * (splits - 1) >= (long)Bp)   // tiny batches: fewer, non-empty splits
-        splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
-    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, wsA1, wsG2, P->WT, (int)Bp, rows_per_wg, wsT, P->d_tmap,
-                      P->thin_total, ntiles, g_params, s));
+// ---------------------------------------------------------------------------------------
+// chained launches: the blocks of a flow (same plan, own parameters) in one kernel each for the
+// forward pass, backward part A and backward part B
+// ---------------------------------------------------------------------------------------
+struct hint_chain {
+    const hint_plan* plan = nullptr;
+    int n = 0, B = 0;
+    bool committed = false;
+    std::vector<ChainBlock> host;
+    std::vector<char> set;
+    ChainBlock* d_table = nullptr;
+};
+
+int hint_chain_create(const hint_plan* P, int32_t n_blocks, int32_t B, hint_chain** out) {
+    if (!P || !out) return fail("hint_chain_create: null argument");
+    if (n_blocks < 1 || B < 1) return fail("hint_chain_create: n_blocks and B must be >= 1");
+    hint_chain* C = new hint_chain();
+    C->plan = P; C->n = n_blocks; C->B = B;
+    C->host.assign(n_blocks, ChainBlock{});
+    C->set.assign(n_blocks, 0);
+    if (hipMalloc((void**)&C->d_table, sizeof(ChainBlock) * (size_t)n_blocks) != hipSuccess) {
+        delete C;
+        return fail("hint_chain_create: hipMalloc failed");
+    }
+    *out = C;
     return 0;
+}
+
+int hint_chain_set_block(hint_chain* C, int32_t i, const float* params, const float* packed, const float* perm,
+                         float* tape, void* workspace, size_t workspace_bytes, float* g_params) {
+    if (!C || !params || !packed) return fail("hint_chain_set_block: null argument");
+    if (i < 0 || i >= C->n) return fail("hint_chain_set_block: block %d out of range (chain has %d)", i, C->n);
+    const hint_plan* P = C->plan;
+    if (!tape && (P->n_levels > 1 || i > 0 || perm) && workspace)
+        return fail("hint_chain_set_block: a trainable chain block needs a tape");
+    ChainBlock b{};
+    b.params = params; b.packed = packed; b.perm = perm; b.tape = tape; b.gparams = g_params;
+    if (workspace) {
+        if (!g_params) return fail("hint_chain_set_block: workspace without g_params");
+        if (workspace_bytes < hint_plan_workspace_bytes(P, C->B))
+            return fail("hint_chain_set_block: workspace too small (%zu < %zu)", workspace_bytes,
+                        hint_plan_workspace_bytes(P, C->B));
+        if (((uintptr_t)workspace & 15) != 0) return fail("hint_chain_set_block: workspace must be 16-byte aligned");
+        split_workspace(P, C->B, workspace, &b);
+    }
+    C->host[i] = b;
+    C->set[i] = 1;
+    C->committed = false;
+    return 0;
+}
+
+int hint_chain_commit(hint_chain* C) {
+    if (!C) return fail("hint_chain_commit: null argument");
+    for (int i = 0; i < C->n; ++i)
+        if (!C->set[i]) return fail("hint_chain_commit: block %d was never set", i);
+    HIP_TRY(hipMemcpy(C->d_table, C->host.data(), sizeof(ChainBlock) * (size_t)C->n, hipMemcpyHostToDevice));
+    C->committed = true;
+    return 0;
+}
+
+int hint_chain_forward(const hint_chain* C, const float* x, const float* c, float* z, float* J, const float* J_in,
+                       float* loss_acc, void* stream) {
+    if (!C || !x || !z || !J) return fail("hint_chain_forward: null argument");
+    if (!C->committed) return fail("hint_chain_forward: hint_chain_commit() has not been called");
+    const hint_plan* P = C->plan;
+    if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
+    const int ntiles = (C->B + ROWS - 1) / ROWS;
+    const int grid = std::min(ntiles, P->num_cu * 8);
+    HIP_TRY(launch_apply(false, make_args(P, C->B), P->lds_fwd, grid, C->host[0], C->d_table, C->n, x, c, z, J,
+                         J_in, loss_acc, (hipStream_t)stream));
+    return 0;
+}
+
+int hint_chain_backward(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
+                        float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate, void* stream) {
+    if (!C || !g_z || !g_x) return fail("hint_chain_backward: null argument");
+    if (!C->committed) return fail("hint_chain_backward: hint_chain_commit() has not been called");
+    const hint_plan* P = C->plan;
+    if (P->dc > 0 && !c) return fail("hint_chain_backward: plan has dc=%d but c is NULL", P->dc);
+    if (!x && !C->host[0].perm) return fail("hint_chain_backward: x is NULL but the first block has no fused permutation");
+    for (int i = 0; i < C->n; ++i)
+        if (!C->host[i].wsA1 || !C->host[i].gparams)
+            return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate)
+        for (int i = 0; i < C->n; ++i) HIP_TRY(launch_zero(C->host[i].gparams, (long)P->param_floats, P->num_cu, s));
+    return run_backward(P, C->host[0], C->d_table, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, s);
+}
+
+void hint_chain_destroy(hint_chain* C) {
+    if (!C) return;
+    (void)hipFree(C->d_table);
+    delete C;
 }
 
 void hint_debug_set_backward_stages(int32_t mask) { g_bwd_stages = mask & 3; }

@@ -71,6 +71,9 @@ class _Engine:
                         cursor += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
                         j += 1
         self.total = max(cursor, _ALIGN)
+        # two trees with equal keys get identical plans (they can share chained launches)
+        self.shape_key = (self.d, self.dc, float(tree.clamp),
+                          tuple((n.off, n.D, n.k, n.r, n.h, n.depth, tuple(n.p_off)) for n in descs))
         self.shapes = [tuple(p.shape) for p in self.params]
         self.numels = [p.numel() for p in self.params]
         handle = C.c_void_p()

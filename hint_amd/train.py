@@ -35,7 +35,7 @@ class _LossPair:
 class FlowTrainer:
     def __init__(self, flow: HintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
                  weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01,
-                 use_graph: bool = True, group=None):
+                 use_graph: bool = True, group=None, use_chain: bool = True):
         self.lib = _lib.load()
         self.flow = flow
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -70,6 +70,52 @@ class FlowTrainer:
                 flow.perms[i].W = flow.perms[i].W.contiguous()
         self._graph = None
         self._static = None
+        # identical blocks (the configs stack copies of one block) run as ONE forward launch and
+        # TWO backward launches for the whole flow (hint_chain_*)
+        self._chainable = use_chain and all(e.shape_key == self.engines[0].shape_key for e in self.engines)
+        self._chain, self._chain_key, self._chain_bufs = None, None, None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_chain", None):
+                self.lib.hint_chain_destroy(self._chain)
+                self._chain = None
+            if getattr(self, "_pack_group", None):
+                self.lib.hint_pack_group_destroy(self._pack_group)
+                self._pack_group = None
+        except Exception:
+            pass
+
+    def _chain_for(self, B: int):
+        """the chain handle for batch size B: tapes and backward workspaces of all blocks are
+        allocated once and the pointer table uploaded; rebuilt when B or any buffer moved"""
+        import ctypes as C
+        flow = self.flow
+        perms = [flow.perms[i].W if flow.has_perm(i) else None for i in range(flow.n_blocks)]
+        key = (B,) + tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) \
+            + tuple(p.data_ptr() if p is not None else 0 for p in perms) + (self.G.data_ptr(),)
+        if self._chain_key == key:
+            return self._chain
+        if self._chain:
+            self.lib.hint_chain_destroy(self._chain)
+            self._chain, self._chain_key = None, None
+        e0, n = self.engines[0], len(self.engines)
+        tape_floats = max(self.lib.hint_plan_tape_floats(e0.plan, B), 1)
+        ws_bytes = (self.lib.hint_plan_workspace_bytes(e0.plan, B) + 255) // 256 * 256
+        tapes = torch.empty(n, tape_floats, dtype=torch.float32, device=self.device)
+        ws = torch.empty(n, max(ws_bytes, 256), dtype=torch.uint8, device=self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.hint_chain_create(e0.plan, n, B, C.byref(handle)), "hint_chain_create")
+            for i, e in enumerate(self.engines):
+                a, _ = self.slices[i]
+                _lib.check(self.lib.hint_chain_set_block(
+                    handle, i, e.arena.data_ptr(), e.packed.data_ptr(),
+                    perms[i].data_ptr() if perms[i] is not None else None, tapes[i].data_ptr(),
+                    ws[i].data_ptr(), ws_bytes, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
+            _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
+        self._chain, self._chain_key, self._chain_bufs = handle, key, (tapes, ws, perms)
+        return handle
 
     # ---- the un-captured step body ----------------------------------------------------
     def _fwd_bwd(self, x: torch.Tensor, c: Optional[torch.Tensor]):
@@ -81,6 +127,20 @@ class FlowTrainer:
         if self.noise > 0:
             x = x.add(torch.randn_like(x), alpha=self.noise)
         self.loss_acc.zero_()
+        if self._chainable and B > 0:
+            chain = self._chain_for(B)
+            z = torch.empty_like(x)
+            J = torch.empty(B, dtype=torch.float32, device=x.device)
+            gx = torch.empty_like(x)
+            cp = c.data_ptr() if c is not None else None
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                _lib.check(self.lib.hint_chain_forward(chain, x.data_ptr(), cp, z.data_ptr(), J.data_ptr(), None,
+                                                       self.loss_acc.data_ptr(), stream), "hint_chain_forward")
+                # dL/dz = z / B and dL/dJ = -1/B: applied inside the kernel
+                _lib.check(self.lib.hint_chain_backward(chain, x.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
+                                                        None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")
+            return B
         inputs, tapes = [], []
         h, J = x, None
         n = len(self.engines)

@@ -139,6 +139,34 @@ int hint_block_backward_ex(const hint_plan* plan, const float* params, const flo
                            const float* perm, float gz_scale, float gJ_const, int32_t B,
                            void* stream);
 
+/* Whole-flow launches.  A chain is n_blocks blocks of ONE plan (the configs stack identical
+ * blocks, power_hint_8.py:56-67), each with its own parameters, optional permutation in front,
+ * tape and backward workspace, laid out for a fixed batch size B.  hint_chain_forward runs
+ * all blocks in one kernel (the lane tile of a row stays on chip from block to block; what
+ * ReversibleGraphNet.forward does node by node), hint_chain_backward runs the row-parallel
+ * part of all blocks in one kernel and all weight gradients in a second one.
+ *   hint_chain_set_block: pointers of block i; they are captured, not copied, and must stay
+ *     valid.  tape: hint_plan_tape_floats(plan, B) floats (required for training).  workspace /
+ *     g_params may be NULL for an inference-only chain.
+ *   hint_chain_commit: uploads the table (synchronous); call after the last set_block and
+ *     before the first forward/backward (and again after changing a block).
+ *   forward: z [B,d], J [B] = sum of the blocks' log-dets (+ J_in); loss_acc as in
+ *     hint_block_forward_ex.  x may alias z.
+ *   backward: arguments as in hint_block_backward_ex; x is only read when block 0 has no
+ *     permutation.  g_c accumulates over the blocks (all blocks see the same c). */
+typedef struct hint_chain hint_chain;
+int hint_chain_create(const hint_plan* plan, int32_t n_blocks, int32_t B, hint_chain** out);
+int hint_chain_set_block(hint_chain* chain, int32_t i, const float* params, const float* packed,
+                         const float* perm, float* tape, void* workspace, size_t workspace_bytes,
+                         float* g_params);
+int hint_chain_commit(hint_chain* chain);
+int hint_chain_forward(const hint_chain* chain, const float* x, const float* c, float* z, float* J,
+                       const float* J_in, float* loss_acc, void* stream);
+int hint_chain_backward(const hint_chain* chain, const float* x, const float* c, const float* g_z,
+                        const float* g_J, float* g_x, float* g_c, float gz_scale, float gJ_const,
+                        int32_t accumulate, void* stream);
+void hint_chain_destroy(hint_chain* chain);
+
 /* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces
  *   for p in params: p.grad.data.clamp_(-5, 5)        (train_unconditional.py:140-141)
  *   torch.optim.Adam(..., eps, weight_decay).step()    (train_unconditional.py:144,174-176)

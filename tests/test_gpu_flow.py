@@ -121,3 +121,33 @@ def test_reference_training_loop_body_on_module_path():
     for bi, blk in enumerate(model.blocks):
         for k, v in blk.state_dict().items():
             assert rel_err(v.cpu().numpy(), g[f"final:{bi}:{k}"]) < 1e-3, (bi, k)
+
+
+@pytest.mark.parametrize("d,dc,widths,perm_first,n_blocks,B", [
+    (6, 0, [32, 16], False, 3, 333),
+    (8, 3, [64, 32, 16], True, 4, 1000),
+    (2, 0, [16], False, 2, 50),
+    (3, 2, [24, 8], True, 1, 17),
+    (21, 0, [48, 40, 24, 16], False, 2, 5000),
+])
+def test_chain_launch_equals_per_block_launches(d, dc, widths, perm_first, n_blocks, B):
+    """hint_chain_forward / hint_chain_backward (one launch for all blocks) against the same
+    step issued block by block through hint_block_*_ex"""
+    torch.manual_seed(3)
+    flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc, perm_first=perm_first).to(DEV)
+    for p in flow.parameters():                      # away from the near-identity init
+        p.data.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(B, d, device=DEV)
+    c = torch.randn(B, dc, device=DEV) if dc > 0 else None
+    tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
+    assert tr._chainable
+    out = {}
+    for mode in (False, True):
+        tr._chainable = mode
+        tr._check_arenas()
+        tr.G.zero_()
+        tr._fwd_bwd(x, c)
+        torch.cuda.synchronize()
+        out[mode] = (tr.G.clone(), tr.loss_acc.sum(0).clone())
+    assert rel_err(out[True][1].cpu().numpy(), out[False][1].cpu().numpy()) < 1e-6
+    assert rel_err(out[True][0].cpu().numpy(), out[False][0].cpu().numpy()) < 1e-5
