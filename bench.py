@@ -115,6 +115,24 @@ def kernel_legs(trainer, x, reps=200):
         lib.hint_debug_set_backward_stages(mask)
         out[name] = timed(bwd)
     lib.hint_debug_set_backward_stages(3)
+    # the launches the timed step actually makes: the whole flow per kernel (hint_chain_*)
+    if trainer._chainable:
+        chain = trainer._chain_for(B)
+        n = len(trainer.engines)
+        zc = torch.empty_like(x); Jc = torch.empty(B, device=x.device); gxc = torch.empty_like(x)
+        acc = torch.zeros(64, 2, device=x.device)
+        out[f"chain{n}:hint_block_apply_kernel<fwd>"] = timed(
+            lambda: lib.hint_chain_forward(chain, x.data_ptr(), None, zc.data_ptr(), Jc.data_ptr(), None,
+                                           acc.data_ptr(), stream))
+
+        def cbwd():
+            return lib.hint_chain_backward(chain, x.data_ptr(), None, zc.data_ptr(), None, gxc.data_ptr(), None,
+                                           1.0 / B, -1.0 / B, 1, stream)
+        for mask, name in ((1, "hint_block_bwd_kernel"), (2, "hint_block_dw_kernel"), (3, "backward_total")):
+            lib.hint_debug_set_backward_stages(mask)
+            out[f"chain{n}:{name}"] = timed(cbwd)
+        lib.hint_debug_set_backward_stages(3)
+        trainer.G.zero_()                    # the timing launches accumulated into the gradient arena
     return out
 
 
@@ -196,8 +214,9 @@ def main():
         if legs:
             # dominant kernel = the row-parallel backward kernel: recompute (F) + dX (F) per sample
             name = "hint_block_bwd_kernel"
-            us = legs[name]
-            flops = 2.0 * F * B
+            nb = cfg["n_blocks"] if trainer._chainable else 1     # blocks one launch processes
+            us = legs[f"chain{nb}:{name}"] if trainer._chainable else legs[name]
+            flops = 2.0 * F * B * nb
             ach = flops / (us * 1e-6) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -206,9 +225,12 @@ def main():
                     traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            if traffic is not None:
+                traffic *= nb                  # the PMC pass profiled single-block launches
             res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                               "avg_launch_us": us, "algorithmic_flops_per_launch": flops}
+                               "avg_launch_us": us, "algorithmic_flops_per_launch": flops,
+                               "blocks_per_launch": nb}
             res["kernels_us"] = legs
             # the element-wise view the north_star asks for: compulsory HBM bytes of one block
             # forward, 4*(2d+1) B/sample, against 8 TB/s

@@ -8,18 +8,12 @@ namespace hint {
 // Tuning knobs (compile-time; the plan builder and the kernels must agree):
 //   HINT_NWAVES  wavefronts per workgroup (8 or 16): with one 16-row tile per CU at B = 4096 the
 //                only latency hiding is between the wavefronts of the one resident workgroup
-//   HINT_CHB     k-blocks per chunk of the GEMM stage pipeline (register sets are 3 x CHB x 4 VGPRs
-//                for B plus the same for A)
 #ifndef HINT_NWAVES
 #define HINT_NWAVES 8
-#endif
-#ifndef HINT_CHB
-#define HINT_CHB 2      // 2: three Stage objects + A sets stay inside 256 VGPRs without scratch; 4 measured no faster
 #endif
 constexpr int ROWS = 16;        // batch rows per workgroup tile = one MFMA M-tile
 constexpr int NWAVES = HINT_NWAVES;
 constexpr int NTHREADS = 64 * NWAVES;
-constexpr int CHB = HINT_CHB;
 constexpr int TILE = 16;        // MFMA 16x16x4 f32 tile edge
 constexpr int MAX_SLABS = 4;    // K-split partial-sum slabs of the thin (N <= 16) layers
 
@@ -69,30 +63,28 @@ struct PackItem {
     int32_t grid_begin, pad;
 };
 
-// One chunk (<= CHB consecutive 16-wide k-blocks) of one 16-column output tile of a GEMM stage:
-//   out[16 rows][16 cols] (+)= A[16][K] * Wlog^T.
-// The host cuts every tile job into chunks, deals the jobs to the 8 wavefronts (longest first)
-// and lays the chunks out per wavefront, so that the device loop is a plain walk over 16-byte
-// records read from LDS with one ds_read_b128 each.
-struct Chunk {
-    int32_t wtile;      // packed offset, in 256-float tiles, of the chunk's first k-block
-    uint16_t acol;      // A column (floats) of the chunk's first k-block in the stage's LDS input
-    uint16_t ocol;      // first output column of the tile in the stage's LDS output
-    uint8_t nv;         // valid k-blocks in this chunk (0 only for K = 0 jobs)
-    uint8_t last;       // 1: last chunk of its tile job -> epilogue
-    uint8_t nvalid;     // valid output columns of the tile (others are written as 0)
+// One job of a GEMM stage: nt (1..3) adjacent 16-column output tiles of one (node, net) that
+// share their A operand, over nb consecutive 16-wide k-blocks:
+//   out[16 rows][16*nt cols] (+)= A[16][16*nb] * Wlog^T.
+// The host cuts every stage into jobs and deals them to the 8 wavefronts so that the four SIMDs
+// (wavefronts w and w+4 share one) carry equal MFMA work; a wavefront's jobs form a list of
+// 16-byte records read from LDS with one ds_read_b128 each.
+struct TJob {
+    int32_t wtile;      // packed offset, in 256-float tiles, of (first n-tile, first k-block)
+    uint16_t acol;      // A column (floats) of the first k-block in the stage's LDS input
+    uint16_t ocol;      // first output column of the first tile in the stage's LDS output
+    uint8_t nb;         // k-blocks (0 only for K = 0 jobs: the tiles are bias-only)
+    uint8_t nt;         // n-tiles; 0 = nothing to do (the single record of an idle wavefront)
+    uint8_t nvalid;     // valid output columns of the LAST tile (the others are full; rest is written as 0)
     uint8_t slab;       // K-split slab the partial result goes to
-    int32_t count;      // in the FIRST record of a wavefront's list: number of chunks in the list
+    uint16_t tstride;   // distance, in tiles, between consecutive n-tiles in the packed buffer
+    uint16_t count;     // in the FIRST record of a wavefront's list: number of jobs in the list
 };
-static_assert(sizeof(Chunk) == 16, "Chunk must be 16 bytes");
-typedef Chunk GJob;     // the per-group lists hold Chunk, stage-header and OJob records, 16 B each
+static_assert(sizeof(TJob) == 16, "TJob must be 16 bytes");
+typedef TJob GJob;      // the per-group lists hold TJob and OJob records, 16 B each
 
 // A stage's lists sit at a fixed stride: wavefront w's list starts at record w*stride (the stage
-// descriptor packs offset and stride into one int, see STAGE_DESC) and is padded with empty
-// chunks (nv = 0, last = 0) up to the stride, which is at least 3 longer than the longest list:
-// the device loop may then read three records ahead without clamping, and stage_begin() needs
-// no header round trip (the length rides in the first record).
-constexpr int STAGE_TAIL = 3;
+// descriptor packs offset and stride into one int, see STAGE_DESC).
 #define STAGE_DESC(OFF, STRIDE) (((OFF) & 0xffff) | ((STRIDE) << 16))
 
 // Thin weight gradient of one (node, net) done inside the row-parallel backward kernel: a grid

@@ -41,15 +41,20 @@ __device__ unsigned long long* g_hint_stamps = nullptr;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
         g_hint_stamps[(threadIdx.x >> 6) * 128 + (ID)] = t_;                                    \
     }
-// per-section cycle sums of one wavefront (wave 0 of workgroup 0), kept in registers
+#endif
+// per-section cycle sums of one wavefront (wave 0 of workgroup 0), kept in registers; needs
+// -DHINT_TSEC on top of -DHINT_STAMPS (the waits it adds serialise the stage pipeline)
+#if defined(HINT_STAMPS) && defined(HINT_TSEC)
 #define TSEC_DECL unsigned long long tsec_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast_ = 0; (void)tsec_; (void)tlast_;
 #define TSEC_START() { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast_)::"memory"); }
 #define TSEC(K) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tsec_[K] += t_ - tlast_; tlast_ = t_; }
 #else
-#define STAMP(ID)
 #define TSEC_DECL
 #define TSEC_START()
 #define TSEC(K)
+#endif
+#ifndef HINT_STAMPS
+#define STAMP(ID)
 #endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0)
@@ -138,49 +143,52 @@ __global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, l
 }
 
 // =======================================================================================
-// Generic GEMM stage.  The host has cut every 16-column output tile of the stage into chunks
-// of <= 4 k-blocks and dealt them to the 8 wavefronts; a wavefront walks its chunk list with a
-// three-deep software pipeline:
-//     step i :  global fetch of the packed B tiles of chunk i+2      (3 register sets rotate)
-//               LDS read of the A fragments of chunk i+1
-//               16 MFMAs of chunk i  (+ epilogue when the chunk ends its tile)
-// Every chunk issues exactly four tile loads with immediate offsets (a short chunk over-reads
-// into the following tiles, which only costs a little L2 bandwidth) so the compiler can count
-// outstanding loads exactly; the stream crosses tile boundaries and, through stage_begin(), the
-// workgroup barrier in front of the stage: weights do not depend on the previous stage, only
-// the A operand in LDS does.
+// Generic GEMM stage:  out[16][N] (+)= A[16][K] * Wlog^T  for every (node, net) of a group.
+// The host cuts the stage into JOBS of 1..3 adjacent 16-column output tiles that share their A
+// operand (same node, same net input) and deals them to the 8 wavefronts (hint_plan.cpp,
+// emit_stage).  A wavefront runs a job as ONE plain k-loop over the job's 16-wide k-blocks:
+//     step kb :  global fetch of the packed B tiles of k-block kb+2   (3 register sets rotate)
+//                LDS read of the A fragment of k-block kb+1           (shared by the NT tiles)
+//                4*NT MFMAs of k-block kb                              (NT independent accumulators)
+// and the epilogue of all NT tiles at the end.  The first two k-blocks of a job are fetched
+// by its PREDECESSOR right before that one's epilogue - also across the workgroup barrier
+// between two stages (weights do not depend on the previous stage, only A in LDS does) - so
+// a job's loop starts with its weights in flight or landed.  A micro-benchmark of this loop
+// against a per-chunk interpreter (tools/stage_bench.hip) is what the structure comes from:
+// sharing A and keeping the inner loop free of record decoding is worth 1.3-1.9x per stage.
 //   MFMA lane map (16x16x4 f32): lane l supplies A[m = l&15][kslot = l>>4] and
 //   B[kslot][n = l&15]; result reg i = C[4*(l>>4)+i][l&15].  Slot kq of step i of a 16-wide
 //   k-block is k = 16*kb + 4*kq + i on both operands, so each lane reads 4 consecutive k with
 //   one 128-bit access (LDS for A, global for packed B).
-// Chunk records and biases live in LDS (staged per group, one group ahead): a global or
-// scalar load in front of every tile would put an L2 round trip on the critical path, and
-// per-chunk bookkeeping instructions, not MFMAs, were what bounded the first versions.
+// Job records and biases live in LDS (staged per group, one group ahead).
 // =======================================================================================
 enum { EPI_RELU = 0, EPI_LINEAR = 1, EPI_MASK = 2, EPI_PLAIN = 3 };
 
-struct ChunkU { int wtile, acol, ocol, nv, last, nvalid, slab; };
+struct JobU { int wtile, acol, ocol, nb, nt, nvalid, slab, tstride, count; };
 
-__device__ __forceinline__ ChunkU decode_chunk(i32x4 raw) {
-    ChunkU u;
+__device__ __forceinline__ JobU decode_job(i32x4 raw) {
+    JobU u;
     u.wtile = __builtin_amdgcn_readfirstlane(raw.x);
     const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane(raw.y);
     const unsigned z = (unsigned)__builtin_amdgcn_readfirstlane(raw.z);
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(raw.w);
     u.acol = (int)(y & 0xffffu);
     u.ocol = (int)(y >> 16);
-    u.nv = (int)(z & 0xffu);
-    u.last = (int)((z >> 8) & 0xffu);
+    u.nb = (int)(z & 0xffu);
+    u.nt = (int)((z >> 8) & 0xffu);
     u.nvalid = (int)((z >> 16) & 0xffu);
     u.slab = (int)(z >> 24);
+    u.tstride = (int)(w & 0xffffu);
+    u.count = (int)(w >> 16);
     return u;
 }
 
+// What a wavefront carries from one stage to the next: its position in the job lists and the
+// first job of the coming stage with the B tiles of that job's first two k-blocks in flight.
 struct Stage {
-    lds_jobs_t cl;      // this wavefront's chunk list (LDS)
-    int n;              // its length (>= 1: the host gives idle wavefronts one empty chunk)
-    ChunkU d0, d1, d2;
-    i32x4 raw;          // record of the next chunk to decode, read from LDS one step ahead
-    f32x4 b0[CHB], b1[CHB], b2[CHB];    // three rotating sets of packed B tiles
+    lds_jobs_t cl;      // this wavefront's job list of the coming stage (LDS)
+    JobU j;             // its first job (count = list length; an idle wavefront has one nt = 0 job)
+    f32x4 b0[3], b1[3]; // packed B tiles of k-blocks 0 and 1 of that job's (up to) three tiles
 };
 
 #ifdef HINT_ABLATE_WLOAD    // diagnostic: every weight fetch hits the same few KiB (L1-resident)
@@ -189,151 +197,143 @@ struct Stage {
 #define HINT_WTILE(T) ((size_t)(T))
 #endif
 
-#define HINT_RAW_AT(S, I) (*(const LDS_AS i32x4*)((S).cl + (I)))     /* lists are padded: no clamp needed */
-
-__device__ __forceinline__ void fetch_b(f32x4 (&R)[CHB], const ChunkU& d, const float* __restrict__ packed, int lane) {
-    const f32x4* wp = (const f32x4*)packed + HINT_WTILE(d.wtile) * 64 + lane;
+// Always six loads (exact vmcnt bookkeeping for the compiler): a job with fewer tiles or a
+// single k-block re-reads a tile it fetches anyway, which the vector L1 serves.
+__device__ __forceinline__ void fetch_first(f32x4 (&b0)[3], f32x4 (&b1)[3], const JobU& j,
+                                            const float* __restrict__ packed, int lane) {
+    const f32x4* wp = (const f32x4*)packed + lane;
+    const int k1 = j.nb > 1 ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < CHB; ++i) R[i] = wp[64 * i];
+    for (int t = 0; t < 3; ++t) {
+        const int tt = t < j.nt ? t : 0;
+        const f32x4* q = wp + HINT_WTILE(j.wtile + tt * j.tstride) * 64;
+        b0[t] = q[0];
+        b1[t] = q[64 * k1];
+    }
 }
 
-// Issue everything of a stage that does not depend on the preceding barrier: the first two
-// chunk records, their packed weights, and the read of the third record.
-__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t jl, int desc, const float* __restrict__ packed,
-                                            int wave, int lane) {
+// desc = offset | stride << 16: wavefront w's list starts at jl + offset + w*stride
+__device__ __forceinline__ lds_jobs_t stage_list(lds_jobs_t jl, int desc, int wave) {
+    return jl + (desc & 0xffff) + wave * (desc >> 16);
+}
+
+// Prime S for a stage from scratch (first stage of a kernel; everything after that is primed by
+// the stage_run() in front of it).
+__device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t cl, const float* __restrict__ packed, int lane) {
+    S.cl = cl;
 #ifdef HINT_SKIP_GEMM          // diagnostic: no GEMM stage work at all
-    S.n = 0;
     return;
 #endif
-    // desc = offset | stride << 16: wavefront w's padded list starts at jl + offset + w*stride
-    S.cl = jl + (desc & 0xffff) + wave * (desc >> 16);
-    const i32x4 r0 = HINT_RAW_AT(S, 0), r1 = HINT_RAW_AT(S, 1);
-    S.raw = HINT_RAW_AT(S, 2);
-    S.n = __builtin_amdgcn_readfirstlane(r0.w);      // list length rides in the first record
-    S.d0 = decode_chunk(r0);
-    fetch_b(S.b0, S.d0, packed, lane);
-    S.d1 = decode_chunk(r1);
-    fetch_b(S.b1, S.d1, packed, lane);
+    S.j = decode_job(*(const LDS_AS i32x4*)cl);
+    fetch_first(S.b0, S.b1, S.j, packed, lane);
 }
 
-template <int EPI>
-__device__ __forceinline__ void stage_epilogue(const ChunkU& jb, f32x4 acc, float bias, float* O, int ldo,
-                                               int slab_stride, int lane) {
+// One job: NT tiles x j.nb k-blocks.  b0/b1 hold k-blocks 0 and 1 on entry and k-blocks 0 and
+// 1 of job `jn` (fetched from packed_n) on exit.
+template <int EPI, int NT>
+__device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b1)[3], const JobU& jn,
+                                        const float* __restrict__ packed, const float* __restrict__ packed_n,
+                                        const float* bias_lds, const float* arow, float* O, int ldo,
+                                        int slab_stride, int lane) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nl = lane & 15;
-    const bool ok = nl < jb.nvalid;
-    float* o = O + jb.slab * slab_stride + (4 * (lane >> 4)) * ldo + jb.ocol + nl;
+    float bias[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v;
-        if (EPI == EPI_RELU) v = ok ? fmaxf(acc[i] + bias, 0.f) : 0.f;
-        else if (EPI == EPI_LINEAR) v = ok ? acc[i] + bias : 0.f;
-        else if (EPI == EPI_MASK) v = (ok && o[i * ldo] > 0.f) ? acc[i] : 0.f;
-        else v = ok ? acc[i] : 0.f;
-        o[i * ldo] = v;
+    for (int t = 0; t < NT; ++t) {
+        bias[t] = 0.f;
+        if (EPI == EPI_RELU || EPI == EPI_LINEAR) bias[t] = bias_lds[j.ocol + 16 * t + nl];   // zero in padding columns
     }
-}
-
-// A fragments of one chunk: CHB 128-bit LDS reads with immediate offsets (a short chunk reads
-// past its last block; those registers are never used).  The bias of the chunk's tile rides
-// along (biases of the group sit in LDS in output-column order, zero in the padding columns;
-// only slab 0 of a K-split stage adds them), so the epilogue never waits for it.
-template <int EPI>
-__device__ __forceinline__ void read_a(f32x4 (&R)[CHB], float& bias, const ChunkU& d, const float* arow,
-                                       const float* bias_lds, int lane) {
-    const float* ap = arow + d.acol;
-#pragma unroll
-    for (int i = 0; i < CHB; ++i) R[i] = *(const f32x4*)(ap + 16 * i);
-    bias = 0.f;
-    if (EPI == EPI_RELU || EPI == EPI_LINEAR) bias = bias_lds[d.ocol + (lane & 15)];
-}
-
-// the MFMAs of one chunk; two accumulators alternate so that no MFMA waits on its predecessor
-template <int EPI>
-__device__ __forceinline__ void mma_chunk(const ChunkU& d, const f32x4 (&A)[CHB], const f32x4 (&Bt)[CHB], float bias,
-                                          f32x4& acc0, f32x4& acc1, float* O, int ldo, int slab_stride, int lane) {
-    if (d.nv >= CHB) {
-#pragma unroll
-        for (int p = 0; p + 1 < CHB; p += 2) {
-            acc0 = mfma4(A[p].x, Bt[p].x, acc0); acc1 = mfma4(A[p + 1].x, Bt[p + 1].x, acc1);
-            acc0 = mfma4(A[p].y, Bt[p].y, acc0); acc1 = mfma4(A[p + 1].y, Bt[p + 1].y, acc1);
-            acc0 = mfma4(A[p].z, Bt[p].z, acc0); acc1 = mfma4(A[p + 1].z, Bt[p + 1].z, acc1);
-            acc0 = mfma4(A[p].w, Bt[p].w, acc0); acc1 = mfma4(A[p + 1].w, Bt[p + 1].w, acc1);
+    if (j.nb > 0) {
+        const int NB = j.nb;
+        const float* ap = arow + j.acol;
+        const f32x4* wp = (const f32x4*)packed + HINT_WTILE(j.wtile) * 64 + lane;
+        const int ts = j.tstride;
+        f32x4 b2[NT], a0, a1;
+#ifdef HINT_ABLATE_AREAD
+        a0 = f32x4{1.f, 2.f, 3.f, 4.f}; a1 = a0;
+#else
+        a0 = *(const f32x4*)ap;
+#endif
+        int kb = 0;
+        // loads past the job's last k-block re-read that block (L1 hit, never used)
+#ifdef HINT_ABLATE_AREAD
+#define HINT_AREAD(AN, KA)
+#else
+#define HINT_AREAD(AN, KA) AN = *(const f32x4*)(ap + 16 * (KA));
+#endif
+#define HINT_STEP(AC, AN, BC, BN2)                                                                     \
+        {                                                                                              \
+            const int kn = kb + 2 < NB ? kb + 2 : NB - 1;                                              \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) BN2[t] = wp[(size_t)(t * ts + kn) * 64];    \
+            const int ka = kb + 1 < NB ? kb + 1 : NB - 1;                                              \
+            HINT_AREAD(AN, ka)                                                                         \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = mfma4(AC.x, BC[t].x, acc[t]);      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = mfma4(AC.y, BC[t].y, acc[t]);      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = mfma4(AC.z, BC[t].z, acc[t]);      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = mfma4(AC.w, BC[t].w, acc[t]);      \
+            ++kb;                                                                                      \
         }
-        if (CHB & 1) {
-            acc0 = mfma4(A[CHB - 1].x, Bt[CHB - 1].x, acc0); acc1 = mfma4(A[CHB - 1].y, Bt[CHB - 1].y, acc1);
-            acc0 = mfma4(A[CHB - 1].z, Bt[CHB - 1].z, acc0); acc1 = mfma4(A[CHB - 1].w, Bt[CHB - 1].w, acc1);
+        while (true) {
+            HINT_STEP(a0, a1, b0, b2) if (kb >= NB) break;
+            HINT_STEP(a1, a0, b1, b0) if (kb >= NB) break;
+            HINT_STEP(a0, a1, b2, b1) if (kb >= NB) break;
+            HINT_STEP(a1, a0, b0, b2) if (kb >= NB) break;
+            HINT_STEP(a0, a1, b1, b0) if (kb >= NB) break;
+            HINT_STEP(a1, a0, b2, b1) if (kb >= NB) break;
         }
-    } else {
-#pragma unroll
-        for (int p = 0; p < CHB - 1; ++p)
-            if (d.nv > p) {
-                acc0 = mfma4(A[p].x, Bt[p].x, acc0); acc1 = mfma4(A[p].y, Bt[p].y, acc1);
-                acc0 = mfma4(A[p].z, Bt[p].z, acc0); acc1 = mfma4(A[p].w, Bt[p].w, acc1);
-            }
+#undef HINT_STEP
+#undef HINT_AREAD
     }
-    if (d.last) {
-        stage_epilogue<EPI>(d, acc0 + acc1, d.slab == 0 ? bias : 0.f, O, ldo, slab_stride, lane);
-        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the successor's first weights go out before this job's epilogue
+    fetch_first(b0, b1, jn, packed_n, lane);
+#ifdef HINT_ABLATE_EPI
+    if (jn.nt > 100)
+#endif
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bool ok = (t < NT - 1) || nl < j.nvalid;       // only the job's last tile can be ragged
+        float* o = O + j.slab * slab_stride + (4 * (lane >> 4)) * ldo + j.ocol + 16 * t + nl;
+        const float bi = j.slab == 0 ? bias[t] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v;
+            if (EPI == EPI_RELU) v = ok ? fmaxf(acc[t][i] + bi, 0.f) : 0.f;
+            else if (EPI == EPI_LINEAR) v = ok ? acc[t][i] + bi : 0.f;
+            else if (EPI == EPI_MASK) v = (ok && o[i * ldo] > 0.f) ? acc[t][i] : 0.f;
+            else v = ok ? acc[t][i] : 0.f;
+            o[i * ldo] = v;
+        }
     }
 }
 
+// Run the stage S is primed for; on return S is primed for the stage whose list (of this
+// wavefront) is `next` with weights in `packed_n`.
 template <int EPI>
-__device__ __forceinline__ void stage_run(Stage& S, const float* __restrict__ packed,
-                                          const float* bias_lds, const float* A, int lda, float* O, int ldo,
-                                          int slab_stride, int lane) {
+__device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float* __restrict__ packed,
+                                          const float* __restrict__ packed_n, const float* bias_lds,
+                                          const float* A, int lda, float* O, int ldo, int slab_stride, int lane) {
 #ifdef HINT_SKIP_GEMM
+    S.cl = next;
     return;
 #endif
     const float* arow = A + (lane & 15) * lda + 4 * (lane >> 4);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a0[CHB], a1[CHB], a2[CHB];
-    float bi0, bi1, bi2;
-
-    TSEC_DECL
-    TSEC_START()
-    read_a<EPI>(a0, bi0, S.d0, arow, bias_lds, lane);
-    TSEC(0)
-    int ci = 0;   // chunk held in (d0, a0, b0) at the top of the loop
-    while (true) {
-        S.d2 = decode_chunk(S.raw);
-        S.raw = HINT_RAW_AT(S, ci + 3);
-        TSEC(1)
-        fetch_b(S.b2, S.d2, packed, lane);
-        TSEC(2)
-        read_a<EPI>(a1, bi1, S.d1, arow, bias_lds, lane);
-        TSEC(3)
-        mma_chunk<EPI>(S.d0, a0, S.b0, bi0, acc0, acc1, O, ldo, slab_stride, lane);
-        TSEC(4)
-        if (ci + 1 >= S.n) break;
-        S.d0 = decode_chunk(S.raw);
-        S.raw = HINT_RAW_AT(S, ci + 4);
-        TSEC(1)
-        fetch_b(S.b0, S.d0, packed, lane);
-        TSEC(2)
-        read_a<EPI>(a2, bi2, S.d2, arow, bias_lds, lane);
-        TSEC(3)
-        mma_chunk<EPI>(S.d1, a1, S.b1, bi1, acc0, acc1, O, ldo, slab_stride, lane);
-        TSEC(4)
-        if (ci + 2 >= S.n) break;
-        S.d1 = decode_chunk(S.raw);
-        S.raw = HINT_RAW_AT(S, ci + 5);
-        TSEC(1)
-        fetch_b(S.b1, S.d1, packed, lane);
-        TSEC(2)
-        read_a<EPI>(a0, bi0, S.d0, arow, bias_lds, lane);
-        TSEC(3)
-        mma_chunk<EPI>(S.d2, a2, S.b2, bi2, acc0, acc1, O, ldo, slab_stride, lane);
-        TSEC(4)
-        if (ci + 3 >= S.n) break;
-        ci += 3;
+    JobU j = S.j;
+    const int n = j.count;
+    for (int ji = 0;; ++ji) {
+        const bool last = ji + 1 >= n;
+        const JobU jn = decode_job(*(const LDS_AS i32x4*)(last ? next : S.cl + ji + 1));
+        const float* pn = last ? packed_n : packed;
+        if (j.nt >= 3) run_job<EPI, 3>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, ldo, slab_stride, lane);
+        else if (j.nt == 2) run_job<EPI, 2>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, ldo, slab_stride, lane);
+        else if (j.nt == 1) run_job<EPI, 1>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, ldo, slab_stride, lane);
+        else fetch_first(S.b0, S.b1, jn, pn, lane);      // idle wavefront: only hand the baton on
+        j = jn;
+        if (last) break;
     }
-#ifdef HINT_STAMPS
-    if (g_hint_stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int k = 0; k < 5; ++k) g_hint_stamps[1024 + k] += tsec_[k];
-        g_hint_stamps[1024 + 5] += 1;      // stage_run calls
-    }
-#endif
+    S.j = j;
+    S.cl = next;
 }
 
 // Small outer-product tiles done inside the backward kernel (dW1, dW3): the reduction runs
@@ -344,7 +344,12 @@ __device__ __forceinline__ void stage_run(Stage& S, const float* __restrict__ pa
 __device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const float* Abuf, int lda,
                                           const float* Bbuf, int ldb, float* __restrict__ g, int wave,
                                           int lane) {
+#ifdef HINT_SKIP_OJOBS
+    return;
+#endif
     const int nl = lane & 15, kq = lane >> 4;
+    const float* ap = Abuf + kq * lda + nl;          // row kq + 4*i of the operand tiles
+    const float* bp = Bbuf + kq * ldb + nl;
     int t0 = wave;                                   // round-robin over the tiles of all grids
     for (int j = 0; j < njobs; ++j) {
         const i32x4 raw = *(const LDS_AS i32x4*)(jobs + j);
@@ -355,37 +360,63 @@ __device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const floa
         const int M = (int)(zz & 0xffffu), N = (int)(zz >> 16);
         const int mtiles = (M + 15) >> 4, ntiles = (N + 15) >> 4, tiles = mtiles * ntiles;
         int t = t0;
+        int mt = 0, nt = t;                          // t < NWAVES <= tiles of one tile row in the common case
+        while (nt >= ntiles && mt < mtiles) { nt -= ntiles; ++mt; }
         for (; t < tiles; t += NWAVES) {
-            const int mt = t / ntiles, nt = t - mt * ntiles;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // all eight operand reads first (one LDS round trip), two accumulators for the four
+            // dependent k-steps
+            float av[4], bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = kq + 4 * i;
-                acc = mfma4(Abuf[row * lda + acol + 16 * mt + nl], Bbuf[row * ldb + bcol + 16 * nt + nl], acc);
+                av[i] = ap[4 * i * lda + acol + 16 * mt];
+                bv[i] = bp[4 * i * ldb + bcol + 16 * nt];
             }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            acc0 = mfma4(av[0], bv[0], acc0);
+            acc1 = mfma4(av[1], bv[1], acc1);
+            acc0 = mfma4(av[2], bv[2], acc0);
+            acc1 = mfma4(av[3], bv[3], acc1);
+            const f32x4 acc = acc0 + acc1;
             const int n = 16 * nt + nl;
+#ifdef HINT_ABLATE_OSTORE
+            asm volatile("" ::"v"(acc));
+            if (n < 0) {
+#else
             if (n < N) {
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = 16 * mt + 4 * kq + i;
                     if (m < M) g[goff + m * N + n] = acc[i];
                 }
             }
+            nt += NWAVES;
+            while (nt >= ntiles && mt < mtiles) { nt -= ntiles; ++mt; }
         }
         t0 = t - tiles;                              // keep the round-robin phase across grids
     }
 }
 
-// bias gradients: column sums over the 16 rows of an LDS buffer, one thread per column
-__device__ __forceinline__ void colsum_store(const int32_t* __restrict__ map, int ncols, const float* buf,
-                                              int ld, float* __restrict__ g, int tid) {
+// bias gradients: column sums over the 16 rows of an LDS buffer, one thread per column; the map
+// (compact thin-gradient index per column, -1 for padding) sits in LDS next to the biases
+__device__ __forceinline__ void colsum_store(const int32_t* map_lds, int ncols, const float* buf, int ld,
+                                             float* __restrict__ g, int tid) {
+#ifdef HINT_SKIP_COLSUM
+    return;
+#endif
     for (int col = tid; col < ncols; col += NTHREADS) {
-        const int off = map[col];
-        if (off < 0) continue;
+        const int off = map_lds[col];
+        float v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) v[r] = buf[r * ld + col];
         float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) s += buf[r * ld + col];
-        g[off] = s;
+        for (int r = 0; r < ROWS; r += 4) s += (v[r] + v[r + 1]) + (v[r + 2] + v[r + 3]);
+#ifdef HINT_ABLATE_OSTORE
+        asm volatile("" ::"v"(s));
+#else
+        if (off >= 0) g[off] = s;
+#endif
     }
 }
 
@@ -493,26 +524,37 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
 // The job list of the NEXT group travels global -> registers at the start of a group and
 // registers -> LDS near its end, so its L2 latency hides behind the group's GEMM stages.
 // (The group's biases, a few KiB, ride along: [b1 | b2 | b3] in LDS column order.)
-struct JobPrefetch { i32x4 r0, r1; f32x4 b0; int count, nbias4; };
+struct JobPrefetch { i32x4 r0, r1, m0; f32x4 b0; int count, nbias4; };
 
+// BMAP: also fetch the group's bias-gradient map (backward kernel; the compact thin-gradient
+// index of every bias column, or -1), which lands behind the biases in the LDS bias buffer.
+template <bool BMAP>
 __device__ __forceinline__ void jobs_issue(JobPrefetch& jp, const GJob* __restrict__ gjobs, int jl_begin,
-                                           int jl_count, const float* __restrict__ bias_src, int nbias,
-                                           int tid) {
+                                           int jl_count, const float* __restrict__ bias_src,
+                                           const int32_t* __restrict__ bmap_src, int nbias, int tid) {
     jp.count = jl_count;
     jp.nbias4 = nbias >> 2;                       // bias blocks are multiples of 16 floats, <= 4*NTHREADS
     const i32x4* src = (const i32x4*)(gjobs + jl_begin);
     if (tid < jp.count) jp.r0 = src[tid];
     if (tid + NTHREADS < jp.count) jp.r1 = src[tid + NTHREADS];
-    if (tid < jp.nbias4) jp.b0 = ((const f32x4*)bias_src)[tid];
+    if (tid < jp.nbias4) {
+        jp.b0 = ((const f32x4*)bias_src)[tid];
+        if (BMAP) jp.m0 = ((const i32x4*)bmap_src)[tid];
+    }
 }
-__device__ __forceinline__ void jobs_commit(const JobPrefetch& jp, LDS_AS GJob* jbuf, float* bias_dst, int tid) {
+template <bool BMAP>
+__device__ __forceinline__ void jobs_commit(const JobPrefetch& jp, LDS_AS GJob* jbuf, float* bias_dst, int bmax,
+                                            int tid) {
     if (tid < jp.count) ((LDS_AS i32x4*)jbuf)[tid] = jp.r0;
     if (tid + NTHREADS < jp.count) ((LDS_AS i32x4*)jbuf)[tid + NTHREADS] = jp.r1;
-    if (tid < jp.nbias4) ((f32x4*)bias_dst)[tid] = jp.b0;
+    if (tid < jp.nbias4) {
+        ((f32x4*)bias_dst)[tid] = jp.b0;
+        if (BMAP) ((i32x4*)(bias_dst + bmax))[tid] = jp.m0;
+    }
 }
 
 // LDS carve-up shared by both block kernels:
-//   [meta: groups | vmap | ents][job buffer 0 | 1][bias buffer 0 | 1][float buffers ...]
+//   [meta: groups | vmap | ents][job buffer 0 | 1][bias+bmap buffer 0 | 1][float buffers ...]
 // The meta copy is split into issue (global -> registers) and commit (registers -> LDS) so
 // that it shares ONE memory round trip with the first chunk lists and the first lane tile.
 struct MetaPrefetch { i32x4 r0, r1; };
@@ -534,7 +576,7 @@ __device__ __forceinline__ void meta_commit(const MetaPrefetch& mp, const KArgs&
     const LDS_AS Ent* ents = (const LDS_AS Ent*)(mbase + a.ents_off);                              \
     LDS_AS GJob* jbuf0 = (LDS_AS GJob*)(mbase + a.meta_bytes);                                     \
     float* bias0 = lds + ((a.meta_bytes + 2 * a.jmax * (int)sizeof(GJob)) >> 2);                   \
-    float* fbase = bias0 + 2 * a.bmax;                                                             \
+    float* fbase = bias0 + 4 * a.bmax;                                                             \
     MetaPrefetch mp_;                                                                              \
     meta_issue(mp_, a, tid);
 
@@ -595,18 +637,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     GBlock blk = HINT_CB(0);
     {   // the first group's chunk lists and biases: issued together with the meta copy
         JobPrefetch jp0;
-        jobs_issue(jp0, a.jobs, a.first[fo][0], a.first[fo][1], (const float*)blk.packed + a.bias_off + a.first[fo][2], a.first[fo][3], tid);
+        jobs_issue<false>(jp0, a.jobs, a.first[fo][0], a.first[fo][1], (const float*)blk.packed + a.bias_off + a.first[fo][2], nullptr, a.first[fo][3], tid);
         meta_commit(mp_, a, mbase, tid);
-        jobs_commit(jp0, jbuf0, bias0, tid);
+        jobs_commit<false>(jp0, jbuf0, bias0, a.bmax, tid);
     }
 
-    // Weight prefetch runs TWO GEMM stages ahead: the stage_begin() of stage k+2 is issued right
-    // after stage k has issued its last fetch.  One stage ahead is not enough (a stage is often
-    // shorter than the ~1500-cycle L2 latency under load), and issuing it earlier would put the
-    // loads in front of stage k's own fetches in the in-order vmcnt queue.  L1, L2, L3 each own
-    // one Stage object, so nothing has to be copied.
+    // One Stage object travels through all GEMM stages: every stage_run() leaves it primed for
+    // the stage that follows (first job decoded, its first weights in flight) - also across
+    // groups, blocks of a chain and row tiles.
     int jb = 0;
-    Stage SA, SB, SC;     // L1, L2, L3
+    Stage S;
     bool first = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
@@ -648,10 +688,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
             }
             GroupU g = load_group(groups + (REV ? a.n_groups - 1 : 0));
-            if (first) {
-                stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
-                stage_begin(SB, jbuf0 + jb * a.jmax, g.l2_off, packed, wave, lane);
-            }
+            if (first) stage_begin(S, stage_list(jbuf0 + jb * a.jmax, g.l1_off, wave), packed, lane);
             first = false;
 
             for (int gi = 0; gi < a.n_groups; ++gi) {
@@ -664,28 +701,28 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 jp.count = 0;
                 jp.nbias4 = 0;
                 if (has_next)
-                    jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed_n + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
+                    jobs_issue<false>(jp, a.jobs, gn.jl_begin, gn.jl_count, packed_n + a.bias_off + gn.bmap_begin, nullptr, 2 * gn.aw + gn.sw, tid);
                 lds_jobs_t jl = jbuf0 + jb * a.jmax;
                 LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
-                const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
+                const float* bias_g = bias0 + jb * 2 * a.bmax;     // [b1 | b2 | b3] of this group
 
                 stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
                 STAMP(2 + 12 * gi)
                 lds_barrier();
                 STAMP(3 + 12 * gi)
-                stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
-                stage_begin(SC, jl, g.l3_off, packed, wave, lane);
-                if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
+                stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+                if (has_next) jobs_commit<false>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
                 STAMP(4 + 12 * gi)
                 lds_barrier();
                 STAMP(5 + 12 * gi)
-                stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
-                if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed_n, wave, lane);
+                stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
                 STAMP(6 + 12 * gi)
                 lds_barrier();
                 STAMP(7 + 12 * gi)
-                stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
-                if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed_n, wave, lane);
+                // the stage after this one: L1 of the next group (next block, next row tile); nothing
+                // follows the very last one, which re-primes its own group's L1 (never run)
+                stage_run<EPI_LINEAR>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
+                                      packed, has_next ? packed_n : packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
                 STAMP(8 + 12 * gi)
                 lds_barrier();
                 STAMP(9 + 12 * gi)
@@ -817,13 +854,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     GBlock blk = HINT_CB(n_chain - 1);         // the chain is walked from its last block to its first
     {
         JobPrefetch jp0;
-        jobs_issue(jp0, a.jobs, a.first[1][0], a.first[1][1], (const float*)blk.packed + a.bias_off + a.first[1][2], a.first[1][3], tid);
+        jobs_issue<true>(jp0, a.jobs, a.first[1][0], a.first[1][1], (const float*)blk.packed + a.bias_off + a.first[1][2], a.bmap + a.first[1][2], a.first[1][3], tid);
         meta_commit(mp_, a, mbase, tid);
-        jobs_commit(jp0, jbuf0, bias0, tid);
+        jobs_commit<true>(jp0, jbuf0, bias0, a.bmax, tid);
     }
 
     int jb = 0;
-    Stage SA, SB, SC;     // rotate over the six GEMM stages: L1, L2, L3, g2, g1, dv (prefetch two ahead)
+    Stage S;              // walks the six GEMM stages L1, L2, L3, g2, g1, dv of every group (see forward kernel)
     bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
@@ -859,10 +896,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         float* wsG2 = (float*)blk.wsG2;
         float* gparams = (float*)blk.wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
         GroupU g = load_group(groups + (a.n_groups - 1));
-        if (first_tile) {
-            stage_begin(SA, jbuf0 + jb * a.jmax, g.l1_off, packed, wave, lane);
-            stage_begin(SB, jbuf0 + jb * a.jmax, g.l2_off, packed, wave, lane);
-        }
+        if (first_tile) stage_begin(S, stage_list(jbuf0 + jb * a.jmax, g.l1_off, wave), packed, lane);
         first_tile = false;
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
@@ -873,10 +907,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             jp.count = 0;
             jp.nbias4 = 0;
             if (has_next)
-                jobs_issue(jp, a.jobs, gn.jl_begin, gn.jl_count, packed_n + a.bias_off + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
+                jobs_issue<true>(jp, a.jobs, gn.jl_begin, gn.jl_count, packed_n + a.bias_off + gn.bmap_begin, a.bmap + gn.bmap_begin, 2 * gn.aw + gn.sw, tid);
             lds_jobs_t jl = jbuf0 + jb * a.jmax;
             LDS_AS GJob* jl_next = jbuf0 + (jb ^ 1) * a.jmax;
-            const float* bias_g = bias0 + jb * a.bmax;     // [b1 | b2 | b3] of this group
+            const float* bias_g = bias0 + jb * 2 * a.bmax;     // [b1 | b2 | b3] of this group, then their gradient map
+            const int32_t* bmap_g = (const int32_t*)(bias_g + a.bmax);
             const int sbase = 2 + 20 * (a.n_groups - 1 - gi);
             (void)sbase;
 
@@ -900,20 +935,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 0)
             lds_barrier();
             STAMP(sbase + 1)
-            stage_run<EPI_RELU>(SA, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
-            stage_begin(SC, jl, g.l3_off, packed, wave, lane);
+            stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
             STAMP(sbase + 2)
             lds_barrier();
             STAMP(sbase + 3)
             copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            stage_run<EPI_RELU>(SB, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
-            stage_begin(SA, jl, g.g2_off, packed, wave, lane);
+            stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
-            stage_run<EPI_LINEAR>(SC, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
-            stage_begin(SB, jl, g.g1_off, packed, wave, lane);
-            if (has_next) jobs_commit(jp, jl_next, bias0 + (jb ^ 1) * a.bmax, tid);
+            stage_run<EPI_LINEAR>(S, stage_list(jl, g.g2_off, wave), packed, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+            if (has_next) jobs_commit<true>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
             STAMP(sbase + 6)
             lds_barrier();
             STAMP(sbase + 7)
@@ -942,29 +974,31 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 9)
             // ---- dW3 += g_st^T a2, db3 += colsum(g_st)  (a2 still holds the activations) ----
             run_ojobs(jl + g.o3_off, g.o3_cnt, gst, a.sld, a2, a.ald, gparams, wave, lane);
-            colsum_store(a.bmap + g.bmap3_begin, g.sw, gst, a.sld, gparams, tid);
+            STAMP(104 + 4 * (a.n_groups - 1 - gi))
+            colsum_store(bmap_g + 2 * g.aw, g.sw, gst, a.sld, gparams, tid);
             STAMP(sbase + 10)
             lds_barrier();
             STAMP(sbase + 11)
             // ---- g2 = (g_st * W3) .* relu'(a2), in place over a2 ----
-            stage_run<EPI_MASK>(SA, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
-            stage_begin(SC, jl, g.dv_off, packed, wave, lane);
+            stage_run<EPI_MASK>(S, stage_list(jl, g.g1_off, wave), packed, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
             STAMP(sbase + 12)
             lds_barrier();
             STAMP(sbase + 13)
             // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1;  db2 += colsum(g2) ----
             copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
-            colsum_store(a.bmap + g.bmap_begin + g.aw, g.aw, a2, a.ald, gparams, tid);
-            stage_run<EPI_MASK>(SB, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
-            if (has_next) stage_begin(SA, jl_next, gn.l1_off, packed_n, wave, lane);
+            STAMP(105 + 4 * (a.n_groups - 1 - gi))
+            colsum_store(bmap_g + g.aw, g.aw, a2, a.ald, gparams, tid);
+            STAMP(106 + 4 * (a.n_groups - 1 - gi))
+            stage_run<EPI_MASK>(S, stage_list(jl, g.dv_off, wave), packed, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
             STAMP(sbase + 14)
             lds_barrier();
             STAMP(sbase + 15)
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
-            stage_run<EPI_PLAIN>(SC, packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
-            if (has_next) stage_begin(SB, jl_next, gn.l2_off, packed_n, wave, lane);
+            stage_run<EPI_PLAIN>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
+                                 packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
+            STAMP(107 + 4 * (a.n_groups - 1 - gi))
             run_ojobs(jl + g.o1_off, g.o1_cnt, a1, a.ald, vb, a.vld, gparams, wave, lane);
-            colsum_store(a.bmap + g.bmap_begin, g.aw, a1, a.ald, gparams, tid);
+            colsum_store(bmap_g, g.aw, a1, a.ald, gparams, tid);
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)

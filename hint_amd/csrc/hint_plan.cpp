@@ -245,10 +245,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
         }
-        struct TileJob { int64_t wtile; int nblk, acol, ocol, nvalid, slab; };
+        // one (slab, node, net) of a stage: NT adjacent output tiles over the same k-blocks
+        struct Segment { int64_t wtile; int NT, nb, tstride, acol, ocol, N, slab; };
         auto emit_stage = [&](int which) -> int {
             // which: 1 = L1, 2 = L2, 3 = L3, 4 = g2, 5 = g1, 6 = dv
-            std::vector<TileJob> tj;
+            std::vector<Segment> segs;
             const int slabs = which == 3 ? g.l3_slabs : (which == 6 ? g.dv_slabs : 1);
             for (int sl = 0; sl < slabs; ++sl)
                 for (int ni = g.node_begin; ni < g.node_end; ++ni) {
@@ -267,59 +268,108 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                         }
                         // this slab's share of the k-blocks
                         const int kb0 = (int)((int64_t)NB * sl / slabs), kb1 = (int)((int64_t)NB * (sl + 1) / slabs);
-                        const int NT = (N + 15) / 16;
-                        for (int nt = 0; nt < NT; ++nt) {
-                            TileJob t{};
-                            if (kb1 > kb0) { t.wtile = wbase / 256 + (int64_t)nt * NB + kb0; t.nblk = kb1 - kb0; t.acol = acol + kb0 * 16; }
-                            else { t.wtile = 0; t.nblk = 0; t.acol = 0; }   // K = 0 (cin = 0) or empty slab
-                            t.ocol = ocol0 + nt * 16;
-                            t.nvalid = std::min(16, N - nt * 16);
-                            t.slab = sl;
-                            tj.push_back(t);
-                        }
+                        Segment sg{};
+                        sg.NT = (N + 15) / 16;
+                        if (sg.NT == 0) continue;
+                        sg.N = N; sg.ocol = ocol0; sg.slab = sl; sg.tstride = std::max(NB, 1);
+                        if (kb1 > kb0) { sg.wtile = wbase / 256 + kb0; sg.nb = kb1 - kb0; sg.acol = acol + kb0 * 16; }
+                        else { sg.wtile = 0; sg.nb = 0; sg.acol = 0; sg.tstride = 0; }   // K = 0 (cin = 0) or empty slab
+                        segs.push_back(sg);
                     }
                 }
-            // deal the tile jobs to the wavefronts, longest first onto the least loaded wavefront
-            std::vector<int> idx(tj.size());
-            for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return tj[x].nblk > tj[y].nblk; });
-            std::vector<std::vector<int>> per_wave(NWAVES);
-            int load[NWAVES] = {0};
-            for (int i : idx) {
-                int w = 0;
-                for (int v = 1; v < NWAVES; ++v) if (load[v] < load[w]) w = v;
-                per_wave[w].push_back(i);
-                load[w] += std::max(tj[i].nblk, 1) + 1;     // +1: epilogue / tile switch cost
+            // Cut the segments into jobs of <= 3 tiles and deal them to the wavefronts.  More, smaller
+            // jobs balance better, fewer, wider ones share more A reads and pay fewer prologues: try
+            // every total job count from the minimum up and keep the cheapest estimated makespan.
+            // Cost model (cycles): 128 per tile and k-block on the SIMD's matrix pipe, which the two
+            // wavefronts of a SIMD (w, w+4) share, plus a per-job prologue/epilogue the partner hides
+            // only in part.
+            struct Cut { int seg, t0, nt; long cost; };
+            auto cut_segments = [&](int extra, std::vector<Cut>& cuts) {
+                // segment s gets ceil(NT/3) jobs plus a share of `extra` (largest work per job first)
+                std::vector<int> cnt(segs.size());
+                for (size_t i = 0; i < segs.size(); ++i) cnt[i] = (segs[i].NT + 2) / 3;
+                for (int e = 0; e < extra; ++e) {
+                    int best = -1; double bw = 0;
+                    for (size_t i = 0; i < segs.size(); ++i) {
+                        if (cnt[i] >= segs[i].NT) continue;
+                        const double w = (double)segs[i].NT * std::max(segs[i].nb, 1) / cnt[i];
+                        if (w > bw) { bw = w; best = (int)i; }
+                    }
+                    if (best < 0) break;
+                    ++cnt[best];
+                }
+                cuts.clear();
+                for (size_t i = 0; i < segs.size(); ++i) {
+                    int t0 = 0;
+                    for (int c = 0; c < cnt[i]; ++c) {
+                        const int nt = (segs[i].NT - t0 + (cnt[i] - c) - 1) / (cnt[i] - c);
+                        cuts.push_back(Cut{(int)i, t0, nt, 128L * nt * std::max(segs[i].nb, 1)});
+                        t0 += nt;
+                    }
+                }
+            };
+            const long JOB_OVERHEAD = 300;
+            auto deal = [&](const std::vector<Cut>& cuts, std::vector<std::vector<int>>& per_wave) -> long {
+                std::vector<int> idx(cuts.size());
+                for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return cuts[x].cost > cuts[y].cost; });
+                per_wave.assign(NWAVES, {});
+                long wload[NWAVES] = {0}, sload[4] = {0};
+                for (int i : idx) {
+                    int w = 0;
+                    for (int v = 1; v < NWAVES; ++v) {
+                        const long sv = sload[v & 3], sw = sload[w & 3];
+                        if (sv < sw || (sv == sw && wload[v] < wload[w])) w = v;
+                    }
+                    per_wave[w].push_back(i);
+                    wload[w] += cuts[i].cost + JOB_OVERHEAD;
+                    sload[w & 3] += cuts[i].cost + JOB_OVERHEAD / 2;
+                }
+                long worst = 0;
+                for (int w = 0; w < NWAVES; ++w) worst = std::max(worst, std::max(wload[w], sload[w & 3]));
+                return worst;
+            };
+            std::vector<Cut> cuts, best_cuts;
+            std::vector<std::vector<int>> per_wave, best_pw(NWAVES);
+            long best_cost = -1;
+            int total_tiles = 0;
+            for (const Segment& sg : segs) total_tiles += sg.NT;
+            for (int extra = 0; extra <= 2 * NWAVES; ++extra) {
+                cut_segments(extra, cuts);
+                const long c = deal(cuts, per_wave);
+                if (best_cost < 0 || c < best_cost) { best_cost = c; best_cuts = cuts; best_pw = per_wave; }
+                if ((int)cuts.size() >= total_tiles) break;
             }
             const int hdr = (int)jobs.size() - g.jl_begin;
-            std::vector<std::vector<Chunk>> lists(NWAVES);
+            std::vector<std::vector<TJob>> lists(NWAVES);
             size_t longest = 1;
             for (int w = 0; w < NWAVES; ++w) {
-                for (int i : per_wave[w]) {
-                    const TileJob& t = tj[i];
-                    const int nch = std::max(1, (t.nblk + CHB - 1) / CHB);
-                    for (int cidx = 0; cidx < nch; ++cidx) {
-                        Chunk c{};
-                        c.wtile = (int32_t)(t.wtile + CHB * cidx);
-                        c.acol = (uint16_t)(t.acol + 16 * CHB * cidx);
-                        c.ocol = (uint16_t)t.ocol;
-                        c.nv = (uint8_t)std::max(0, std::min(CHB, t.nblk - CHB * cidx));
-                        c.last = (uint8_t)(cidx == nch - 1);
-                        c.nvalid = (uint8_t)t.nvalid;
-                        c.slab = (uint8_t)t.slab;
-                        lists[w].push_back(c);
-                    }
+                for (int i : best_pw[w]) {
+                    const Cut& c = best_cuts[i];
+                    const Segment& sg = segs[c.seg];
+                    TJob t{};
+                    const int64_t wt = sg.wtile + (int64_t)c.t0 * sg.tstride;
+                    if (wt > 0x7fffffff || sg.tstride > 0xffff) return -1;
+                    t.wtile = (int32_t)wt;
+                    t.acol = (uint16_t)sg.acol;
+                    t.ocol = (uint16_t)(sg.ocol + 16 * c.t0);
+                    t.nb = (uint8_t)sg.nb;
+                    t.nt = (uint8_t)c.nt;
+                    t.nvalid = (uint8_t)std::min(16, sg.N - 16 * (c.t0 + c.nt - 1));
+                    t.slab = (uint8_t)sg.slab;
+                    t.tstride = (uint16_t)sg.tstride;
+                    lists[w].push_back(t);
                 }
-                // an idle wavefront still walks one empty chunk: every wavefront issues the same,
-                // unconditional sequence of loads per stage (exact vmcnt counts for the compiler)
-                if (lists[w].empty()) lists[w].push_back(Chunk{});
+                // an idle wavefront still has one record (nt = 0): it only hands the prefetch baton on
+                if (lists[w].empty()) lists[w].push_back(TJob{});
                 longest = std::max(longest, lists[w].size());
             }
-            const int stride = (int)longest + STAGE_TAIL;
+            const int stride = (int)longest;
             for (int w = 0; w < NWAVES; ++w) {
-                lists[w][0].count = (int32_t)lists[w].size();
-                lists[w].resize(stride, Chunk{});      // empty tail: nv = 0, last = 0, tile 0
-                for (const Chunk& c : lists[w]) jobs.push_back(c);
+                if (lists[w].size() > 0xffff) return -1;
+                lists[w][0].count = (uint16_t)lists[w].size();
+                lists[w].resize(stride, TJob{});
+                for (const TJob& c : lists[w]) jobs.push_back(c);
             }
             if (hdr > 0xffff || stride > 0x7fff) return -1;
             return STAGE_DESC(hdr, stride);
@@ -444,7 +494,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->first[o][2] = fg.bmap_begin; P->first[o][3] = 2 * fg.aw + fg.sw;
     }
     P->n_bias = (int)bmap.size();
-    const int fixed = P->meta_bytes + 2 * P->jmax * (int)sizeof(GJob) + 2 * P->bmax * 4;
+    const int fixed = P->meta_bytes + 2 * P->jmax * (int)sizeof(GJob) + 4 * P->bmax * 4;   // [biases | bias-gradient map] x 2
     P->lds_fwd = fixed + fwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3);
     P->lds_bwd = fixed + bwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3, P->sv);
     if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT || d + 16 > 32000 || max_aw > 60000 ||
@@ -548,7 +598,7 @@ void hint_plan_destroy(hint_plan* P) {
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
 // +1 KiB of slack: the chunk prefetcher of the GEMM stages never reads past a job's last
 // k-block, but keeping a margin makes that robust against future tuning
-int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + (CHB + 1) * 256 : -1; }
+int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 3 * 256 : -1; }
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;

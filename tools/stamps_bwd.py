@@ -29,6 +29,9 @@ stages = ["build_v", "sync", "L1(+begin L3)", "sync", "L2(+copy a1,begin g2)", "
 for gi in range(5):
     for k, nm in enumerate(stages):
         names[2 + 20 * gi + k] = f"g{gi}:{nm}"
+for gi in range(4):
+    names[104 + 4 * gi] = f"g{gi}:  o3 ojobs done"; names[105 + 4 * gi] = f"g{gi}:  g2 copied out"
+    names[106 + 4 * gi] = f"g{gi}:  colsum(g2) done"; names[107 + 4 * gi] = f"g{gi}:  dv stage done"
 ids = sorted([i for i in names if s[0, i] != 0], key=lambda i: s[0, i].item())
 t0 = s[:, 0].min().item()
 prev = None
