@@ -81,23 +81,15 @@ struct TJob {
     uint16_t count;     // in the FIRST record of a wavefront's list: number of jobs in the list
 };
 static_assert(sizeof(TJob) == 16, "TJob must be 16 bytes");
+// nt == TJOB_OUTER marks an outer-product tile of a thin weight gradient (dW1, dW3) that rides in
+// a GEMM stage's lists of the backward kernel:  T[m][n] = sum_rows A[row][acol+m] * B[row][ocol+n],
+// stored at slab[wtile + m*tstride + n] for m <= (nvalid & 15), n <= (nvalid >> 4); nb = 0.
+constexpr int TJOB_OUTER = 0xff;
 typedef TJob GJob;      // the per-group lists hold TJob and OJob records, 16 B each
 
 // A stage's lists sit at a fixed stride: wavefront w's list starts at record w*stride (the stage
 // descriptor packs offset and stride into one int, see STAGE_DESC).
 #define STAGE_DESC(OFF, STRIDE) (((OFF) & 0xffff) | ((STRIDE) << 16))
-
-// Thin weight gradient of one (node, net) done inside the row-parallel backward kernel: a grid
-// of 16x16 outer-product tiles  T[m][n] = sum_rows A[row][acol+m] * B[row][bcol+n],  M x N valid,
-// stored at slab[goff + m*N + n] (row stride N).  One record per (node, net); the wavefronts
-// share the grid's tiles round-robin.
-struct OJob {
-    int32_t goff;
-    uint16_t acol, bcol;
-    uint16_t M, N;
-    int32_t pad;
-};
-static_assert(sizeof(OJob) == 16, "OJob must be 16 bytes");
 
 struct Ent { int16_t xcol, scol, tcol, pad; };                  // one transformed lane of a group
 
@@ -143,6 +135,7 @@ struct KArgs {
     int32_t xld, cld, ald, vld, sld;   // LDS row strides (floats)
     int32_t s3, sv;                    // slab counts of the st / gv buffers
     int32_t WT;                        // workspace row width (floats)
+    int32_t split_o3;                  // backward: no LDS for a separate g2 buffer -> dW3 tiles run as their own phase
     float alpha;
     int32_t B;
 };

@@ -203,10 +203,11 @@ __device__ __forceinline__ void fetch_first(f32x4 (&b0)[3], f32x4 (&b1)[3], cons
                                             const float* __restrict__ packed, int lane) {
     const f32x4* wp = (const f32x4*)packed + lane;
     const int k1 = j.nb > 1 ? 1 : 0;
+    const int base = j.nb > 0 ? j.wtile : 0;          // K = 0 jobs and outer-product tiles have no weights
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int tt = t < j.nt ? t : 0;
-        const f32x4* q = wp + HINT_WTILE(j.wtile + tt * j.tstride) * 64;
+        const int tt = (j.nb > 0 && t < j.nt) ? t : 0;
+        const f32x4* q = wp + HINT_WTILE(base + tt * j.tstride) * 64;
         b0[t] = q[0];
         b1[t] = q[64 * k1];
     }
@@ -233,8 +234,8 @@ __device__ __forceinline__ void stage_begin(Stage& S, lds_jobs_t cl, const float
 template <int EPI, int NT>
 __device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b1)[3], const JobU& jn,
                                         const float* __restrict__ packed, const float* __restrict__ packed_n,
-                                        const float* bias_lds, const float* arow, float* O, int ldo,
-                                        int slab_stride, int lane) {
+                                        const float* bias_lds, const float* arow, float* O, const float* Mk,
+                                        int ldo, int slab_stride, int lane) {
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -294,26 +295,62 @@ __device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const bool ok = (t < NT - 1) || nl < j.nvalid;       // only the job's last tile can be ragged
-        float* o = O + j.slab * slab_stride + (4 * (lane >> 4)) * ldo + j.ocol + 16 * t + nl;
+        const int oo = j.slab * slab_stride + (4 * (lane >> 4)) * ldo + j.ocol + 16 * t + nl;
+        float* o = O + oo;
+        const float* mk = Mk + oo;                         // EPI_MASK: relu'() of the forward activation
         const float bi = j.slab == 0 ? bias[t] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v;
             if (EPI == EPI_RELU) v = ok ? fmaxf(acc[t][i] + bi, 0.f) : 0.f;
             else if (EPI == EPI_LINEAR) v = ok ? acc[t][i] + bi : 0.f;
-            else if (EPI == EPI_MASK) v = (ok && o[i * ldo] > 0.f) ? acc[t][i] : 0.f;
+            else if (EPI == EPI_MASK) v = (ok && mk[i * ldo] > 0.f) ? acc[t][i] : 0.f;
             else v = ok ? acc[t][i] : 0.f;
             o[i * ldo] = v;
         }
     }
 }
 
+// One 16x16 outer-product tile of a thin weight gradient (TJOB_OUTER record): the reduction runs
+// over the 16 rows of the row tile; the partial goes to this row tile's own slab of the
+// workspace with plain stores (every slab element is written exactly once) and part B sums the
+// slabs.  Atomics straight into the gradient buffer would have all 256 workgroups hammer the
+// same few KiB at once: measured 65 us of a 115 us kernel.
+__device__ __forceinline__ void run_outer(const JobU& j, f32x4 (&b0)[3], f32x4 (&b1)[3], const JobU& jn,
+                                          const float* __restrict__ packed_n, const float* Abuf, int lda,
+                                          const float* Bbuf, int ldb, float* __restrict__ g, int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+    const float* ap = Abuf + kq * lda + nl + j.acol;       // rows kq + 4*i of the two operand tiles
+    const float* bp = Bbuf + kq * ldb + nl + j.ocol;
+    float av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { av[i] = ap[4 * i * lda]; bv[i] = bp[4 * i * ldb]; }
+    fetch_first(b0, b1, jn, packed_n, lane);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    acc0 = mfma4(av[0], bv[0], acc0);
+    acc1 = mfma4(av[1], bv[1], acc1);
+    acc0 = mfma4(av[2], bv[2], acc0);
+    acc1 = mfma4(av[3], bv[3], acc1);
+    const f32x4 acc = acc0 + acc1;
+    const int mvalid = (j.nvalid & 15) + 1, nvalid = (j.nvalid >> 4) + 1;
+    if (nl < nvalid) {
+        float* o = g + j.wtile + (4 * kq) * j.tstride + nl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * kq + i < mvalid) o[i * j.tstride] = acc[i];
+    }
+}
+
 // Run the stage S is primed for; on return S is primed for the stage whose list (of this
-// wavefront) is `next` with weights in `packed_n`.
-template <int EPI>
+// wavefront) is `next` with weights in `packed_n`.  Mk: EPI_MASK's relu mask source (laid out
+// like O; may be O itself).  OUTER: the lists also hold outer-product tiles A_o^T B_o -> g_o.
+template <int EPI, bool OUTER = false>
 __device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float* __restrict__ packed,
                                           const float* __restrict__ packed_n, const float* bias_lds,
-                                          const float* A, int lda, float* O, int ldo, int slab_stride, int lane) {
+                                          const float* A, int lda, float* O, const float* Mk, int ldo,
+                                          int slab_stride, int lane, const float* A_o = nullptr, int lda_o = 0,
+                                          const float* B_o = nullptr, int ldb_o = 0,
+                                          float* __restrict__ g_o = nullptr) {
 #ifdef HINT_SKIP_GEMM
     S.cl = next;
     return;
@@ -325,76 +362,16 @@ __device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float
         const bool last = ji + 1 >= n;
         const JobU jn = decode_job(*(const LDS_AS i32x4*)(last ? next : S.cl + ji + 1));
         const float* pn = last ? packed_n : packed;
-        if (j.nt >= 3) run_job<EPI, 3>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, ldo, slab_stride, lane);
-        else if (j.nt == 2) run_job<EPI, 2>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, ldo, slab_stride, lane);
-        else if (j.nt == 1) run_job<EPI, 1>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, ldo, slab_stride, lane);
+        if (OUTER && j.nt == TJOB_OUTER) run_outer(j, S.b0, S.b1, jn, pn, A_o, lda_o, B_o, ldb_o, g_o, lane);
+        else if (j.nt >= 3) run_job<EPI, 3>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
+        else if (j.nt == 2) run_job<EPI, 2>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
+        else if (j.nt == 1) run_job<EPI, 1>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
         else fetch_first(S.b0, S.b1, jn, pn, lane);      // idle wavefront: only hand the baton on
         j = jn;
         if (last) break;
     }
     S.j = j;
     S.cl = next;
-}
-
-// Small outer-product tiles done inside the backward kernel (dW1, dW3): the reduction runs
-// over the 16 rows of the tile; the partial goes to this row tile's own slab of the workspace
-// with plain stores (every slab element is written exactly once) and part B sums the slabs.
-// Atomics straight into the gradient buffer would have all 256 workgroups hammer the same few
-// KiB at once: measured 65 us of a 115 us kernel.
-__device__ __forceinline__ void run_ojobs(lds_jobs_t jobs, int njobs, const float* Abuf, int lda,
-                                          const float* Bbuf, int ldb, float* __restrict__ g, int wave,
-                                          int lane) {
-#ifdef HINT_SKIP_OJOBS
-    return;
-#endif
-    const int nl = lane & 15, kq = lane >> 4;
-    const float* ap = Abuf + kq * lda + nl;          // row kq + 4*i of the operand tiles
-    const float* bp = Bbuf + kq * ldb + nl;
-    int t0 = wave;                                   // round-robin over the tiles of all grids
-    for (int j = 0; j < njobs; ++j) {
-        const i32x4 raw = *(const LDS_AS i32x4*)(jobs + j);
-        const int goff = __builtin_amdgcn_readfirstlane(raw.x);
-        const unsigned y = (unsigned)__builtin_amdgcn_readfirstlane(raw.y);
-        const unsigned zz = (unsigned)__builtin_amdgcn_readfirstlane(raw.z);
-        const int acol = (int)(y & 0xffffu), bcol = (int)(y >> 16);
-        const int M = (int)(zz & 0xffffu), N = (int)(zz >> 16);
-        const int mtiles = (M + 15) >> 4, ntiles = (N + 15) >> 4, tiles = mtiles * ntiles;
-        int t = t0;
-        int mt = 0, nt = t;                          // t < NWAVES <= tiles of one tile row in the common case
-        while (nt >= ntiles && mt < mtiles) { nt -= ntiles; ++mt; }
-        for (; t < tiles; t += NWAVES) {
-            // all eight operand reads first (one LDS round trip), two accumulators for the four
-            // dependent k-steps
-            float av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = ap[4 * i * lda + acol + 16 * mt];
-                bv[i] = bp[4 * i * ldb + bcol + 16 * nt];
-            }
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            acc0 = mfma4(av[0], bv[0], acc0);
-            acc1 = mfma4(av[1], bv[1], acc1);
-            acc0 = mfma4(av[2], bv[2], acc0);
-            acc1 = mfma4(av[3], bv[3], acc1);
-            const f32x4 acc = acc0 + acc1;
-            const int n = 16 * nt + nl;
-#ifdef HINT_ABLATE_OSTORE
-            asm volatile("" ::"v"(acc));
-            if (n < 0) {
-#else
-            if (n < N) {
-#endif
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = 16 * mt + 4 * kq + i;
-                    if (m < M) g[goff + m * N + n] = acc[i];
-                }
-            }
-            nt += NWAVES;
-            while (nt >= ntiles && mt < mtiles) { nt -= ntiles; ++mt; }
-        }
-        t0 = t - tiles;                              // keep the round-robin phase across grids
-    }
 }
 
 // bias gradients: column sums over the 16 rows of an LDS buffer, one thread per column; the map
@@ -710,19 +687,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 STAMP(2 + 12 * gi)
                 lds_barrier();
                 STAMP(3 + 12 * gi)
-                stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+                stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, nullptr, a.ald, 0, lane);
                 if (has_next) jobs_commit<false>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
                 STAMP(4 + 12 * gi)
                 lds_barrier();
                 STAMP(5 + 12 * gi)
-                stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
+                stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, nullptr, a.ald, 0, lane);
                 STAMP(6 + 12 * gi)
                 lds_barrier();
                 STAMP(7 + 12 * gi)
                 // the stage after this one: L1 of the next group (next block, next row tile); nothing
                 // follows the very last one, which re-primes its own group's L1 (never run)
                 stage_run<EPI_LINEAR>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
-                                      packed, has_next ? packed_n : packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+                                      packed, has_next ? packed_n : packed, bias_g + 2 * g.aw, a2, a.ald, st, nullptr, a.sld, sstride, lane);
                 STAMP(8 + 12 * gi)
                 lds_barrier();
                 STAMP(9 + 12 * gi)
@@ -845,7 +822,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     float* gv = vb + ROWS * a.vld;           // [sv][ROWS][vld]
     float* a1 = gv + a.sv * ROWS * a.vld;
     float* a2 = a1 + ROWS * a.ald;
-    float* st = a2 + ROWS * a.ald;           // [s3][ROWS][sld]
+    // g2 gets its own buffer so that the dW3 tiles (which read a2) can run in the g2 stage's phase;
+    // plans that cannot afford it (a.split_o3) write g2 over a2 and run dW3 as a phase of its own
+    float* a3 = a2 + (a.split_o3 ? 0 : ROWS * a.ald);
+    float* st = a3 + ROWS * a.ald;           // [s3][ROWS][sld]
     float* gst = st + a.s3 * ROWS * a.sld;
     float* gj = gst + ROWS * a.sld;
     const int sstride = ROWS * a.sld, vstride = ROWS * a.vld;
@@ -935,16 +915,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 0)
             lds_barrier();
             STAMP(sbase + 1)
-            stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, a.ald, 0, lane);
+            stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, nullptr, a.ald, 0, lane);
             STAMP(sbase + 2)
             lds_barrier();
             STAMP(sbase + 3)
             copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, a.ald, 0, lane);
+            stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, nullptr, a.ald, 0, lane);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
-            stage_run<EPI_LINEAR>(S, stage_list(jl, g.g2_off, wave), packed, packed, bias_g + 2 * g.aw, a2, a.ald, st, a.sld, sstride, lane);
+            stage_run<EPI_LINEAR>(S, stage_list(jl, a.split_o3 ? g.o3_off : g.g2_off, wave), packed, packed, bias_g + 2 * g.aw, a2, a.ald, st, nullptr, a.sld, sstride, lane);
             if (has_next) jobs_commit<true>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
             STAMP(sbase + 6)
             lds_barrier();
@@ -972,33 +952,34 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 8)
             lds_barrier();
             STAMP(sbase + 9)
-            // ---- dW3 += g_st^T a2, db3 += colsum(g_st)  (a2 still holds the activations) ----
-            run_ojobs(jl + g.o3_off, g.o3_cnt, gst, a.sld, a2, a.ald, gparams, wave, lane);
-            STAMP(104 + 4 * (a.n_groups - 1 - gi))
+            // ---- g2 = (g_st * W3) .* relu'(a2) -> a3;  dW3 += g_st^T a2 (outer-product tiles in the
+            //      same lists);  db3 += colsum(g_st) ----
             colsum_store(bmap_g + 2 * g.aw, g.sw, gst, a.sld, gparams, tid);
-            STAMP(sbase + 10)
-            lds_barrier();
-            STAMP(sbase + 11)
-            // ---- g2 = (g_st * W3) .* relu'(a2), in place over a2 ----
-            stage_run<EPI_MASK>(S, stage_list(jl, g.g1_off, wave), packed, packed, bias_g, gst, a.sld, a2, a.ald, 0, lane);
+            if (a.split_o3) {                  // outer-product tiles only; then g2 may overwrite a2
+                stage_run<EPI_PLAIN, true>(S, stage_list(jl, g.g2_off, wave), packed, packed, bias_g, gst, a.sld, a3, nullptr,
+                                           a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
+                lds_barrier();
+            }
+            stage_run<EPI_MASK, true>(S, stage_list(jl, g.g1_off, wave), packed, packed, bias_g, gst, a.sld, a3, a2,
+                                      a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
             STAMP(sbase + 12)
             lds_barrier();
             STAMP(sbase + 13)
             // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1;  db2 += colsum(g2) ----
-            copy_rows_out(wsG2, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
+            copy_rows_out(wsG2, a.WT, g.wcol0, a3, a.ald, g.aw, row0, tid);
             STAMP(105 + 4 * (a.n_groups - 1 - gi))
-            colsum_store(bmap_g + g.aw, g.aw, a2, a.ald, gparams, tid);
+            colsum_store(bmap_g + g.aw, g.aw, a3, a.ald, gparams, tid);
             STAMP(106 + 4 * (a.n_groups - 1 - gi))
-            stage_run<EPI_MASK>(S, stage_list(jl, g.dv_off, wave), packed, packed, bias_g, a2, a.ald, a1, a.ald, 0, lane);
+            stage_run<EPI_MASK>(S, stage_list(jl, g.dv_off, wave), packed, packed, bias_g, a3, a.ald, a1, a1, a.ald, 0, lane);
             STAMP(sbase + 14)
             lds_barrier();
             STAMP(sbase + 15)
-            // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v;  db1 += colsum(g1) ----
-            stage_run<EPI_PLAIN>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
-                                 packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, a.vld, vstride, lane);
-            STAMP(107 + 4 * (a.n_groups - 1 - gi))
-            run_ojobs(jl + g.o1_off, g.o1_cnt, a1, a.ald, vb, a.vld, gparams, wave, lane);
+            // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v (outer-product tiles);
+            //      db1 += colsum(g1) ----
             colsum_store(bmap_g, g.aw, a1, a.ald, gparams, tid);
+            stage_run<EPI_PLAIN, true>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
+                                       packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, nullptr, a.vld, vstride,
+                                       lane, a1, a.ald, vb, a.vld, gparams);
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)

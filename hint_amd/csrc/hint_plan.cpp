@@ -78,7 +78,7 @@ struct hint_plan {
     int s3 = 1, sv = 1;   // max K-split slabs of the layer-3 / dv stages
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
-    int meta_bytes = 0, vmap_off = 0, ents_off = 0, jmax = 0, bmax = 0, n_bias = 0;
+    int meta_bytes = 0, vmap_off = 0, ents_off = 0, jmax = 0, bmax = 0, n_bias = 0, split_o3 = 0;
     int first[2][4] = {{0}};
     int thin_total = 0;
     int32_t* d_tmap = nullptr;
@@ -98,8 +98,8 @@ static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part
 static int fwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3) {
     return 4 * ROWS * (2 * xld + cld + vld + 2 * ald + s3 * sld + 1);
 }
-static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, int sv) {
-    return 4 * ROWS * (2 * xld + 2 * cld + (1 + sv) * vld + 2 * ald + (s3 + 1) * sld + 1);
+static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, int sv, int n_abuf) {
+    return 4 * ROWS * (2 * xld + 2 * cld + (1 + sv) * vld + n_abuf * ald + (s3 + 1) * sld + 1);
 }
 static constexpr int JOBS_PER_GROUP_MAX = 2 * NTHREADS;   // what the in-kernel job prefetch moves
 
@@ -113,7 +113,7 @@ static int pick_slabs(int n_tile_jobs, int min_nblk, int max_slabs) {
 }
 
 static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
-                      int max_slabs, int cap_scale, hint_plan** out, bool* retry_smaller) {
+                      int max_slabs, int cap_scale, bool use_a3, hint_plan** out, bool* retry_smaller) {
     *retry_smaller = false;
     int max_depth = 0;
     for (int i = 0; i < n_nodes; ++i) max_depth = std::max(max_depth, nodes[i].depth);
@@ -147,7 +147,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // rough size of what rides along in LDS besides the float buffers (group/node/lane tables)
     const int meta_guess = 16 * n_nodes + 8 * d + 160 * (max_depth + 2);
     auto bwd_bytes = [&](int aw_, int vw_, int sw_) {
-        return meta_guess + bwd_lds_bytes(P->xld, P->cld, lds_stride(vw_), lds_stride(aw_), lds_stride(sw_), 1, 1);
+        return meta_guess + bwd_lds_bytes(P->xld, P->cld, lds_stride(vw_), lds_stride(aw_), lds_stride(sw_), 1, 1, 2);
     };
 
     struct DNode {            // host-side working copy of a node
@@ -245,13 +245,42 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
         }
+        // ---- thin weight gradients done inside the row-parallel backward kernel: 16x16 outer-product
+        //      tiles  T[m][n] = sum_rows A[row][acol+m] * B[row][bcol+n]  of dW3 = g_st^T a2 (with the g2
+        //      stage) and dW1 = g1^T v (with the dv stage), stored at slab[goff + m*N + n] ----
+        struct OuterTile { int32_t goff; int acol, bcol, mvalid, nvalid, N; };
+        std::vector<OuterTile> outer3, outer1;
+        auto thin_alloc = [&](int64_t param_off, int count) {   // contiguous compact range mirroring a tensor
+            const int base = (int)tmap.size();
+            for (int i = 0; i < count; ++i) tmap.push_back((int32_t)(param_off + i));
+            return base;
+        };
+        auto add_outer = [&](std::vector<OuterTile>& out, int base, int acol, int bcol, int M, int N) {
+            for (int mt = 0; mt * 16 < M; ++mt)
+                for (int nt = 0; nt * 16 < N; ++nt)
+                    out.push_back(OuterTile{base + 16 * mt * N + 16 * nt, acol + 16 * mt, bcol + 16 * nt,
+                                            std::min(16, M - 16 * mt), std::min(16, N - 16 * nt), N});
+        };
+        for (int ni = g.node_begin; ni < g.node_end; ++ni)
+            for (int net = 0; net < 2; ++net) {            // dW3[r][h] = g_st^T a2
+                const DNode& q = dn[ni];
+                add_outer(outer3, thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h), q.scol + net * q.rp,
+                          q.acol + net * q.hp, q.r, q.h);
+            }
+        for (int ni = g.node_begin; ni < g.node_end; ++ni)
+            for (int net = 0; net < 2; ++net) {            // dW1[h][cin] = g1^T v
+                const DNode& q = dn[ni];
+                if (q.cin == 0) continue;
+                add_outer(outer1, thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin), q.acol + net * q.hp, q.vcol,
+                          q.h, q.cin);
+            }
         // one (slab, node, net) of a stage: NT adjacent output tiles over the same k-blocks
         struct Segment { int64_t wtile; int NT, nb, tstride, acol, ocol, N, slab; };
         auto emit_stage = [&](int which) -> int {
             // which: 1 = L1, 2 = L2, 3 = L3, 4 = g2, 5 = g1, 6 = dv
             std::vector<Segment> segs;
             const int slabs = which == 3 ? g.l3_slabs : (which == 6 ? g.dv_slabs : 1);
-            for (int sl = 0; sl < slabs; ++sl)
+            for (int sl = 0; sl < slabs && which != 7; ++sl)
                 for (int ni = g.node_begin; ni < g.node_end; ++ni) {
                     const DNode& q = dn[ni];
                     const NodePack& k = np[ni - g.node_begin];
@@ -280,10 +309,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             // Cut the segments into jobs of <= 3 tiles and deal them to the wavefronts.  More, smaller
             // jobs balance better, fewer, wider ones share more A reads and pay fewer prologues: try
             // every total job count from the minimum up and keep the cheapest estimated makespan.
+            const long JOB_OVERHEAD = 300;
             // Cost model (cycles): 128 per tile and k-block on the SIMD's matrix pipe, which the two
             // wavefronts of a SIMD (w, w+4) share, plus a per-job prologue/epilogue the partner hides
             // only in part.
-            struct Cut { int seg, t0, nt; long cost; };
+            struct Cut { int seg, t0, nt; long cost, overhead; };   // seg < 0: outer tile -1-seg
+            // which == 7: the dW3 tiles as a stage of their own (plans without LDS for the g2 buffer)
+            const std::vector<OuterTile>* outer = (which == 4 && use_a3) || which == 7 ? &outer3 : (which == 6 ? &outer1 : nullptr);
             auto cut_segments = [&](int extra, std::vector<Cut>& cuts) {
                 // segment s gets ceil(NT/3) jobs plus a share of `extra` (largest work per job first)
                 std::vector<int> cnt(segs.size());
@@ -303,16 +335,18 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                     int t0 = 0;
                     for (int c = 0; c < cnt[i]; ++c) {
                         const int nt = (segs[i].NT - t0 + (cnt[i] - c) - 1) / (cnt[i] - c);
-                        cuts.push_back(Cut{(int)i, t0, nt, 128L * nt * std::max(segs[i].nb, 1)});
+                        cuts.push_back(Cut{(int)i, t0, nt, 128L * nt * std::max(segs[i].nb, 1), JOB_OVERHEAD});
                         t0 += nt;
                     }
                 }
+                if (outer)      // one LDS round trip + 4 MFMAs + stores: latency, hardly any pipe time
+                    for (size_t i = 0; i < outer->size(); ++i) cuts.push_back(Cut{-1 - (int)i, 0, 1, 128, 500});
             };
-            const long JOB_OVERHEAD = 300;
             auto deal = [&](const std::vector<Cut>& cuts, std::vector<std::vector<int>>& per_wave) -> long {
                 std::vector<int> idx(cuts.size());
                 for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return cuts[x].cost > cuts[y].cost; });
+                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
+                    return cuts[x].cost + cuts[x].overhead > cuts[y].cost + cuts[y].overhead; });
                 per_wave.assign(NWAVES, {});
                 long wload[NWAVES] = {0}, sload[4] = {0};
                 for (int i : idx) {
@@ -322,8 +356,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                         if (sv < sw || (sv == sw && wload[v] < wload[w])) w = v;
                     }
                     per_wave[w].push_back(i);
-                    wload[w] += cuts[i].cost + JOB_OVERHEAD;
-                    sload[w & 3] += cuts[i].cost + JOB_OVERHEAD / 2;
+                    wload[w] += cuts[i].cost + cuts[i].overhead;
+                    sload[w & 3] += cuts[i].cost + cuts[i].overhead / 2;
                 }
                 long worst = 0;
                 for (int w = 0; w < NWAVES; ++w) worst = std::max(worst, std::max(wload[w], sload[w & 3]));
@@ -338,7 +372,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 cut_segments(extra, cuts);
                 const long c = deal(cuts, per_wave);
                 if (best_cost < 0 || c < best_cost) { best_cost = c; best_cuts = cuts; best_pw = per_wave; }
-                if ((int)cuts.size() >= total_tiles) break;
+                if ((int)cuts.size() >= total_tiles + (outer ? (int)outer->size() : 0)) break;
             }
             const int hdr = (int)jobs.size() - g.jl_begin;
             std::vector<std::vector<TJob>> lists(NWAVES);
@@ -346,8 +380,19 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             for (int w = 0; w < NWAVES; ++w) {
                 for (int i : best_pw[w]) {
                     const Cut& c = best_cuts[i];
-                    const Segment& sg = segs[c.seg];
                     TJob t{};
+                    if (c.seg < 0) {                       // outer-product tile (see TJob)
+                        const OuterTile& o = (*outer)[-1 - c.seg];
+                        if (o.N > 0xffff) return -1;
+                        t.wtile = o.goff;
+                        t.acol = (uint16_t)o.acol; t.ocol = (uint16_t)o.bcol;
+                        t.nb = 0; t.nt = TJOB_OUTER;
+                        t.nvalid = (uint8_t)((o.mvalid - 1) | ((o.nvalid - 1) << 4));
+                        t.tstride = (uint16_t)o.N;
+                        lists[w].push_back(t);
+                        continue;
+                    }
+                    const Segment& sg = segs[c.seg];
                     const int64_t wt = sg.wtile + (int64_t)c.t0 * sg.tstride;
                     if (wt > 0x7fffffff || sg.tstride > 0xffff) return -1;
                     t.wtile = (int32_t)wt;
@@ -381,47 +426,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         g.g2_off = emit_stage(4);
         g.g1_off = emit_stage(5);
         g.dv_off = emit_stage(6);
-        if (g.l1_off < 0 || g.l2_off < 0 || g.l3_off < 0 || g.g2_off < 0 || g.g1_off < 0 || g.dv_off < 0) {
+        g.o3_off = use_a3 ? 0 : emit_stage(7);
+        if (g.o3_off < 0 || g.l1_off < 0 || g.l2_off < 0 || g.l3_off < 0 || g.g2_off < 0 || g.g1_off < 0 || g.dv_off < 0) {
             delete P;
             if (cap_scale < 16) { *retry_smaller = true; return 1; }
             return fail("hint_plan_create: a group's chunk lists exceed the 16-bit stage descriptor");
         }
-        auto push_ojob = [&](const OJob& o) {
-            GJob raw;
-            static_assert(sizeof(OJob) == sizeof(GJob), "job records share one 16-byte array");
-            std::memcpy(&raw, &o, sizeof raw);
-            jobs.push_back(raw);
-        };
-
-        // ---- in-kernel outer-product jobs (dW3 = g_st^T a2, dW1 = g1^T v) + bias maps ----
-        auto thin_alloc = [&](int64_t param_off, int count) {   // contiguous compact range mirroring a tensor
-            const int base = (int)tmap.size();
-            for (int i = 0; i < count; ++i) tmap.push_back((int32_t)(param_off + i));
-            return base;
-        };
-        g.o3_off = (int)jobs.size() - g.jl_begin;
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net) {            // dW3[r][h] = g_st^T a2
-                const DNode& q = dn[ni];
-                OJob o{};
-                o.goff = thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h);
-                o.acol = (uint16_t)(q.scol + net * q.rp); o.bcol = (uint16_t)(q.acol + net * q.hp);
-                o.M = (uint16_t)q.r; o.N = (uint16_t)q.h;
-                push_ojob(o);
-            }
-        g.o3_cnt = (int)jobs.size() - g.jl_begin - g.o3_off;
-        g.o1_off = (int)jobs.size() - g.jl_begin;
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net) {            // dW1[h][cin] = g1^T v
-                const DNode& q = dn[ni];
-                if (q.cin == 0) continue;
-                OJob o{};
-                o.goff = thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin);
-                o.acol = (uint16_t)(q.acol + net * q.hp); o.bcol = (uint16_t)q.vcol;
-                o.M = (uint16_t)q.h; o.N = (uint16_t)q.cin;
-                push_ojob(o);
-            }
-        g.o1_cnt = (int)jobs.size() - g.jl_begin - g.o1_off;
+        g.o3_cnt = g.o1_off = g.o1_cnt = 0;      // outer-product tiles ride in the g2 / dv stage lists (or o3_off's)
         g.jl_count = (int)jobs.size() - g.jl_begin;
         if (g.jl_count > JOBS_PER_GROUP_MAX) {
             delete P;
@@ -494,13 +505,14 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->first[o][2] = fg.bmap_begin; P->first[o][3] = 2 * fg.aw + fg.sw;
     }
     P->n_bias = (int)bmap.size();
+    P->split_o3 = use_a3 ? 0 : 1;
     const int fixed = P->meta_bytes + 2 * P->jmax * (int)sizeof(GJob) + 4 * P->bmax * 4;   // [biases | bias-gradient map] x 2
     P->lds_fwd = fixed + fwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3);
-    P->lds_bwd = fixed + bwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3, P->sv);
+    P->lds_bwd = fixed + bwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3, P->sv, use_a3 ? 3 : 2);
     if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT || d + 16 > 32000 || max_aw > 60000 ||
         P->bmax > 4 * NTHREADS) {
         const int need = std::max(P->lds_bwd, P->lds_fwd);
-        const bool can_retry = max_slabs > 1 || cap_scale < 16;
+        const bool can_retry = use_a3 || max_slabs > 1 || cap_scale < 16;
         delete P;
         if (can_retry) { *retry_smaller = true; return 1; }   // rebuild with fewer slabs / smaller groups
         return fail("hint_plan_create: block needs %d bytes of LDS (> %d); d/dc/h too large", need, LDS_LIMIT);
@@ -574,9 +586,10 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
                 return fail("hint_plan_create: nodes %d and %d of depth %d overlap", i, j, nodes[i].depth);
     // first choice: full K-split and large groups; fall back to fewer slabs, then smaller groups
     for (int cap_scale = 1; cap_scale <= 16; cap_scale *= 2)
-        for (int max_slabs = MAX_SLABS; max_slabs >= 1; max_slabs /= 2) {
+        for (int max_slabs = MAX_SLABS; max_slabs >= 1; max_slabs /= 2)
+            for (int use_a3 = 1; use_a3 >= 0; --use_a3) {
             bool retry = false;
-            const int st = build_plan(nodes, n_nodes, d, dc, clamp, max_slabs, cap_scale, out, &retry);
+            const int st = build_plan(nodes, n_nodes, d, dc, clamp, max_slabs, cap_scale, use_a3 != 0, out, &retry);
             if (st == 0 || !retry) return st;
         }
     return fail("hint_plan_create: could not fit the block into LDS");
@@ -628,7 +641,7 @@ static KArgs make_args(const hint_plan* P, int B) {
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
     a.xld = P->xld; a.cld = P->cld; a.ald = P->ald; a.vld = P->vld; a.sld = P->sld;
     a.WT = P->WT;
-    a.alpha = P->alpha; a.B = B;
+    a.alpha = P->alpha; a.B = B; a.split_o3 = P->split_o3;
     return a;
 }
 
