@@ -867,6 +867,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         }
         __syncthreads();
         STAMP(1)
+        // v = [upper lanes | c] of a group's nodes and a cleared g_st: for the first group here,
+        // for every later one in the scatter phase of its predecessor
+#define HINT_BUILD_V(G)                                                              \
+        {                                                                            \
+            stage_build_v(a, vmap + (G).vmap_begin, (G).vw, xs, cs, vb, tid);        \
+            for (int i = tid; i < ROWS * (G).sw; i += NTHREADS) {                    \
+                const int r = i / (G).sw;                                            \
+                gst[r * a.sld + (i - r * (G).sw)] = 0.f;                             \
+            }                                                                        \
+        }
+        {
+            const GroupU g0 = load_group(groups + (a.n_groups - 1));
+            HINT_BUILD_V(g0)
+        }
+        lds_barrier();
       for (int cb = n_chain - 1; cb >= 0; --cb) {
         const GBlock nblk = HINT_CB(cb > 0 ? cb - 1 : n_chain - 1);    // the block worked on after this one
         const float* packed = (const float*)blk.packed;
@@ -906,15 +921,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                     : LEVEL_SRC(gn.level);
                 tile_issue(xnext, src, a.d, row0, a.B, tid);
             }
-            // ---- recompute s, t of every node of the group (bit-identical to the forward) ----
-            stage_build_v(a, vmap + g.vmap_begin, g.vw, xs, cs, vb, tid);
-            for (int i = tid; i < ROWS * g.sw; i += NTHREADS) {
-                const int r = i / g.sw;
-                gst[r * a.sld + (i - r * g.sw)] = 0.f;
-            }
-            STAMP(sbase + 0)
-            lds_barrier();
-            STAMP(sbase + 1)
+            // ---- recompute s, t of every node of the group (bit-identical to the forward); the
+            //      group's v and its cleared g_st were set up in the phase before (HINT_BUILD_V) ----
             stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, nullptr, a.ald, 0, lane);
             STAMP(sbase + 2)
             lds_barrier();
@@ -952,6 +960,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 8)
             lds_barrier();
             STAMP(sbase + 9)
+            if (level_switch) tile_commit(xnext, xs, a.xld, a.d, tid);   // xs is not read again in this group
             // ---- g2 = (g_st * W3) .* relu'(a2) -> a3;  dW3 += g_st^T a2 (outer-product tiles in the
             //      same lists);  db3 += colsum(g_st) ----
             colsum_store(bmap_g + 2 * g.aw, g.sw, gst, a.sld, gparams, tid);
@@ -983,7 +992,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)
-            if (level_switch) tile_commit(xnext, xs, a.xld, a.d, tid);
             // ---- scatter g_v: upper-lane columns to g (each lane has one v column per group),
             //      condition columns to g_c (every node of the group contributes) ----
             {
@@ -1008,6 +1016,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                     }
                 }
             }
+            if ((gi > 0) || (cb > 0)) HINT_BUILD_V(gn)      // xs holds the next group's level since the g2 phase
             STAMP(sbase + 18)
             lds_barrier();
             STAMP(sbase + 19)
