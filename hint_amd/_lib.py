@@ -41,6 +41,7 @@ _PROTOS = {
     "hint_pack_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.c_int32, C.POINTER(C.c_void_p)]),
     "hint_pack_group_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hint_pack_group_run_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "hint_pack_group_destroy": (None, [C.c_void_p]),
     "hint_block_forward": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]),
     "hint_block_inverse": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
@@ -54,6 +55,7 @@ _PROTOS = {
     "hint_chain_set_block": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "hint_chain_commit": (C.c_int, [C.c_void_p]),
     "hint_chain_forward": (C.c_int, [C.c_void_p] * 8),
+    "hint_chain_forward_noisy": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hint_chain_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "hint_chain_destroy": (None, [C.c_void_p]),
     "hint_debug_set_backward_stages": (None, [C.c_int32]),

@@ -126,7 +126,16 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restric
 }
 
 // all blocks of a flow in ONE launch (the trainer re-packs every block after each optimizer step)
-__global__ __launch_bounds__(256) void hint_pack_many_kernel(const PackItem* __restrict__ items, int n_items) {
+// The launch doubles as the prologue of a training step: one extra workgroup clears the loss sums
+// of the step before and advances the noise counter (hint_pack_group_run_ex).
+__global__ __launch_bounds__(256) void hint_pack_many_kernel(const PackItem* __restrict__ items, int n_items,
+                                                             int pack_grid, float* __restrict__ zero_buf, int zero_floats,
+                                                             unsigned long long* __restrict__ rng_state) {
+    if ((int)blockIdx.x >= pack_grid) {
+        for (int i = threadIdx.x; i < zero_floats; i += 256) zero_buf[i] = 0.f;
+        if (rng_state != nullptr && threadIdx.x == 0) rng_state[1] += 1ull;
+        return;
+    }
     int it = 0;
     while (it + 1 < n_items && (int)blockIdx.x >= items[it + 1].grid_begin) ++it;
     const PackItem q = items[it];
@@ -588,11 +597,37 @@ __device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ cha
     return g;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11) + Box-Muller: four standard normals per (key, counter).
+// Used for the dequantisation noise of a training step (train_unconditional.py:121,
+// x += 0.01*randn_like(x)) so that it costs no extra launch and no HBM round trip.
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long step, unsigned idx,
+                                               float (&out)[4]) {
+    unsigned c0 = idx, c1 = (unsigned)step, c2 = (unsigned)(step >> 32), c3 = 0x48494e54u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)c0 + 1.0f) * 2.3283064365386963e-10f;     // (0, 1]
+    const float u1 = (float)c1 * 2.3283064365386963e-10f;
+    const float u2 = ((float)c2 + 1.0f) * 2.3283064365386963e-10f;
+    const float u3 = (float)c3 * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.0f * logf(fminf(u0, 1.0f))), r1 = sqrtf(-2.0f * logf(fminf(u2, 1.0f)));
+    float s0, cs0, s1, cs1;
+    sincosf(6.283185307179586f * u1, &s0, &cs0);
+    sincosf(6.283185307179586f * u3, &s1, &cs1);
+    out[0] = r0 * cs0; out[1] = r0 * s0; out[2] = r1 * cs1; out[3] = r1 * s1;
+}
+
 template <bool REV>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void hint_block_apply_kernel(
     KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
-    float* __restrict__ J, const float* __restrict__ J_in, float* __restrict__ loss_acc) {
+    float* __restrict__ J, const float* __restrict__ J_in, float* __restrict__ loss_acc,
+    float noise, const unsigned long long* __restrict__ rng_state, float* __restrict__ x_noisy) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -639,6 +674,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
         if (tid < ROWS) jac[tid] = 0.f;
         __syncthreads();                      // meta, first chunk lists and the lane tile visible
+        if (!REV && rng_state != nullptr) {
+            // x += noise * N(0,1), four values per Philox call, keyed by (seed, step, element group)
+            const unsigned long long seed = rng_state[0], step = rng_state[1];
+            const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
+            for (int q = tid; 4 * q < nvalid; q += NTHREADS) {
+                float nz[4];
+                philox_normal4(seed, step, (unsigned)(((size_t)row0 * a.d) / 4 + (size_t)q), nz);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    if (i < nvalid) { const int r = i / a.d; xs[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
+                }
+            }
+            __syncthreads();
+            if (x_noisy != nullptr) store_tile(x_noisy, xs, a.xld, a.d, row0, a.B, tid);   // what the backward pass starts from
+        }
         STAMP(1)
 
         // ---- the blocks of the chain (one for the plain per-block entry points): the lane tile
@@ -1208,8 +1259,12 @@ hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, con
     return hipGetLastError();
 }
 
-hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, hipStream_t stream) {
-    if (grid > 0) hipLaunchKernelGGL(hint_pack_many_kernel, dim3(grid), dim3(256), 0, stream, items, n_items);
+hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
+                            unsigned long long* rng_state, hipStream_t stream) {
+    const int extra = (zero_floats > 0 || rng_state != nullptr) ? 1 : 0;
+    if (grid + extra > 0)
+        hipLaunchKernelGGL(hint_pack_many_kernel, dim3(grid + extra), dim3(256), 0, stream, items, n_items, grid, zero_buf,
+                           zero_floats, rng_state);
     return hipGetLastError();
 }
 
@@ -1223,13 +1278,15 @@ hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream) {
 
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
                         const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
-                        const float* J_in, float* loss_acc, hipStream_t stream) {
+                        const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
+                        float* x_noisy, hipStream_t stream) {
     if (rev)
         hipLaunchKernelGGL(hint_block_apply_kernel<true>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one,
-                           chain, n_chain, x, c, z, J, J_in, (float*)nullptr);
+                           chain, n_chain, x, c, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr,
+                           (float*)nullptr);
     else
         hipLaunchKernelGGL(hint_block_apply_kernel<false>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one,
-                           chain, n_chain, x, c, z, J, J_in, loss_acc);
+                           chain, n_chain, x, c, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
     return hipGetLastError();
 }
 

@@ -18,11 +18,13 @@
 namespace hint {
 hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
                        long bias_off, const float* params, float* packed, hipStream_t stream);
-hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, hipStream_t stream);
+hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
+                            unsigned long long* rng_state, hipStream_t stream);
 hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
                         const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
-                        const float* J_in, float* loss_acc, hipStream_t stream);
+                        const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
+                        float* x_noisy, hipStream_t stream);
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
                       int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                       float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
@@ -680,8 +682,15 @@ int hint_pack_group_create(const hint_plan* const* plans, const float* const* pa
 }
 
 int hint_pack_group_run(const hint_pack_group* G, void* stream) {
+    return hint_pack_group_run_ex(G, nullptr, 0, nullptr, stream);
+}
+
+int hint_pack_group_run_ex(const hint_pack_group* G, float* zero_buf, int32_t zero_floats, uint64_t* rng_state,
+                           void* stream) {
     if (!G) return fail("hint_pack_group_run: null group");
-    HIP_TRY(launch_pack_many(G->d_items, G->n, G->grid, (hipStream_t)stream));
+    if (zero_floats < 0 || (zero_floats > 0 && !zero_buf)) return fail("hint_pack_group_run_ex: bad zero buffer");
+    HIP_TRY(launch_pack_many(G->d_items, G->n, G->grid, zero_buf, zero_floats, (unsigned long long*)rng_state,
+                             (hipStream_t)stream));
     return 0;
 }
 
@@ -735,8 +744,8 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     const int grid = std::min(ntiles, P->num_cu * 8);
     ChainBlock one{};
     one.params = params; one.packed = packed; one.perm = perm; one.tape = tape;
-    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc,
-                         (hipStream_t)stream));
+    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
+                         nullptr, nullptr, (hipStream_t)stream));
     return 0;
 }
 
@@ -856,6 +865,12 @@ int hint_chain_commit(hint_chain* C) {
 
 int hint_chain_forward(const hint_chain* C, const float* x, const float* c, float* z, float* J, const float* J_in,
                        float* loss_acc, void* stream) {
+    return hint_chain_forward_noisy(C, x, c, z, J, J_in, loss_acc, 0.f, nullptr, nullptr, stream);
+}
+
+int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c, float* z, float* J,
+                             const float* J_in, float* loss_acc, float noise, const uint64_t* rng_state,
+                             float* x_noisy, void* stream) {
     if (!C || !x || !z || !J) return fail("hint_chain_forward: null argument");
     if (!C->committed) return fail("hint_chain_forward: hint_chain_commit() has not been called");
     const hint_plan* P = C->plan;
@@ -863,7 +878,7 @@ int hint_chain_forward(const hint_chain* C, const float* x, const float* c, floa
     const int ntiles = (C->B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
     HIP_TRY(launch_apply(false, make_args(P, C->B), P->lds_fwd, grid, C->host[0], C->d_table, C->n, x, c, z, J,
-                         J_in, loss_acc, (hipStream_t)stream));
+                         J_in, loss_acc, noise, (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
     return 0;
 }
 

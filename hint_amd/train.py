@@ -35,7 +35,7 @@ class _LossPair:
 class FlowTrainer:
     def __init__(self, flow: HintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
                  weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01,
-                 use_graph: bool = True, group=None, use_chain: bool = True):
+                 use_graph: bool = True, group=None, use_chain: bool = True, seed: Optional[int] = None):
         self.lib = _lib.load()
         self.flow = flow
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -74,6 +74,13 @@ class FlowTrainer:
         # TWO backward launches for the whole flow (hint_chain_*)
         self._chainable = use_chain and all(e.shape_key == self.engines[0].shape_key for e in self.engines)
         self._chain, self._chain_key, self._chain_bufs = None, None, None
+        # state of the in-kernel noise generator (hint_chain_forward_noisy): {seed, step}; every rank
+        # of a data-parallel job draws its own stream
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        rank = dp.world_info(group)[0] if hasattr(dp, "world_info") else 0
+        self.rng_state = torch.tensor([(seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 63 - 1), 0], dtype=torch.int64,
+                                      device=dev)
 
     def __del__(self):
         try:
@@ -123,24 +130,29 @@ class FlowTrainer:
         permutations, the running log-det, the two loss sums and the loss gradient are folded
         into the block kernels (hint_block_*_ex)."""
         flow, B = self.flow, x.shape[0]
-        self._pack_all()                     # weights of the previous optimizer step, MFMA order
-        if self.noise > 0:
-            x = x.add(torch.randn_like(x), alpha=self.noise)
-        self.loss_acc.zero_()
+        # weights of the previous optimizer step -> MFMA order; the same launch clears the loss sums
+        # and advances the noise counter
+        self._pack_all(step_prologue=True)
         if self._chainable and B > 0:
             chain = self._chain_for(B)
             z = torch.empty_like(x)
             J = torch.empty(B, dtype=torch.float32, device=x.device)
             gx = torch.empty_like(x)
             cp = c.data_ptr() if c is not None else None
+            noisy = self.noise > 0
+            xn = torch.empty_like(x) if noisy else x          # the perturbed input, for the backward pass
             with torch.cuda.device(self.device):
                 stream = torch.cuda.current_stream(self.device).cuda_stream
-                _lib.check(self.lib.hint_chain_forward(chain, x.data_ptr(), cp, z.data_ptr(), J.data_ptr(), None,
-                                                       self.loss_acc.data_ptr(), stream), "hint_chain_forward")
+                _lib.check(self.lib.hint_chain_forward_noisy(
+                    chain, x.data_ptr(), cp, z.data_ptr(), J.data_ptr(), None, self.loss_acc.data_ptr(),
+                    float(self.noise), self.rng_state.data_ptr() if noisy else None, xn.data_ptr() if noisy else None,
+                    stream), "hint_chain_forward_noisy")
                 # dL/dz = z / B and dL/dJ = -1/B: applied inside the kernel
-                _lib.check(self.lib.hint_chain_backward(chain, x.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
+                _lib.check(self.lib.hint_chain_backward(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
                                                         None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")
             return B
+        if self.noise > 0:
+            x = x.add(torch.randn_like(x), alpha=self.noise)
         inputs, tapes = [], []
         h, J = x, None
         n = len(self.engines)
@@ -158,9 +170,10 @@ class FlowTrainer:
                                                -1.0 / B, perm, self.G[a:b], accumulate=True)
         return B
 
-    def _pack_all(self):
+    def _pack_all(self, step_prologue: bool = False):
         """one launch re-packs every block (hint_pack_group_*); the group is rebuilt whenever an
-        arena or packed buffer moved"""
+        arena or packed buffer moved.  step_prologue: the launch also zeroes the loss sums and
+        advances the noise counter."""
         import ctypes as C
         key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines)
         if self._pack_key != key:
@@ -176,7 +189,12 @@ class FlowTrainer:
                            "hint_pack_group_create")
             self._pack_group, self._pack_key = handle, key
         with torch.cuda.device(self.device):
-            st = self.lib.hint_pack_group_run(self._pack_group, torch.cuda.current_stream(self.device).cuda_stream)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if step_prologue:
+                st = self.lib.hint_pack_group_run_ex(self._pack_group, self.loss_acc.data_ptr(), self.loss_acc.numel(),
+                                                     self.rng_state.data_ptr(), stream)
+            else:
+                st = self.lib.hint_pack_group_run(self._pack_group, stream)
         _lib.check(st, "hint_pack_group_run")
 
     def _check_arenas(self):

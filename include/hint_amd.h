@@ -85,6 +85,11 @@ typedef struct hint_pack_group hint_pack_group;
 int hint_pack_group_create(const hint_plan* const* plans, const float* const* params,
                            float* const* packed, int32_t n, hint_pack_group** out);
 int hint_pack_group_run(const hint_pack_group* group, void* stream);
+/* The same launch as the prologue of a training step: additionally clears zero_floats floats at
+ * zero_buf (the loss sums of the step before; NULL/0 = nothing) and adds 1 to rng_state[1] (the
+ * step counter of hint_chain_forward_noisy; NULL = no counter). */
+int hint_pack_group_run_ex(const hint_pack_group* group, float* zero_buf, int32_t zero_floats,
+                           uint64_t* rng_state, void* stream);
 void hint_pack_group_destroy(hint_pack_group* group);
 
 /* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0.
@@ -162,6 +167,14 @@ int hint_chain_set_block(hint_chain* chain, int32_t i, const float* params, cons
 int hint_chain_commit(hint_chain* chain);
 int hint_chain_forward(const hint_chain* chain, const float* x, const float* c, float* z, float* J,
                        const float* J_in, float* loss_acc, void* stream);
+/* hint_chain_forward on x + noise * N(0,1) (train_unconditional.py:121), the noise drawn inside
+ * the kernel: Philox4x32-10 keyed by rng_state = {seed, step} (device memory, read only here;
+ * hint_pack_group_run_ex advances step) and the element index, Box-Muller.  x_noisy [B,d]
+ * (may be NULL) receives the perturbed input, which is what hint_chain_backward must be given
+ * as x.  rng_state == NULL: no noise. */
+int hint_chain_forward_noisy(const hint_chain* chain, const float* x, const float* c, float* z,
+                             float* J, const float* J_in, float* loss_acc, float noise,
+                             const uint64_t* rng_state, float* x_noisy, void* stream);
 int hint_chain_backward(const hint_chain* chain, const float* x, const float* c, const float* g_z,
                         const float* g_J, float* g_x, float* g_c, float gz_scale, float gJ_const,
                         int32_t accumulate, void* stream);

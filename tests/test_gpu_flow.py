@@ -151,3 +151,60 @@ def test_chain_launch_equals_per_block_launches(d, dc, widths, perm_first, n_blo
         out[mode] = (tr.G.clone(), tr.loss_acc.sum(0).clone())
     assert rel_err(out[True][1].cpu().numpy(), out[False][1].cpu().numpy()) < 1e-6
     assert rel_err(out[True][0].cpu().numpy(), out[False][0].cpu().numpy()) < 1e-5
+
+
+def test_in_kernel_noise_is_standard_normal_and_consistent():
+    """hint_chain_forward_noisy: x_noisy - x is noise * N(0,1) (train_unconditional.py:121), changes
+    with the step counter, repeats for the same (seed, step), and z, J are the plain forward of
+    x_noisy"""
+    from hint_amd import _lib
+    torch.manual_seed(5)
+    d, B, noise = 6, 8192, 0.25
+    flow = hint_amd.HintFlow(d, 3, [32, 16]).to(DEV)
+    tr = hint_amd.FlowTrainer(flow, noise=noise, use_graph=False, seed=1234)
+    lib, chain = tr.lib, tr._chain_for(B)
+    x = torch.randn(B, d, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(step):
+        tr.rng_state[1] = step
+        z = torch.empty_like(x); J = torch.empty(B, device=DEV); xn = torch.empty_like(x)
+        _lib.check(lib.hint_chain_forward_noisy(chain, x.data_ptr(), None, z.data_ptr(), J.data_ptr(), None, None,
+                                                noise, tr.rng_state.data_ptr(), xn.data_ptr(), st), "noisy")
+        torch.cuda.synchronize()
+        return z, J, xn
+
+    z1, J1, xn1 = run(1)
+    z1b, _, xn1b = run(1)
+    z2, _, xn2 = run(2)
+    assert torch.equal(xn1, xn1b) and torch.equal(z1, z1b)
+    e1, e2 = ((xn1 - x) / noise).double().flatten(), ((xn2 - x) / noise).double().flatten()
+    n = e1.numel()
+    for e in (e1, e2):
+        assert abs(e.mean().item()) < 5.0 / np.sqrt(n)
+        assert abs(e.var().item() - 1.0) < 0.03
+        assert abs((e ** 4).mean().item() - 3.0) < 0.2            # kurtosis of a Gaussian
+        assert abs((e ** 3).mean().item()) < 0.1
+    assert abs(torch.dot(e1, e2).item() / n) < 5.0 / np.sqrt(n)   # different steps are uncorrelated
+    # neighbouring elements / rows are uncorrelated too
+    E = ((xn1 - x) / noise).double()
+    assert abs((E[:, 0] * E[:, 1]).mean().item()) < 5.0 / np.sqrt(B)
+    assert abs((E[:-1, 0] * E[1:, 0]).mean().item()) < 5.0 / np.sqrt(B)
+    zc = torch.empty_like(x); Jc = torch.empty(B, device=DEV)
+    _lib.check(lib.hint_chain_forward(chain, xn1.data_ptr(), None, zc.data_ptr(), Jc.data_ptr(), None, None, st), "plain")
+    torch.cuda.synchronize()
+    assert torch.equal(zc, z1) and torch.equal(Jc, J1)
+
+
+def test_trainer_step_prologue_clears_losses_and_advances_counter():
+    torch.manual_seed(6)
+    flow = hint_amd.HintFlow(6, 2, [32, 16]).to(DEV)
+    tr = hint_amd.FlowTrainer(flow, noise=0.01, use_graph=True, seed=7)
+    x = torch.randn(512, 6, device=DEV)
+    vals = []
+    for k in range(3):
+        l0, l1 = tr.step(x)
+        vals.append((float(l0), float(l1)))
+        assert int(tr.rng_state[1].item()) >= k + 1
+    # the sums are per step (not running totals): the same batch gives nearly the same loss pair
+    assert abs(vals[2][0] - vals[0][0]) < 0.2 * abs(vals[0][0]) + 0.1
