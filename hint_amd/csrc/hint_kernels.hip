@@ -615,10 +615,11 @@ __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned
     const float u1 = (float)c1 * 2.3283064365386963e-10f;
     const float u2 = ((float)c2 + 1.0f) * 2.3283064365386963e-10f;
     const float u3 = (float)c3 * 2.3283064365386963e-10f;
-    const float r0 = sqrtf(-2.0f * logf(fminf(u0, 1.0f))), r1 = sqrtf(-2.0f * logf(fminf(u2, 1.0f)));
-    float s0, cs0, s1, cs1;
-    sincosf(6.283185307179586f * u1, &s0, &cs0);
-    sincosf(6.283185307179586f * u3, &s1, &cs1);
+    // hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take their argument in turns
+    const float r0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u0, 1.0f)));
+    const float r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u2, 1.0f)));
+    const float s0 = __builtin_amdgcn_sinf(u1), cs0 = __builtin_amdgcn_cosf(u1);
+    const float s1 = __builtin_amdgcn_sinf(u3), cs1 = __builtin_amdgcn_cosf(u3);
     out[0] = r0 * cs0; out[1] = r0 * s0; out[2] = r1 * cs1; out[3] = r1 * s1;
 }
 

@@ -1,0 +1,38 @@
+"""Merge rocprofv3 counter passes (one directory per pass: --pmc FETCH_SIZE / WRITE_SIZE / SQ_*) of
+tools/steps.py into profiles/<round>_pmc_summary.json: per-kernel averages per launch.
+HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE (KB) is doubled on gfx950 (128-B requests are
+tallied at 64 B), WRITE_SIZE (KB) is taken as is.
+   python tools/pmc_summary.py out.json blocks_per_launch dir1 dir2 ..."""
+import csv, glob, collections, json, sys
+
+out, nblk, dirs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in dirs:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            k = k.split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, v in agg.items():
+    if "hint_" not in k:
+        continue
+    e = {"launches": max(len(x) for x in v.values()), "blocks_per_launch": nblk if "block" in k else None}
+    sq = {}
+    for c, x in sorted(v.items()):
+        m = sum(x) / len(x)
+        if c in ("FETCH_SIZE", "WRITE_SIZE"):
+            e[c + "_KB"] = m
+        else:
+            sq[c] = m
+    if "FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e:
+        e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024
+        e["note"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)"
+    if sq:
+        e["sq"] = sq
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "SQ_BUSY_CU_CYCLES" in sq and sq["SQ_BUSY_CU_CYCLES"] > 0:
+            e["mfma_busy_frac_of_cu_busy"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * sq["SQ_BUSY_CU_CYCLES"])
+    res[k] = e
+json.dump(res, open(out, "w"), indent=1)
+for k, e in res.items():
+    print(k, {a: b for a, b in e.items() if a not in ("sq", "note")})
