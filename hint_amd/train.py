@@ -240,6 +240,46 @@ class FlowTrainer:
         self._optimizer(scale)
         return _LossPair(self)
 
+    def timed_step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
+        """one un-captured training step with HIP events between the launches (on the stream they
+        are issued to); returns {launch: microseconds}.  For bench.py's roofline: the durations are
+        those of the kernels inside a real step (weights just re-packed, caches as they are), not
+        of a hot back-to-back loop."""
+        if not self._chainable:
+            raise HintAmdError("timed_step needs the chained launches (identical blocks)")
+        self._check_arenas()
+        B = x.shape[0]
+        chain = self._chain_for(B)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        z = torch.empty_like(x); J = torch.empty(B, dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x); xn = torch.empty_like(x)
+        cp = c.data_ptr() if c is not None else None
+        noisy = self.noise > 0
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            ev[0].record()
+            self._pack_all(step_prologue=True)
+            ev[1].record()
+            _lib.check(self.lib.hint_chain_forward_noisy(
+                chain, x.data_ptr(), cp, z.data_ptr(), J.data_ptr(), None, self.loss_acc.data_ptr(), float(self.noise),
+                self.rng_state.data_ptr() if noisy else None, xn.data_ptr() if noisy else None, stream), "forward")
+            ev[2].record()
+            xin = xn if noisy else x
+            for k, mask in ((3, 1), (4, 2)):          # part A (row-parallel), then part B (weight gradients)
+                self.lib.hint_debug_set_backward_stages(mask)
+                _lib.check(self.lib.hint_chain_backward(chain, xin.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(), None,
+                                                        1.0 / B, -1.0 / B, 1, stream), "backward")
+                ev[k].record()
+            self.lib.hint_debug_set_backward_stages(3)
+            self._last_B = B
+            scale = dp.allreduce_sum_(self.G, self.group)
+            self._optimizer(scale)
+            ev[5].record()
+        torch.cuda.synchronize(self.device)
+        names = ["hint_pack_many_kernel", "hint_block_apply_kernel<fwd>", "hint_block_bwd_kernel", "hint_block_dw_kernel",
+                 "allreduce+hint_adam_kernel"]
+        return {n: ev[i].elapsed_time(ev[i + 1]) * 1e3 for i, n in enumerate(names)}
+
     def _capture(self, x, c):
         self._check_arenas()
         sx = x.clone()
