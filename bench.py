@@ -29,6 +29,8 @@ WORKLOADS = {
     "gas_hint_8": dict(d=8, n_blocks=8, c_internal=[128, 64, 32, 16], batch=8192),
     "miniboone_hint_10": dict(d=43, n_blocks=10, c_internal=[67, 33, 16, 8], batch=4096),
     "plus_hint_4": dict(d=100, n_blocks=4, c_internal=[224, 112, 56], batch=4096),
+    # configs/plus_shape/unconditional_hint_4_3_big.py (h = 512: the s and t nets of the wide nodes run one at a time)
+    "plus_hint_4_big": dict(d=100, n_blocks=4, c_internal=[512, 256, 128, 64], batch=4096),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
 PEAK_HBM_GBS = 8000.0

@@ -419,7 +419,7 @@ __device__ __forceinline__ EntU load_ent(const LDS_AS Ent* ents, int e) {
 struct GroupU {
     int node_begin, node_end, jl_begin, jl_count, l1_off, l2_off, l3_off, g2_off, g1_off, dv_off, o3_off, o3_cnt,
         o1_off, o1_cnt, ent_begin, ent_cnt, bmap_begin, bmap3_begin, aw, vw, sw, l3_slabs, dv_slabs, wcol0, level,
-        level_last, vmap_begin;
+        level_last, vmap_begin, cont;     // cont: 0 whole nodes, 1 / 2 the t / s unit of a node whose nets run one at a time
 };
 __device__ __forceinline__ GroupU load_group(const LDS_AS DGroup* g) {
     const LDS_AS i32x4* p = (const LDS_AS i32x4*)g;
@@ -432,7 +432,7 @@ __device__ __forceinline__ GroupU load_group(const LDS_AS DGroup* g) {
     u.o1_off = RFL(q3.x); u.o1_cnt = RFL(q3.y); u.ent_begin = RFL(q3.z); u.ent_cnt = RFL(q3.w);
     u.bmap_begin = RFL(q4.x); u.bmap3_begin = RFL(q4.y); u.aw = RFL(q4.z); u.vw = RFL(q4.w);
     u.sw = RFL(q5.x); u.l3_slabs = RFL(q5.y); u.dv_slabs = RFL(q5.z); u.wcol0 = RFL(q5.w);
-    u.level = RFL(q6.x); u.level_last = RFL(q6.y); u.vmap_begin = RFL(q6.z);
+    u.level = RFL(q6.x); u.level_last = RFL(q6.y); u.vmap_begin = RFL(q6.z); u.cont = RFL(q6.w);
 #undef RFL
     return u;
 }
@@ -773,10 +773,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 {   // element-wise affine coupling + log-det partial sums (hint.py:79-83)
                     const int sub = tid & 15, row = tid >> 4;
                     float part = 0.f;
+                    // (a split node couples in the unit that comes second: s unit forward, t unit inverse)
+                    const bool couple_here = g.cont == 0 || g.cont == (REV ? 1 : 2);
 #ifdef HINT_SKIP_COUPLE
                     if (false) {
 #else
-                    if (row < ROWS) {
+                    if (row < ROWS && couple_here) {
 #endif
                         for (int e = sub; e < g.ent_cnt; e += 16) {
                             const EntU en = load_ent(ents, g.ent_begin + e);
@@ -937,7 +939,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 #define HINT_BUILD_V(G)                                                              \
         {                                                                            \
             stage_build_v(a, vmap + (G).vmap_begin, (G).vw, xs, cs, vb, tid);        \
-            for (int i = tid; i < ROWS * (G).sw; i += NTHREADS) {                    \
+            for (int i = tid; i < ROWS * (G).sw && (G).cont != 1; i += NTHREADS) {   \
                 const int r = i / (G).sw;                                            \
                 gst[r * a.sld + (i - r * (G).sw)] = 0.f;                             \
             }                                                                        \
@@ -1002,9 +1004,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(sbase + 6)
             lds_barrier();
             STAMP(sbase + 7)
-            {   // ---- coupling backward ----
+            {   // ---- coupling backward (a split node: in its s unit, the first of the two here) ----
                 const int sub = tid & 15, row = tid >> 4;
-                if (row < ROWS) {
+                if (row < ROWS && g.cont != 1) {
                     const float gJr = gj[row];
                     for (int e = sub; e < g.ent_cnt; e += 16) {
                         const EntU en = load_ent(ents, g.ent_begin + e);

@@ -104,6 +104,7 @@ static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, in
     return 4 * ROWS * (2 * xld + 2 * cld + (1 + sv) * vld + n_abuf * ald + (s3 + 1) * sld + 1);
 }
 static constexpr int JOBS_PER_GROUP_MAX = 2 * NTHREADS;   // what the in-kernel job prefetch moves
+static constexpr int SPLIT_HP = 384;   // nodes with pad16(h) beyond this are planned one net at a time
 
 // how many K-split slabs a thin stage gets: enough jobs to occupy the 8 wavefronts, each slab
 // at least 2 k-blocks deep
@@ -140,7 +141,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // levels end up with similar footprints.
     int min_aw = 0, min_vw = 0, min_sw = 0;
     for (int i = 0; i < n_nodes; ++i) {
-        min_aw = std::max(min_aw, 2 * pad16(nodes[i].h));
+        min_aw = std::max(min_aw, (pad16(nodes[i].h) > SPLIT_HP ? 1 : 2) * pad16(nodes[i].h));
         min_vw = std::max(min_vw, pad16(nodes[i].k + dc));
         min_sw = std::max(min_sw, 2 * pad16(nodes[i].r));
     }
@@ -152,9 +153,18 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return meta_guess + bwd_lds_bytes(P->xld, P->cld, lds_stride(vw_), lds_stride(aw_), lds_stride(sw_), 1, 1, 2);
     };
 
-    struct DNode {            // host-side working copy of a node
+    // Host-side working copy of a node - or of ONE of its two nets: a node whose two nets do not fit
+    // the LDS side by side (h > 384) is planned as two units in two consecutive single-unit groups,
+    // the t net first (forward order), then the s net, which carries the coupling.  Both units keep
+    // the node's full [s | t] column layout in the s/t and g_st buffers (those are not cleared
+    // between the two groups), everything else is per net.
+    struct DNode {
         int off, k, r, h, cin, hp, rp, cinp, acol, vcol, scol, wcol;
+        int net0, nn;         // nets of this unit: [net0, net0 + nn)
+        bool couples;         // this unit runs the node's coupling (false for the t-only unit)
     };
+    auto has_net = [](const DNode& q, int net) { return net >= q.net0 && net < q.net0 + q.nn; };
+    auto acol_of = [](const DNode& q, int net) { return q.acol + (net - q.net0) * q.hp; };
     std::vector<DNode> dn;
     std::vector<const hint_node_desc*> src;   // parallel to dn
     std::vector<DGroup> dg;
@@ -183,6 +193,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     };
 
     size_t pos = 0;
+    bool split_pending = false;       // the t unit of order[pos] is planned, its s unit comes next
     while (pos < order.size()) {
         DGroup g{};
         g.node_begin = (int)dn.size();
@@ -192,41 +203,58 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         while (pos < order.size() && nodes[order[pos]].depth == depth) {
             const hint_node_desc& n = nodes[order[pos]];
             const int hp = pad16(n.h), rp = pad16(n.r), cin = n.k + dc, cinp = pad16(cin);
-            if (bwd_bytes(2 * hp, cinp, 2 * rp) > LDS_LIMIT) {
+            const bool split = hp > SPLIT_HP;
+            const int unit_aw = split ? hp : 2 * hp;
+            if (bwd_bytes(unit_aw, cinp, 2 * rp) > LDS_LIMIT) {
                 delete P;
                 return fail("hint_plan_create: a node with h=%d, cin=%d, r=%d does not fit the 160 KiB LDS", n.h, cin, n.r);
             }
-            // start a new group at the same depth when this node would overflow the budget
-            if (aw > 0 && (aw + 2 * hp > cap_aw || vw + cinp > cap_vw || sw + 2 * rp > cap_sw ||
-                           bwd_bytes(std::max(min_aw, aw + 2 * hp), std::max(min_vw, vw + cinp),
+            // start a new group at the same depth when this node would overflow the budget; the two
+            // units of a split node are single-unit groups
+            if (aw > 0 && (split || aw + unit_aw > cap_aw || vw + cinp > cap_vw || sw + 2 * rp > cap_sw ||
+                           bwd_bytes(std::max(min_aw, aw + unit_aw), std::max(min_vw, vw + cinp),
                                      std::max(min_sw, sw + 2 * rp)) > LDS_LIMIT))
                 break;
             DNode q{};
             q.off = n.off; q.k = n.k; q.r = n.r; q.h = n.h; q.cin = cin;
             q.hp = hp; q.rp = rp; q.cinp = cinp;
             q.acol = aw; q.vcol = vw; q.scol = sw; q.wcol = wcol;
+            q.net0 = 0; q.nn = 2; q.couples = true;
+            if (split) {                     // t unit now, s unit (with the coupling) as the next group
+                q.net0 = split_pending ? 0 : 1; q.nn = 1; q.couples = split_pending;
+            }
             const int64_t sizes[6] = {(int64_t)n.h * cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
             for (int t = 0; t < 12; ++t) pmax = std::max(pmax, n.p_off[t] + sizes[t % 6]);
-            aw += 2 * hp; vw += cinp; sw += 2 * rp; wcol += 2 * hp;
+            aw += unit_aw; vw += cinp; sw += 2 * rp; wcol += unit_aw;
             dn.push_back(q);
             src.push_back(&n);
+            if (split) {
+                if (!split_pending) { split_pending = true; break; }     // same node again: its s unit
+                split_pending = false;
+                ++pos;
+                break;
+            }
             ++pos;
         }
         g.node_end = (int)dn.size();
         g.aw = aw; g.vw = vw; g.sw = sw;
         g.level = max_depth - depth;
-        g.level_last = (pos >= order.size() || nodes[order[pos]].depth != depth) ? 1 : 0;
+        g.level_last = (!split_pending && (pos >= order.size() || nodes[order[pos]].depth != depth)) ? 1 : 0;
+        // Units of a split node: the coupling needs s and t, so it runs in whichever unit comes second
+        // (forward: the s unit, inverse: the t unit); the backward pass, which only needs s, couples in
+        // the s unit (first in its order) and the t unit after it must keep the g_st columns written there.
+        g.pad = dn.back().nn == 2 ? 0 : (dn.back().net0 == 1 ? 1 : 2);      // 0 whole nodes, 1 t unit, 2 s unit
         max_aw = std::max(max_aw, aw); max_vw = std::max(max_vw, vw); max_sw = std::max(max_sw, sw);
 
         // ---- K-split factors of the thin stages of this group ----
         int l3_tiles = 0, dv_tiles = 0, min_hb = 1 << 30;
         for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-            l3_tiles += 2 * (dn[ni].rp / 16);
+            l3_tiles += 2 * (dn[ni].rp / 16);        // (a split node's units use the slab count of the whole node)
             dv_tiles += dn[ni].cinp / 16;
             min_hb = std::min(min_hb, dn[ni].hp / 16);
         }
         g.l3_slabs = pick_slabs(l3_tiles, min_hb, max_slabs);
-        g.dv_slabs = pick_slabs(dv_tiles, 2 * min_hb, max_slabs);
+        g.dv_slabs = pick_slabs(dv_tiles, (dn[g.node_begin].nn == 1 ? 1 : 2) * min_hb, max_slabs);
         P->s3 = std::max(P->s3, g.l3_slabs);
         P->sv = std::max(P->sv, g.dv_slabs);
 
@@ -238,6 +266,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             const hint_node_desc& n = *src[ni];
             NodePack& k = np[ni - g.node_begin];
             for (int net = 0; net < 2; ++net) {
+                if (!has_net(q, net)) continue;
                 const int64_t* po = n.p_off + net * 6;
                 k.f1[net] = add_seg(q.h, q.cin, q.cinp / 16, q.cin, 0, po[0], 0, q.hp, q.h);   // v  -> a1
                 k.f2[net] = add_seg(q.h, q.h, q.hp / 16, q.h, 0, po[2], 0, q.hp, q.h);         // a1 -> a2
@@ -245,7 +274,10 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 k.b3[net] = add_seg(q.h, q.r, q.rp / 16, q.h, 1, po[4], 0, q.hp, q.h);         // g_st -> g2
                 k.b2[net] = add_seg(q.h, q.h, q.hp / 16, q.h, 1, po[2], 0, q.hp, q.h);         // g2 -> g1
             }
-            k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
+            if (q.nn == 2)
+                k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
+            else        // one net: the "stack" is that net's W1 alone
+                k.bdv = add_seg(q.cin, q.hp, q.hp / 16, q.cin, 2, n.p_off[6 * q.net0], n.p_off[6 * q.net0], q.hp, q.h);
         }
         // ---- thin weight gradients done inside the row-parallel backward kernel: 16x16 outer-product
         //      tiles  T[m][n] = sum_rows A[row][acol+m] * B[row][bcol+n]  of dW3 = g_st^T a2 (with the g2
@@ -266,14 +298,15 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net) {            // dW3[r][h] = g_st^T a2
                 const DNode& q = dn[ni];
+                if (!has_net(q, net)) continue;
                 add_outer(outer3, thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h), q.scol + net * q.rp,
-                          q.acol + net * q.hp, q.r, q.h);
+                          acol_of(q, net), q.r, q.h);
             }
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net) {            // dW1[h][cin] = g1^T v
                 const DNode& q = dn[ni];
-                if (q.cin == 0) continue;
-                add_outer(outer1, thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin), q.acol + net * q.hp, q.vcol,
+                if (q.cin == 0 || !has_net(q, net)) continue;
+                add_outer(outer1, thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin), acol_of(q, net), q.vcol,
                           q.h, q.cin);
             }
         // one (slab, node, net) of a stage: NT adjacent output tiles over the same k-blocks
@@ -288,14 +321,16 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                     const NodePack& k = np[ni - g.node_begin];
                     const int nets = which == 6 ? 1 : 2;
                     for (int net = 0; net < nets; ++net) {
+                        if (which != 6 && !has_net(q, net)) continue;
                         int N, NB, acol, ocol0; int64_t wbase;
+                        const int ac = which == 6 ? q.acol : acol_of(q, net);
                         switch (which) {
-                            case 1: N = q.h; NB = q.cinp / 16; acol = q.vcol; ocol0 = q.acol + net * q.hp; wbase = k.f1[net]; break;
-                            case 2: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.f2[net]; break;
-                            case 3: N = q.r; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.scol + net * q.rp; wbase = k.f3[net]; break;
-                            case 4: N = q.h; NB = q.rp / 16; acol = q.scol + net * q.rp; ocol0 = q.acol + net * q.hp; wbase = k.b3[net]; break;
-                            case 5: N = q.h; NB = q.hp / 16; acol = q.acol + net * q.hp; ocol0 = q.acol + net * q.hp; wbase = k.b2[net]; break;
-                            default: N = q.cin; NB = 2 * q.hp / 16; acol = q.acol; ocol0 = q.vcol; wbase = k.bdv; break;
+                            case 1: N = q.h; NB = q.cinp / 16; acol = q.vcol; ocol0 = ac; wbase = k.f1[net]; break;
+                            case 2: N = q.h; NB = q.hp / 16; acol = ac; ocol0 = ac; wbase = k.f2[net]; break;
+                            case 3: N = q.r; NB = q.hp / 16; acol = ac; ocol0 = q.scol + net * q.rp; wbase = k.f3[net]; break;
+                            case 4: N = q.h; NB = q.rp / 16; acol = q.scol + net * q.rp; ocol0 = ac; wbase = k.b3[net]; break;
+                            case 5: N = q.h; NB = q.hp / 16; acol = ac; ocol0 = ac; wbase = k.b2[net]; break;
+                            default: N = q.cin; NB = q.nn * q.hp / 16; acol = q.acol; ocol0 = q.vcol; wbase = k.bdv; break;
                         }
                         // this slab's share of the k-blocks
                         const int kb0 = (int)((int64_t)NB * sl / slabs), kb1 = (int)((int64_t)NB * (sl + 1) / slabs);
@@ -448,6 +483,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             for (int ni = g.node_begin; ni < g.node_end; ++ni)
                 for (int net = 0; net < 2; ++net)
                 {
+                    if (!has_net(dn[ni], net)) continue;
                     const int tb = thin_alloc(src[ni]->p_off[net * 6 + (layer ? 3 : 1)], dn[ni].h);
                     for (int j = 0; j < dn[ni].hp; ++j) {
                         bmap.push_back(j < dn[ni].h ? (int32_t)(src[ni]->p_off[net * 6 + (layer ? 3 : 1)] + j) : -1);
@@ -458,10 +494,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net)
             {
-                const int tb = thin_alloc(src[ni]->p_off[net * 6 + 5], dn[ni].r);
+                // (the [s | t] column layout is kept by both units of a split node; the absent net's
+                // columns carry no bias and no gradient slot)
+                const bool here = has_net(dn[ni], net);
+                const int tb = here ? thin_alloc(src[ni]->p_off[net * 6 + 5], dn[ni].r) : 0;
                 for (int j = 0; j < dn[ni].rp; ++j) {
-                    bmap.push_back(j < dn[ni].r ? (int32_t)(src[ni]->p_off[net * 6 + 5] + j) : -1);
-                    tbmap.push_back(j < dn[ni].r ? tb + j : -1);
+                    bmap.push_back(here && j < dn[ni].r ? (int32_t)(src[ni]->p_off[net * 6 + 5] + j) : -1);
+                    tbmap.push_back(here && j < dn[ni].r ? tb + j : -1);
                 }
             }
 
@@ -472,7 +511,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                                              : (j < dn[ni].cin ? (int16_t)(-2 - (j - dn[ni].k)) : (int16_t)-1));
         g.ent_begin = (int)ents.size();
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int j = 0; j < dn[ni].r; ++j)
+            for (int j = 0; j < dn[ni].r; ++j)       // (both units of a split node list the lanes: which one couples depends on the direction)
                 ents.push_back(Ent{(int16_t)(dn[ni].off + dn[ni].k + j), (int16_t)(dn[ni].scol + j),
                                    (int16_t)(dn[ni].scol + dn[ni].rp + j), 0});
         g.ent_cnt = (int)ents.size() - g.ent_begin;
@@ -523,10 +562,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // ---- weight-gradient jobs: 48x48 output tiles of dW2 of every (node, net) ----
     for (size_t ni = 0; ni < dn.size(); ++ni)
         for (int net = 0; net < 2; ++net) {
+            if (!has_net(dn[ni], net)) continue;
             const int T = dn[ni].hp / 16;          // padded extent in 16-wide tiles, cut into groups of <= 3
             for (int mt = 0; mt < T; mt += 3)
                 for (int nt = 0; nt < T; nt += 3)
-                    dwj.push_back(DWJob{dn[ni].wcol + net * dn[ni].hp, dn[ni].h, mt * 16, nt * 16, std::min(3, T - mt),
+                    dwj.push_back(DWJob{dn[ni].wcol + (net - dn[ni].net0) * dn[ni].hp, dn[ni].h, mt * 16, nt * 16, std::min(3, T - mt),
                                         std::min(3, T - nt), src[ni]->p_off[net * 6 + 2]});
         }
     P->n_dwjobs = (int)dwj.size();

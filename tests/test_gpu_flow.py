@@ -129,6 +129,7 @@ def test_reference_training_loop_body_on_module_path():
     (2, 0, [16], False, 2, 50),
     (3, 2, [24, 8], True, 1, 17),
     (21, 0, [48, 40, 24, 16], False, 2, 5000),
+    (6, 0, [448, 64], False, 2, 300),               # split (h > 384) root
 ])
 def test_chain_launch_equals_per_block_launches(d, dc, widths, perm_first, n_blocks, B):
     """hint_chain_forward / hint_chain_backward (one launch for all blocks) against the same

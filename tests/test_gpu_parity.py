@@ -74,6 +74,9 @@ def test_block_vs_reference_golden(case):
     (100, [224, 112, 56], 4, 77),         # conditional_recursive_cinn_4 style
     (6, [200, 100, 50, 25], 0, 1),        # single row
     (6, [200, 100, 50, 25], 0, 17),
+    (6, [512, 256, 128], 0, 200),         # the reference's *_big configs: h > 384, nets planned one at a time
+    (8, [472, 400, 64], 2, 333),          # two split levels, condition
+    (5, [385], 0, 64),                    # just over the split threshold, max_splits by list length
 ])
 def test_block_vs_oracle_seeded(d, widths, dc, B):
     dims_c = [(dc,)] if dc else []
@@ -110,7 +113,7 @@ def test_block_vs_oracle_seeded(d, widths, dc, B):
 
 
 @pytest.mark.parametrize("d,widths,B", [(6, [140, 70, 35, 17], 4096), (8, [128, 64, 32, 16], 8192),
-                                        (43, [67, 33, 16, 8], 4096)])
+                                        (43, [67, 33, 16, 8], 4096), (6, [512, 256, 128], 1000)])
 def test_full_size_properties(d, widths, B):
     """encode -> decode round trip, J_fwd + J_rev = 0, row independence (batch-size invariance)."""
     torch.manual_seed(0)
