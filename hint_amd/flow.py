@@ -50,7 +50,8 @@ class HintFlow(nn.Module):
     condition input fed to every block, as conditional_recursive_cinn_4.py:58-70 does)."""
 
     def __init__(self, ndim_x: int, n_blocks: int, c_internal: Sequence[int], ndim_c: int = 0, clamp: float = 4.0,
-                 max_splits: int = -1, min_split_size: int = 2, perm_seed: int = 1, perm_first: bool = False):
+                 max_splits: int = -1, min_split_size: int = 2, perm_seed: int = 1, perm_first: bool = False,
+                 reshuffle: bool = False):
         super().__init__()
         self.ndim_x, self.ndim_c, self.n_blocks = ndim_x, ndim_c, n_blocks
         dims_c = [(ndim_c,)] if ndim_c > 0 else []
@@ -61,7 +62,7 @@ class HintFlow(nn.Module):
             self.perms.append(FixedOrthogonal([(ndim_x,)], seed=perm_seed + i) if has_perm else nn.Identity())
             self.blocks.append(HierarchicalAffineCouplingBlock([(ndim_x,)], dims_c=dims_c, c_internal=list(c_internal),
                                                                clamp=clamp, max_splits=max_splits,
-                                                               min_split_size=min_split_size))
+                                                               min_split_size=min_split_size, reshuffle=reshuffle))
         self._jac = None
 
     def has_perm(self, i: int) -> bool:

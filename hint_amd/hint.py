@@ -86,6 +86,43 @@ class _Engine:
         self._ext_arena: Optional[torch.Tensor] = None
         self._ptrs: List[int] = []
         self._regathered = False
+        # reshuffle=True: the per-node matrices act top-down before any coupling of their subtree
+        # (hint.py:64-65), so all of them compose into ONE [d,d] orthogonal matrix in front of the
+        # block (and its transpose behind the inverse), which the kernels apply fused
+        self._perm_nodes = [(node.perm, off, node.data_shape[0], depth) for node, off, depth in nodes
+                            if node.perm is not None]
+        self._perm_total: Optional[torch.Tensor] = None
+        self._perm_key = None
+
+    def total_perm(self) -> Optional[torch.Tensor]:
+        """the block's composed node permutations as a contiguous [d,d] device tensor (None if the tree
+        has none); recomputed when a node's matrix was replaced (load_state_dict, .to())"""
+        if not self._perm_nodes:
+            return None
+        key = tuple((m.W.data_ptr(), m.W._version) for m, _, _, _ in self._perm_nodes)
+        if key != self._perm_key or self._perm_total is None:
+            tot = torch.eye(self.d, dtype=torch.float64)
+            for m, off, D, _ in sorted(self._perm_nodes, key=lambda t: t[3]):
+                blk = torch.eye(self.d, dtype=torch.float64)
+                blk[off:off + D, off:off + D] = m.W.detach().double().cpu()
+                tot = tot @ blk
+            self._perm_total = tot.to(torch.float32).contiguous().to(self.device)
+            self._perm_key = key
+        return self._perm_total
+
+    def compose_perm(self, front: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """permutation in front of the block for the chained entry points: `front` (a flow's fixed
+        inter-block matrix, or None) followed by the block's own node permutations"""
+        own = self.total_perm()
+        if own is None:
+            return front
+        if front is None:
+            return own
+        key = (front.data_ptr(), front._version, own.data_ptr())
+        if getattr(self, "_composed_key", None) != key:       # cached: callers key on its address
+            self._composed = (front.double() @ own.double()).to(torch.float32).contiguous()
+            self._composed_key = key
+        return self._composed
 
     def __del__(self):
         try:
@@ -159,17 +196,19 @@ class _Engine:
                                device=x.device)
         if B > 0:
             cptr = c.data_ptr() if c is not None else None
+            perm = self.total_perm()
+            pptr = perm.data_ptr() if perm is not None else None
             with torch.cuda.device(self.device):
                 if rev:
-                    st = self.lib.hint_block_inverse(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
-                                                     x.data_ptr(), cptr, out.data_ptr(), J.data_ptr(), B,
-                                                     self._stream())
+                    st = self.lib.hint_block_inverse_ex(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
+                                                        x.data_ptr(), cptr, out.data_ptr(), J.data_ptr(), pptr, None,
+                                                        B, self._stream())
                 else:
-                    st = self.lib.hint_block_forward(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
-                                                     x.data_ptr(), cptr, out.data_ptr(), J.data_ptr(),
-                                                     tape.data_ptr() if tape is not None else None, B,
-                                                     self._stream())
-            _lib.check(st, "hint_block_inverse" if rev else "hint_block_forward")
+                    st = self.lib.hint_block_forward_ex(self.plan, self.arena.data_ptr(), self.packed.data_ptr(),
+                                                        x.data_ptr(), cptr, out.data_ptr(), J.data_ptr(),
+                                                        tape.data_ptr() if tape is not None else None, pptr, None,
+                                                        None, B, self._stream())
+            _lib.check(st, "hint_block_inverse_ex" if rev else "hint_block_forward_ex")
         return (out, J, tape) if with_tape else (out, J)
 
     # ---- chained forms (flow container / trainer): permutation, J accumulation, loss fused ----
@@ -220,13 +259,15 @@ class _Engine:
             return gx, gc, g_params
         nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        perm = self.total_perm()
         with torch.cuda.device(self.device):
-            st = self.lib.hint_block_backward(
+            st = self.lib.hint_block_backward_ex(
                 self.plan, self.arena.data_ptr(), self.packed.data_ptr(), x.data_ptr(),
                 tape.data_ptr() if tape is not None else None, c.data_ptr() if c is not None else None,
                 gz.data_ptr() if gz is not None else None, gJ.data_ptr() if gJ is not None else None,
                 gx.data_ptr(), gc.data_ptr() if gc is not None else None, g_params.data_ptr(),
-                1 if accumulate else 0, ws.data_ptr(), nbytes, B, self._stream())
+                1 if accumulate else 0, ws.data_ptr(), nbytes, perm.data_ptr() if perm is not None else None,
+                1.0, 0.0, B, self._stream())
         _lib.check(st, "hint_block_backward")
         return gx, gc, g_params
 
@@ -267,6 +308,25 @@ def _as_f32_2d(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+class NodePermutation(nn.Module):
+    """Stand-in for FrEIA's `HouseholderPerm(fixed=True)` of reshuffle=True trees (hint.py:36-39): a
+    fixed random orthogonal [D,D] matrix applied to the node's lanes on entry (x W) and undone on
+    exit of the inverse pass (x W^T).  FrEIA's own construction is not available, so the matrix is
+    drawn here (QR of a Gaussian, torch's global RNG) and stored as a buffer; any orthogonal matrix
+    loaded into `W` is used as it is.  Its log-det is 0."""
+
+    def __init__(self, D: int):
+        super().__init__()
+        q, r = torch.linalg.qr(torch.randn(D, D, dtype=torch.float64))
+        self.register_buffer("W", (q * torch.sign(torch.diagonal(r))).to(torch.float32).contiguous())
+
+    def forward(self, x, c=[], rev=False):
+        return [x[0] @ (self.W.t() if rev else self.W)]
+
+    def jacobian(self, x, c=[], rev=False):
+        return 0.
+
+
 class HierarchicalAffineCouplingTree(nn.Module):
     """Recursive coupling tree (hint.py:21-101).  Parameter container with the reference's
     layout; `forward` runs the whole (sub)tree in one fused kernel launch."""
@@ -278,8 +338,6 @@ class HierarchicalAffineCouplingTree(nn.Module):
             raise NotImplementedError("conv=True (hint.py:15-18,29) is out of scope")
         if subnet_constructor is not None and subnet_constructor is not linear_subnet_constructor:
             raise NotImplementedError("only linear_subnet_constructor (hint.py:10-13) is implemented in HIP")
-        if reshuffle:
-            raise NotImplementedError("reshuffle=True needs FrEIA's HouseholderPerm (hint.py:36-39); deferred")
         if len(tuple(data_shape)) != 1:
             raise NotImplementedError("only flat [B, d] data is supported")
         self.data_shape = tuple(data_shape)
@@ -289,8 +347,8 @@ class HierarchicalAffineCouplingTree(nn.Module):
             widths = [self.data_shape[0]]
         if len(widths) == 1:
             widths = widths + widths
-        self.perm = None
         D = self.data_shape[0]
+        self.perm = NodePermutation(D) if reshuffle else None          # hint.py:36-39
         self.split_idx = D // 2                                        # hint.py:41
         self.conditional = len(dims_c) > 0
         self.condition_length = sum(dims_c[i][0] for i in range(len(dims_c)))

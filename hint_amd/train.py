@@ -98,7 +98,10 @@ class FlowTrainer:
         allocated once and the pointer table uploaded; rebuilt when B or any buffer moved"""
         import ctypes as C
         flow = self.flow
-        perms = [flow.perms[i].W if flow.has_perm(i) else None for i in range(flow.n_blocks)]
+        # permutation in front of block i: the flow's fixed matrix, then the block's own node
+        # permutations (reshuffle=True trees), composed into one [d,d] matrix
+        front = [flow.perms[i].W if flow.has_perm(i) else None for i in range(flow.n_blocks)]
+        perms = [e.compose_perm(f) for e, f in zip(self.engines, front)]
         key = (B,) + tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) \
             + tuple(p.data_ptr() if p is not None else 0 for p in perms) + (self.G.data_ptr(),)
         if self._chain_key == key:
@@ -157,7 +160,7 @@ class FlowTrainer:
         h, J = x, None
         n = len(self.engines)
         for i, eng in enumerate(self.engines):
-            perm = flow.perms[i].W if flow.has_perm(i) else None
+            perm = eng.compose_perm(flow.perms[i].W if flow.has_perm(i) else None)
             inputs.append(h if perm is None else None)
             h, J, tape = eng.forward_chain(h, c, perm, J, self.loss_acc if i == n - 1 else None, with_tape=True)
             tapes.append(tape)
@@ -165,7 +168,7 @@ class FlowTrainer:
         g = z                                  # dL/dz = z / B : the scale is applied inside the kernel
         for i in reversed(range(n)):
             a, b = self.slices[i]
-            perm = flow.perms[i].W if flow.has_perm(i) else None
+            perm = self.engines[i].compose_perm(flow.perms[i].W if flow.has_perm(i) else None)
             g = self.engines[i].backward_chain(inputs[i], tapes[i], c, g, (1.0 / B) if i == n - 1 else 1.0,
                                                -1.0 / B, perm, self.G[a:b], accumulate=True)
         return B

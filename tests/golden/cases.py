@@ -43,6 +43,10 @@ BLOCK_CASES = [
     dict(name="tiny_d3",        d=3,   dc=0, c_internal=[8], init="uniform"),
     dict(name="minsplit1_d4",   d=4,   dc=0, c_internal=[8, 4, 4], init="uniform", min_split_size=1),
     dict(name="big_s_d6",       d=6,   dc=0, c_internal=[40, 20], init="uniform", wscale=6.0),
+    # reshuffle=True (hint.py:36-39,64-65,93-94) with a stand-in for FrEIA's HouseholderPerm: pins WHERE
+    # the per-node orthogonal matrices act, not how FrEIA builds them; the matrices are in the fixture
+    dict(name="reshuffle_d6",   d=6,   dc=0, c_internal=[24, 12], init="uniform", reshuffle=True),
+    dict(name="reshuffle_d9c2", d=9,   dc=2, c_internal=[20, 10, 6], init="uniform", reshuffle=True),
 ]
 
 # chained flows: (blocks chained by stored orthogonal matrices) + K Adam steps
@@ -59,6 +63,7 @@ def norm_case(case):
     c.setdefault("min_split_size", 2)
     c.setdefault("B", 64)
     c.setdefault("wscale", 1.0)
+    c.setdefault("reshuffle", False)
     dc = c.get("dc", 0)
     if isinstance(dc, int):
         c["dims_c"] = [(dc,)] if dc > 0 else []

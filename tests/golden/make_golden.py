@@ -2,8 +2,10 @@
 """Generate golden vectors by running the REAL reference (`/root/reference/hint.py`).
 
 Runs only in the dev container (the reference does not exist on the GPU box).  FrEIA is not
-installed, so `FrEIA.modules.orthogonal.HouseholderPerm` is stubbed; it is only touched
-when reshuffle=True (hint.py:36-39), which no fixture uses.  Nothing from the reference is
+installed, so `FrEIA.modules.orthogonal.HouseholderPerm` is a stand-in (a fixed random orthogonal
+matrix, stored in the fixture); it is only touched by the two reshuffle=True cases
+(hint.py:36-39): those pin where the reference applies the per-node matrices, not FrEIA's
+Householder construction.  Nothing from the reference is
 copied: the fixtures hold inputs' checksums and the reference's numerical OUTPUTS.
 
     python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
@@ -30,9 +32,17 @@ def import_reference():
     for name in ("FrEIA", "FrEIA.modules", "FrEIA.modules.orthogonal"):
         sys.modules.setdefault(name, types.ModuleType(name))
 
-    class HouseholderPerm:  # placeholder; never instantiated (reshuffle=False everywhere)
-        def __init__(self, *a, **k):
-            raise RuntimeError("FrEIA stub: HouseholderPerm is not available")
+    class HouseholderPerm:
+        """stand-in with FrEIA's call protocol (hint.py:37,65,94): module([x], rev) -> [x W] / [x W^T]"""
+        rs = np.random.RandomState(0)
+
+        def __init__(self, dims_in, dims_c=[], n_reflections=1, fixed=True):
+            D = dims_in[0][0]
+            q, r = np.linalg.qr(HouseholderPerm.rs.standard_normal((D, D)))
+            self.W = torch.from_numpy(np.ascontiguousarray((q * np.sign(np.diag(r))).astype(np.float32)))
+
+        def __call__(self, x, c=[], rev=False):
+            return [x[0] @ (self.W.t() if rev else self.W)]
 
     sys.modules["FrEIA.modules.orthogonal"].HouseholderPerm = HouseholderPerm
     sys.path.insert(0, REF)
@@ -43,7 +53,8 @@ def import_reference():
 def build_ref_block(ref_hint, c):
     blk = ref_hint.HierarchicalAffineCouplingBlock(
         [(c["d"],)], dims_c=list(c["dims_c"]), c_internal=list(c["c_internal"]),
-        clamp=c["clamp"], max_splits=c["max_splits"], min_split_size=c["min_split_size"])
+        clamp=c["clamp"], max_splits=c["max_splits"], min_split_size=c["min_split_size"],
+        reshuffle=c["reshuffle"])
     return blk
 
 
@@ -60,6 +71,7 @@ def check_contract(blk, c):
 def gen_block(ref_hint, case):
     c = norm_case(case)
     torch.manual_seed(0)
+    sys.modules["FrEIA.modules.orthogonal"].HouseholderPerm.rs = np.random.RandomState(len(case["name"]) + 7 * case["d"])
     blk = build_ref_block(ref_hint, c)
     shapes = check_contract(blk, c)
     params, x_np, conds_np = make_block_inputs(case, shapes)
@@ -87,6 +99,10 @@ def gen_block(ref_hint, case):
     out.update(x_rec=xr.numpy(), J_rev=Jr.numpy(), x_inv=xs.numpy(), J_inv=Js.numpy())
     out["in_checksum"] = np.float64(checksum(list(params.values()) + [x_np] + conds_np))
     out["keys"] = np.array(list(shapes.keys()))
+    if c["reshuffle"]:            # the stand-in's matrices, by module path ("tree", "tree.upper", ...)
+        for path, m in blk.named_modules():
+            if getattr(m, "perm", None) is not None:
+                out["perm:" + path] = m.perm.W.numpy()
     return out
 
 

@@ -55,11 +55,12 @@ def test_trainer_reproduces_reference_adam_steps(use_graph):
             np.testing.assert_allclose(v.cpu().numpy(), g[f"final:{bi}:{k}"], rtol=1e-2, atol=3e-5)
 
 
-def test_autograd_path_equals_fast_path():
+@pytest.mark.parametrize("reshuffle", [False, True])
+def test_autograd_path_equals_fast_path(reshuffle):
     """the nn.Module/autograd route (drop-in for the reference loop) and the FlowTrainer route
     give the same gradients"""
     torch.manual_seed(0)
-    flow = hint_amd.HintFlow(8, 3, [64, 32, 16]).to(DEV)
+    flow = hint_amd.HintFlow(8, 3, [64, 32, 16], reshuffle=reshuffle).to(DEV)
     x = torch.randn(333, 8, device=DEV)
     tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
     z = flow(x)
@@ -123,19 +124,20 @@ def test_reference_training_loop_body_on_module_path():
             assert rel_err(v.cpu().numpy(), g[f"final:{bi}:{k}"]) < 1e-3, (bi, k)
 
 
-@pytest.mark.parametrize("d,dc,widths,perm_first,n_blocks,B", [
-    (6, 0, [32, 16], False, 3, 333),
-    (8, 3, [64, 32, 16], True, 4, 1000),
-    (2, 0, [16], False, 2, 50),
-    (3, 2, [24, 8], True, 1, 17),
-    (21, 0, [48, 40, 24, 16], False, 2, 5000),
-    (6, 0, [448, 64], False, 2, 300),               # split (h > 384) root
+@pytest.mark.parametrize("d,dc,widths,perm_first,n_blocks,B,reshuffle", [
+    (6, 0, [32, 16], False, 3, 333, False),
+    (8, 3, [64, 32, 16], True, 4, 1000, False),
+    (2, 0, [16], False, 2, 50, False),
+    (3, 2, [24, 8], True, 1, 17, False),
+    (21, 0, [48, 40, 24, 16], False, 2, 5000, False),
+    (6, 0, [448, 64], False, 2, 300, False),               # split (h > 384) root
+    (7, 0, [24, 12, 6], False, 3, 200, True),              # node permutations folded into the chain's matrices
 ])
-def test_chain_launch_equals_per_block_launches(d, dc, widths, perm_first, n_blocks, B):
+def test_chain_launch_equals_per_block_launches(d, dc, widths, perm_first, n_blocks, B, reshuffle):
     """hint_chain_forward / hint_chain_backward (one launch for all blocks) against the same
     step issued block by block through hint_block_*_ex"""
     torch.manual_seed(3)
-    flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc, perm_first=perm_first).to(DEV)
+    flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc, perm_first=perm_first, reshuffle=reshuffle).to(DEV)
     for p in flow.parameters():                      # away from the near-identity init
         p.data.add_(0.05 * torch.randn_like(p))
     x = torch.randn(B, d, device=DEV)

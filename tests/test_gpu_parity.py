@@ -11,18 +11,22 @@ import torch
 
 import hint_amd
 from oracle import hint_oracle as orc
-from util import BLOCK_CASES, load_block_case, rel_err, to_torch
+from util import BLOCK_CASES, case_perms, load_block_case, rel_err, to_torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def make_block(c, params=None):
+def make_block(c, params=None, perms=None):
     blk = hint_amd.HierarchicalAffineCouplingBlock([(c["d"],)], dims_c=c["dims_c"], c_internal=list(c["c_internal"]),
                                                    clamp=c["clamp"], max_splits=c["max_splits"],
-                                                   min_split_size=c["min_split_size"])
+                                                   min_split_size=c["min_split_size"],
+                                                   reshuffle=c.get("reshuffle", False))
     if params is not None:
-        blk.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()})
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}
+        for path, W in (perms or {}).items():          # reshuffle=True fixtures carry the node matrices
+            sd[path + ".perm.W"] = torch.from_numpy(np.ascontiguousarray(W))
+        blk.load_state_dict(sd)
     return blk.to(DEV)
 
 
@@ -35,7 +39,7 @@ def close(a, b, rtol=1e-5, atol=1e-5):
 @pytest.mark.parametrize("case", BLOCK_CASES, ids=lambda c: c["name"])
 def test_block_vs_reference_golden(case):
     c, nodes, shapes, params, x_np, conds_np, g = load_block_case(case)
-    blk = make_block(c, params)
+    blk = make_block(c, params, case_perms(g))
     x = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
     conds = [torch.from_numpy(a).to(DEV).requires_grad_(True) for a in conds_np]
     (z,) = blk([x], c=conds)

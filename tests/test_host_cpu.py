@@ -38,12 +38,18 @@ def test_state_dict_contract(case):
     c, nodes, shapes, params, x, conds, g = load_block_case(case)
     blk = hint_amd.HierarchicalAffineCouplingBlock([(c["d"],)], dims_c=c["dims_c"], c_internal=list(c["c_internal"]),
                                                    clamp=c["clamp"], max_splits=c["max_splits"],
-                                                   min_split_size=c["min_split_size"])
+                                                   min_split_size=c["min_split_size"], reshuffle=c["reshuffle"])
     sd = blk.state_dict()
-    assert list(sd.keys()) == list(g["keys"])
+    perm_keys = [k for k in sd if k.endswith(".perm.W")]       # stand-in for FrEIA's HouseholderPerm state
+    assert bool(perm_keys) == c["reshuffle"]
+    assert [k for k in sd if k not in perm_keys] == list(g["keys"])
     for k, v in sd.items():
-        assert tuple(v.shape) == tuple(shapes[k])
-    blk.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        if k in perm_keys:
+            W = v.double()
+            assert torch.allclose(W @ W.t(), torch.eye(W.shape[0], dtype=torch.float64), atol=1e-5)
+        else:
+            assert tuple(v.shape) == tuple(shapes[k])
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=not c["reshuffle"])
     # flat node list agrees with the oracle's restatement of hint.py:25-54
     flat = blk.tree._flat_nodes()
     assert [(o, n.data_shape[0], n.split_idx, d, n.leaf) for n, o, d in flat] == \
@@ -64,9 +70,29 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         hint_amd.HierarchicalAffineCouplingBlock([(6,)], conv=True)
     with pytest.raises(NotImplementedError):
-        hint_amd.HierarchicalAffineCouplingBlock([(6,)], reshuffle=True)
-    with pytest.raises(NotImplementedError):
         hint_amd.HierarchicalAffineCouplingBlock([(6,)], subnet_constructor=lambda a, b, c: None)
+
+
+def test_reshuffle_composes_to_one_orthogonal_matrix():
+    """reshuffle=True (hint.py:36-39): every node owns a fixed orthogonal matrix; the engine folds
+    them (top-down, block-diagonal per level) into the one [d,d] matrix the kernels apply"""
+    torch.manual_seed(3)
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(9,)], c_internal=[8, 4, 4], reshuffle=True)
+    mods = [(n, o, d) for n, o, d in blk.tree._flat_nodes()]
+    assert all(n.perm is not None for n, _, _ in mods)
+    x = torch.randn(5, 9, dtype=torch.float64)
+    y = x.clone()
+    for n, off, depth in sorted(mods, key=lambda t: t[2]):          # what the recursion does, level by level
+        D = n.data_shape[0]
+        y[:, off:off + D] = y[:, off:off + D] @ n.perm.W.double()
+    tot = torch.eye(9, dtype=torch.float64)
+    for n, off, depth in sorted(mods, key=lambda t: t[2]):
+        D = n.data_shape[0]
+        b = torch.eye(9, dtype=torch.float64)
+        b[off:off + D, off:off + D] = n.perm.W.double()
+        tot = tot @ b
+    assert torch.allclose(x @ tot, y, atol=1e-12)
+    assert torch.allclose(tot @ tot.t(), torch.eye(9, dtype=torch.float64), atol=1e-5)
 
 
 def test_no_cpu_fallback():

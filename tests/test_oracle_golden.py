@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import hint_oracle as orc
-from util import BLOCK_CASES, CHAIN_CASES, load_block_case, load_chain_case, rel_err, to_torch
+from util import BLOCK_CASES, CHAIN_CASES, case_perms, load_block_case, load_chain_case, rel_err, to_torch
 
 TOL = dict(rtol=1e-5, atol=1e-5)
 
@@ -22,7 +22,9 @@ def test_block_forward_inverse_grads(case):
         p.requires_grad_(True)
     x = torch.from_numpy(x_np).requires_grad_(True)
     conds = [torch.from_numpy(a).requires_grad_(True) for a in conds_np]
-    z, J = orc.block_apply(nodes, P, x, conds, rev=False, clamp=c["clamp"])
+    perms = {k: torch.from_numpy(v) for k, v in case_perms(g).items()}
+    assert bool(perms) == c["reshuffle"]
+    z, J = orc.block_apply(nodes, P, x, conds, rev=False, clamp=c["clamp"], perms=perms)
     np.testing.assert_allclose(z.detach().numpy(), g["z"], **TOL)
     np.testing.assert_allclose(J.detach().numpy(), g["J"], **TOL)
     L = (0.5 * torch.sum(z ** 2, dim=1) - J).mean()
@@ -34,8 +36,8 @@ def test_block_forward_inverse_grads(case):
     for k in shapes:
         assert rel_err(P[k].grad.numpy(), g["g:" + k]) < 1e-4, k
     with torch.no_grad():
-        xr, Jr = orc.block_apply(nodes, P, z.detach(), [cc.detach() for cc in conds], rev=True, clamp=c["clamp"])
-        xi, Ji = orc.block_apply(nodes, P, x.detach(), [cc.detach() for cc in conds], rev=True, clamp=c["clamp"])
+        xr, Jr = orc.block_apply(nodes, P, z.detach(), [cc.detach() for cc in conds], rev=True, clamp=c["clamp"], perms=perms)
+        xi, Ji = orc.block_apply(nodes, P, x.detach(), [cc.detach() for cc in conds], rev=True, clamp=c["clamp"], perms=perms)
     scale = max(1.0, float(np.abs(g["x_rec"]).max()))
     np.testing.assert_allclose(xr.numpy(), g["x_rec"], rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(Jr.numpy(), g["J_rev"], **TOL)

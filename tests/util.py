@@ -35,6 +35,11 @@ def load_chain_case(case):
     return c, nodes, shapes, params, perms, xs, g
 
 
+def case_perms(g):
+    """{node path: matrix} of a reshuffle=True fixture (empty for the others)"""
+    return {k[len("perm:"):]: g[k] for k in g.files if k.startswith("perm:")}
+
+
 def to_torch(P, dtype=torch.float32):
     return {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in P.items()}
 
