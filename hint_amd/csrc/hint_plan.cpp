@@ -615,7 +615,8 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
     // ---- validate the tree: lane ranges inside [0,d), same-depth nodes disjoint ----
     for (int i = 0; i < n_nodes; ++i) {
         const hint_node_desc& n = nodes[i];
-        if (n.D < 1 || n.k != n.D / 2 || n.r != n.D - n.k || n.off < 0 || n.off + n.D > d || n.h < 1 || n.depth < 0)
+        // (hint.py:41 always splits at D/2; the conditional-lane couplings use other splits, e.g. k = 0)
+        if (n.D < 1 || n.k < 0 || n.r < 1 || n.r != n.D - n.k || n.off < 0 || n.off + n.D > d || n.h < 1 || n.depth < 0)
             return fail("hint_plan_create: node %d is malformed (off=%d D=%d k=%d r=%d h=%d depth=%d)", i,
                         n.off, n.D, n.k, n.r, n.h, n.depth);
         for (int t = 0; t < 12; ++t)

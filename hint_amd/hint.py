@@ -332,7 +332,7 @@ class HierarchicalAffineCouplingTree(nn.Module):
     layout; `forward` runs the whole (sub)tree in one fused kernel launch."""
 
     def __init__(self, data_shape, dims_c, conv=False, subnet_constructor=None, c_internal=[], clamp=2,
-                 max_splits=-1, min_split_size=2, reshuffle=False):
+                 max_splits=-1, min_split_size=2, reshuffle=False, _split_idx=None):
         super().__init__()
         if conv:
             raise NotImplementedError("conv=True (hint.py:15-18,29) is out of scope")
@@ -349,12 +349,14 @@ class HierarchicalAffineCouplingTree(nn.Module):
             widths = widths + widths
         D = self.data_shape[0]
         self.perm = NodePermutation(D) if reshuffle else None          # hint.py:36-39
-        self.split_idx = D // 2                                        # hint.py:41
+        # hint.py:41; _split_idx (not a reference keyword) lets the conditional-lane couplings of
+        # hint_amd/conditional.py reuse the node kernels with another upper/lower split
+        self.split_idx = D // 2 if _split_idx is None else int(_split_idx)
         self.conditional = len(dims_c) > 0
         self.condition_length = sum(dims_c[i][0] for i in range(len(dims_c)))
         self.s = linear_subnet_constructor(self.split_idx + self.condition_length, D - self.split_idx, widths[0])
         self.t = linear_subnet_constructor(self.split_idx + self.condition_length, D - self.split_idx, widths[0])
-        if D >= 2 * min_split_size and max_splits != 0:                # hint.py:47
+        if D >= 2 * min_split_size and max_splits != 0 and _split_idx is None:   # hint.py:47
             self.leaf = False
             self.upper = HierarchicalAffineCouplingTree((self.split_idx,), dims_c, conv, subnet_constructor,
                                                         widths[1:], clamp, max_splits - 1, min_split_size, reshuffle)

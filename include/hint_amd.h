@@ -41,8 +41,10 @@ extern "C" {
 enum { HINT_W1 = 0, HINT_B1 = 1, HINT_W2 = 2, HINT_B2 = 3, HINT_W3 = 4, HINT_B3 = 5 };
 
 /* One node of the coupling tree (hint.py:25-54), in any order.  A node owns lanes
- * [off, off+D); its first k = D/2 lanes condition the transform of the other r = D-k
- * (hint.py:41,68).  depth = 0 for the root.  Nodes of equal depth own disjoint lanes. */
+ * [off, off+D); its first k lanes condition the transform of the other r = D-k >= 1
+ * (hint.py:41,68 always split at k = D/2; other splits are accepted, e.g. k = 0 for a coupling
+ * that transforms all its lanes given the condition only, conditional_hint_4_full.py:76-82).
+ * depth = 0 for the root.  Nodes of equal depth own disjoint lanes. */
 typedef struct hint_node_desc {
     int32_t off, D, k, r;
     int32_t h;          /* hidden width of both subnets (hint.py:44-45) */

@@ -107,3 +107,20 @@ def test_product_code_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def test_conditional_lane_modules_structure():
+    """conditional_hint_4_full.py:55-95: the two-lane model and its couplings are single-node trees
+    of the same kernels (AffineCoupling: split at D // 2; ExternalAffineCoupling: empty upper half)"""
+    m = hint_amd.ConditionalHintFlow(100, 4, 4, 224)
+    assert len(m.hac_x) == len(m.ac_y_to_x) == len(m.ac_y) == 4
+    e = m.ac_y_to_x[0].tree
+    assert e.leaf and e.split_idx == 0 and e.s[0].in_features == 4 and e.s[4].out_features == 100
+    a = m.ac_y[1].tree
+    assert a.leaf and a.split_idx == 2 and a.s[0].in_features == 2 and a.s[0].out_features == 112
+    assert [w for w in (m.hac_x[0].tree.s[0].out_features, m.hac_x[0].tree.upper.s[0].out_features)] == [224, 112]
+    assert isinstance(m.perm_x[0], torch.nn.Identity) and hasattr(m.perm_x[1], "W")
+    with pytest.raises(hint_amd.HintAmdError):
+        hint_amd.ExternalAffineCoupling([(5,)])                  # needs a condition
+    with pytest.raises(hint_amd.HintAmdError):
+        m([torch.randn(3, 4), torch.randn(3, 100)])              # CPU tensors: no fallback
