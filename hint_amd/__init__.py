@@ -8,7 +8,7 @@ from .hint import (HierarchicalAffineCouplingBlock, HierarchicalAffineCouplingTr
 
 from .flow import FixedOrthogonal, HintFlow  # noqa: F401,E402
 from .train import FlowTrainer  # noqa: F401,E402
-from .conditional import (AffineCoupling, ConditionalHintFlow, ExternalAffineCoupling,  # noqa: F401,E402
-                          F_fully_connected)
+from .conditional import (AffineCoupling, ConditionalFlowTrainer, ConditionalHintFlow,  # noqa: F401,E402
+                          ExternalAffineCoupling, F_fully_connected)
 
 __version__ = "0.1.0"

@@ -141,3 +141,130 @@ class ConditionalHintFlow(nn.Module):
     def x_jac(self):
         """train_conditional.py:50-55: log-det of the x lane (hac_x_* and ac_y_to_x_* nodes)"""
         return self._jac_x
+
+
+class ConditionalFlowTrainer:
+    """Fast training step for a ConditionalHintFlow (what FlowTrainer is for a HintFlow): one
+    iteration of /root/reference/train_conditional.py:120-150 -
+
+        x += 0.01*randn_like(x); z_y, z_x = model([y, x]); z = cat(z_x, z_y)
+        loss = 0.5*sum(z^2,1).mean() - model.log_jacobian(...).mean()
+        loss.backward(); clamp grads to +-5; Adam.step()
+
+    - without an autograd graph and without per-parameter kernels: every module's forward and
+    backward is a direct C-ABI launch into model-wide flat parameter / gradient / Adam arenas
+    (the 3 500 parameter tensors of the cfg-4 model cost the module path ~65 ms of per-tensor
+    launches per step), one re-pack launch, one gradient all-reduce (hint_amd/dp.py), one fused
+    clamp+Adam launch.  The two lanes meet in the backward pass: dL/dy of block i is the sum of
+    what ac_y_i and ac_y_to_x_i (through its condition) send back."""
+
+    def __init__(self, flow: ConditionalHintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
+                 weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01, group=None):
+        from . import _lib, dp
+        self._lib, self._dp = _lib, dp
+        self.lib = _lib.load()
+        self.flow, self.group = flow, group
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.grad_clamp, self.noise = grad_clamp, noise
+        self.step_count = 0
+        dev = next(flow.parameters()).device
+        if dev.type != "cuda":
+            raise HintAmdError("ConditionalFlowTrainer needs the model on a GPU (no CPU path)")
+        self.device = dev
+        self.mods = []                                    # (kind, block index, module) in forward order
+        for i in range(flow.n_blocks):
+            self.mods += [("hac_x", i, flow.hac_x[i]), ("ac_y_to_x", i, flow.ac_y_to_x[i]), ("ac_y", i, flow.ac_y[i])]
+        self.engines = [m.tree.engine(dev) for _, _, m in self.mods]
+        self.slices, cursor = [], 0
+        for e in self.engines:
+            self.slices.append((cursor, cursor + e.total))
+            cursor += e.total
+        self.n_floats = cursor
+        self.P, self.G, self.M, self.V = (torch.zeros(cursor, dtype=torch.float32, device=dev) for _ in range(4))
+        for e, (a, b) in zip(self.engines, self.slices):
+            e.bind_external_arena(self.P[a:b])
+            e.ensure_arena()
+            e.pack()
+        self._pack_group, self._pack_key = None, None
+        self.last = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_pack_group", None):
+                self.lib.hint_pack_group_destroy(self._pack_group)
+        except Exception:
+            pass
+
+    def _pack_all(self):
+        import ctypes as C
+        key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines)
+        if self._pack_key != key:
+            if self._pack_group:
+                self.lib.hint_pack_group_destroy(self._pack_group)
+            n = len(self.engines)
+            plans = (C.c_void_p * n)(*[e.plan.value for e in self.engines])
+            params = (C.c_void_p * n)(*[e.arena.data_ptr() for e in self.engines])
+            packed = (C.c_void_p * n)(*[e.packed.data_ptr() for e in self.engines])
+            handle = C.c_void_p()
+            with torch.cuda.device(self.device):
+                self._lib.check(self.lib.hint_pack_group_create(plans, params, packed, n, C.byref(handle)),
+                                "hint_pack_group_create")
+            self._pack_group, self._pack_key = handle, key
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_pack_group_run(self._pack_group, torch.cuda.current_stream(self.device).cuda_stream)
+        self._lib.check(st, "hint_pack_group_run")
+
+    def step(self, x: torch.Tensor, y: torch.Tensor):
+        """one iteration on this rank's rows; returns device scalars (0.5*|z|^2 mean, -log|det J| mean)"""
+        flow, B = self.flow, x.shape[0]
+        for e in self.engines:
+            e.ensure_arena()
+        self._pack_all()
+        if self.noise > 0:
+            x = x.add(torch.randn_like(x), alpha=self.noise)
+        eng = dict(zip([(k, i) for k, i, _ in self.mods], self.engines))
+        sl = dict(zip([(k, i) for k, i, _ in self.mods], self.slices))
+        saved = {}
+        Jx = torch.zeros(B, dtype=torch.float32, device=x.device)
+        Jy = torch.zeros_like(Jx)
+        for i in range(flow.n_blocks):                              # ---- forward, both lanes ----
+            if i > 0:
+                y = y @ flow.perm_y[i].W
+                x = x @ flow.perm_x[i].W
+            xin = x
+            x, j, tape = eng[("hac_x", i)].apply(xin, None, rev=False, with_tape=True)
+            saved[("hac_x", i)] = (xin, tape, None); Jx = Jx + j
+            xin = x
+            x, j, tape = eng[("ac_y_to_x", i)].apply(xin, y, rev=False, with_tape=True)
+            saved[("ac_y_to_x", i)] = (xin, tape, y); Jx = Jx + j
+            yin = y
+            y, j, tape = eng[("ac_y", i)].apply(yin, None, rev=False, with_tape=True)
+            saved[("ac_y", i)] = (yin, tape, None); Jy = Jy + j
+        zx, zy = x, y
+        l0 = 0.5 * (zx.pow(2).sum(1).mean() + zy.pow(2).sum(1).mean())
+        l1 = -(Jx + Jy).mean()
+        gx, gy = zx / B, zy / B                                     # dL/dz
+        gJ = torch.full((B,), -1.0 / B, dtype=torch.float32, device=x.device)
+        for i in reversed(range(flow.n_blocks)):                    # ---- backward ----
+            def bwd(kind, g, need_gc=False):
+                xin, tape, c = saved[(kind, i)]
+                a, b = sl[(kind, i)]
+                gin, gc, _ = eng[(kind, i)].backward(xin, tape, c, g.contiguous(), gJ, need_gc, self.G[a:b], accumulate=True)
+                return gin, gc
+            gy, _ = bwd("ac_y", gy)
+            gx, gc = bwd("ac_y_to_x", gx, need_gc=True)
+            gy = gy + gc                                            # the condition of ac_y_to_x_i is the y lane
+            gx, _ = bwd("hac_x", gx)
+            if i > 0:
+                gy = gy @ flow.perm_y[i].W.t()
+                gx = gx @ flow.perm_x[i].W.t()
+        scale = self._dp.allreduce_sum_(self.G, self.group)
+        self.step_count += 1
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_adam_step(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                         self.n_floats, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.wd, scale, self.grad_clamp, 1,
+                                         torch.cuda.current_stream(self.device).cuda_stream)
+        self._lib.check(st, "hint_adam_step")
+        self.last = (zy, zx, Jx, Jy)
+        return l0, l1
