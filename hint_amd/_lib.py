@@ -41,7 +41,7 @@ _PROTOS = {
     "hint_pack_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.c_int32, C.POINTER(C.c_void_p)]),
     "hint_pack_group_run": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "hint_pack_group_run_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hint_pack_group_run_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hint_pack_group_destroy": (None, [C.c_void_p]),
     "hint_block_forward": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]),
     "hint_block_inverse": (C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]),
@@ -60,6 +60,7 @@ _PROTOS = {
     "hint_chain_destroy": (None, [C.c_void_p]),
     "hint_debug_set_backward_stages": (None, [C.c_int32]),
     "hint_debug_set_stamp_buffer": (C.c_int, [C.c_void_p]),
+    "hint_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_void_p] + [C.c_float] * 6 + [C.c_int32, C.c_void_p]),
     "hint_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32] + [C.c_float] * 7 + [C.c_int32,
                                                                                                  C.c_void_p]),
 }

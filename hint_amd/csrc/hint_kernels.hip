@@ -130,10 +130,21 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restric
 // of the step before and advances the noise counter (hint_pack_group_run_ex).
 __global__ __launch_bounds__(256) void hint_pack_many_kernel(const PackItem* __restrict__ items, int n_items,
                                                              int pack_grid, float* __restrict__ zero_buf, int zero_floats,
-                                                             unsigned long long* __restrict__ rng_state) {
+                                                             unsigned long long* __restrict__ rng_state,
+                                                             float* __restrict__ opt_state) {
     if ((int)blockIdx.x >= pack_grid) {
         for (int i = threadIdx.x; i < zero_floats; i += 256) zero_buf[i] = 0.f;
-        if (rng_state != nullptr && threadIdx.x == 0) rng_state[1] += 1ull;
+        if (rng_state != nullptr && threadIdx.x == 0) {
+            const unsigned long long step = rng_state[1] + 1ull;
+            rng_state[1] = step;
+            if (opt_state != nullptr) {
+                // Adam's bias corrections of this step (torch.optim.Adam evaluates them in double):
+                // opt_state = {lr, beta1, beta2, -> lr/(1-beta1^t), -> 1/sqrt(1-beta2^t)}
+                const double b1 = opt_state[1], b2 = opt_state[2], t = (double)step;
+                opt_state[3] = (float)((double)opt_state[0] / (1.0 - pow(b1, t)));
+                opt_state[4] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+            }
+        }
         return;
     }
     int it = 0;
@@ -1276,11 +1287,11 @@ hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, con
 }
 
 hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
-                            unsigned long long* rng_state, hipStream_t stream) {
+                            unsigned long long* rng_state, float* opt_state, hipStream_t stream) {
     const int extra = (zero_floats > 0 || rng_state != nullptr) ? 1 : 0;
     if (grid + extra > 0)
         hipLaunchKernelGGL(hint_pack_many_kernel, dim3(grid + extra), dim3(256), 0, stream, items, n_items, grid, zero_buf,
-                           zero_floats, rng_state);
+                           zero_floats, rng_state, opt_state);
     return hipGetLastError();
 }
 

@@ -20,7 +20,11 @@ __global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, f
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         long n4, long n, float lr_t, float b1, float b2,
                                                         float inv_sqrt_bc2, float eps, float wd,
-                                                        float gscale, float gclamp, int zero_grads) {
+                                                        float gscale, float gclamp, int zero_grads,
+                                                        const float* __restrict__ dev_state) {
+    // dev_state (hint_adam_step_dev): step-dependent factors computed on the device by the step
+    // prologue (hint_pack_group_run_ex), so that the launch can sit inside a captured graph
+    if (dev_state != nullptr) { lr_t = dev_state[3]; inv_sqrt_bc2 = dev_state[4]; }
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         f32x4 pp = ((f32x4*)p)[i], gg = ((f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
@@ -55,13 +59,13 @@ __global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, f
 namespace hint {
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
                        float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads, int num_cu,
-                       hipStream_t stream) {
+                       const float* dev_state, hipStream_t stream) {
     const long n4 = n / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > (long)num_cu * 8) blocks = (long)num_cu * 8;
     hipLaunchKernelGGL(hint_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n4, n, lr_t,
-                       b1, b2, inv_sqrt_bc2, eps, wd, gscale, gclamp, zero_grads);
+                       b1, b2, inv_sqrt_bc2, eps, wd, gscale, gclamp, zero_grads, dev_state);
     return hipGetLastError();
 }
 }  // namespace hint

@@ -19,7 +19,7 @@ namespace hint {
 hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
                        long bias_off, const float* params, float* packed, hipStream_t stream);
 hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
-                            unsigned long long* rng_state, hipStream_t stream);
+                            unsigned long long* rng_state, float* opt_state, hipStream_t stream);
 hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
                         const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
@@ -35,7 +35,7 @@ hipError_t set_max_lds(int fwd_bytes, int bwd_bytes);
 hipError_t set_stamp_buffer(unsigned long long* p);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
                        float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads,
-                       int num_cu, hipStream_t stream);
+                       int num_cu, const float* dev_state, hipStream_t stream);
 }  // namespace hint
 
 using namespace hint;
@@ -723,15 +723,16 @@ int hint_pack_group_create(const hint_plan* const* plans, const float* const* pa
 }
 
 int hint_pack_group_run(const hint_pack_group* G, void* stream) {
-    return hint_pack_group_run_ex(G, nullptr, 0, nullptr, stream);
+    return hint_pack_group_run_ex(G, nullptr, 0, nullptr, nullptr, stream);
 }
 
 int hint_pack_group_run_ex(const hint_pack_group* G, float* zero_buf, int32_t zero_floats, uint64_t* rng_state,
-                           void* stream) {
+                           float* opt_state, void* stream) {
     if (!G) return fail("hint_pack_group_run: null group");
     if (zero_floats < 0 || (zero_floats > 0 && !zero_buf)) return fail("hint_pack_group_run_ex: bad zero buffer");
+    if (opt_state && !rng_state) return fail("hint_pack_group_run_ex: opt_state needs the step counter of rng_state");
     HIP_TRY(launch_pack_many(G->d_items, G->n, G->grid, zero_buf, zero_floats, (unsigned long long*)rng_state,
-                             (hipStream_t)stream));
+                             opt_state, (hipStream_t)stream));
     return 0;
 }
 
@@ -952,6 +953,16 @@ int hint_debug_set_stamp_buffer(void* device_buffer) {
     return 0;
 }
 
+static int adam_num_cu() {
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    return num_cu;
+}
+
 int hint_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                    float grad_clamp, int32_t zero_grads, void* stream) {
@@ -963,15 +974,24 @@ int hint_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_s
     // bias corrections in double like torch.optim.Adam's python scalars
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-        if (num_cu <= 0) num_cu = 256;
-    }
     HIP_TRY(launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, (float)((double)lr / bc1), beta1, beta2,
                         (float)(1.0 / std::sqrt(bc2)), eps, weight_decay, grad_scale,
-                        grad_clamp > 0.f ? grad_clamp : 3.0e38f, zero_grads ? 1 : 0, num_cu, (hipStream_t)stream));
+                        grad_clamp > 0.f ? grad_clamp : 3.0e38f, zero_grads ? 1 : 0, adam_num_cu(), nullptr,
+                        (hipStream_t)stream));
+    return 0;
+}
+
+int hint_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const float* opt_state, float beta1, float beta2, float eps, float weight_decay,
+                       float grad_scale, float grad_clamp, int32_t zero_grads, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !opt_state) return fail("hint_adam_step_dev: null argument");
+    if (n < 0) return fail("hint_adam_step_dev: n must be >= 0");
+    if (n == 0) return 0;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
+        return fail("hint_adam_step_dev: buffers must be 16-byte aligned");
+    HIP_TRY(launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, 0.f, beta1, beta2, 0.f, eps, weight_decay,
+                        grad_scale, grad_clamp > 0.f ? grad_clamp : 3.0e38f, zero_grads ? 1 : 0, adam_num_cu(),
+                        opt_state, (hipStream_t)stream));
     return 0;
 }
 

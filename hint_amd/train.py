@@ -38,7 +38,7 @@ class FlowTrainer:
                  use_graph: bool = True, group=None, use_chain: bool = True, seed: Optional[int] = None):
         self.lib = _lib.load()
         self.flow = flow
-        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self._lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.grad_clamp, self.noise = grad_clamp, noise
         self.use_graph = use_graph
         self.group = group
@@ -81,6 +81,21 @@ class FlowTrainer:
         rank = dp.world_info(group)[0] if hasattr(dp, "world_info") else 0
         self.rng_state = torch.tensor([(seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 63 - 1), 0], dtype=torch.int64,
                                       device=dev)
+        # Adam's hyper-parameters and per-step factors in device memory: with one process (no
+        # all-reduce between backward and optimizer) the fused clamp+Adam launch is captured in the
+        # step's graph and reads them there (hint_adam_step_dev); rng_state[1] is the step count
+        self.opt_state = torch.tensor([lr, betas[0], betas[1], 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32,
+                                      device=dev)
+        self._adam_in_graph = False
+
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):          # learning-rate schedules (train_unconditional.py:191-199) need no re-capture
+        self._lr = float(value)
+        self.opt_state[0] = self._lr
 
     def __del__(self):
         try:
@@ -128,7 +143,16 @@ class FlowTrainer:
         return handle
 
     # ---- the un-captured step body ----------------------------------------------------
-    def _fwd_bwd(self, x: torch.Tensor, c: Optional[torch.Tensor]):
+    def _adam_dev(self):
+        """the fused clamp+Adam launch with its step factors read from opt_state (world size 1)"""
+        with torch.cuda.device(self.device):
+            st = self.lib.hint_adam_step_dev(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                             self.n_floats, self.opt_state.data_ptr(), self.betas[0], self.betas[1],
+                                             self.eps, self.wd, 1.0, self.grad_clamp, 1,
+                                             torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(st, "hint_adam_step_dev")
+
+    def _fwd_bwd(self, x: torch.Tensor, c: Optional[torch.Tensor], with_adam: bool = False):
         """pack -> forward chain -> backward chain, every piece a direct C-ABI launch: the fixed
         permutations, the running log-det, the two loss sums and the loss gradient are folded
         into the block kernels (hint_block_*_ex)."""
@@ -153,6 +177,8 @@ class FlowTrainer:
                 # dL/dz = z / B and dL/dJ = -1/B: applied inside the kernel
                 _lib.check(self.lib.hint_chain_backward(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
                                                         None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")
+            if with_adam:
+                self._adam_dev()
             return B
         if self.noise > 0:
             x = x.add(torch.randn_like(x), alpha=self.noise)
@@ -195,7 +221,7 @@ class FlowTrainer:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             if step_prologue:
                 st = self.lib.hint_pack_group_run_ex(self._pack_group, self.loss_acc.data_ptr(), self.loss_acc.numel(),
-                                                     self.rng_state.data_ptr(), stream)
+                                                     self.rng_state.data_ptr(), self.opt_state.data_ptr(), stream)
             else:
                 st = self.lib.hint_pack_group_run(self._pack_group, stream)
         _lib.check(st, "hint_pack_group_run")
@@ -239,8 +265,11 @@ class FlowTrainer:
                 self._static["c"].copy_(c)
             self._graph.replay()
         self._last_B = x.shape[0]
-        scale = dp.allreduce_sum_(self.G, self.group)
-        self._optimizer(scale)
+        if self.use_graph and self._adam_in_graph:
+            self.step_count += 1               # the optimizer ran inside the graph
+        else:
+            scale = dp.allreduce_sum_(self.G, self.group)
+            self._optimizer(scale)
         return _LossPair(self)
 
     def timed_step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
@@ -295,9 +324,22 @@ class FlowTrainer:
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.G.zero_()                         # the warm-up runs accumulated into the gradient arena
         torch.cuda.synchronize(self.device)
+        # one process, identical blocks: the optimizer launch goes into the graph as well (no host
+        # gap between the weight-gradient kernel and Adam).  Its kernel has been loaded by a launch
+        # outside the capture; the device step counter is aligned with the host's.
+        self._adam_in_graph = self._chainable and dp.world_info(self.group)[1] == 1 and \
+            not (torch.distributed.is_available() and torch.distributed.is_initialized())
+        if self._adam_in_graph:
+            scratch = torch.zeros(4, 4, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                self.lib.hint_adam_step(scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(),
+                                        scratch[3].data_ptr(), 4, 1, 0.0, 0.9, 0.95, 1e-4, 0.0, 1.0, 0.0, 0,
+                                        torch.cuda.current_stream(self.device).cuda_stream)
+        self.rng_state[1] = self.step_count
+        torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._fwd_bwd(sx, sc)
+            self._fwd_bwd(sx, sc, with_adam=self._adam_in_graph)
         self._graph = g
         self._static = dict(x=sx, c=sc)
 

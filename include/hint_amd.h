@@ -88,10 +88,13 @@ int hint_pack_group_create(const hint_plan* const* plans, const float* const* pa
                            float* const* packed, int32_t n, hint_pack_group** out);
 int hint_pack_group_run(const hint_pack_group* group, void* stream);
 /* The same launch as the prologue of a training step: additionally clears zero_floats floats at
- * zero_buf (the loss sums of the step before; NULL/0 = nothing) and adds 1 to rng_state[1] (the
- * step counter of hint_chain_forward_noisy; NULL = no counter). */
+ * zero_buf (the loss sums of the step before; NULL/0 = nothing), adds 1 to rng_state[1] (the step
+ * counter t of hint_chain_forward_noisy; NULL = no counter) and, if opt_state is given (device
+ * float[5] = {lr, beta1, beta2, out, out}; needs rng_state), writes Adam's factors of step t,
+ * opt_state[3] = lr / (1 - beta1^t) and opt_state[4] = 1 / sqrt(1 - beta2^t), for
+ * hint_adam_step_dev. */
 int hint_pack_group_run_ex(const hint_pack_group* group, float* zero_buf, int32_t zero_floats,
-                           uint64_t* rng_state, void* stream);
+                           uint64_t* rng_state, float* opt_state, void* stream);
 void hint_pack_group_destroy(hint_pack_group* group);
 
 /* z, J = block(x | c), rev=False (hint.py:62-80,90,97-99).  c may be NULL iff dc == 0.
@@ -193,6 +196,13 @@ void hint_chain_destroy(hint_chain* chain);
 int hint_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                    int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float grad_scale, float grad_clamp, int32_t zero_grads, void* stream);
+/* The same step with its step-dependent factors read from device memory (opt_state as written by
+ * hint_pack_group_run_ex), so that the launch carries no per-step host argument and can be
+ * captured in a graph together with the kernels of the step. */
+int hint_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const float* opt_state, float beta1, float beta2, float eps,
+                       float weight_decay, float grad_scale, float grad_clamp, int32_t zero_grads,
+                       void* stream);
 
 /* Profiling aid (process-global, not for production use): restrict hint_block_backward to its
  * row-parallel kernel (mask 1), its weight-gradient kernel (mask 2, reuses whatever the
