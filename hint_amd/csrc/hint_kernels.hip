@@ -800,6 +800,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                             }
                             const float aa = a.alpha * atanf(s);
                             float* px = xs + row * a.xld + en.xcol;
+                            // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it
+                            // scales), so that the backward pass needs no third-layer recompute
+                            if (!REV && tape != nullptr && row0 + row < a.B)
+                                tape[((size_t)(a.n_levels + g.level) * a.B + row0 + row) * a.d + en.xcol] = s;
                             if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
                             else      { *px = ((*px) - t) / expf(aa); part -= aa; }
                         }
@@ -903,10 +907,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     // g2 gets its own buffer so that the dW3 tiles (which read a2) can run in the g2 stage's phase;
     // plans that cannot afford it (a.split_o3) write g2 over a2 and run dW3 as a phase of its own
     float* a3 = a2 + (a.split_o3 ? 0 : ROWS * a.ald);
-    float* st = a3 + ROWS * a.ald;           // [s3][ROWS][sld]
-    float* gst = st + a.s3 * ROWS * a.sld;
+    float* sb = a3 + ROWS * a.ald;           // [ROWS][xld]: s of the group's level as the forward pass computed it (tape)
+    float* gst = sb + ROWS * a.xld;
     float* gj = gst + ROWS * a.sld;
-    const int sstride = ROWS * a.sld, vstride = ROWS * a.vld;
+    const int vstride = ROWS * a.vld;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
 #define HINT_CB(I) chain_block(chain, one, I)
     GBlock blk = HINT_CB(n_chain - 1);         // the chain is walked from its last block to its first
@@ -1006,23 +1010,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             lds_barrier();
             STAMP(sbase + 3)
             copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, nullptr, a.ald, 0, lane);
+            // s of this level comes from the tape (no third-layer recompute): fetched across the L2
+            // stage; the stage after L2 is g2 (or the dW3 tiles of plans without their own g2 buffer)
+            TilePrefetch stile;
+            tile_issue(stile, tape + (size_t)(a.n_levels + g.level) * a.B * a.d, a.d, row0, a.B, tid);
+            stage_run<EPI_RELU>(S, stage_list(jl, a.split_o3 ? g.o3_off : g.g2_off, wave), packed, packed, bias_g + g.aw, a1,
+                                a.ald, a2, nullptr, a.ald, 0, lane);
+            tile_commit(stile, sb, a.xld, a.d, tid);
+            if (has_next) jobs_commit<true>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
-            stage_run<EPI_LINEAR>(S, stage_list(jl, a.split_o3 ? g.o3_off : g.g2_off, wave), packed, packed, bias_g + 2 * g.aw, a2, a.ald, st, nullptr, a.sld, sstride, lane);
-            if (has_next) jobs_commit<true>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
-            STAMP(sbase + 6)
-            lds_barrier();
-            STAMP(sbase + 7)
             {   // ---- coupling backward (a split node: in its s unit, the first of the two here) ----
                 const int sub = tid & 15, row = tid >> 4;
                 if (row < ROWS && g.cont != 1) {
                     const float gJr = gj[row];
                     for (int e = sub; e < g.ent_cnt; e += 16) {
                         const EntU en = load_ent(ents, g.ent_begin + e);
-                        float s = 0.f;
-                        for (int sl = 0; sl < g.l3_slabs; ++sl) s += st[sl * sstride + row * a.sld + en.scol];
+                        const float s = sb[row * a.xld + en.xcol];
                         const float aa = a.alpha * atanf(s);
                         const float ea = expf(aa);
                         const float l = xs[row * a.xld + en.xcol];       // lower input of the node

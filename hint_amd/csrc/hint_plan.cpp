@@ -101,7 +101,8 @@ static int fwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3) {
     return 4 * ROWS * (2 * xld + cld + vld + 2 * ald + s3 * sld + 1);
 }
 static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, int sv, int n_abuf) {
-    return 4 * ROWS * (2 * xld + 2 * cld + (1 + sv) * vld + n_abuf * ald + (s3 + 1) * sld + 1);
+    (void)s3;
+    return 4 * ROWS * (3 * xld + 2 * cld + (1 + sv) * vld + n_abuf * ald + sld + 1);
 }
 static constexpr int JOBS_PER_GROUP_MAX = 2 * NTHREADS;   // what the in-kernel job prefetch moves
 static constexpr int SPLIT_HP = 384;   // nodes with pad16(h) beyond this are planned one net at a time
@@ -658,7 +659,9 @@ int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_float
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
-    return (int64_t)P->n_levels * B * P->d;    // (levels-1) snapshots + the permuted input of the _ex form
+    // per level: the lane tile as the level saw it (the last slice: the block's permuted input) and
+    // the s values of the level's couplings, both [B, d]
+    return 2 * (int64_t)P->n_levels * B * P->d;
 }
 
 static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
@@ -829,7 +832,7 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
     if (!P || !params || !packed || (!x && !perm) || !g_x || !g_params) return fail("hint_block_backward: null argument");
     if (perm && !tape) return fail("hint_block_backward_ex: a fused permutation needs the tape of hint_block_forward_ex");
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
-    if (P->n_levels > 1 && !tape && B > 0) return fail("hint_block_backward: tape is NULL but the tree has %d levels", P->n_levels);
+    if (!tape && B > 0) return fail("hint_block_backward: tape is NULL (the backward pass reads the forward's lane tiles and s values from it)");
     if (B < 0) return fail("negative batch");
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
@@ -878,7 +881,7 @@ int hint_chain_set_block(hint_chain* C, int32_t i, const float* params, const fl
     if (!C || !params || !packed) return fail("hint_chain_set_block: null argument");
     if (i < 0 || i >= C->n) return fail("hint_chain_set_block: block %d out of range (chain has %d)", i, C->n);
     const hint_plan* P = C->plan;
-    if (!tape && (P->n_levels > 1 || i > 0 || perm) && workspace)
+    if (!tape && workspace)
         return fail("hint_chain_set_block: a trainable chain block needs a tape");
     ChainBlock b{};
     b.params = params; b.packed = packed; b.perm = perm; b.tape = tape; b.gparams = g_params;

@@ -66,10 +66,12 @@ int64_t hint_plan_param_floats(const hint_plan* plan);
 /* floats of the packed-weight buffer (both subnets of every node, forward and transposed
  * copies, in MFMA fragment order, zero padded). */
 int64_t hint_plan_packed_floats(const hint_plan* plan);
-/* floats of the forward "tape" for a batch of B rows: (levels-1) snapshots [B,d] of the lane
- * tensor between tree levels (+ one [B,d] slice for the permuted input of the _ex forms), recorded by hint_block_forward and read by hint_block_backward
- * so that the backward pass re-derives bit-identical subnet inputs (d floats per level and
- * row instead of the ~6*h floats per node autograd keeps for hint.py:77). */
+/* floats of the forward "tape" for a batch of B rows: per tree level one [B,d] snapshot of the
+ * lane tensor as that level saw it (the last slice holds the block's permuted input for the _ex /
+ * chain forms) and one [B,d] array of the level's coupling arguments s (indexed by the lane each
+ * one scales), recorded by the training forward and read by the backward pass, which so
+ * re-derives bit-identical subnet inputs and skips the last layer (2*d floats per level and row
+ * instead of the ~6*h floats per node autograd keeps for hint.py:77). */
 int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
 /* bytes of scratch hint_block_backward needs for a batch of B rows. */
 size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
@@ -108,7 +110,7 @@ int hint_block_forward(const hint_plan* plan, const float* params, const float* 
 int hint_block_inverse(const hint_plan* plan, const float* params, const float* packed,
                        const float* z, const float* c, float* x, float* J, int32_t B, void* stream);
 /* Backward of hint_block_forward.  Takes the block INPUT x and the tape the forward call
- * recorded (subnet activations are recomputed from them, not stored), upstream g_z [B,d] and
+ * recorded (required; hidden activations are recomputed from it, not stored), upstream g_z [B,d] and
  * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and the
  * flat parameter gradient g_params (same layout as params): overwritten when accumulate == 0,
  * added to when accumulate != 0 (the caller then owns zeroing, e.g. hint_adam_step's
