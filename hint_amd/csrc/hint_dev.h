@@ -94,9 +94,12 @@ typedef TJob GJob;      // the per-group lists hold TJob and OJob records, 16 B 
 struct Ent { int16_t xcol, scol, tcol, pad; };                  // one transformed lane of a group
 
 // A group = a set of same-depth nodes processed together by one workgroup pass.  28 int32
-// fields = 7 x 16 bytes, read from LDS in one burst (see load_group()).  All *_off fields index
-// the group's job list (16-byte records from jl_begin); the six GEMM stages point at their
-// stage header.
+// fields = 7 x 16 bytes, read from LDS in one burst (see load_group()).  The *_off fields are stage
+// descriptors (STAGE_DESC) into the group's job list (16-byte records from jl_begin): L1, L2, L3
+// of the forward pass, g2, g1, dv of the backward pass (the thin weight gradients' outer-product
+// tiles ride in g2's and dv's lists), o3_off: the dW3 tiles as a stage of their own (plans without
+// LDS for a separate g2 buffer, KArgs.split_o3).  o3_cnt, o1_off, o1_cnt are unused.
+// pad: 0 = whole nodes; 1 / 2 = the t / s unit of a node whose two nets run one at a time.
 struct DGroup {
     int32_t node_begin, node_end, jl_begin, jl_count;
     int32_t l1_off, l2_off, l3_off, g2_off;

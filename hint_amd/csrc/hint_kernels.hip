@@ -8,13 +8,13 @@
 //
 // Design: samples are independent, so one workgroup owns a tile of 16 batch
 // rows (= one M-tile of v_mfma_f32_16x16x4_f32) and carries it through ALL tree levels of
-// the block inside one launch; the lane tile, the conditioning input, both hidden
-// activations and s/t live in LDS for the whole pass, HBM sees x once in and z, J once out.
-// The eight wavefronts split the 16-wide output tiles of the s- and t-subnets of every node
-// of a level; weights stream from L2 as pre-packed MFMA B-fragments (one coalesced 1 KiB load
-// per 16x16 tile), one chunk of four tiles ahead of the MFMAs that consume them.  fp32 MFMA
-// is an exact fp32 FMA chain, so results differ from the CPU reference only by summation
-// order.
+// ALL blocks of a flow inside one launch; the lane tile, the conditioning input, both hidden
+// activations and s/t live in LDS for the whole pass, HBM sees x once in and z, J once out
+// (plus the training tape).  The eight wavefronts split the 16-wide output tiles of the s- and
+// t-subnets of every node of a level as jobs of 1-3 tiles; weights stream from L2 as
+// pre-packed MFMA B-fragments (one coalesced 1 KiB load per 16x16 tile), two k-blocks ahead of
+// the MFMAs that consume them.  fp32 MFMA is an exact fp32 FMA chain, so results differ from
+// the CPU reference only by summation order.
 #include <hip/hip_runtime.h>
 #include "hint_dev.h"
 
@@ -553,7 +553,7 @@ __device__ __forceinline__ void jobs_commit(const JobPrefetch& jp, LDS_AS GJob* 
 // LDS carve-up shared by both block kernels:
 //   [meta: groups | vmap | ents][job buffer 0 | 1][bias+bmap buffer 0 | 1][float buffers ...]
 // The meta copy is split into issue (global -> registers) and commit (registers -> LDS) so
-// that it shares ONE memory round trip with the first chunk lists and the first lane tile.
+// that it shares ONE memory round trip with the first job lists and the first lane tile.
 struct MetaPrefetch { i32x4 r0, r1; };
 __device__ __forceinline__ void meta_issue(MetaPrefetch& mp, const KArgs& a, int tid) {
     const int n16 = a.meta_bytes >> 4;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     const int fo = REV ? 1 : 0;               // which "first group" record of the kernel arguments
 #define HINT_CB(I) chain_block(chain, one, I)
     GBlock blk = HINT_CB(0);
-    {   // the first group's chunk lists and biases: issued together with the meta copy
+    {   // the first group's job lists and biases: issued together with the meta copy
         JobPrefetch jp0;
         jobs_issue<false>(jp0, a.jobs, a.first[fo][0], a.first[fo][1], (const float*)blk.packed + a.bias_off + a.first[fo][2], nullptr, a.first[fo][3], tid);
         meta_commit(mp_, a, mbase, tid);
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         load_tile(xs, a.xld, x, a.d, row0, a.B, tid);
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
         if (tid < ROWS) jac[tid] = 0.f;
-        __syncthreads();                      // meta, first chunk lists and the lane tile visible
+        __syncthreads();                      // meta, first job lists and the lane tile visible
         if (!REV && rng_state != nullptr) {
             // x += noise * N(0,1), four values per Philox call, keyed by (seed, step, element group)
             const unsigned long long seed = rng_state[0], step = rng_state[1];

@@ -468,7 +468,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         if (g.o3_off < 0 || g.l1_off < 0 || g.l2_off < 0 || g.l3_off < 0 || g.g2_off < 0 || g.g1_off < 0 || g.dv_off < 0) {
             delete P;
             if (cap_scale < 16) { *retry_smaller = true; return 1; }
-            return fail("hint_plan_create: a group's chunk lists exceed the 16-bit stage descriptor");
+            return fail("hint_plan_create: a group's job lists exceed the 16-bit stage descriptor");
         }
         g.o3_cnt = g.o1_off = g.o1_cnt = 0;      // outer-product tiles ride in the g2 / dv stage lists (or o3_off's)
         g.jl_count = (int)jobs.size() - g.jl_begin;
@@ -653,7 +653,7 @@ void hint_plan_destroy(hint_plan* P) {
 }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
-// +1 KiB of slack: the chunk prefetcher of the GEMM stages never reads past a job's last
+// +3 KiB of slack: the weight prefetch of the GEMM stages never reads past a job's last
 // k-block, but keeping a margin makes that robust against future tuning
 int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 3 * 256 : -1; }
 
