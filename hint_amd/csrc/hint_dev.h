@@ -45,7 +45,7 @@ struct ChainBlock {
     const float* packed;
     const float* perm;     // [d,d] permutation in front of the block, or nullptr
     float* tape;           // forward tape of this block (or nullptr)
-    float* wsA1;           // backward workspace of this block
+    float* wsA1;           // hidden activations a1 [Bp][WT] inside the tape (a2 follows act_stride later); NULL = inference
     float* wsG2;
     float* wsT;
     float* gparams;        // flat parameter gradient of this block (part B)
@@ -133,6 +133,7 @@ struct KArgs {
     int32_t jmax;                  // capacity (jobs) of one LDS job buffer
     int32_t bmax;                  // capacity (floats) of one LDS bias buffer
     int64_t bias_off;              // float offset of the bias region inside the packed buffer
+    int64_t act_stride;            // floats between the a1 and a2 activation arrays of the tape (ChainBlock.wsA1)
     int32_t n_groups, n_levels;
     int32_t d, dc;
     int32_t xld, cld, ald, vld, sld;   // LDS row strides (floats)

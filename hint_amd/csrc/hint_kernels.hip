@@ -518,6 +518,21 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
     }
 }
 
+// 16 rows x `width` columns of an LDS buffer to a [rows][dld] global array (hidden activations)
+__device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, int dcol,
+                                              const float* src, int sld, int width, int row0,
+                                              int tid) {
+    // width is a multiple of 16, dcol/dld multiples of 4 -> 128-bit rows
+    const int w4 = width >> 2;
+#ifdef HINT_SKIP_WSCOPY
+    if (width > 0) return;
+#endif
+    for (int i = tid; i < ROWS * w4; i += NTHREADS) {
+        const int r = i / w4, j = (i - r * w4) << 2;
+        *(f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j) = *(const f32x4*)(src + r * sld + j);
+    }
+}
+
 // The job list of the NEXT group travels global -> registers at the start of a group and
 // registers -> LDS near its end, so its L2 latency hides behind the group's GEMM stages.
 // (The group's biases, a few KiB, ride along: [b1 | b2 | b3] in LDS column order.)
@@ -728,6 +743,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             const float* packed = (const float*)blk.packed;
             const float* perm = (const float*)blk.perm;
             float* tape = (float*)blk.tape;
+            float* actA1 = (float*)blk.wsA1;
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
                 for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
@@ -770,10 +786,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 STAMP(4 + 12 * gi)
                 lds_barrier();
                 STAMP(5 + 12 * gi)
+                // training: both hidden activations go to the tape, [Bp][WT] row-major - the backward pass
+                // reloads them instead of recomputing two GEMM stages, and part B reads a1 from there
+                if (!REV && actA1 != nullptr) copy_rows_out(actA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
                 stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, nullptr, a.ald, 0, lane);
                 STAMP(6 + 12 * gi)
                 lds_barrier();
                 STAMP(7 + 12 * gi)
+                if (!REV && actA1 != nullptr) copy_rows_out(actA1 + a.act_stride, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
                 // the stage after this one: L1 of the next group (next block, next row tile); nothing
                 // follows the very last one, which re-primes its own group's L1 (never run)
                 stage_run<EPI_LINEAR>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
@@ -871,17 +891,31 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 // gradient dW2 = g2^T a1, go to the workspace for part B.
 //   g_t = g_l' ; g_a = g_l'*exp(a)*l + g_J ; g_l = g_l'*exp(a) ; g_s = g_a*alpha/(1+s^2)
 // =======================================================================================
-__device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, int dcol,
-                                              const float* src, int sld, int width, int row0,
-                                              int tid) {
-    // width is a multiple of 16, dcol/dld multiples of 4 -> 128-bit rows
-    const int w4 = width >> 2;
-#ifdef HINT_SKIP_WSCOPY
-    if (width > 0) return;
-#endif
-    for (int i = tid; i < ROWS * w4; i += NTHREADS) {
-        const int r = i / w4, j = (i - r * w4) << 2;
-        *(f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j) = *(const f32x4*)(src + r * sld + j);
+// The reverse: 16 rows x `width` columns of a [rows][sld] global array into an LDS buffer, issue
+// and commit split like TilePrefetch.  6 float4 per thread cover width <= 768 (two nets of h <= 384).
+constexpr int ROW_REGS = 6;
+struct RowsPrefetch { f32x4 r[ROW_REGS]; };
+__device__ __forceinline__ void rows_issue(RowsPrefetch& rp, const float* __restrict__ src, int sld, int scol, int width,
+                                           int row0, int tid) {
+    const int w4 = width >> 2, n4 = ROWS * w4;
+#pragma unroll
+    for (int k = 0; k < ROW_REGS; ++k) {
+        if (k * NTHREADS < n4) {                       // wave-uniform
+            const int i = min(tid + k * NTHREADS, n4 - 1);
+            const int r = i / w4, j = (i - r * w4) << 2;
+            rp.r[k] = *(const f32x4*)(src + (size_t)(row0 + r) * sld + scol + j);
+        }
+    }
+}
+__device__ __forceinline__ void rows_commit(const RowsPrefetch& rp, float* dst, int dld, int width, int tid) {
+    const int w4 = width >> 2, n4 = ROWS * w4;
+#pragma unroll
+    for (int k = 0; k < ROW_REGS; ++k) {
+        const int i = tid + k * NTHREADS;
+        if (i < n4) {
+            const int r = i / w4, j = (i - r * w4) << 2;
+            *(f32x4*)(dst + r * dld + j) = rp.r[k];
+        }
     }
 }
 
@@ -922,7 +956,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     }
 
     int jb = 0;
-    Stage S;              // walks the six GEMM stages L1, L2, L3, g2, g1, dv of every group (see forward kernel)
+    Stage S;              // walks the GEMM stages g2, g1, dv of every group (see forward kernel)
     bool first_tile = true;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
@@ -959,9 +993,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 gst[r * a.sld + (i - r * (G).sw)] = 0.f;                             \
             }                                                                        \
         }
+        // s of a level and the group's hidden activations a2 come from the tape: fetched one group
+        // ahead (here: for the first group), committed to LDS at the top of the group
+        TilePrefetch stile;
+        RowsPrefetch a2t;
+#define HINT_FIRST_DESC(G) (a.split_o3 ? (G).o3_off : (G).g2_off)     /* the first GEMM stage of a group */
         {
             const GroupU g0 = load_group(groups + (a.n_groups - 1));
             HINT_BUILD_V(g0)
+            tile_issue(stile, (const float*)blk.tape + (size_t)(a.n_levels + g0.level) * a.B * a.d, a.d, row0, a.B, tid);
+            rows_issue(a2t, (const float*)blk.wsA1 + a.act_stride, a.WT, g0.wcol0, g0.aw, row0, tid);
         }
         lds_barrier();
       for (int cb = n_chain - 1; cb >= 0; --cb) {
@@ -969,11 +1010,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         const float* packed = (const float*)blk.packed;
         const float* perm = (const float*)blk.perm;
         const float* tape = (const float*)blk.tape;
-        float* wsA1 = (float*)blk.wsA1;
+        const float* actA1 = (const float*)blk.wsA1;
         float* wsG2 = (float*)blk.wsG2;
         float* gparams = (float*)blk.wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
         GroupU g = load_group(groups + (a.n_groups - 1));
-        if (first_tile) stage_begin(S, stage_list(jbuf0 + jb * a.jmax, g.l1_off, wave), packed, lane);
+        if (first_tile) stage_begin(S, stage_list(jbuf0 + jb * a.jmax, HINT_FIRST_DESC(g), wave), packed, lane);
         first_tile = false;
 
         for (int gi = a.n_groups - 1; gi >= 0; --gi) {
@@ -1003,21 +1044,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                     : LEVEL_SRC(gn.level);
                 tile_issue(xnext, src, a.d, row0, a.B, tid);
             }
-            // ---- recompute s, t of every node of the group (bit-identical to the forward); the
-            //      group's v and its cleared g_st were set up in the phase before (HINT_BUILD_V) ----
-            stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, nullptr, a.ald, 0, lane);
-            STAMP(sbase + 2)
-            lds_barrier();
-            STAMP(sbase + 3)
-            copy_rows_out(wsA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-            // s of this level comes from the tape (no third-layer recompute): fetched across the L2
-            // stage; the stage after L2 is g2 (or the dW3 tiles of plans without their own g2 buffer)
-            TilePrefetch stile;
-            tile_issue(stile, tape + (size_t)(a.n_levels + g.level) * a.B * a.d, a.d, row0, a.B, tid);
-            stage_run<EPI_RELU>(S, stage_list(jl, a.split_o3 ? g.o3_off : g.g2_off, wave), packed, packed, bias_g + g.aw, a1,
-                                a.ald, a2, nullptr, a.ald, 0, lane);
+            // ---- nothing is recomputed: s and a2 of the group (bit-identical to the forward's) land
+            //      in LDS now, a1 during the g2 stage ----
             tile_commit(stile, sb, a.xld, a.d, tid);
-            if (has_next) jobs_commit<true>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
+            rows_commit(a2t, a2, a.ald, g.aw, tid);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
@@ -1040,10 +1070,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                     }
                 }
             }
+            if (has_next) jobs_commit<true>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
             STAMP(sbase + 8)
             lds_barrier();
             STAMP(sbase + 9)
             if (level_switch) tile_commit(xnext, xs, a.xld, a.d, tid);   // xs is not read again in this group
+            RowsPrefetch a1t;                                             // a1: fetched across the g2 stage
+            rows_issue(a1t, actA1, a.WT, g.wcol0, g.aw, row0, tid);
             // ---- g2 = (g_st * W3) .* relu'(a2) -> a3;  dW3 += g_st^T a2 (outer-product tiles in the
             //      same lists);  db3 += colsum(g_st) ----
             colsum_store(bmap_g + 2 * g.aw, g.sw, gst, a.sld, gparams, tid);
@@ -1054,6 +1087,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             }
             stage_run<EPI_MASK, true>(S, stage_list(jl, g.g1_off, wave), packed, packed, bias_g, gst, a.sld, a3, a2,
                                       a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
+            rows_commit(a1t, a1, a.ald, g.aw, tid);       // (a1 has been free since the dv stage of the group before)
             STAMP(sbase + 12)
             lds_barrier();
             STAMP(sbase + 13)
@@ -1069,7 +1103,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v (outer-product tiles);
             //      db1 += colsum(g1) ----
             colsum_store(bmap_g, g.aw, a1, a.ald, gparams, tid);
-            stage_run<EPI_PLAIN, true>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
+            stage_run<EPI_PLAIN, true>(S, has_next ? stage_list(jl_next, HINT_FIRST_DESC(gn), wave)
+                                                   : stage_list(jl, HINT_FIRST_DESC(g), wave),
                                        packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, nullptr, a.vld, vstride,
                                        lane, a1, a.ald, vb, a.vld, gparams);
             STAMP(sbase + 16)
@@ -1099,7 +1134,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                     }
                 }
             }
-            if ((gi > 0) || (cb > 0)) HINT_BUILD_V(gn)      // xs holds the next group's level since the g2 phase
+            if ((gi > 0) || (cb > 0)) {
+                HINT_BUILD_V(gn)                // xs holds the next group's level since the g2 phase
+                const float* tape_n = block_switch ? (const float*)nblk.tape : tape;
+                const float* act_n = block_switch ? (const float*)nblk.wsA1 : actA1;
+                tile_issue(stile, tape_n + (size_t)(a.n_levels + gn.level) * a.B * a.d, a.d, row0, a.B, tid);
+                rows_issue(a2t, act_n + a.act_stride, a.WT, gn.wcol0, gn.aw, row0, tid);
+            }
             STAMP(sbase + 18)
             lds_barrier();
             STAMP(sbase + 19)

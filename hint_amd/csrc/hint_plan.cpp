@@ -657,19 +657,28 @@ int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats 
 // k-block, but keeping a margin makes that robust against future tuning
 int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 3 * 256 : -1; }
 
+static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
+
+// Tape layout (floats): [lane tiles: L x B x d][s: L x B x d][pad to 4][a1: Bp x WT + slack][a2: same]
+static inline int64_t tape_act_off(const hint_plan* P, int B) {
+    return (2 * (int64_t)P->n_levels * B * P->d + 3) / 4 * 4;
+}
+static inline int64_t tape_act_stride(const hint_plan* P, int B) {
+    return (int64_t)rows_padded(B) * P->WT + WS_SLACK;
+}
+
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
     // per level: the lane tile as the level saw it (the last slice: the block's permuted input) and
-    // the s values of the level's couplings, both [B, d]
-    return 2 * (int64_t)P->n_levels * B * P->d;
+    // the s values of the level's couplings, both [B, d]; then both hidden activations of every
+    // (node, net), [Bp, WT] each (the operand a1 of part B's dW2 = g2^T a1 lives here as well)
+    return tape_act_off(P, B) + 2 * tape_act_stride(P, B);
 }
-
-static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
     if (!P || B <= 0) return 0;
     const size_t Bp = rows_padded(B);
-    const size_t floats = 2 * (Bp * (size_t)P->WT + WS_SLACK) + (Bp / ROWS) * (size_t)P->thin_total + WS_SLACK;
+    const size_t floats = (Bp * (size_t)P->WT + WS_SLACK) + (Bp / ROWS) * (size_t)P->thin_total + WS_SLACK;
     return floats * sizeof(float);
 }
 
@@ -682,7 +691,7 @@ static KArgs make_args(const hint_plan* P, int B) {
     a.meta = P->d_meta; a.jobs = P->d_jobs; a.bmap = P->d_tbmap; a.thin_total = P->thin_total;
     a.meta_bytes = P->meta_bytes; a.vmap_off = P->vmap_off; a.ents_off = P->ents_off; a.jmax = P->jmax;
     std::memcpy(a.first, P->first, sizeof a.first);
-    a.bmax = P->bmax; a.bias_off = P->packed_floats;
+    a.bmax = P->bmax; a.bias_off = P->packed_floats; a.act_stride = tape_act_stride(P, B);
     a.s3 = P->s3; a.sv = P->sv;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
     a.xld = P->xld; a.cld = P->cld; a.ald = P->ald; a.vld = P->vld; a.sld = P->sld;
@@ -747,9 +756,14 @@ void hint_pack_group_destroy(hint_pack_group* G) {
 
 static void split_workspace(const hint_plan* P, int B, void* workspace, ChainBlock* b) {
     const size_t Bp = rows_padded(B);
-    b->wsA1 = (float*)workspace;
-    b->wsG2 = b->wsA1 + Bp * P->WT + WS_SLACK;
+    b->wsG2 = (float*)workspace;
     b->wsT = b->wsG2 + Bp * P->WT + WS_SLACK;       // [row tile][thin_total] partial thin gradients
+}
+
+// the hidden activations live inside the tape (the training forward writes them)
+static void bind_tape(const hint_plan* P, int B, float* tape, ChainBlock* b) {
+    b->tape = tape;
+    b->wsA1 = tape ? tape + tape_act_off(P, B) : nullptr;
 }
 
 // part A (row-parallel) + part B (weight gradients) of the backward pass of one block or a chain
@@ -788,7 +802,8 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
     ChainBlock one{};
-    one.params = params; one.packed = packed; one.perm = perm; one.tape = tape;
+    one.params = params; one.packed = packed; one.perm = perm;
+    bind_tape(P, B, rev ? nullptr : tape, &one);
     HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
@@ -842,7 +857,8 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
                     hint_plan_workspace_bytes(P, B));
     if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_backward: workspace must be 16-byte aligned");
     ChainBlock one{};
-    one.params = params; one.packed = packed; one.perm = perm; one.tape = const_cast<float*>(tape);
+    one.params = params; one.packed = packed; one.perm = perm;
+    bind_tape(P, B, const_cast<float*>(tape), &one);
     one.gparams = g_params;
     split_workspace(P, B, workspace, &one);
     return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, s);
@@ -884,7 +900,8 @@ int hint_chain_set_block(hint_chain* C, int32_t i, const float* params, const fl
     if (!tape && workspace)
         return fail("hint_chain_set_block: a trainable chain block needs a tape");
     ChainBlock b{};
-    b.params = params; b.packed = packed; b.perm = perm; b.tape = tape; b.gparams = g_params;
+    b.params = params; b.packed = packed; b.perm = perm; b.gparams = g_params;
+    bind_tape(P, C->B, tape, &b);
     if (workspace) {
         if (!g_params) return fail("hint_chain_set_block: workspace without g_params");
         if (workspace_bytes < hint_plan_workspace_bytes(P, C->B))
@@ -935,7 +952,7 @@ int hint_chain_backward(const hint_chain* C, const float* x, const float* c, con
     if (P->dc > 0 && !c) return fail("hint_chain_backward: plan has dc=%d but c is NULL", P->dc);
     if (!x && !C->host[0].perm) return fail("hint_chain_backward: x is NULL but the first block has no fused permutation");
     for (int i = 0; i < C->n; ++i)
-        if (!C->host[i].wsA1 || !C->host[i].gparams)
+        if (!C->host[i].wsG2 || !C->host[i].wsA1 || !C->host[i].gparams)
             return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate)

@@ -66,12 +66,13 @@ int64_t hint_plan_param_floats(const hint_plan* plan);
 /* floats of the packed-weight buffer (both subnets of every node, forward and transposed
  * copies, in MFMA fragment order, zero padded). */
 int64_t hint_plan_packed_floats(const hint_plan* plan);
-/* floats of the forward "tape" for a batch of B rows: per tree level one [B,d] snapshot of the
- * lane tensor as that level saw it (the last slice holds the block's permuted input for the _ex /
- * chain forms) and one [B,d] array of the level's coupling arguments s (indexed by the lane each
- * one scales), recorded by the training forward and read by the backward pass, which so
- * re-derives bit-identical subnet inputs and skips the last layer (2*d floats per level and row
- * instead of the ~6*h floats per node autograd keeps for hint.py:77). */
+/* floats of the forward "tape" for a batch of B rows, recorded by the training forward and read
+ * by the backward pass: per tree level one [B,d] snapshot of the lane tensor as that level saw it
+ * (the last slice holds the block's permuted input for the _ex / chain forms) and one [B,d] array
+ * of the level's coupling arguments s (indexed by the lane each one scales), then both hidden
+ * activations of every subnet, [B rounded up to 16, sum of 2*pad16(h)] each.  The backward pass
+ * recomputes nothing (what autograd keeps for hint.py:77, minus the pre-activations), and the
+ * weight-gradient kernel takes its a1 operand from here. */
 int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
 /* bytes of scratch hint_block_backward needs for a batch of B rows. */
 size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
@@ -110,7 +111,7 @@ int hint_block_forward(const hint_plan* plan, const float* params, const float* 
 int hint_block_inverse(const hint_plan* plan, const float* params, const float* packed,
                        const float* z, const float* c, float* x, float* J, int32_t B, void* stream);
 /* Backward of hint_block_forward.  Takes the block INPUT x and the tape the forward call
- * recorded (required; hidden activations are recomputed from it, not stored), upstream g_z [B,d] and
+ * recorded (required), upstream g_z [B,d] and
  * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and the
  * flat parameter gradient g_params (same layout as params): overwritten when accumulate == 0,
  * added to when accumulate != 0 (the caller then owns zeroing, e.g. hint_adam_step's
