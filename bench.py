@@ -44,6 +44,14 @@ def flops_per_sample_block(d, widths, dc=0):
     return sum(2 * 2 * (n.cin * n.h + n.h * n.h + n.h * n.r) for n in nodes)
 
 
+def thin_flops_per_sample_block(d, widths, dc=0):
+    """FLOPs per sample of the weight gradients the row-parallel backward kernel computes itself
+    (dW1 and dW3 of both subnets; dW2 is part B's)"""
+    from oracle import hint_oracle as orc
+    nodes = orc.build_nodes(d, [(dc,)] if dc else [], widths)
+    return sum(2 * 2 * (n.cin * n.h + n.h * n.r) for n in nodes)
+
+
 def cpu_baseline(cfg, budget_s=12.0, max_steps=200):
     """the reference's CPU path (oracle restatement of hint.py in plain torch CPU ops +
     autograd + clamp + Adam), timed on this box's host cores on a bounded number of steps.
@@ -227,11 +235,12 @@ def main():
         }
         if in_step:
             # dominant kernel = the row-parallel backward kernel (part A), one launch for all blocks:
-            # recompute (F) + dX (F) per sample and block
+            # dX through the three layers (F) + the thin weight gradients dW1, dW3 per sample and block
+            # (nothing is recomputed: the hidden activations come from the forward's tape)
             name = "hint_block_bwd_kernel"
             nb = cfg["n_blocks"]                       # blocks one launch processes
             us = in_step[name]
-            flops = 2.0 * F * B * nb
+            flops = (F + thin_flops_per_sample_block(d, cfg["c_internal"])) * B * nb
             ach = flops / (us * 1e-6) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
