@@ -893,13 +893,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 // =======================================================================================
 // The reverse: 16 rows x `width` columns of a [rows][sld] global array into an LDS buffer, issue
 // and commit split like TilePrefetch.  6 float4 per thread cover width <= 768 (two nets of h <= 384).
-constexpr int ROW_REGS = 6;
-struct RowsPrefetch { f32x4 r[ROW_REGS]; };
-__device__ __forceinline__ void rows_issue(RowsPrefetch& rp, const float* __restrict__ src, int sld, int scol, int width,
-                                           int row0, int tid) {
+// RR float4 per thread cover width <= 128*RR columns; the backward kernel is instantiated for
+// RR = 3, 4, 6 (widest group <= 384, 512, 768 columns) because these registers are live across
+// GEMM stages and every spare one there costs scratch traffic.
+template <int RR> struct RowsPrefetch { f32x4 r[RR]; };
+template <int RR>
+__device__ __forceinline__ void rows_issue(RowsPrefetch<RR>& rp, const float* __restrict__ src, int sld, int scol,
+                                           int width, int row0, int tid) {
     const int w4 = width >> 2, n4 = ROWS * w4;
 #pragma unroll
-    for (int k = 0; k < ROW_REGS; ++k) {
+    for (int k = 0; k < RR; ++k) {
         if (k * NTHREADS < n4) {                       // wave-uniform
             const int i = min(tid + k * NTHREADS, n4 - 1);
             const int r = i / w4, j = (i - r * w4) << 2;
@@ -907,10 +910,11 @@ __device__ __forceinline__ void rows_issue(RowsPrefetch& rp, const float* __rest
         }
     }
 }
-__device__ __forceinline__ void rows_commit(const RowsPrefetch& rp, float* dst, int dld, int width, int tid) {
+template <int RR>
+__device__ __forceinline__ void rows_commit(const RowsPrefetch<RR>& rp, float* dst, int dld, int width, int tid) {
     const int w4 = width >> 2, n4 = ROWS * w4;
 #pragma unroll
-    for (int k = 0; k < ROW_REGS; ++k) {
+    for (int k = 0; k < RR; ++k) {
         const int i = tid + k * NTHREADS;
         if (i < n4) {
             const int r = i / w4, j = (i - r * w4) << 2;
@@ -919,6 +923,7 @@ __device__ __forceinline__ void rows_commit(const RowsPrefetch& rp, float* dst, 
     }
 }
 
+template <int RR>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4))) void hint_block_bwd_kernel(
     KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, const float* __restrict__ c,
@@ -996,7 +1001,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         // s of a level and the group's hidden activations a2 come from the tape: fetched one group
         // ahead (here: for the first group), committed to LDS at the top of the group
         TilePrefetch stile;
-        RowsPrefetch a2t;
+        RowsPrefetch<RR> a2t;
 #define HINT_FIRST_DESC(G) (a.split_o3 ? (G).o3_off : (G).g2_off)     /* the first GEMM stage of a group */
         {
             const GroupU g0 = load_group(groups + (a.n_groups - 1));
@@ -1048,6 +1053,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             //      in LDS now, a1 during the g2 stage ----
             tile_commit(stile, sb, a.xld, a.d, tid);
             rows_commit(a2t, a2, a.ald, g.aw, tid);
+            RowsPrefetch<RR> a1t;                                         // a1: fetched across the coupling and the g2 stage
+            rows_issue(a1t, actA1, a.WT, g.wcol0, g.aw, row0, tid);
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
@@ -1075,8 +1082,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             lds_barrier();
             STAMP(sbase + 9)
             if (level_switch) tile_commit(xnext, xs, a.xld, a.d, tid);   // xs is not read again in this group
-            RowsPrefetch a1t;                                             // a1: fetched across the g2 stage
-            rows_issue(a1t, actA1, a.WT, g.wcol0, g.aw, row0, tid);
             // ---- g2 = (g_st * W3) .* relu'(a2) -> a3;  dW3 += g_st^T a2 (outer-product tiles in the
             //      same lists);  db3 += colsum(g_st) ----
             colsum_store(bmap_g + 2 * g.aw, g.sw, gst, a.sld, gparams, tid);
@@ -1103,6 +1108,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             // ---- g_v = [g1_s | g1_t] * [W1_s ; W1_t];  dW1 += g1^T v (outer-product tiles);
             //      db1 += colsum(g1) ----
             colsum_store(bmap_g, g.aw, a1, a.ald, gparams, tid);
+            if ((gi > 0) || (cb > 0)) {
+                const float* tape_n = block_switch ? (const float*)nblk.tape : tape;
+                const float* act_n = block_switch ? (const float*)nblk.wsA1 : actA1;
+                tile_issue(stile, tape_n + (size_t)(a.n_levels + gn.level) * a.B * a.d, a.d, row0, a.B, tid);
+                rows_issue(a2t, act_n + a.act_stride, a.WT, gn.wcol0, gn.aw, row0, tid);
+            }
             stage_run<EPI_PLAIN, true>(S, has_next ? stage_list(jl_next, HINT_FIRST_DESC(gn), wave)
                                                    : stage_list(jl, HINT_FIRST_DESC(g), wave),
                                        packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, nullptr, a.vld, vstride,
@@ -1136,10 +1147,6 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             }
             if ((gi > 0) || (cb > 0)) {
                 HINT_BUILD_V(gn)                // xs holds the next group's level since the g2 phase
-                const float* tape_n = block_switch ? (const float*)nblk.tape : tape;
-                const float* act_n = block_switch ? (const float*)nblk.wsA1 : actA1;
-                tile_issue(stile, tape_n + (size_t)(a.n_levels + gn.level) * a.B * a.d, a.d, row0, a.B, tid);
-                rows_issue(a2t, act_n + a.act_stride, a.WT, gn.wcol0, gn.aw, row0, tid);
             }
             STAMP(sbase + 18)
             lds_barrier();
@@ -1366,8 +1373,14 @@ hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
                       int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                       float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream) {
-    hipLaunchKernelGGL(hint_block_bwd_kernel, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one, chain,
-                       n_chain, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const);
+    const int max_aw = a.max_aw;       // widest group of the plan
+#define HINT_LAUNCH_BWD(RR)                                                                                      \
+    hipLaunchKernelGGL(hint_block_bwd_kernel<RR>, dim3(grid), dim3(NTHREADS), lds_bytes, stream, a, one, chain,   \
+                       n_chain, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const)
+    if (max_aw <= 128 * 3) HINT_LAUNCH_BWD(3);
+    else if (max_aw <= 128 * 4) HINT_LAUNCH_BWD(4);
+    else HINT_LAUNCH_BWD(6);
+#undef HINT_LAUNCH_BWD
     return hipGetLastError();
 }
 
@@ -1402,7 +1415,11 @@ hipError_t set_max_lds(int fwd_bytes, int bwd_bytes) {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)hint_block_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fwd_bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)hint_block_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_bytes);
+    e = hipFuncSetAttribute((const void*)hint_block_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)hint_block_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)hint_block_bwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_bytes);
 }
 
 }  // namespace hint

@@ -76,7 +76,7 @@ struct hint_plan {
     float alpha = 0.f;
     int64_t param_floats = 0, packed_floats = 0;
     int WT = 0;
-    int xld = 0, cld = 0, ald = 0, vld = 0, sld = 0;
+    int xld = 0, cld = 0, ald = 0, vld = 0, sld = 0, max_aw = 0;
     int s3 = 1, sv = 1;   // max K-split slabs of the layer-3 / dv stages
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
@@ -527,6 +527,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->param_floats = pmax;
     P->packed_floats = packed;
     P->ald = lds_stride(max_aw);
+    P->max_aw = max_aw;
     P->vld = lds_stride(max_vw);
     P->sld = lds_stride(max_sw);
     // ---- meta blob staged in LDS by the kernels: [groups | vmap | ents] ----
@@ -696,7 +697,7 @@ static KArgs make_args(const hint_plan* P, int B) {
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
     a.xld = P->xld; a.cld = P->cld; a.ald = P->ald; a.vld = P->vld; a.sld = P->sld;
     a.WT = P->WT;
-    a.alpha = P->alpha; a.B = B; a.split_o3 = P->split_o3;
+    a.alpha = P->alpha; a.B = B; a.split_o3 = P->split_o3; a.max_aw = P->max_aw;
     return a;
 }
 
