@@ -786,14 +786,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 STAMP(4 + 12 * gi)
                 lds_barrier();
                 STAMP(5 + 12 * gi)
-                // training: both hidden activations go to the tape, [Bp][WT] row-major - the backward pass
-                // reloads them instead of recomputing two GEMM stages, and part B reads a1 from there
-                if (!REV && actA1 != nullptr) copy_rows_out(actA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
                 stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, nullptr, a.ald, 0, lane);
                 STAMP(6 + 12 * gi)
                 lds_barrier();
                 STAMP(7 + 12 * gi)
-                if (!REV && actA1 != nullptr) copy_rows_out(actA1 + a.act_stride, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
+                // training: both hidden activations go to the tape, [Bp][WT] row-major - the backward pass
+                // reloads them instead of recomputing, and part B reads a1 from there.  Both in this phase
+                // (a1 is still intact): stores in front of a stage's weight loads hold up the in-order vmcnt
+                // waits of its k-loops, and the third layer's are the shortest (measured: -7 us per step
+                // against storing a1 in the second layer's phase, -9 us against the coupling phase)
+                if (!REV && actA1 != nullptr) {
+                    copy_rows_out(actA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
+                    copy_rows_out(actA1 + a.act_stride, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
+                }
                 // the stage after this one: L1 of the next group (next block, next row tile); nothing
                 // follows the very last one, which re-primes its own group's L1 (never run)
                 stage_run<EPI_LINEAR>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
