@@ -246,7 +246,8 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
             if os.path.exists(pmc) and args.workload == "power_hint_8":
                 try:
-                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                    summary = json.load(open(pmc))       # (the kernel is a template: "hint_block_bwd_kernel<3>")
+                    traffic = next((v.get("hbm_bytes_per_launch") for k, v in summary.items() if k.startswith(name)), None)
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
