@@ -24,8 +24,9 @@ torch.cuda.synchronize()
 lib.hint_debug_set_backward_stages(3)
 s = buf.cpu()[:1024].view(8, 128)
 names = {0: "start", 1: "loaded+sync", 120: "stored"}
-stages = ["build_v", "sync", "L1(+begin L3)", "sync", "L2(+copy a1,begin g2)", "sync", "L3(+begin g1)", "sync", "couple", "sync",
-          "o3+colsum", "sync", "g2(+begin dv)", "sync", "g1(+copy g2,colsum)", "sync", "dv+o1+colsum", "sync", "scatter", "sync"]
+# phase stamps of the tape-based backward kernel (ids 2 + 20*group + k)
+stages = ["-", "-", "-", "-", "commit s,a2", "sync", "-", "-", "couple", "sync",
+          "-", "-", "g2+dW3 tiles", "sync", "g1(+copy g2,colsum)", "sync", "dv+dW1 tiles", "sync", "scatter+build v", "sync"]
 for gi in range(5):
     for k, nm in enumerate(stages):
         names[2 + 20 * gi + k] = f"g{gi}:{nm}"
