@@ -519,6 +519,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
 }
 
 // 16 rows x `width` columns of an LDS buffer to a [rows][dld] global array (hidden activations)
+// NT: non-temporal stores for rows that are read much later (the forward's tape: tens of MB on,
+// by another kernel), plain ones for rows the next kernel reads (g2 -> part B).
+template <bool NT>
 __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, int dcol,
                                               const float* src, int sld, int width, int row0,
                                               int tid) {
@@ -529,7 +532,10 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
 #endif
     for (int i = tid; i < ROWS * w4; i += NTHREADS) {
         const int r = i / w4, j = (i - r * w4) << 2;
-        *(f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j) = *(const f32x4*)(src + r * sld + j);
+        const f32x4 v = *(const f32x4*)(src + r * sld + j);
+        f32x4* p = (f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j);
+        if (NT) __builtin_nontemporal_store(v, p);
+        else *p = v;
     }
 }
 
@@ -796,8 +802,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 // waits of its k-loops, and the third layer's are the shortest (measured: -7 us per step
                 // against storing a1 in the second layer's phase, -9 us against the coupling phase)
                 if (!REV && actA1 != nullptr) {
-                    copy_rows_out(actA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
-                    copy_rows_out(actA1 + a.act_stride, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
+                    copy_rows_out<true>(actA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
+                    copy_rows_out<true>(actA1 + a.act_stride, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
                 }
                 // the stage after this one: L1 of the next group (next block, next row tile); nothing
                 // follows the very last one, which re-primes its own group's L1 (never run)
@@ -1102,7 +1108,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             lds_barrier();
             STAMP(sbase + 13)
             // ---- g1 = (g2 * W2) .* relu'(a1), in place over a1;  db2 += colsum(g2) ----
-            copy_rows_out(wsG2, a.WT, g.wcol0, a3, a.ald, g.aw, row0, tid);
+            copy_rows_out<false>(wsG2, a.WT, g.wcol0, a3, a.ald, g.aw, row0, tid);
             STAMP(105 + 4 * (a.n_groups - 1 - gi))
             colsum_store(bmap_g + g.aw, g.aw, a3, a.ald, gparams, tid);
             STAMP(106 + 4 * (a.n_groups - 1 - gi))
