@@ -34,27 +34,44 @@ __device__ __forceinline__ int lds_int(const LDS_AS int32_t* p) { return __built
 // Diagnostic build only (-DHINT_STAMPS): shader-clock stamps of workgroup 0 at stage boundaries,
 // written to a buffer nothing else reads (cdna_hip_programming.md §7 "In-kernel stamps").
 #ifdef HINT_STAMPS
+// Stamps are collected in LDS and flushed when the kernel ends: a global store per stamp would sit in
+// the in-order vmcnt queue in front of the weight loads of the next stage and distort what it measures.
+// Ids 0..127: stage boundaries; 128..255: job starts inside the GEMM stages (STAMP_JOBS / STAMP_JOB).
+#define STAMP_IDS 256
 __device__ unsigned long long* g_hint_stamps = nullptr;
+__shared__ unsigned long long hint_stamp_lds[hint::NWAVES * STAMP_IDS];
+__shared__ int hint_stamp_jb[hint::NWAVES];
 #define STAMP(ID)                                                                              \
-    if (g_hint_stamps != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {               \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                           \
         unsigned long long t_;                                                                 \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
-        g_hint_stamps[(threadIdx.x >> 6) * 128 + (ID)] = t_;                                    \
+        hint_stamp_lds[(threadIdx.x >> 6) * STAMP_IDS + (ID)] = t_;                             \
     }
-#endif
-// per-section cycle sums of one wavefront (wave 0 of workgroup 0), kept in registers; needs
-// -DHINT_TSEC on top of -DHINT_STAMPS (the waits it adds serialise the stage pipeline)
-#if defined(HINT_STAMPS) && defined(HINT_TSEC)
-#define TSEC_DECL unsigned long long tsec_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast_ = 0; (void)tsec_; (void)tlast_;
-#define TSEC_START() { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast_)::"memory"); }
-#define TSEC(K) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tsec_[K] += t_ - tlast_; tlast_ = t_; }
+#define STAMP_INIT()                                                                           \
+    {                                                                                          \
+        for (int i_ = threadIdx.x; i_ < hint::NWAVES * STAMP_IDS; i_ += blockDim.x) hint_stamp_lds[i_] = 0ull; \
+        if (threadIdx.x < hint::NWAVES) hint_stamp_jb[threadIdx.x] = 0;                         \
+        __syncthreads();                                                                       \
+    }
+#define STAMP_FLUSH()                                                                          \
+    {                                                                                          \
+        __syncthreads();                                                                       \
+        if (g_hint_stamps != nullptr && blockIdx.x == 0)                                        \
+            for (int i_ = threadIdx.x; i_ < hint::NWAVES * STAMP_IDS; i_ += blockDim.x)         \
+                if (hint_stamp_lds[i_] != 0ull) g_hint_stamps[i_] = hint_stamp_lds[i_];         \
+    }
+#define STAMP_JOBS(BASE) { if ((threadIdx.x & 63) == 0) hint_stamp_jb[threadIdx.x >> 6] = (BASE); }
+#define STAMP_JOB(JI)                                                                          \
+    {                                                                                          \
+        const int b_ = hint_stamp_jb[threadIdx.x >> 6];                                         \
+        if (b_ != 0) STAMP(b_ + ((JI) < 11 ? (JI) : 11))                                        \
+    }
 #else
-#define TSEC_DECL
-#define TSEC_START()
-#define TSEC(K)
-#endif
-#ifndef HINT_STAMPS
 #define STAMP(ID)
+#define STAMP_INIT()
+#define STAMP_FLUSH()
+#define STAMP_JOBS(BASE)
+#define STAMP_JOB(JI)
 #endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt(0)
@@ -357,7 +374,11 @@ __device__ __forceinline__ void run_outer(const JobU& j, f32x4 (&b0)[3], f32x4 (
         float* o = g + j.wtile + (4 * kq) * j.tstride + nl;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
+#ifdef HINT_ABLATE_OUTER_STORE
+            asm volatile("" ::"v"(acc[i]), "v"(o));
+#else
             if (4 * kq + i < mvalid) o[i * j.tstride] = acc[i];
+#endif
     }
 }
 
@@ -380,6 +401,7 @@ __device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float
     const int n = j.count;
     for (int ji = 0;; ++ji) {
         const bool last = ji + 1 >= n;
+        STAMP_JOB(ji)
         const JobU jn = decode_job(*(const LDS_AS i32x4*)(last ? next : S.cl + ji + 1));
         const float* pn = last ? packed_n : packed;
         if (OUTER && j.nt == TJOB_OUTER) run_outer(j, S.b0, S.b1, jn, pn, A_o, lda_o, B_o, ldb_o, g_o, lane);
@@ -509,10 +531,10 @@ __device__ __forceinline__ void tile_commit(const TilePrefetch& tp, float* dst, 
 }
 
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* src, int ld,
-                                           int width, int row0, int B, int tid) {
+                                           int width, int row0, int B, int tid, int nthreads = NTHREADS) {
     float* p = dst + (size_t)row0 * width;
     const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
-    for (int i = tid; i < nvalid; i += NTHREADS) {
+    for (int i = tid; i < nvalid; i += nthreads) {
         const int r = i / width;
         p[i] = src[r * ld + (i - r * width)];
     }
@@ -524,13 +546,13 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
 template <bool NT>
 __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, int dcol,
                                               const float* src, int sld, int width, int row0,
-                                              int tid) {
+                                              int tid, int nthreads = NTHREADS) {
     // width is a multiple of 16, dcol/dld multiples of 4 -> 128-bit rows
     const int w4 = width >> 2;
 #ifdef HINT_SKIP_WSCOPY
     if (width > 0) return;
 #endif
-    for (int i = tid; i < ROWS * w4; i += NTHREADS) {
+    for (int i = tid; i < ROWS * w4; i += nthreads) {
         const int r = i / w4, j = (i - r * w4) << 2;
         const f32x4 v = *(const f32x4*)(src + r * sld + j);
         f32x4* p = (f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j);
@@ -682,6 +704,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    STAMP_INIT()
     STAMP(0)
     HINT_LDS_TABLES()
     float* t0 = fbase;                        // two lane tiles: a fused permutation ping-pongs between them
@@ -750,6 +773,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             const float* perm = (const float*)blk.perm;
             float* tape = (float*)blk.tape;
             float* actA1 = (float*)blk.wsA1;
+            const bool train = !REV && actA1 != nullptr;
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
                 for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
@@ -787,11 +811,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 STAMP(2 + 12 * gi)
                 lds_barrier();
                 STAMP(3 + 12 * gi)
+                STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 0) * 12 : 0)
                 stage_run<EPI_RELU>(S, stage_list(jl, g.l2_off, wave), packed, packed, bias_g, vb, a.vld, a1, nullptr, a.ald, 0, lane);
                 if (has_next) jobs_commit<false>(jp, jl_next, bias0 + (jb ^ 1) * 2 * a.bmax, a.bmax, tid);
                 STAMP(4 + 12 * gi)
                 lds_barrier();
                 STAMP(5 + 12 * gi)
+                STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 1) * 12 : 0)
                 stage_run<EPI_RELU>(S, stage_list(jl, g.l3_off, wave), packed, packed, bias_g + g.aw, a1, a.ald, a2, nullptr, a.ald, 0, lane);
                 STAMP(6 + 12 * gi)
                 lds_barrier();
@@ -800,13 +826,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 // reloads them instead of recomputing, and part B reads a1 from there.  Both in this phase
                 // (a1 is still intact): stores in front of a stage's weight loads hold up the in-order vmcnt
                 // waits of its k-loops, and the third layer's are the shortest (measured: -7 us per step
-                // against storing a1 in the second layer's phase, -9 us against the coupling phase)
-                if (!REV && actA1 != nullptr) {
+                // against storing a1 in the second layer's phase, -9 us against the coupling phase).
+                // (Leaving all tape stores to one wavefront that takes no GEMM jobs was measured too:
+                // +33 us - seven wavefronts balance the tiles worse, and nothing was gained back.)
+                if (train) {
                     copy_rows_out<true>(actA1, a.WT, g.wcol0, a1, a.ald, g.aw, row0, tid);
                     copy_rows_out<true>(actA1 + a.act_stride, a.WT, g.wcol0, a2, a.ald, g.aw, row0, tid);
                 }
                 // the stage after this one: L1 of the next group (next block, next row tile); nothing
                 // follows the very last one, which re-primes its own group's L1 (never run)
+                STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 2) * 12 : 0)
                 stage_run<EPI_LINEAR>(S, has_next ? stage_list(jl_next, gn.l1_off, wave) : stage_list(jl, g.l1_off, wave),
                                       packed, has_next ? packed_n : packed, bias_g + 2 * g.aw, a2, a.ald, st, nullptr, a.sld, sstride, lane);
                 STAMP(8 + 12 * gi)
@@ -889,6 +918,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 #undef xs
 #undef xo
     }
+    STAMP_FLUSH()
 #undef HINT_CB
 }
 
@@ -944,6 +974,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    STAMP_INIT()
     STAMP(0)
     HINT_LDS_TABLES()
     float* xs = fbase;
@@ -1097,10 +1128,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             //      same lists);  db3 += colsum(g_st) ----
             colsum_store(bmap_g + 2 * g.aw, g.sw, gst, a.sld, gparams, tid);
             if (a.split_o3) {                  // outer-product tiles only; then g2 may overwrite a2
+                STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 0) * 12 : 0)
                 stage_run<EPI_PLAIN, true>(S, stage_list(jl, g.g2_off, wave), packed, packed, bias_g, gst, a.sld, a3, nullptr,
                                            a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
                 lds_barrier();
             }
+            STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 0) * 12 : 0)
             stage_run<EPI_MASK, true>(S, stage_list(jl, g.g1_off, wave), packed, packed, bias_g, gst, a.sld, a3, a2,
                                       a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
             rows_commit(a1t, a1, a.ald, g.aw, tid);       // (a1 has been free since the dv stage of the group before)
@@ -1112,6 +1145,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             STAMP(105 + 4 * (a.n_groups - 1 - gi))
             colsum_store(bmap_g + g.aw, g.aw, a3, a.ald, gparams, tid);
             STAMP(106 + 4 * (a.n_groups - 1 - gi))
+            STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 1) * 12 : 0)
             stage_run<EPI_MASK>(S, stage_list(jl, g.dv_off, wave), packed, packed, bias_g, a3, a.ald, a1, a1, a.ald, 0, lane);
             STAMP(sbase + 14)
             lds_barrier();
@@ -1125,6 +1159,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 tile_issue(stile, tape_n + (size_t)(a.n_levels + gn.level) * a.B * a.d, a.d, row0, a.B, tid);
                 rows_issue(a2t, act_n + a.act_stride, a.WT, gn.wcol0, gn.aw, row0, tid);
             }
+            STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 2) * 12 : 0)
             stage_run<EPI_PLAIN, true>(S, has_next ? stage_list(jl_next, HINT_FIRST_DESC(gn), wave)
                                                    : stage_list(jl, HINT_FIRST_DESC(g), wave),
                                        packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, nullptr, a.vld, vstride,
@@ -1194,6 +1229,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         STAMP(120)
         lds_barrier();
     }
+    STAMP_FLUSH()
 #undef HINT_CB
 }
 

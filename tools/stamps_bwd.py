@@ -11,7 +11,7 @@ dev = "cuda:0"
 lib = _lib.load()
 blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(dev)
 x = torch.randn(B, d, device=dev, requires_grad=True)
-buf = torch.zeros(8 * 128 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 256 + 64, dtype=torch.int64, device=dev)
 (z,) = blk([x]); J = blk.jacobian(None)
 L = (0.5 * (z ** 2).sum(1) - J).mean()
 for _ in range(5):
@@ -22,7 +22,7 @@ lib.hint_debug_set_backward_stages(1)
 L.backward(retain_graph=True)
 torch.cuda.synchronize()
 lib.hint_debug_set_backward_stages(3)
-s = buf.cpu()[:1024].view(8, 128)
+s = buf.cpu()[:2048].view(8, 256)
 names = {0: "start", 1: "loaded+sync", 120: "stored"}
 # phase stamps of the tape-based backward kernel (ids 2 + 20*group + k)
 stages = ["-", "-", "-", "-", "commit s,a2", "sync", "-", "-", "couple", "sync",
@@ -41,3 +41,14 @@ for i in ids:
     dl = "" if prev is None else f"  +{row[0]-prev}"
     prev = row[0]
     print(names[i].ljust(28) + f"{row[0]:9d} {max(row):9d}" + dl)
+
+# job starts inside the GEMM stages (ids 128 + (group*3 + stage)*12 + job), cycles after the wave's first job
+print("\njob starts per wave (cycles since kernel start of the first job, then deltas):")
+for gi in range(3):
+    for st, nm in enumerate(['g2+dW3', 'g1', 'dv+dW1']):
+        base = 128 + (gi * 3 + st) * 12
+        if s[:, base].max().item() == 0: continue
+        print(f"g{gi}:{nm}")
+        for w in range(8):
+            ts = [s[w, base + k].item() for k in range(12) if s[w, base + k].item() != 0]
+            if ts: print(f"   w{w}  start {ts[0]-t0:7d}  " + " ".join(f"+{b-a}" for a, b in zip(ts, ts[1:])))

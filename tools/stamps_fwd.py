@@ -13,14 +13,13 @@ dev = "cuda:0"
 lib = _lib.load()
 blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(dev)
 x = torch.randn(B, d, device=dev)
-buf = torch.zeros(8 * 128 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 256 + 64, dtype=torch.int64, device=dev)
 assert lib.hint_debug_set_stamp_buffer(buf.data_ptr()) == 0, "not a stamps build"
 with torch.no_grad():
     for _ in range(20):
         blk([x])
 torch.cuda.synchronize()
-sec = buf.cpu()[1024:1032].tolist()
-s = buf.cpu()[:1024].view(8, 128)
+s = buf.cpu()[:2048].view(8, 256)
 names = {0: "start", 1: "x loaded+sync"}
 for gi in range(4):
     for k, nm in enumerate(["build_v", "sync", "L1", "sync", "L2", "sync", "L3", "sync", "couple", "sync"]):
@@ -40,7 +39,14 @@ for i in ids:
     prev = row[0]
     print(names[i].ljust(16) + "".join(f"{v:9d}" for v in row) + dl)
 
-calls = max(sec[5], 1)
-print("stage_run sections, wave 0 of WG 0, summed over", calls, "stage_run calls (", calls // 6, "kernel launches ):")
-for k, nm in enumerate(["first read_a", "decode+raw", "fetch_b", "read_a", "mma+epilogue"]):
-    print(f"   {nm:14s} {sec[k] / (calls / 6):10.0f} cycles per launch")
+
+# job starts inside the GEMM stages (ids 128 + (group*3 + stage)*12 + job), cycles after the wave's first job
+print("\njob starts per wave (cycles since kernel start of the first job, then deltas):")
+for gi in range(3):
+    for st, nm in enumerate(['L1', 'L2', 'L3']):
+        base = 128 + (gi * 3 + st) * 12
+        if s[:, base].max().item() == 0: continue
+        print(f"g{gi}:{nm}")
+        for w in range(8):
+            ts = [s[w, base + k].item() for k in range(12) if s[w, base + k].item() != 0]
+            if ts: print(f"   w{w}  start {ts[0]-t0:7d}  " + " ".join(f"+{b-a}" for a, b in zip(ts, ts[1:])))
