@@ -84,6 +84,9 @@ static_assert(sizeof(TJob) == 16, "TJob must be 16 bytes");
 // nt == TJOB_OUTER marks an outer-product tile of a thin weight gradient (dW1, dW3) that rides in
 // a GEMM stage's lists of the backward kernel:  T[m][n] = sum_rows A[row][acol+m] * B[row][ocol+n],
 // stored at slab[wtile + m*tstride + n] for m <= (nvalid & 15), n <= (nvalid >> 4); nb = 0.
+// A record covers a run of adjacent tiles (up to 127) that share one operand: slab = direction | tiles << 1, direction
+// 0 = along n (ocol += 16 per tile, A shared), 1 = along m (acol += 16, B shared); nvalid describes the
+// LAST tile (the others are full in the direction the record walks).
 constexpr int TJOB_OUTER = 0xff;
 typedef TJob GJob;      // the per-group lists hold TJob and OJob records, 16 B each
 

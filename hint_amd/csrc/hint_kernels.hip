@@ -37,10 +37,11 @@ __device__ __forceinline__ int lds_int(const LDS_AS int32_t* p) { return __built
 // Stamps are collected in LDS and flushed when the kernel ends: a global store per stamp would sit in
 // the in-order vmcnt queue in front of the weight loads of the next stage and distort what it measures.
 // Ids 0..127: stage boundaries; 128..255: job starts inside the GEMM stages (STAMP_JOBS / STAMP_JOB).
-#define STAMP_IDS 256
+#define STAMP_IDS 512
 __device__ unsigned long long* g_hint_stamps = nullptr;
 __shared__ unsigned long long hint_stamp_lds[hint::NWAVES * STAMP_IDS];
 __shared__ int hint_stamp_jb[hint::NWAVES];
+__shared__ int hint_stamp_sub[hint::NWAVES];
 #define STAMP(ID)                                                                              \
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                           \
         unsigned long long t_;                                                                 \
@@ -50,7 +51,7 @@ __shared__ int hint_stamp_jb[hint::NWAVES];
 #define STAMP_INIT()                                                                           \
     {                                                                                          \
         for (int i_ = threadIdx.x; i_ < hint::NWAVES * STAMP_IDS; i_ += blockDim.x) hint_stamp_lds[i_] = 0ull; \
-        if (threadIdx.x < hint::NWAVES) hint_stamp_jb[threadIdx.x] = 0;                         \
+        if (threadIdx.x < hint::NWAVES) { hint_stamp_jb[threadIdx.x] = 0; hint_stamp_sub[threadIdx.x] = 0; } \
         __syncthreads();                                                                       \
     }
 #define STAMP_FLUSH()                                                                          \
@@ -66,7 +67,23 @@ __shared__ int hint_stamp_jb[hint::NWAVES];
         const int b_ = hint_stamp_jb[threadIdx.x >> 6];                                         \
         if (b_ != 0) STAMP(b_ + ((JI) < 11 ? (JI) : 11))                                        \
     }
+// a sequential log (ids 256..511: section K << 56 | time) inside the stage whose job base is HINT_STAMP_STAGE
+#ifdef HINT_STAMP_STAGE
+#define STAMP_SUB(K)                                                                           \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && hint_stamp_jb[threadIdx.x >> 6] == (HINT_STAMP_STAGE)) { \
+        const int n_ = hint_stamp_sub[threadIdx.x >> 6];                                        \
+        if (n_ < 256) {                                                                        \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            hint_stamp_lds[(threadIdx.x >> 6) * STAMP_IDS + 256 + n_] = t_ | ((unsigned long long)(K) << 56); \
+            hint_stamp_sub[threadIdx.x >> 6] = n_ + 1;                                          \
+        }                                                                                      \
+    }
 #else
+#define STAMP_SUB(K)
+#endif
+#else
+#define STAMP_SUB(K)
 #define STAMP(ID)
 #define STAMP_INIT()
 #define STAMP_FLUSH()
@@ -86,6 +103,12 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
+
+// floor(i / d) for 0 <= i < 2^20 through the float unit: three instructions instead of the ~25 of an
+// integer division by a run-time divisor (the tile loops below split a flat index into row and column;
+// they made up a third of the vector instructions of the backward kernel).  inv = frcp(d).
+__device__ __forceinline__ float frcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ int fdiv(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #ifdef HINT_ABLATE_MFMA     // diagnostic: keep operands alive, skip the matrix pipe
@@ -283,6 +306,7 @@ __device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b
         bias[t] = 0.f;
         if (EPI == EPI_RELU || EPI == EPI_LINEAR) bias[t] = bias_lds[j.ocol + 16 * t + nl];   // zero in padding columns
     }
+    STAMP_SUB(3)
     if (j.nb > 0) {
         const int NB = j.nb;
         const float* ap = arow + j.acol;
@@ -324,8 +348,10 @@ __device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b
 #undef HINT_STEP
 #undef HINT_AREAD
     }
+    STAMP_SUB(5)
     // the successor's first weights go out before this job's epilogue
     fetch_first(b0, b1, jn, packed_n, lane);
+    STAMP_SUB(6)
 #ifdef HINT_ABLATE_EPI
     if (jn.nt > 100)
 #endif
@@ -355,30 +381,56 @@ __device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b
 // same few KiB at once: measured 65 us of a 115 us kernel.
 __device__ __forceinline__ void run_outer(const JobU& j, f32x4 (&b0)[3], f32x4 (&b1)[3], const JobU& jn,
                                           const float* __restrict__ packed_n, const float* Abuf, int lda,
-                                          const float* Bbuf, int ldb, float* __restrict__ g, int lane) {
+                                          const float* Bbuf, int ldb, float* __restrict__ g,
+                                          float* __restrict__ trash, int lane) {
     const int nl = lane & 15, kq = lane >> 4;
+    // a run of adjacent tiles per record, walking along n (dir 0) or m (dir 1), three at a time: a
+    // record's fixed cost (decode, baton, LDS round trips) is ten times a tile's.  The body is branch
+    // free - a wavefront issues one instruction per four cycles whatever its kind, and the compiler's
+    // version of "store if valid" was fifty branches per round: elements outside the matrix (and the
+    // tiles a short last round computes again) go to a 64-float dump behind the slabs instead.
+    const int dir = j.slab & 1, cnt = j.slab >> 1;
+    const int astep = dir ? 16 : 0, bstep = dir ? 0 : 16;
     const float* ap = Abuf + kq * lda + nl + j.acol;       // rows kq + 4*i of the two operand tiles
     const float* bp = Bbuf + kq * ldb + nl + j.ocol;
-    float av[4], bv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { av[i] = ap[4 * i * lda]; bv[i] = bp[4 * i * ldb]; }
+    const int mlast = (j.nvalid & 15) + 1, nlast = (j.nvalid >> 4) + 1;
+    const int gstep = dir ? 16 * j.tstride : 16;
+    float* o0 = g + j.wtile + (4 * kq) * j.tstride + nl;
+    float* dump = trash + lane;
     fetch_first(b0, b1, jn, packed_n, lane);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    acc0 = mfma4(av[0], bv[0], acc0);
-    acc1 = mfma4(av[1], bv[1], acc1);
-    acc0 = mfma4(av[2], bv[2], acc0);
-    acc1 = mfma4(av[3], bv[3], acc1);
-    const f32x4 acc = acc0 + acc1;
-    const int mvalid = (j.nvalid & 15) + 1, nvalid = (j.nvalid >> 4) + 1;
-    if (nl < nvalid) {
-        float* o = g + j.wtile + (4 * kq) * j.tstride + nl;
+    for (int t0 = 0; t0 < cnt; t0 += 3) {
+        const int c3 = cnt - t0;                           // tiles left (this round does min(c3, 3))
+        float av[3][4], bv[3][4];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int tt = t0 + (t < c3 ? t : 0);          // (a short round re-reads its first tile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[t][i] = ap[4 * i * lda + tt * astep]; bv[t][i] = bp[4 * i * ldb + tt * bstep]; }
+        }
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t][i & 1] = mfma4(av[t][i], bv[t][i], acc[t][i & 1]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f32x4 r = acc[t][0] + acc[t][1];
+            const bool lastt = t0 + t + 1 >= cnt;
+            const int mvalid = t >= c3 ? 0 : ((dir && !lastt) ? 16 : mlast), nvalid = (!dir && !lastt) ? 16 : nlast;
+            float* o = o0 + (t0 + t) * gstep;
+            const int mrem = nl < nvalid ? mvalid - 4 * kq : 0;      // valid rows among this lane's four
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
 #ifdef HINT_ABLATE_OUTER_STORE
-            asm volatile("" ::"v"(acc[i]), "v"(o));
+                asm volatile("" ::"v"(r[i]), "v"(o));
 #else
-            if (4 * kq + i < mvalid) o[i * j.tstride] = acc[i];
+                float* p = i < mrem ? o + i * j.tstride : dump;
+                *p = r[i];
 #endif
+            }
+        }
     }
 }
 
@@ -391,7 +443,7 @@ __device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float
                                           const float* A, int lda, float* O, const float* Mk, int ldo,
                                           int slab_stride, int lane, const float* A_o = nullptr, int lda_o = 0,
                                           const float* B_o = nullptr, int ldb_o = 0,
-                                          float* __restrict__ g_o = nullptr) {
+                                          float* __restrict__ g_o = nullptr, float* __restrict__ trash = nullptr) {
 #ifdef HINT_SKIP_GEMM
     S.cl = next;
     return;
@@ -402,13 +454,15 @@ __device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float
     for (int ji = 0;; ++ji) {
         const bool last = ji + 1 >= n;
         STAMP_JOB(ji)
+        STAMP_SUB(1)
         const JobU jn = decode_job(*(const LDS_AS i32x4*)(last ? next : S.cl + ji + 1));
         const float* pn = last ? packed_n : packed;
-        if (OUTER && j.nt == TJOB_OUTER) run_outer(j, S.b0, S.b1, jn, pn, A_o, lda_o, B_o, ldb_o, g_o, lane);
+        if (OUTER && j.nt == TJOB_OUTER) run_outer(j, S.b0, S.b1, jn, pn, A_o, lda_o, B_o, ldb_o, g_o, trash, lane);
         else if (j.nt >= 3) run_job<EPI, 3>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
         else if (j.nt == 2) run_job<EPI, 2>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
         else if (j.nt == 1) run_job<EPI, 1>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
         else fetch_first(S.b0, S.b1, jn, pn, lane);      // idle wavefront: only hand the baton on
+        STAMP_SUB(7)
         j = jn;
         if (last) break;
     }
@@ -483,8 +537,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // v columns through a per-column source map (>= 0: lane column, -1: zero, <= -2: condition column)
 __device__ __forceinline__ void stage_build_v(const KArgs& a, const LDS_AS int16_t* vmap, int vw,
                                               const float* xs, const float* cs, float* vb, int tid) {
+    const float inv = frcp(vw);
     for (int i = tid; i < ROWS * vw; i += NTHREADS) {
-        const int r = i / vw, j = i - r * vw;
+        const int r = fdiv(i, inv), j = i - r * vw;
         const int m = vmap[j];
         float v = 0.f;
         if (m >= 0) v = xs[r * a.xld + m];
@@ -497,13 +552,15 @@ __device__ __forceinline__ void load_tile(float* dst, int ld, const float* __res
                                           int width, int row0, int B, int tid) {
     // a 16-row tile of a row-major [B,width] tensor is one contiguous run of 16*width floats
     if (src == nullptr) {
-        for (int i = tid; i < ROWS * width; i += NTHREADS) { const int r = i / width; dst[r * ld + (i - r * width)] = 0.f; }
+        const float inv0 = frcp(width);
+        for (int i = tid; i < ROWS * width; i += NTHREADS) { const int r = fdiv(i, inv0); dst[r * ld + (i - r * width)] = 0.f; }
         return;
     }
     const float* p = src + (size_t)row0 * width;
     const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
+    const float inv = frcp(width);
     for (int i = tid; i < ROWS * width; i += NTHREADS) {
-        const int r = i / width;
+        const int r = fdiv(i, inv);
         dst[r * ld + (i - r * width)] = (i < nvalid) ? p[i] : 0.f;
     }
 }
@@ -523,10 +580,11 @@ __device__ __forceinline__ void tile_issue(TilePrefetch& tp, const float* __rest
     }
 }
 __device__ __forceinline__ void tile_commit(const TilePrefetch& tp, float* dst, int ld, int width, int tid) {
+    const float inv = frcp(width);
 #pragma unroll
     for (int k = 0; k < TILE_REGS; ++k) {
         const int i = tid + k * NTHREADS;
-        if (i < ROWS * width) { const int r = i / width; dst[r * ld + (i - r * width)] = tp.r[k]; }
+        if (i < ROWS * width) { const int r = fdiv(i, inv); dst[r * ld + (i - r * width)] = tp.r[k]; }
     }
 }
 
@@ -534,8 +592,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
                                            int width, int row0, int B, int tid, int nthreads = NTHREADS) {
     float* p = dst + (size_t)row0 * width;
     const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
+    const float inv = frcp(width);
     for (int i = tid; i < nvalid; i += nthreads) {
-        const int r = i / width;
+        const int r = fdiv(i, inv);
         p[i] = src[r * ld + (i - r * width)];
     }
 }
@@ -552,8 +611,9 @@ __device__ __forceinline__ void copy_rows_out(float* __restrict__ dst, int dld, 
 #ifdef HINT_SKIP_WSCOPY
     if (width > 0) return;
 #endif
+    const float inv = frcp(w4);
     for (int i = tid; i < ROWS * w4; i += nthreads) {
-        const int r = i / w4, j = (i - r * w4) << 2;
+        const int r = fdiv(i, inv), j = (i - r * w4) << 2;
         const f32x4 v = *(const f32x4*)(src + r * sld + j);
         f32x4* p = (f32x4*)(dst + (size_t)(row0 + r) * dld + dcol + j);
         if (NT) __builtin_nontemporal_store(v, p);
@@ -704,6 +764,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float inv_d = frcp(a.d);
     STAMP_INIT()
     STAMP(0)
     HINT_LDS_TABLES()
@@ -757,7 +818,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * q + e;
-                    if (i < nvalid) { const int r = i / a.d; xs[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
+                    if (i < nvalid) { const int r = fdiv(i, inv_d); xs[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
                 }
             }
             __syncthreads();
@@ -777,7 +838,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
                 for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
-                    const int r = i / a.d, j = i - r * a.d;
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
                     xo[r * a.xld + j] = perm_dot(xs + r * a.xld, perm + j, a.d, a.d);
                 }
                 xcur = xflip - xcur;
@@ -883,7 +944,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
                 for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
-                    const int r = i / a.d, j = i - r * a.d;
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
                     xo[r * a.xld + j] = perm_dot(xs + r * a.xld, perm + (size_t)j * a.d, 1, a.d);
                 }
                 xcur = xflip - xcur;
@@ -898,7 +959,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             // slot[0] += sum_rows 0.5*|z|^2, slot[1] += sum_rows J_total
             float zz = 0.f;
             const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS);
-            for (int i = tid; i < nvalid * a.d; i += NTHREADS) { const int r = i / a.d; const float v = xs[r * a.xld + (i - r * a.d)]; zz += v * v; }
+            for (int i = tid; i < nvalid * a.d; i += NTHREADS) { const int r = fdiv(i, inv_d); const float v = xs[r * a.xld + (i - r * a.d)]; zz += v * v; }
             for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o, 64);
             if (lane == 0) vb[wave] = zz;      // vb is free at this point
             __syncthreads();
@@ -942,11 +1003,12 @@ template <int RR>
 __device__ __forceinline__ void rows_issue(RowsPrefetch<RR>& rp, const float* __restrict__ src, int sld, int scol,
                                            int width, int row0, int tid) {
     const int w4 = width >> 2, n4 = ROWS * w4;
+    const float inv = frcp(w4);
 #pragma unroll
     for (int k = 0; k < RR; ++k) {
         if (k * NTHREADS < n4) {                       // wave-uniform
             const int i = min(tid + k * NTHREADS, n4 - 1);
-            const int r = i / w4, j = (i - r * w4) << 2;
+            const int r = fdiv(i, inv), j = (i - r * w4) << 2;
             rp.r[k] = *(const f32x4*)(src + (size_t)(row0 + r) * sld + scol + j);
         }
     }
@@ -954,11 +1016,12 @@ __device__ __forceinline__ void rows_issue(RowsPrefetch<RR>& rp, const float* __
 template <int RR>
 __device__ __forceinline__ void rows_commit(const RowsPrefetch<RR>& rp, float* dst, int dld, int width, int tid) {
     const int w4 = width >> 2, n4 = ROWS * w4;
+    const float inv = frcp(w4);
 #pragma unroll
     for (int k = 0; k < RR; ++k) {
         const int i = tid + k * NTHREADS;
         if (i < n4) {
-            const int r = i / w4, j = (i - r * w4) << 2;
+            const int r = fdiv(i, inv), j = (i - r * w4) << 2;
             *(f32x4*)(dst + r * dld + j) = rp.r[k];
         }
     }
@@ -974,6 +1037,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float inv_d = frcp(a.d);
     STAMP_INIT()
     STAMP(0)
     HINT_LDS_TABLES()
@@ -1010,7 +1074,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         const bool more_tiles = tile + (int)gridDim.x < ntiles;
         load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid);
         if (gz_scale != 1.f)                   // loss gradient fused: g_z = z / B given z
-            for (int i = tid; i < ROWS * a.d; i += NTHREADS) { const int r = i / a.d; gs[r * a.xld + (i - r * a.d)] *= gz_scale; }
+            for (int i = tid; i < ROWS * a.d; i += NTHREADS) { const int r = fdiv(i, inv_d); gs[r * a.xld + (i - r * a.d)] *= gz_scale; }
         if (a.dc > 0) {
             load_tile(cs, a.cld, c, a.dc, row0, a.B, tid);
             load_tile(gcs, a.cld, nullptr, a.dc, row0, a.B, tid);
@@ -1036,7 +1100,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         {                                                                            \
             stage_build_v(a, vmap + (G).vmap_begin, (G).vw, xs, cs, vb, tid);        \
             for (int i = tid; i < ROWS * (G).sw && (G).cont != 1; i += NTHREADS) {   \
-                const int r = i / (G).sw;                                            \
+                const int r = fdiv(i, frcp((G).sw));                                           \
                 gst[r * a.sld + (i - r * (G).sw)] = 0.f;                             \
             }                                                                        \
         }
@@ -1060,6 +1124,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         const float* actA1 = (const float*)blk.wsA1;
         float* wsG2 = (float*)blk.wsG2;
         float* gparams = (float*)blk.wsT + (size_t)tile * a.thin_total;   // this row tile's thin-gradient slab
+        float* dump = (float*)blk.wsT + (size_t)ntiles * a.thin_total + (size_t)tile * 64;   // this row tile's 64 floats behind the slabs
         GroupU g = load_group(groups + (a.n_groups - 1));
         if (first_tile) stage_begin(S, stage_list(jbuf0 + jb * a.jmax, HINT_FIRST_DESC(g), wave), packed, lane);
         first_tile = false;
@@ -1096,7 +1161,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             tile_commit(stile, sb, a.xld, a.d, tid);
             rows_commit(a2t, a2, a.ald, g.aw, tid);
             RowsPrefetch<RR> a1t;                                         // a1: fetched across the coupling and the g2 stage
+#ifndef HINT_VAR_LATE_A1
             rows_issue(a1t, actA1, a.WT, g.wcol0, g.aw, row0, tid);
+#endif
             STAMP(sbase + 4)
             lds_barrier();
             STAMP(sbase + 5)
@@ -1130,12 +1197,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             if (a.split_o3) {                  // outer-product tiles only; then g2 may overwrite a2
                 STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 0) * 12 : 0)
                 stage_run<EPI_PLAIN, true>(S, stage_list(jl, g.g2_off, wave), packed, packed, bias_g, gst, a.sld, a3, nullptr,
-                                           a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
+                                           a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams, dump);
                 lds_barrier();
             }
             STAMP_JOBS(gi < 3 ? 128 + (gi * 3 + 0) * 12 : 0)
             stage_run<EPI_MASK, true>(S, stage_list(jl, g.g1_off, wave), packed, packed, bias_g, gst, a.sld, a3, a2,
-                                      a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams);
+                                      a.ald, 0, lane, gst, a.sld, a2, a.ald, gparams, dump);
+#ifdef HINT_VAR_LATE_A1
+            STAMP(104 + 4 * (a.n_groups - 1 - gi))
+            rows_issue(a1t, actA1, a.WT, g.wcol0, g.aw, row0, tid);
+#endif
             rows_commit(a1t, a1, a.ald, g.aw, tid);       // (a1 has been free since the dv stage of the group before)
             STAMP(sbase + 12)
             lds_barrier();
@@ -1163,7 +1234,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             stage_run<EPI_PLAIN, true>(S, has_next ? stage_list(jl_next, HINT_FIRST_DESC(gn), wave)
                                                    : stage_list(jl, HINT_FIRST_DESC(g), wave),
                                        packed, has_next ? packed_n : packed, bias_g, a1, a.ald, gv, nullptr, a.vld, vstride,
-                                       lane, a1, a.ald, vb, a.vld, gparams);
+                                       lane, a1, a.ald, vb, a.vld, gparams, dump);
             STAMP(sbase + 16)
             lds_barrier();
             STAMP(sbase + 17)
@@ -1172,7 +1243,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             {
                 const LDS_AS int16_t* vm = vmap + g.vmap_begin;
                 for (int i = tid; i < ROWS * g.vw; i += NTHREADS) {
-                    const int r = i / g.vw, j = i - r * g.vw;
+                    const int r = fdiv(i, frcp(g.vw)), j = i - r * g.vw;
                     const int m = vm[j];
                     if (m >= 0) {
                         float acc = gs[r * a.xld + m];
@@ -1182,7 +1253,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 }
                 if (a.dc > 0) {
                     for (int i = tid; i < ROWS * a.dc; i += NTHREADS) {
-                        const int r = i / a.dc, cc = i - r * a.dc;
+                        const int r = fdiv(i, frcp(a.dc)), cc = i - r * a.dc;
                         float acc = gcs[r * a.cld + cc];
                         for (int j = 0; j < g.vw; ++j)
                             if (vm[j] == -2 - cc)
@@ -1209,7 +1280,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 const int i = tid + q * NTHREADS;
                 float acc = 0.f;
                 if (i < ROWS * a.d) {
-                    const int r = i / a.d, j = i - r * a.d;
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
                     acc = perm_dot(gs + r * a.xld, perm + (size_t)j * a.d, 1, a.d);
                 }
                 pacc[q] = acc;
@@ -1218,7 +1289,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = tid + q * NTHREADS;
-                if (i < ROWS * a.d) { const int r = i / a.d; gs[r * a.xld + (i - r * a.d)] = pacc[q]; }
+                if (i < ROWS * a.d) { const int r = fdiv(i, inv_d); gs[r * a.xld + (i - r * a.d)] = pacc[q]; }
             }
             __syncthreads();
         }

@@ -94,6 +94,9 @@ struct hint_plan {
 };
 
 static constexpr int LDS_LIMIT = 160 * 1024;
+#ifndef HINT_JOB_OVERHEAD
+#define HINT_JOB_OVERHEAD 1200
+#endif
 static constexpr int WS_SLACK = 64;   // floats of slack at the end of every workspace array
 static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 
@@ -283,32 +286,46 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         // ---- thin weight gradients done inside the row-parallel backward kernel: 16x16 outer-product
         //      tiles  T[m][n] = sum_rows A[row][acol+m] * B[row][bcol+n]  of dW3 = g_st^T a2 (with the g2
         //      stage) and dW1 = g1^T v (with the dv stage), stored at slab[goff + m*N + n] ----
-        struct OuterTile { int32_t goff; int acol, bcol, mvalid, nvalid, N; };
-        std::vector<OuterTile> outer3, outer1;
+        struct OuterTile { int32_t goff; int acol, bcol, mvalid, nvalid, N, cnt, dir; };   // cnt tiles along dir (0: n, 1: m)
+        struct OuterMat { int base, acol, bcol, M, N; };       // one thin gradient matrix [M x N]
+        std::vector<OuterMat> outer3, outer1;
         auto thin_alloc = [&](int64_t param_off, int count) {   // contiguous compact range mirroring a tensor
             const int base = (int)tmap.size();
             for (int i = 0; i < count; ++i) tmap.push_back((int32_t)(param_off + i));
             return base;
         };
-        auto add_outer = [&](std::vector<OuterTile>& out, int base, int acol, int bcol, int M, int N) {
-            for (int mt = 0; mt * 16 < M; ++mt)
-                for (int nt = 0; nt * 16 < N; ++nt)
-                    out.push_back(OuterTile{base + 16 * mt * N + 16 * nt, acol + 16 * mt, bcol + 16 * nt,
-                                            std::min(16, M - 16 * mt), std::min(16, N - 16 * nt), N});
+        // Records of adjacent tiles along a matrix's longer side (they share the other side's operand and
+        // one decode / baton hand-over): `per` evenly sized records per row of tiles.
+        auto outer_records = [&](const std::vector<OuterMat>& mats, int per, std::vector<OuterTile>& out) {
+            out.clear();
+            for (const OuterMat& m : mats) {
+                const int MT = (m.M + 15) / 16, NTl = (m.N + 15) / 16;
+                const int dir = MT > NTl ? 1 : 0, L = dir ? MT : NTl, O = dir ? NTl : MT;
+                const int nrec = std::max(std::min(L, per), (L + 126) / 127);
+                for (int o = 0; o < O; ++o)
+                    for (int rc = 0, l0 = 0; rc < nrec; ++rc) {
+                        const int cnt = (L - l0 + (nrec - rc) - 1) / (nrec - rc);
+                        const int mt = dir ? l0 : o, nt = dir ? o : l0;
+                        const int mlast = dir ? l0 + cnt - 1 : o, nlast = dir ? o : l0 + cnt - 1;
+                        out.push_back(OuterTile{m.base + 16 * mt * m.N + 16 * nt, m.acol + 16 * mt, m.bcol + 16 * nt,
+                                                std::min(16, m.M - 16 * mlast), std::min(16, m.N - 16 * nlast), m.N, cnt, dir});
+                        l0 += cnt;
+                    }
+            }
         };
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net) {            // dW3[r][h] = g_st^T a2
                 const DNode& q = dn[ni];
                 if (!has_net(q, net)) continue;
-                add_outer(outer3, thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h), q.scol + net * q.rp,
-                          acol_of(q, net), q.r, q.h);
+                outer3.push_back(OuterMat{thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h), q.scol + net * q.rp,
+                                          acol_of(q, net), q.r, q.h});
             }
         for (int ni = g.node_begin; ni < g.node_end; ++ni)
             for (int net = 0; net < 2; ++net) {            // dW1[h][cin] = g1^T v
                 const DNode& q = dn[ni];
                 if (q.cin == 0 || !has_net(q, net)) continue;
-                add_outer(outer1, thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin), acol_of(q, net), q.vcol,
-                          q.h, q.cin);
+                outer1.push_back(OuterMat{thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin), acol_of(q, net), q.vcol,
+                                          q.h, q.cin});
             }
         // one (slab, node, net) of a stage: NT adjacent output tiles over the same k-blocks
         struct Segment { int64_t wtile; int NT, nb, tstride, acol, ocol, N, slab; };
@@ -347,13 +364,15 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             // Cut the segments into jobs of <= 3 tiles and deal them to the wavefronts.  More, smaller
             // jobs balance better, fewer, wider ones share more A reads and pay fewer prologues: try
             // every total job count from the minimum up and keep the cheapest estimated makespan.
-            const long JOB_OVERHEAD = 300;
-            // Cost model (cycles): 128 per tile and k-block on the SIMD's matrix pipe, which the two
-            // wavefronts of a SIMD (w, w+4) share, plus a per-job prologue/epilogue the partner hides
-            // only in part.
+            // Cost model (cycles, from in-kernel stamps): 128 per tile and k-block on the SIMD's matrix pipe,
+            // which the two wavefronts of a SIMD (w, w+4) share, plus a per-job prologue/epilogue - decode,
+            // dispatch, LDS round trips, the baton hand-over - that the partner hides only in part and that
+            // dwarfs the pipe time of a thin job; an outer-product record costs about as much plus 150 per tile.
+            const long JOB_OVERHEAD = HINT_JOB_OVERHEAD, OUTER_OVERHEAD = HINT_JOB_OVERHEAD, OUTER_TILE = 150;
             struct Cut { int seg, t0, nt; long cost, overhead; };   // seg < 0: outer tile -1-seg
             // which == 7: the dW3 tiles as a stage of their own (plans without LDS for the g2 buffer)
-            const std::vector<OuterTile>* outer = (which == 4 && use_a3) || which == 7 ? &outer3 : (which == 6 ? &outer1 : nullptr);
+            const std::vector<OuterMat>* outer_mats = (which == 4 && use_a3) || which == 7 ? &outer3 : (which == 6 ? &outer1 : nullptr);
+            std::vector<OuterTile> orec, best_orec;
             auto cut_segments = [&](int extra, std::vector<Cut>& cuts) {
                 // segment s gets ceil(NT/3) jobs plus a share of `extra` (largest work per job first)
                 std::vector<int> cnt(segs.size());
@@ -377,8 +396,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                         t0 += nt;
                     }
                 }
-                if (outer)      // one LDS round trip + 4 MFMAs + stores: latency, hardly any pipe time
-                    for (size_t i = 0; i < outer->size(); ++i) cuts.push_back(Cut{-1 - (int)i, 0, 1, 128, 500});
+                for (size_t i = 0; i < orec.size(); ++i) cuts.push_back(Cut{-1 - (int)i, 0, 1, OUTER_TILE * orec[i].cnt, OUTER_OVERHEAD});
             };
             auto deal = [&](const std::vector<Cut>& cuts, std::vector<std::vector<int>>& per_wave) -> long {
                 std::vector<int> idx(cuts.size());
@@ -406,11 +424,17 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             long best_cost = -1;
             int total_tiles = 0;
             for (const Segment& sg : segs) total_tiles += sg.NT;
-            for (int extra = 0; extra <= 2 * NWAVES; ++extra) {
-                cut_segments(extra, cuts);
-                const long c = deal(cuts, per_wave);
-                if (best_cost < 0 || c < best_cost) { best_cost = c; best_cuts = cuts; best_pw = per_wave; }
-                if ((int)cuts.size() >= total_tiles + (outer ? (int)outer->size() : 0)) break;
+            int max_run = 1;      // longest row of tiles of the stage's thin gradient matrices
+            if (outer_mats)
+                for (const OuterMat& m : *outer_mats) max_run = std::max(max_run, (std::max(m.M, m.N) + 15) / 16);
+            for (int per = 1; per <= std::min(max_run, 16); ++per) {     // records per row of outer-product tiles
+                if (outer_mats) outer_records(*outer_mats, per, orec);
+                for (int extra = 0; extra <= 2 * NWAVES; ++extra) {
+                    cut_segments(extra, cuts);
+                    const long c = deal(cuts, per_wave);
+                    if (best_cost < 0 || c < best_cost) { best_cost = c; best_cuts = cuts; best_pw = per_wave; best_orec = orec; }
+                    if ((int)cuts.size() >= total_tiles + (int)orec.size()) break;
+                }
             }
             const int hdr = (int)jobs.size() - g.jl_begin;
             std::vector<std::vector<TJob>> lists(NWAVES);
@@ -420,11 +444,12 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                     const Cut& c = best_cuts[i];
                     TJob t{};
                     if (c.seg < 0) {                       // outer-product tile (see TJob)
-                        const OuterTile& o = (*outer)[-1 - c.seg];
+                        const OuterTile& o = best_orec[-1 - c.seg];
                         if (o.N > 0xffff) return -1;
                         t.wtile = o.goff;
                         t.acol = (uint16_t)o.acol; t.ocol = (uint16_t)o.bcol;
                         t.nb = 0; t.nt = TJOB_OUTER;
+                        t.slab = (uint8_t)(o.dir | (o.cnt << 1));
                         t.nvalid = (uint8_t)((o.mvalid - 1) | ((o.nvalid - 1) << 4));
                         t.tstride = (uint16_t)o.N;
                         lists[w].push_back(t);
@@ -679,7 +704,9 @@ int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
     if (!P || B <= 0) return 0;
     const size_t Bp = rows_padded(B);
-    const size_t floats = (Bp * (size_t)P->WT + WS_SLACK) + (Bp / ROWS) * (size_t)P->thin_total + WS_SLACK;
+    // [g2 rows][slack][thin-gradient slabs, one per row tile][one 64-float dump per row tile: where the
+    // backward kernel's branch-free outer-product stores put the elements that fall outside a matrix]
+    const size_t floats = (Bp * (size_t)P->WT + WS_SLACK) + (Bp / ROWS) * (size_t)P->thin_total + (Bp / ROWS) * (size_t)64 + WS_SLACK;
     return floats * sizeof(float);
 }
 

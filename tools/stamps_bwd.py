@@ -11,7 +11,7 @@ dev = "cuda:0"
 lib = _lib.load()
 blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(dev)
 x = torch.randn(B, d, device=dev, requires_grad=True)
-buf = torch.zeros(8 * 256 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 512 + 64, dtype=torch.int64, device=dev)
 (z,) = blk([x]); J = blk.jacobian(None)
 L = (0.5 * (z ** 2).sum(1) - J).mean()
 for _ in range(5):
@@ -22,7 +22,7 @@ lib.hint_debug_set_backward_stages(1)
 L.backward(retain_graph=True)
 torch.cuda.synchronize()
 lib.hint_debug_set_backward_stages(3)
-s = buf.cpu()[:2048].view(8, 256)
+s = buf.cpu()[:4096].view(8, 512)
 names = {0: "start", 1: "loaded+sync", 120: "stored"}
 # phase stamps of the tape-based backward kernel (ids 2 + 20*group + k)
 stages = ["-", "-", "-", "-", "commit s,a2", "sync", "-", "-", "couple", "sync",
@@ -52,3 +52,10 @@ for gi in range(3):
         for w in range(8):
             ts = [s[w, base + k].item() for k in range(12) if s[w, base + k].item() != 0]
             if ts: print(f"   w{w}  start {ts[0]-t0:7d}  " + " ".join(f"+{b-a}" for a, b in zip(ts, ts[1:])))
+
+# sequential section log of one stage (-DHINT_STAMP_STAGE=<job base id>): section id, cycles since the previous entry
+if s[:, 256].max().item() != 0:
+    print("\nsection log (K:+cycles)  1 job top, 3 run_job entered, 5 k-loop issued, 6 next weights requested, 7 job done, 8 outer operands read, 9 outer: next weights requested")
+    for w in range(8):
+        ent = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in s[w, 256:512].tolist() if v != 0]
+        if ent: print(f"   w{w} @{ent[0][1]-t0}: " + " ".join(f"{k}:+{b-a}" for (k, b), (_, a) in zip(ent[1:], ent[:-1])))

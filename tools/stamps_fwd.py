@@ -13,13 +13,13 @@ dev = "cuda:0"
 lib = _lib.load()
 blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(dev)
 x = torch.randn(B, d, device=dev)
-buf = torch.zeros(8 * 256 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 512 + 64, dtype=torch.int64, device=dev)
 assert lib.hint_debug_set_stamp_buffer(buf.data_ptr()) == 0, "not a stamps build"
 with torch.no_grad():
     for _ in range(20):
         blk([x])
 torch.cuda.synchronize()
-s = buf.cpu()[:2048].view(8, 256)
+s = buf.cpu()[:4096].view(8, 512)
 names = {0: "start", 1: "x loaded+sync"}
 for gi in range(4):
     for k, nm in enumerate(["build_v", "sync", "L1", "sync", "L2", "sync", "L3", "sync", "couple", "sync"]):
