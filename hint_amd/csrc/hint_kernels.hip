@@ -319,6 +319,19 @@ __device__ __forceinline__ void run_job(const JobU& j, f32x4 (&b0)[3], f32x4 (&b
         a0 = *(const f32x4*)ap;
 #endif
         int kb = 0;
+        // (forward epilogues only: in the backward kernel, which sits at the register limit, the extra
+        // path costs 36 more bytes of scratch per lane and 17 us)
+        if ((EPI == EPI_RELU || EPI == EPI_LINEAR) && NB == 1) {
+            // a thin job (K <= 16: the first layers): no ring, no loads, one way out
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(a0.x, b0[t].x, acc[t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(a0.y, b0[t].y, acc[t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(a0.z, b0[t].z, acc[t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(a0.w, b0[t].w, acc[t]);
+        } else
         // loads past the job's last k-block re-read that block (L1 hit, never used)
 #ifdef HINT_ABLATE_AREAD
 #define HINT_AREAD(AN, KA)
