@@ -141,6 +141,7 @@ struct KArgs {
     int32_t d, dc;
     int32_t xld, cld, ald, vld, sld;   // LDS row strides (floats)
     int32_t max_aw;                    // widest group's activation columns (a1 / a2 buffers)
+    int32_t perm_lds;                  // float offset in LDS of the chain's d x d permutation matrices ([n_chain][d][d]); 0: read them from global memory
     int32_t s3, sv;                    // slab counts of the st / gv buffers
     int32_t WT;                        // workspace row width (floats)
     int32_t split_o3;                  // backward: no LDS for a separate g2 buffer -> dW3 tiles run as their own phase

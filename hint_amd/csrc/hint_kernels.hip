@@ -187,8 +187,14 @@ __global__ __launch_bounds__(256) void hint_pack_many_kernel(const PackItem* __r
         }
         return;
     }
+    // which item: one parallel look at every item's first workgroup instead of a chain of dependent loads
     int it = 0;
-    while (it + 1 < n_items && (int)blockIdx.x >= items[it + 1].grid_begin) ++it;
+    for (int i0 = 0; i0 < n_items; i0 += 64) {
+        const int i = i0 + (int)(threadIdx.x & 63);
+        const bool ge = i < n_items && (int)blockIdx.x >= items[i].grid_begin;
+        it += __builtin_popcountll(__ballot(ge));
+    }
+    it = __builtin_amdgcn_readfirstlane(it - 1);
     const PackItem q = items[it];
     pack_body((int)blockIdx.x - q.grid_begin, q.segs, (const int2*)q.ptiles, q.n_tiles, q.bmap, q.n_bias, q.bias_off, q.params,
               q.packed);
@@ -800,6 +806,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
         meta_commit(mp_, a, mbase, tid);
         jobs_commit<false>(jp0, jbuf0, bias0, a.bmax, tid);
     }
+    // The chain's fixed d x d permutation matrices, once per workgroup (when the launch found LDS for
+    // them): read from global memory at every block boundary they cost an exposed L2 round trip there.
+    float* ptab = lds + a.perm_lds;
+    const int pdd = a.d * a.d;
+    if (a.perm_lds > 0) {
+        for (int i = tid; i < n_chain * pdd; i += NTHREADS) {
+            const int cbi = fdiv(i, frcp(pdd));
+            const float* pp = (chain != nullptr) ? chain[cbi].perm : one.perm;
+            ptab[i] = pp != nullptr ? ((const GLOBAL_AS float*)pp)[i - cbi * pdd] : 0.f;
+        }
+    }
 
     // One Stage object travels through all GEMM stages: every stage_run() leaves it primed for
     // the stage that follows (first job decoded, its first weights in flight) - also across
@@ -850,12 +867,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
             const bool train = !REV && actA1 != nullptr;
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
-                for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    xo[r * a.xld + j] = perm_dot(xs + r * a.xld, perm + j, a.d, a.d);
+                if (a.perm_lds > 0) {
+                    for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        xo[r * a.xld + j] = perm_dot(xs + r * a.xld, ptab + cb * pdd + j, a.d, a.d);
+                    }
+                    xcur = xflip - xcur;
+                    lds_barrier();            // (no global load to wait for: the weight prefetch stays in flight)
+                } else {
+                    for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        xo[r * a.xld + j] = perm_dot(xs + r * a.xld, perm + j, a.d, a.d);
+                    }
+                    xcur = xflip - xcur;
+                    __syncthreads();
                 }
-                xcur = xflip - xcur;
-                __syncthreads();
                 if (tape != nullptr)      // the permuted input is what the backward pass starts from
                     store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, xs, a.xld, a.d, row0, a.B, tid);
             } else if (!REV && cb > 0 && tape != nullptr) {
@@ -956,12 +982,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(NWAVES
                 g = gn;
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
-                for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    xo[r * a.xld + j] = perm_dot(xs + r * a.xld, perm + (size_t)j * a.d, 1, a.d);
+                if (a.perm_lds > 0) {
+                    for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        xo[r * a.xld + j] = perm_dot(xs + r * a.xld, ptab + cb * pdd + j * a.d, 1, a.d);
+                    }
+                    xcur = xflip - xcur;
+                    lds_barrier();
+                } else {
+                    for (int i = tid; i < ROWS * a.d; i += NTHREADS) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        xo[r * a.xld + j] = perm_dot(xs + r * a.xld, perm + (size_t)j * a.d, 1, a.d);
+                    }
+                    xcur = xflip - xcur;
+                    __syncthreads();
                 }
-                xcur = xflip - xcur;
-                __syncthreads();
             }
             blk = nblk;
         }

@@ -97,6 +97,7 @@ static constexpr int LDS_LIMIT = 160 * 1024;
 #ifndef HINT_JOB_OVERHEAD
 #define HINT_JOB_OVERHEAD 1200
 #endif
+static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
 static constexpr int WS_SLACK = 64;   // floats of slack at the end of every workspace array
 static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 
@@ -619,7 +620,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (e == hipSuccess) e = upload((void**)&P->d_dwjobs, dwj.data(), dwj.size() * sizeof(DWJob));
     if (e == hipSuccess) e = upload((void**)&P->d_segs, segs.data(), segs.size() * sizeof(PackSeg));
     if (e == hipSuccess) e = upload((void**)&P->d_ptiles, ptiles.data(), ptiles.size() * sizeof(int2));
-    if (e == hipSuccess) e = set_max_lds(P->lds_fwd, P->lds_bwd);
+    if (e == hipSuccess) e = set_max_lds(std::min(LDS_LIMIT, P->lds_fwd + PERM_LDS_MAX), std::min(LDS_LIMIT, P->lds_bwd + PERM_LDS_MAX));
     if (e != hipSuccess) {
         hint_plan_destroy(P);
         return fail("hint_plan_create: device setup failed: %s", hipGetErrorString(e));
@@ -714,6 +715,14 @@ int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
     return P ? (backward ? P->lds_bwd : P->lds_fwd) : -1;
 }
 
+// LDS bytes of the launch: the plan's, plus the chain's permutation matrices when they fit behind it
+static int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a) {
+    const long extra = (long)n_blocks * P->d * P->d * (long)sizeof(float);
+    a->perm_lds = 0;
+    if (!any_perm || extra > PERM_LDS_MAX || lds_plan + extra > LDS_LIMIT) return lds_plan;
+    a->perm_lds = lds_plan / (int)sizeof(float);
+    return lds_plan + (int)extra;
+}
 static KArgs make_args(const hint_plan* P, int B) {
     KArgs a{};
     a.meta = P->d_meta; a.jobs = P->d_jobs; a.bmap = P->d_tbmap; a.thin_total = P->thin_total;
@@ -797,14 +806,18 @@ static void bind_tape(const hint_plan* P, int B, float* tape, ChainBlock* b) {
 // part A (row-parallel) + part B (weight gradients) of the backward pass of one block or a chain
 static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, int n_chain,
                         const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
-                        float gz_scale, float gJ_const, int B, hipStream_t s) {
+                        float gz_scale, float gJ_const, int B, hipStream_t s, bool any_perm) {
     const size_t Bp = rows_padded(B);
     const int ntiles = (B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
     const int stages = g_bwd_stages;
-    if (stages & 1)
+    if (stages & 1) {
+        // (the permutation matrices stay in global memory here: the LDS table was measured +5 us in this
+        // kernel, which has no register to spare)
+        (void)any_perm;
         HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, one, chain, n_chain, x, c, g_z, g_J, g_x, g_c,
                            gz_scale, gJ_const, s));
+    }
     if (!(stages & 2)) return 0;
     // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
     // to cover the chip, every workgroup reducing at least 128 rows
@@ -832,7 +845,9 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     ChainBlock one{};
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, rev ? nullptr : tape, &one);
-    HIP_TRY(launch_apply(rev, make_args(P, B), P->lds_fwd, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
+    KArgs a = make_args(P, B);
+    const int lds = lds_with_perms(P, P->lds_fwd, 1, perm != nullptr, &a);
+    HIP_TRY(launch_apply(rev, a, lds, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
 }
@@ -889,7 +904,7 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
     bind_tape(P, B, const_cast<float*>(tape), &one);
     one.gparams = g_params;
     split_workspace(P, B, workspace, &one);
-    return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, s);
+    return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, s, one.perm != nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -904,6 +919,11 @@ struct hint_chain {
     std::vector<char> set;
     ChainBlock* d_table = nullptr;
 };
+
+static bool chain_any_perm(const hint_chain* C) {
+    for (const ChainBlock& b : C->host) if (b.perm != nullptr) return true;
+    return false;
+}
 
 int hint_chain_create(const hint_plan* P, int32_t n_blocks, int32_t B, hint_chain** out) {
     if (!P || !out) return fail("hint_chain_create: null argument");
@@ -967,7 +987,9 @@ int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c
     if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
     const int ntiles = (C->B + ROWS - 1) / ROWS;
     const int grid = std::min(ntiles, P->num_cu * 8);
-    HIP_TRY(launch_apply(false, make_args(P, C->B), P->lds_fwd, grid, C->host[0], C->d_table, C->n, x, c, z, J,
+    KArgs a = make_args(P, C->B);
+    const int lds = lds_with_perms(P, P->lds_fwd, C->n, chain_any_perm(C), &a);
+    HIP_TRY(launch_apply(false, a, lds, grid, C->host[0], C->d_table, C->n, x, c, z, J,
                          J_in, loss_acc, noise, (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
     return 0;
 }
@@ -985,7 +1007,7 @@ int hint_chain_backward(const hint_chain* C, const float* x, const float* c, con
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate)
         for (int i = 0; i < C->n; ++i) HIP_TRY(launch_zero(C->host[i].gparams, (long)P->param_floats, P->num_cu, s));
-    return run_backward(P, C->host[0], C->d_table, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, s);
+    return run_backward(P, C->host[0], C->d_table, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, s, chain_any_perm(C));
 }
 
 void hint_chain_destroy(hint_chain* C) {
