@@ -133,6 +133,7 @@ def test_reference_training_loop_body_on_module_path():
     (6, 0, [448, 64], False, 2, 300, False),               # split (h > 384) root
     (7, 0, [24, 12, 6], False, 3, 200, True),              # node permutations folded into the chain's matrices
     (6, 0, [16, 8], False, 2, 40007, False),               # more row tiles than workgroups (persistent loop), ragged
+    (70, 0, [24, 12], True, 2, 100, False),                # permutation matrices too big for the LDS table (read from global memory)
 ])
 def test_chain_launch_equals_per_block_launches(d, dc, widths, perm_first, n_blocks, B, reshuffle):
     """hint_chain_forward / hint_chain_backward (one launch for all blocks) against the same

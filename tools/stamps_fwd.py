@@ -50,3 +50,10 @@ for gi in range(3):
         for w in range(8):
             ts = [s[w, base + k].item() for k in range(12) if s[w, base + k].item() != 0]
             if ts: print(f"   w{w}  start {ts[0]-t0:7d}  " + " ".join(f"+{b-a}" for a, b in zip(ts, ts[1:])))
+
+# sequential section log of one stage (-DHINT_STAMP_STAGE=<job base id>): section id, cycles since the previous entry
+if s[:, 256].max().item() != 0:
+    print("\nsection log (K:+cycles)  1 job top, 3 run_job entered, 5 k-loop issued, 6 next weights requested, 7 job done, 8 outer operands read, 9 outer: next weights requested")
+    for w in range(8):
+        ent = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in s[w, 256:512].tolist() if v != 0]
+        if ent: print(f"   w{w} @{ent[0][1]-t0}: " + " ".join(f"{k}:+{b-a}" for (k, b), (_, a) in zip(ent[1:], ent[:-1])))
