@@ -156,17 +156,24 @@ class ConditionalFlowTrainer:
     (the 3 500 parameter tensors of the cfg-4 model cost the module path ~65 ms of per-tensor
     launches per step), one re-pack launch, one gradient all-reduce (hint_amd/dp.py), one fused
     clamp+Adam launch.  The two lanes meet in the backward pass: dL/dy of block i is the sum of
-    what ac_y_i and ac_y_to_x_i (through its condition) send back."""
+    what ac_y_i and ac_y_to_x_i (through its condition) send back.
+    use_graph (one process): the whole iteration - re-pack, both lanes forward and backward, the small
+    torch ops between them, clamp+Adam - is captured once per batch shape into a hipGraph and replayed
+    (the step counter and Adam's bias corrections live in device memory, written by the re-pack
+    launch's prologue, so nothing in the graph depends on the host's step count)."""
 
     def __init__(self, flow: ConditionalHintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
-                 weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01, group=None):
+                 weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01, group=None,
+                 use_graph: bool = True):
         from . import _lib, dp
         self._lib, self._dp = _lib, dp
         self.lib = _lib.load()
         self.flow, self.group = flow, group
-        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self._lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.grad_clamp, self.noise = grad_clamp, noise
         self.step_count = 0
+        self.use_graph = use_graph
+        self._graph, self._static, self._out = None, None, None
         dev = next(flow.parameters()).device
         if dev.type != "cuda":
             raise HintAmdError("ConditionalFlowTrainer needs the model on a GPU (no CPU path)")
@@ -187,6 +194,20 @@ class ConditionalFlowTrainer:
             e.pack()
         self._pack_group, self._pack_key = None, None
         self.last = None
+        # device-side step state (see FlowTrainer): opt_state = {lr, beta1, beta2, lr/(1-beta1^t),
+        # 1/sqrt(1-beta2^t), ...}, rng_state[1] = step count; the re-pack launch's prologue advances them
+        self.opt_state = torch.tensor([lr, betas[0], betas[1], 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+        self.rng_state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._zero = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, v: float):
+        self._lr = float(v)
+        self.opt_state[0] = self._lr            # read by the optimizer launch on the device: no re-capture
 
     def __del__(self):
         try:
@@ -195,7 +216,7 @@ class ConditionalFlowTrainer:
         except Exception:
             pass
 
-    def _pack_all(self):
+    def _pack_all(self, prologue: bool = False):
         import ctypes as C
         key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines)
         if self._pack_key != key:
@@ -211,15 +232,55 @@ class ConditionalFlowTrainer:
                                 "hint_pack_group_create")
             self._pack_group, self._pack_key = handle, key
         with torch.cuda.device(self.device):
-            st = self.lib.hint_pack_group_run(self._pack_group, torch.cuda.current_stream(self.device).cuda_stream)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if prologue:      # also: step counter += 1, Adam's bias corrections of that step -> opt_state
+                st = self.lib.hint_pack_group_run_ex(self._pack_group, self._zero.data_ptr(), self._zero.numel(),
+                                                     self.rng_state.data_ptr(), self.opt_state.data_ptr(), stream)
+            else:
+                st = self.lib.hint_pack_group_run(self._pack_group, stream)
         self._lib.check(st, "hint_pack_group_run")
+
+    def _graphable(self) -> bool:
+        return self.use_graph and self._dp.world_info(self.group)[1] == 1 and \
+            not (torch.distributed.is_available() and torch.distributed.is_initialized())
 
     def step(self, x: torch.Tensor, y: torch.Tensor):
         """one iteration on this rank's rows; returns device scalars (0.5*|z|^2 mean, -log|det J| mean)"""
-        flow, B = self.flow, x.shape[0]
         for e in self.engines:
             e.ensure_arena()
-        self._pack_all()
+        if not self._graphable():
+            return self._iteration(x, y, on_device_adam=False)
+        if self._graph is None or self._static[0].shape != x.shape or self._static[1].shape != y.shape:
+            self._capture(x, y)
+        self._static[0].copy_(x)
+        self._static[1].copy_(y)
+        self._graph.replay()
+        self.step_count += 1
+        return self._out
+
+    def _capture(self, x, y):
+        sx, sy = x.clone(), y.clone()
+        snap = [t.clone() for t in (self.P, self.M, self.V)]
+        state = (self.opt_state.clone(), self.rng_state.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):          # warm-up on a side stream (allocator, kernel loading) ...
+            self._iteration(sx, sy, on_device_adam=True)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        for t, s0 in zip((self.P, self.M, self.V), snap):      # ... whose optimizer step is taken back
+            t.copy_(s0)
+        self.opt_state.copy_(state[0]); self.rng_state.copy_(state[1])
+        self.G.zero_()
+        self.rng_state[1] = self.step_count
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._out = self._iteration(sx, sy, on_device_adam=True)
+        self._graph, self._static = g, (sx, sy)
+
+    def _iteration(self, x: torch.Tensor, y: torch.Tensor, on_device_adam: bool):
+        flow, B = self.flow, x.shape[0]
+        self._pack_all(prologue=on_device_adam)
         if self.noise > 0:
             x = x.add(torch.randn_like(x), alpha=self.noise)
         eng = dict(zip([(k, i) for k, i, _ in self.mods], self.engines))
@@ -258,13 +319,22 @@ class ConditionalFlowTrainer:
             if i > 0:
                 gy = gy @ flow.perm_y[i].W.t()
                 gx = gx @ flow.perm_x[i].W.t()
-        scale = self._dp.allreduce_sum_(self.G, self.group)
-        self.step_count += 1
-        with torch.cuda.device(self.device):
-            st = self.lib.hint_adam_step(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
-                                         self.n_floats, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
-                                         self.wd, scale, self.grad_clamp, 1,
-                                         torch.cuda.current_stream(self.device).cuda_stream)
-        self._lib.check(st, "hint_adam_step")
+        if on_device_adam:                      # one process: step factors come from opt_state (prologue above)
+            with torch.cuda.device(self.device):
+                st = self.lib.hint_adam_step_dev(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                 self.n_floats, self.opt_state.data_ptr(), self.betas[0], self.betas[1],
+                                                 self.eps, self.wd, 1.0, self.grad_clamp, 1,
+                                                 torch.cuda.current_stream(self.device).cuda_stream)
+            self._lib.check(st, "hint_adam_step_dev")
+        else:
+            scale = self._dp.allreduce_sum_(self.G, self.group)
+            self.step_count += 1
+            with torch.cuda.device(self.device):
+                st = self.lib.hint_adam_step(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                             self.n_floats, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                             self.wd, scale, self.grad_clamp, 1,
+                                             torch.cuda.current_stream(self.device).cuda_stream)
+            self._lib.check(st, "hint_adam_step")
+            self.rng_state[1] = self.step_count          # keep the device counter in step for a later capture
         self.last = (zy, zx, Jx, Jy)
         return l0, l1

@@ -107,9 +107,12 @@ def test_conditional_flow_matches_oracle_composition():
     assert (xr.cpu() - x).abs().max().item() < 1e-4 * scale
 
 
-def test_conditional_trainer_equals_reference_loop_on_module_path():
-    """ConditionalFlowTrainer (flat arenas, fused clamp+Adam, manual two-lane backward) against the
-    statements of train_conditional.py:120-150 executed on the drop-in modules with torch.optim.Adam"""
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_conditional_trainer_equals_reference_loop_on_module_path(use_graph):
+    """ConditionalFlowTrainer (flat arenas, fused clamp+Adam, manual two-lane backward; with use_graph
+    the whole iteration replayed from one hipGraph) against the statements of
+    train_conditional.py:120-150 executed on the drop-in modules with torch.optim.Adam; the learning
+    rate changes before the last step (a schedule: the graph reads it from device memory)"""
     import copy
     torch.manual_seed(4)
     nx, ny, nb, hidden, B = 10, 3, 2, 24, 256
@@ -123,7 +126,10 @@ def test_conditional_trainer_equals_reference_loop_on_module_path():
     params = [p for p in m1.parameters() if p.requires_grad]
     optim = torch.optim.Adam(params, lr=0.01 * 3e-2, betas=(0.9, 0.95), eps=1e-4, weight_decay=1.86e-5)
     ref_losses = []
-    for x, y in zip(xs, ys):
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        if k == 2:
+            for grp in optim.param_groups:
+                grp["lr"] = 0.5 * grp["lr"]
         optim.zero_grad()
         z_y, z_x = m1([y, x])
         z = torch.cat([z_x, z_y], dim=-1)
@@ -135,9 +141,11 @@ def test_conditional_trainer_equals_reference_loop_on_module_path():
         optim.step()
         ref_losses.append([l.item() for l in batch_losses])
 
-    tr = hint_amd.ConditionalFlowTrainer(m2, noise=0.0)
+    tr = hint_amd.ConditionalFlowTrainer(m2, noise=0.0, use_graph=use_graph)
     losses = []
-    for x, y in zip(xs, ys):
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        if k == 2:
+            tr.lr = 0.5 * tr.lr
         l0, l1 = tr.step(x, y)
         losses.append([float(l0), float(l1)])
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=1e-4, atol=1e-5)
