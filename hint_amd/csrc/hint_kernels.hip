@@ -426,16 +426,16 @@ __device__ __forceinline__ void run_outer(const JobU& j, f32x4 (&b0)[3], f32x4 (
 #pragma unroll
             for (int i = 0; i < 4; ++i) { av[t][i] = ap[4 * i * lda + tt * astep]; bv[t][i] = bp[4 * i * ldb + tt * bstep]; }
         }
-        f32x4 acc[3][2];
+        f32x4 acc[3];      // (three tiles interleave: consecutive MFMAs on one accumulator are three apart)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t][i & 1] = mfma4(av[t][i], bv[t][i], acc[t][i & 1]);
+            for (int t = 0; t < 3; ++t) acc[t] = mfma4(av[t][i], bv[t][i], acc[t]);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const f32x4 r = acc[t][0] + acc[t][1];
+            const f32x4 r = acc[t];
             const bool lastt = t0 + t + 1 >= cnt;
             const int mvalid = t >= c3 ? 0 : ((dir && !lastt) ? 16 : mlast), nvalid = (!dir && !lastt) ? 16 : nlast;
             float* o = o0 + (t0 + t) * gstep;
