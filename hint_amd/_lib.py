@@ -31,6 +31,8 @@ _PROTOS = {
     "hint_last_error": (C.c_char_p, []),
     "hint_plan_create": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.POINTER(C.c_void_p)]),
+    "hint_plan_check": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                  C.POINTER(C.c_int64)]),
     "hint_plan_destroy": (None, [C.c_void_p]),
     "hint_plan_param_floats": (C.c_int64, [C.c_void_p]),
     "hint_plan_packed_floats": (C.c_int64, [C.c_void_p]),

@@ -98,7 +98,8 @@ static constexpr int LDS_LIMIT = 160 * 1024;
 #define HINT_JOB_OVERHEAD 1200
 #endif
 static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
-static constexpr int WS_SLACK = 64;   // floats of slack at the end of every workspace array
+static constexpr int WS_SLACK = 64;
+static thread_local bool g_host_only = false;   // hint_plan_check: build and verify the plan, touch no device   // floats of slack at the end of every workspace array
 static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
 
 static int fwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3) {
@@ -473,6 +474,47 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 if (lists[w].empty()) lists[w].push_back(TJob{});
                 longest = std::max(longest, lists[w].size());
             }
+            // ---- self-check (always on; also what hint_plan_check exists for): read the records back the
+            //      way the kernels do and make sure every output tile of the stage is produced exactly
+            //      once, by the right k-blocks, and every outer-product tile exactly once ----
+            {
+                std::vector<std::vector<int>> seen(segs.size());
+                for (size_t i = 0; i < segs.size(); ++i) seen[i].assign(segs[i].NT, 0);
+                std::vector<int64_t> outer_seen;
+                for (int w = 0; w < NWAVES; ++w)
+                    for (const TJob& t : lists[w]) {
+                        if (t.nt == 0) continue;
+                        if (t.nt == TJOB_OUTER) {
+                            const int dir = t.slab & 1, cnt = t.slab >> 1;
+                            if (cnt < 1) return -2;
+                            for (int k = 0; k < cnt; ++k) outer_seen.push_back((int64_t)t.wtile + (int64_t)k * (dir ? 16 * t.tstride : 16));
+                            continue;
+                        }
+                        bool found = false;
+                        for (size_t i = 0; i < segs.size() && !found; ++i) {
+                            const Segment& sg = segs[i];
+                            if (sg.slab != t.slab || t.ocol < sg.ocol || t.ocol >= sg.ocol + 16 * sg.NT || sg.nb != t.nb) continue;
+                            const int t0 = (t.ocol - sg.ocol) / 16;
+                            if ((t.ocol - sg.ocol) % 16 || t0 + t.nt > sg.NT || t.nt > 3) return -2;
+                            if (sg.nb > 0 && (t.wtile != sg.wtile + (int64_t)t0 * sg.tstride || t.acol != sg.acol || t.tstride != sg.tstride)) continue;
+                            const int want_valid = std::min(16, sg.N - 16 * (t0 + t.nt - 1));
+                            if (t.nvalid != want_valid) return -2;
+                            for (int k = 0; k < t.nt; ++k) ++seen[i][t0 + k];
+                            found = true;
+                        }
+                        if (!found) return -2;
+                    }
+                for (size_t i = 0; i < segs.size(); ++i)
+                    for (int c : seen[i]) if (c != 1) return -2;
+                std::vector<int64_t> outer_want;
+                if (outer_mats)
+                    for (const OuterMat& m : *outer_mats)
+                        for (int mt = 0; mt * 16 < m.M; ++mt)
+                            for (int nt = 0; nt * 16 < m.N; ++nt) outer_want.push_back((int64_t)m.base + 16 * mt * m.N + 16 * nt);
+                std::sort(outer_seen.begin(), outer_seen.end());
+                std::sort(outer_want.begin(), outer_want.end());
+                if (outer_seen != outer_want) return -2;
+            }
             const int stride = (int)longest;
             for (int w = 0; w < NWAVES; ++w) {
                 if (lists[w].size() > 0xffff) return -1;
@@ -491,6 +533,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         g.g1_off = emit_stage(5);
         g.dv_off = emit_stage(6);
         g.o3_off = use_a3 ? 0 : emit_stage(7);
+        if (g.o3_off == -2 || g.l1_off == -2 || g.l2_off == -2 || g.l3_off == -2 || g.g2_off == -2 || g.g1_off == -2 ||
+            g.dv_off == -2) {
+            delete P;
+            return fail("hint_plan_create: internal error, a stage's job lists do not cover its tiles exactly once");
+        }
         if (g.o3_off < 0 || g.l1_off < 0 || g.l2_off < 0 || g.l3_off < 0 || g.g2_off < 0 || g.g1_off < 0 || g.dv_off < 0) {
             delete P;
             if (cap_scale < 16) { *retry_smaller = true; return 1; }
@@ -600,6 +647,12 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->n_dwjobs = (int)dwj.size();
     P->n_ptiles = (int)ptiles.size();
 
+    P->thin_total = (int)tmap.size();
+    if (g_host_only) {           // hint_plan_check: everything above ran (and checked itself); no device
+        P->num_cu = 256;
+        *out = P;
+        return 0;
+    }
     // ---- upload ----
     HIP_TRY(hipGetDevice(&P->device));
     hipDeviceProp_t prop;
@@ -664,6 +717,21 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
             if (st == 0 || !retry) return st;
         }
     return fail("hint_plan_create: could not fit the block into LDS");
+}
+
+int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int64_t* stats) {
+    hint_plan* P = nullptr;
+    g_host_only = true;
+    const int st = hint_plan_create(nodes, n_nodes, d, dc, clamp, &P);
+    g_host_only = false;
+    if (st != 0) return st;
+    if (stats) {
+        stats[0] = P->n_groups; stats[1] = P->n_levels; stats[2] = P->WT; stats[3] = P->thin_total;
+        stats[4] = P->lds_fwd; stats[5] = P->lds_bwd; stats[6] = P->jmax; stats[7] = P->n_dwjobs;
+        stats[8] = P->param_floats; stats[9] = P->packed_floats; stats[10] = P->split_o3; stats[11] = P->max_aw;
+    }
+    delete P;                   // (host-only plans own no device memory)
+    return 0;
 }
 
 void hint_plan_destroy(hint_plan* P) {

@@ -43,6 +43,30 @@ def conv_subnet_constructor(c_in, c_out, c_internal):
     raise NotImplementedError("conv subnets (hint.py:15-18) are out of scope: no reference config uses conv=True")
 
 
+def node_descs(nodes):
+    """the C ABI's node table (hint_node_desc[]) of a flattened tree, its parameters in arena order,
+    their float offsets and the arena size: what hint_plan_create / hint_plan_check take"""
+    params: List[nn.Parameter] = []
+    offsets: List[int] = []
+    descs = (NodeDesc * len(nodes))()
+    cursor = 0
+    for i, (node, off, depth) in enumerate(nodes):
+        D = node.data_shape[0]
+        dsc = descs[i]
+        dsc.off, dsc.D, dsc.k, dsc.r = off, D, node.split_idx, D - node.split_idx
+        dsc.h, dsc.depth = node.s[0].out_features, depth
+        j = 0
+        for net in (node.s, node.t):
+            for li in (0, 2, 4):
+                for p in (net[li].weight, net[li].bias):
+                    dsc.p_off[j] = cursor
+                    params.append(p)
+                    offsets.append(cursor)
+                    cursor += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                    j += 1
+    return descs, params, offsets, cursor
+
+
 class _Engine:
     """Plan + flat parameter arena of one (root) tree on one device."""
 
@@ -52,24 +76,7 @@ class _Engine:
         self.d = tree.data_shape[0]
         self.dc = tree.condition_length
         nodes = tree._flat_nodes()
-        self.params: List[nn.Parameter] = []
-        self.offsets: List[int] = []
-        descs = (NodeDesc * len(nodes))()
-        cursor = 0
-        for i, (node, off, depth) in enumerate(nodes):
-            D = node.data_shape[0]
-            dsc = descs[i]
-            dsc.off, dsc.D, dsc.k, dsc.r = off, D, node.split_idx, D - node.split_idx
-            dsc.h, dsc.depth = node.s[0].out_features, depth
-            j = 0
-            for net in (node.s, node.t):
-                for li in (0, 2, 4):
-                    for p in (net[li].weight, net[li].bias):
-                        dsc.p_off[j] = cursor
-                        self.params.append(p)
-                        self.offsets.append(cursor)
-                        cursor += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
-                        j += 1
+        descs, self.params, self.offsets, cursor = node_descs(nodes)
         self.total = max(cursor, _ALIGN)
         # two trees with equal keys get identical plans (they can share chained launches)
         self.shape_key = (self.d, self.dc, float(tree.clamp),

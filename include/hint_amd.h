@@ -59,6 +59,15 @@ typedef struct hint_plan hint_plan;
  * hint.py:57,60).  Replaces HierarchicalAffineCouplingTree.__init__ (hint.py:25-54). */
 int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc,
                      float clamp, hint_plan** out);
+
+/* Host-only dry run of hint_plan_create (no device needed, nothing uploaded): builds the plan, lets the
+ * planner verify its own job lists (every output tile of every GEMM stage produced exactly once, every
+ * outer-product tile of the thin weight gradients exactly once) and reports what it came to:
+ * stats[12] = { groups, levels, WT (activation columns), thin-gradient slab floats, LDS bytes forward,
+ * LDS bytes backward, longest per-group job list, part-B tile jobs, parameter floats, packed floats,
+ * split_o3, widest group }.  For tests and tools; same return convention as hint_plan_create. */
+int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
+                    int64_t* stats);
 void hint_plan_destroy(hint_plan* plan);
 
 /* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size). */

@@ -1,0 +1,88 @@
+"""Planner (hint_amd/csrc/hint_plan.cpp) without a GPU: hint_plan_check builds the launch plan of a block
+on the host, lets the planner verify its own job lists (every output tile of every GEMM stage of the
+forward and backward kernels produced exactly once, every outer-product tile of the thin weight
+gradients exactly once) and reports the plan's figures.  Covers the BASELINE configs' block shapes
+(SURVEY.md §8a/d), the conditional lanes, split (h > 384) nodes and ragged widths."""
+import ctypes as C
+
+import pytest
+import torch
+
+import hint_amd
+from hint_amd import _lib
+from hint_amd.hint import node_descs
+
+STAT = ["groups", "levels", "WT", "thin", "lds_fwd", "lds_bwd", "jmax", "dwjobs", "params", "packed", "split_o3", "max_aw"]
+
+
+def check(tree, d, dc, clamp=4.0):
+    lib = _lib.load()
+    nodes = tree._flat_nodes()
+    descs, params, offsets, total = node_descs(nodes)
+    stats = (C.c_int64 * 12)()
+    st = lib.hint_plan_check(descs, len(nodes), d, dc, clamp, stats)
+    assert st == 0, lib.hint_last_error().decode()
+    return dict(zip(STAT, list(stats))), nodes, total
+
+
+@pytest.mark.parametrize("d,dc,widths,n_nodes,n_levels", [
+    (6, 0, [200, 100, 50, 25], 3, 2),        # cfg 1 (power_hint_4.py); nodes / levels as SURVEY.md §8a counts them
+    (6, 0, [140, 70, 35, 17], 3, 2),         # cfg 2 (power_hint_8.py)
+    (8, 0, [128, 64, 32, 16], 7, 3),         # cfg 3 (gas_hint_8.py)
+    (100, 0, [224, 112, 56], 71, 7),         # cfg 4 x lane (conditional_hint_4_full.py)
+    (100, 4, [224, 112, 56], 71, 7),         # conditional_recursive_cinn_4.py style
+    (43, 0, [67, 33, 16, 8], 31, 5),         # cfg 5 as BASELINE words it
+    (42, 0, [67, 33, 16, 8], 31, 5),         # the reference's MINIBOONE width (data.py:423)
+    (6, 0, [512, 256, 128], 3, 2),           # *_big: h > 384, nets planned one at a time
+    (5, 0, [385], None, None),
+    (1, 0, [8], 1, 1),
+    (2, 3, [7, 5], 1, 1),
+    (128, 0, [32, 16], None, None),
+    (9, 2, [19, 11, 3], 7, 3),               # ragged everything
+])
+def test_planner_covers_every_tile_exactly_once(d, dc, widths, n_nodes, n_levels):
+    dims_c = [(dc,)] if dc else []
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], dims_c=dims_c, c_internal=widths)
+    st, nodes, total = check(blk.tree, d, dc)
+    if n_nodes is not None:
+        assert len(nodes) == n_nodes and st["levels"] == n_levels
+    assert st["levels"] == 1 + max(depth for _, _, depth in nodes)
+    assert total == sum((p.numel() + 3) // 4 * 4 for p in blk.parameters())
+    assert total - 4 < st["params"] <= total          # (the last tensor's padding is not part of the plan)
+    assert 0 < st["lds_fwd"] <= 160 * 1024 and 0 < st["lds_bwd"] <= 160 * 1024
+    assert st["groups"] >= st["levels"]
+    # activation columns: every (node, net) once, h padded to 16 (split nodes: two units)
+    want_wt = sum(2 * ((n.s[0].out_features + 15) // 16 * 16) for n, _, _ in nodes)
+    assert st["WT"] == want_wt
+    # thin-gradient slab: dW1, dW3 and the three biases of every net
+    thin = 0
+    for n, _, _ in nodes:
+        for net in (n.s, n.t):
+            thin += net[0].weight.numel() + net[4].weight.numel() + net[0].bias.numel() + net[2].bias.numel() + net[4].bias.numel()
+    assert st["thin"] == thin
+    # part B: 48x48 tiles of every dW2
+    dw = sum(2 * (((n.s[0].out_features + 15) // 16 + 2) // 3) ** 2 for n, _, _ in nodes)
+    assert st["dwjobs"] == dw
+
+
+def test_planner_accepts_the_conditional_lane_couplings():
+    """ExternalAffineCoupling (all of x transformed, conditioned on y: k = 0) and the y lane's AffineCoupling"""
+    flow = hint_amd.ConditionalHintFlow(10, 3, 1, 24)
+    for m, d, dc in ((flow.ac_y_to_x[0], 10, 3), (flow.ac_y[0], 3, 0), (flow.hac_x[0], 10, 0)):
+        st, nodes, _ = check(m.tree, d, dc)
+        assert st["groups"] >= 1 and st["lds_bwd"] <= 160 * 1024
+
+
+def test_planner_rejects_malformed_trees():
+    lib = _lib.load()
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(6,)], c_internal=[16, 8])
+    nodes = blk.tree._flat_nodes()
+    descs, _, _, _ = node_descs(nodes)
+    stats = (C.c_int64 * 12)()
+    descs[1].off = 1                       # overlaps its sibling
+    assert lib.hint_plan_check(descs, len(nodes), 6, 0, 4.0, stats) != 0
+    assert b"overlap" in lib.hint_last_error()
+    descs, _, _, _ = node_descs(nodes)
+    descs[0].r = 2                         # r != D - k
+    assert lib.hint_plan_check(descs, len(nodes), 6, 0, 4.0, stats) != 0
+    assert lib.hint_plan_check(descs, len(nodes), 600, 0, 4.0, stats) != 0     # more lanes than the kernels take
