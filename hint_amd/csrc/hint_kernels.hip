@@ -476,7 +476,11 @@ __device__ __forceinline__ void stage_run(Stage& S, lds_jobs_t next, const float
         STAMP_SUB(1)
         const JobU jn = decode_job(*(const LDS_AS i32x4*)(last ? next : S.cl + ji + 1));
         const float* pn = last ? packed_n : packed;
+#ifdef HINT_ABLATE_OUTER
+        if (OUTER && j.nt == TJOB_OUTER) fetch_first(S.b0, S.b1, jn, pn, lane);
+#else
         if (OUTER && j.nt == TJOB_OUTER) run_outer(j, S.b0, S.b1, jn, pn, A_o, lda_o, B_o, ldb_o, g_o, trash, lane);
+#endif
         else if (j.nt >= 3) run_job<EPI, 3>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
         else if (j.nt == 2) run_job<EPI, 2>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
         else if (j.nt == 1) run_job<EPI, 1>(j, S.b0, S.b1, jn, packed, pn, bias_lds, arow, O, Mk, ldo, slab_stride, lane);
