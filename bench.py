@@ -192,6 +192,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the batch is resident in HBM before the timed region starts (the bench contract): it is written
+    # once into the captured step's own input buffer, so that no device-to-device copy of it runs per step
+    x, _ = trainer.input_buffers(x)
     for _ in range(args.warmup):
         trainer.step(x)
     barrier()
@@ -230,7 +233,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: d={d}, {cfg['n_blocks']} recursive coupling blocks, "
                                    f"c_internal={cfg['c_internal']}, batch {B} per GPU",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "input": "batch resident in the captured step's input buffer (no per-step copy)"},
             "mean_nll_nats": nll, "last_step_loss": loss_last,
         }
         if in_step:

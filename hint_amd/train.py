@@ -260,8 +260,10 @@ class FlowTrainer:
         else:
             if self._graph is None or self._static["x"].shape != x.shape:
                 self._capture(x, c)
-            self._static["x"].copy_(x)
-            if c is not None:
+            # (a batch that already sits in the graph's input buffers - input_buffers() - is not copied again)
+            if x.data_ptr() != self._static["x"].data_ptr():
+                self._static["x"].copy_(x)
+            if c is not None and c.data_ptr() != self._static["c"].data_ptr():
                 self._static["c"].copy_(c)
             self._graph.replay()
         self._last_B = x.shape[0]
@@ -271,6 +273,20 @@ class FlowTrainer:
             scale = dp.allreduce_sum_(self.G, self.group)
             self._optimizer(scale)
         return _LossPair(self)
+
+    def input_buffers(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
+        """the captured step's own input tensors (x, c) for this batch shape, holding a copy of the
+        arguments: a data pipeline that writes its batches straight into them (index_select(..., out=),
+        copy_ from pinned memory) and passes them to step() saves the device-to-device copy step()
+        otherwise makes per iteration.  Without use_graph the arguments are returned as they are."""
+        if not self.use_graph:
+            return x, c
+        if self._graph is None or self._static["x"].shape != x.shape:
+            self._capture(x, c)
+        self._static["x"].copy_(x)
+        if c is not None:
+            self._static["c"].copy_(c)
+        return self._static["x"], self._static["c"]
 
     def timed_step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
         """one un-captured training step with HIP events between the launches (on the stream they

@@ -213,3 +213,27 @@ def test_trainer_step_prologue_clears_losses_and_advances_counter():
         assert int(tr.rng_state[1].item()) >= k + 1
     # the sums are per step (not running totals): the same batch gives nearly the same loss pair
     assert abs(vals[2][0] - vals[0][0]) < 0.2 * abs(vals[0][0]) + 0.1
+
+
+def test_input_buffers_skip_the_per_step_copy():
+    """a batch written into the captured step's own input buffer (FlowTrainer.input_buffers) gives the
+    same steps as one passed by value (and copied) every iteration"""
+    import copy
+    torch.manual_seed(7)
+    flow1 = hint_amd.HintFlow(6, 3, [32, 16]).to(DEV)
+    for p in flow1.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    flow2 = copy.deepcopy(flow1)
+    xs = [torch.randn(300, 6, device=DEV) for _ in range(3)]
+    t1 = hint_amd.FlowTrainer(flow1, noise=0.0, use_graph=True)
+    t2 = hint_amd.FlowTrainer(flow2, noise=0.0, use_graph=True)
+    buf, _ = t2.input_buffers(xs[0])
+    for x in xs:
+        t1.step(x)
+        a = [float(v) for v in t1.last_losses()]
+        buf.copy_(x)                                   # the "data pipeline" writes the batch in place
+        t2.step(buf)
+        b = [float(v) for v in t2.last_losses()]
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)        # (float atomics: not bit-reproducible)
+    for p1, p2 in zip(flow1.parameters(), flow2.parameters()):
+        assert rel_err(p2.detach().cpu().numpy(), p1.detach().cpu().numpy()) < 1e-4
