@@ -64,6 +64,7 @@ class FlowTrainer:
             e.ensure_arena()
             e.pack()
         self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)   # per-slot partial loss sums
+        self._loss_single = self.loss_acc      # (step_many points loss_acc at its last iteration's sums)
         self._pack_group, self._pack_key = None, None
         for i in range(flow.n_blocks):          # the kernels read W through its raw pointer (row-major)
             if flow.has_perm(i) and not flow.perms[i].W.is_contiguous():
@@ -254,6 +255,7 @@ class FlowTrainer:
     def step(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
         """one training iteration on this rank's shard; returns device scalars (l0, l1) =
         ('-log p(z)', '-log |det J|') of the LOCAL shard (train_unconditional.py:162)"""
+        self.loss_acc = self._loss_single
         if not self.use_graph:
             self._check_arenas()
             self._fwd_bwd(x, c)
@@ -273,6 +275,86 @@ class FlowTrainer:
             scale = dp.allreduce_sum_(self.G, self.group)
             self._optimizer(scale)
         return _LossPair(self)
+
+    # ---- several iterations per graph replay ----------------------------------------------------
+    def _many_ok(self) -> bool:
+        return self.use_graph and self._chainable and dp.world_info(self.group)[1] == 1 and \
+            not (torch.distributed.is_available() and torch.distributed.is_initialized())
+
+    def _capture_many(self, xs: torch.Tensor, cs: Optional[torch.Tensor]):
+        """K = xs.shape[0] consecutive iterations (re-pack, forward, backward, clamp+Adam each) in ONE
+        hipGraph: the ~8 us between the end of one graph replay and the start of the next are paid once
+        per K steps.  One process only (the gradient all-reduce of a data-parallel job is not captured)."""
+        K = xs.shape[0]
+        self._check_arenas()
+        sx = xs.clone()
+        sc = cs.clone() if cs is not None else None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):          # warm-up on a side stream (allocator, plan LDS attrs); no optimizer
+            for _ in range(2):
+                self._fwd_bwd(sx[0], sc[0] if sc is not None else None)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.G.zero_()
+        scratch = torch.zeros(4, 4, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):   # load the optimizer kernel outside the capture
+            self.lib.hint_adam_step(scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[2].data_ptr(),
+                                    scratch[3].data_ptr(), 4, 1, 0.0, 0.9, 0.95, 1e-4, 0.0, 1.0, 0.0, 0,
+                                    torch.cuda.current_stream(self.device).cuda_stream)
+        self.rng_state[1] = self.step_count
+        self._loss_all = torch.zeros(K, 64, 2, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(K):
+                self.loss_acc = self._loss_all[k]             # every iteration its own loss sums
+                self._fwd_bwd(sx[k], sc[k] if sc is not None else None, with_adam=True)
+        self._graph_many, self._static_many = g, dict(x=sx, c=sc)
+
+    def step_many(self, xs: torch.Tensor, cs: Optional[torch.Tensor] = None):
+        """K = xs.shape[0] training iterations on the batches xs[k] ([K, B, d]; cs [K, B, dc]); with
+        use_graph and one process they are ONE graph replay.  Per-iteration losses: step_losses()."""
+        K, B = xs.shape[0], xs.shape[1]
+        if not self._many_ok():
+            out = []
+            for k in range(K):
+                self.step(xs[k], cs[k] if cs is not None else None)
+                out.append(torch.stack(self.last_losses()))
+            self._many_losses = torch.stack(out)
+            return
+        st = getattr(self, "_static_many", None)
+        if getattr(self, "_graph_many", None) is None or st["x"].shape != xs.shape:
+            self._capture_many(xs, cs)
+            st = self._static_many
+        if xs.data_ptr() != st["x"].data_ptr():
+            st["x"].copy_(xs)
+        if cs is not None and cs.data_ptr() != st["c"].data_ptr():
+            st["c"].copy_(cs)
+        self._graph_many.replay()
+        self.loss_acc = self._loss_all[K - 1]
+        self.step_count += K
+        self._last_B = B
+        self._many_losses = None
+
+    def step_losses(self) -> torch.Tensor:
+        """[K, 2] device tensor: (-log p(z), -log|det J|) of every iteration of the last step_many()"""
+        if getattr(self, "_many_losses", None) is not None:
+            return self._many_losses
+        s = self._loss_all.sum(dim=1)
+        return torch.stack([s[:, 0] / self._last_B, -s[:, 1] / self._last_B], dim=1)
+
+    def input_buffers_many(self, xs: torch.Tensor, cs: Optional[torch.Tensor] = None):
+        """step_many()'s own input tensors ([K, B, d], [K, B, dc]) holding a copy of the arguments (see input_buffers)"""
+        if not self._many_ok():
+            return xs, cs
+        st = getattr(self, "_static_many", None)
+        if getattr(self, "_graph_many", None) is None or st["x"].shape != xs.shape:
+            self._capture_many(xs, cs)
+            st = self._static_many
+        st["x"].copy_(xs)
+        if cs is not None:
+            st["c"].copy_(cs)
+        return st["x"], st["c"]
 
     def input_buffers(self, x: torch.Tensor, c: Optional[torch.Tensor] = None):
         """the captured step's own input tensors (x, c) for this batch shape, holding a copy of the

@@ -237,3 +237,33 @@ def test_input_buffers_skip_the_per_step_copy():
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)        # (float atomics: not bit-reproducible)
     for p1, p2 in zip(flow1.parameters(), flow2.parameters()):
         assert rel_err(p2.detach().cpu().numpy(), p1.detach().cpu().numpy()) < 1e-4
+
+
+def test_step_many_equals_single_steps():
+    """K iterations in one graph replay (FlowTrainer.step_many) take the same steps, with the same
+    per-iteration losses, as K step() calls; a learning-rate change between two replays needs no re-capture"""
+    import copy
+    torch.manual_seed(8)
+    flow1 = hint_amd.HintFlow(6, 3, [32, 16]).to(DEV)
+    for p in flow1.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    flow2 = copy.deepcopy(flow1)
+    K, B = 3, 200
+    t1 = hint_amd.FlowTrainer(flow1, noise=0.0, use_graph=True)
+    t2 = hint_amd.FlowTrainer(flow2, noise=0.0, use_graph=True)
+    for rep in range(2):
+        xs = torch.randn(K, B, 6, device=DEV)
+        if rep == 1:
+            t1.lr = 0.5 * t1.lr; t2.lr = 0.5 * t2.lr
+        want = []
+        for k in range(K):
+            t1.step(xs[k])
+            want.append([float(v) for v in t1.last_losses()])
+        t2.step_many(xs)
+        got = t2.step_losses().cpu().numpy()
+        assert np.allclose(got, np.array(want), rtol=1e-5, atol=1e-6), (got, want)
+    assert t1.step_count == t2.step_count == 2 * K
+    for p1, p2 in zip(flow1.parameters(), flow2.parameters()):
+        assert rel_err(p2.detach().cpu().numpy(), p1.detach().cpu().numpy()) < 1e-4
+    t2.step(xs[0])                                    # the single-step path still works afterwards
+    assert np.isfinite(float(t2.last_losses()[0]))
