@@ -12,6 +12,7 @@ ONE all-reduce of the gradient arena (hint_amd/dp.py) and ONE fused clamp+Adam l
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -88,6 +89,7 @@ class FlowTrainer:
         self.opt_state = torch.tensor([lr, betas[0], betas[1], 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32,
                                       device=dev)
         self._adam_in_graph = False
+        self._allreduce_in_graph = False
 
     @property
     def lr(self) -> float:
@@ -144,12 +146,13 @@ class FlowTrainer:
         return handle
 
     # ---- the un-captured step body ----------------------------------------------------
-    def _adam_dev(self):
-        """the fused clamp+Adam launch with its step factors read from opt_state (world size 1)"""
+    def _adam_dev(self, scale: float = 1.0):
+        """the fused clamp+Adam launch with its step factors read from opt_state (capturable: nothing in
+        it depends on the host's step count); scale = 1/world turns the all-reduced sum into the mean"""
         with torch.cuda.device(self.device):
             st = self.lib.hint_adam_step_dev(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                              self.n_floats, self.opt_state.data_ptr(), self.betas[0], self.betas[1],
-                                             self.eps, self.wd, 1.0, self.grad_clamp, 1,
+                                             self.eps, self.wd, scale, self.grad_clamp, 1,
                                              torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(st, "hint_adam_step_dev")
 
@@ -179,7 +182,11 @@ class FlowTrainer:
                 _lib.check(self.lib.hint_chain_backward(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
                                                         None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")
             if with_adam:
-                self._adam_dev()
+                if self._allreduce_in_graph:      # data-parallel job: the RCCL all-reduce is captured as well
+                    torch.distributed.all_reduce(self.G, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                    self._adam_dev(1.0 / dp.world_info(self.group)[1])
+                else:
+                    self._adam_dev()
             return B
         if self.noise > 0:
             x = x.add(torch.randn_like(x), alpha=self.noise)
@@ -425,8 +432,16 @@ class FlowTrainer:
         # one process, identical blocks: the optimizer launch goes into the graph as well (no host
         # gap between the weight-gradient kernel and Adam).  Its kernel has been loaded by a launch
         # outside the capture; the device step counter is aligned with the host's.
-        self._adam_in_graph = self._chainable and dp.world_info(self.group)[1] == 1 and \
-            not (torch.distributed.is_available() and torch.distributed.is_initialized())
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        # RCCL collectives can be captured (backend "nccl"): the whole data-parallel iteration - backward,
+        # gradient all-reduce, clamp+Adam - is then one graph replay per rank (HINT_GRAPH_ALLREDUCE=0: off)
+        self._allreduce_in_graph = self._chainable and dist_on and self.P.is_cuda and \
+            torch.distributed.get_backend(self.group) == "nccl" and os.environ.get("HINT_GRAPH_ALLREDUCE", "1") != "0"
+        self._adam_in_graph = self._chainable and ((dp.world_info(self.group)[1] == 1 and not dist_on) or self._allreduce_in_graph)
+        if self._allreduce_in_graph:           # communicator set up and used once outside the capture
+            warm = torch.zeros(8, dtype=torch.float32, device=self.device)
+            torch.distributed.all_reduce(warm, group=self.group)
+            torch.cuda.synchronize(self.device)
         if self._adam_in_graph:
             scratch = torch.zeros(4, 4, dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
@@ -436,8 +451,19 @@ class FlowTrainer:
         self.rng_state[1] = self.step_count
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._fwd_bwd(sx, sc, with_adam=self._adam_in_graph)
+        try:
+            with torch.cuda.graph(g):
+                self._fwd_bwd(sx, sc, with_adam=self._adam_in_graph)
+        except Exception:
+            if not self._allreduce_in_graph:
+                raise
+            # the collective could not be captured here: keep it (and the optimizer) outside the graph
+            self._allreduce_in_graph = self._adam_in_graph = False
+            torch.cuda.synchronize(self.device)
+            self.G.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._fwd_bwd(sx, sc, with_adam=False)
         self._graph = g
         self._static = dict(x=sx, c=sc)
 
