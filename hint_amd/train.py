@@ -452,7 +452,8 @@ class FlowTrainer:
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            # (thread_local: the process group's watchdog thread may touch the HIP runtime meanwhile)
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if self._allreduce_in_graph else "global"):
                 self._fwd_bwd(sx, sc, with_adam=self._adam_in_graph)
         except Exception:
             if not self._allreduce_in_graph:
