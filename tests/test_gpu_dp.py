@@ -78,3 +78,49 @@ def test_two_rank_gpu_step_equals_single_process_global_batch(use_graph):
     np.testing.assert_allclose(res[0][0], ref, rtol=2e-4, atol=2e-6)       # == global-batch step
     # the mean of the two shards' loss terms is the global batch's
     np.testing.assert_allclose(0.5 * (res[0][1] + res[1][1]), ref_losses, rtol=1e-4, atol=1e-5)
+
+
+def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
+    """a one-rank RCCL group in this process: the gradient all-reduce and the optimizer are captured in
+    the step's graph; when the collective cannot be captured (simulated) the trainer issues both from
+    the host - same steps either way as a trainer without any process group"""
+    import copy
+    import hint_amd
+    DEV = "cuda:0"
+    torch.manual_seed(11)
+    flow0 = hint_amd.HintFlow(6, 2, [32, 16]).to(DEV)
+    for p in flow0.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    xs = [torch.randn(256, 6, device=DEV) for _ in range(3)]
+
+    def run(flow, break_capture=False):
+        tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=True)
+        real = dist.all_reduce
+        if break_capture:
+            def flaky(t, *a, **k):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("simulated: collective not capturable")
+                return real(t, *a, **k)
+            dist.all_reduce = flaky
+        try:
+            out = []
+            for x in xs:
+                tr.step(x)
+                out.append([float(v) for v in tr.last_losses()])
+        finally:
+            dist.all_reduce = real
+        return tr, out
+
+    _, want = run(copy.deepcopy(flow0))                      # no process group at all
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tr1, got1 = run(copy.deepcopy(flow0))
+        assert tr1._allreduce_in_graph and tr1._adam_in_graph
+        tr2, got2 = run(copy.deepcopy(flow0), break_capture=True)
+        assert not tr2._allreduce_in_graph and not tr2._adam_in_graph
+    finally:
+        dist.destroy_process_group()
+    assert np.allclose(got1, want, rtol=1e-5, atol=1e-6), (got1, want)
+    assert np.allclose(got2, want, rtol=1e-5, atol=1e-6), (got2, want)
