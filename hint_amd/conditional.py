@@ -241,8 +241,13 @@ class ConditionalFlowTrainer:
         self._lib.check(st, "hint_pack_group_run")
 
     def _graphable(self) -> bool:
-        return self.use_graph and self._dp.world_info(self.group)[1] == 1 and \
-            not (torch.distributed.is_available() and torch.distributed.is_initialized())
+        """one process, or a data-parallel job over RCCL (whose all-reduce is captured with the step)"""
+        if not self.use_graph or getattr(self, "_graph_failed", False):
+            return False
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return True
+        import os
+        return torch.distributed.get_backend(self.group) == "nccl" and os.environ.get("HINT_GRAPH_ALLREDUCE", "1") != "0"
 
     def step(self, x: torch.Tensor, y: torch.Tensor):
         """one iteration on this rank's rows; returns device scalars (0.5*|z|^2 mean, -log|det J| mean)"""
@@ -251,7 +256,8 @@ class ConditionalFlowTrainer:
         if not self._graphable():
             return self._iteration(x, y, on_device_adam=False)
         if self._graph is None or self._static[0].shape != x.shape or self._static[1].shape != y.shape:
-            self._capture(x, y)
+            if not self._capture(x, y):
+                return self._iteration(x, y, on_device_adam=False)
         self._static[0].copy_(x)
         self._static[1].copy_(y)
         self._graph.replay()
@@ -274,9 +280,22 @@ class ConditionalFlowTrainer:
         self.rng_state[1] = self.step_count
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._out = self._iteration(sx, sy, on_device_adam=True)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if dist_on else "global"):
+                self._out = self._iteration(sx, sy, on_device_adam=True)
+        except Exception:
+            if not dist_on:
+                raise
+            self._graph_failed = True           # the collective could not be captured: plain launches from now on
+            torch.cuda.synchronize(self.device)
+            for t, s0 in zip((self.P, self.M, self.V), snap):
+                t.copy_(s0)
+            self.opt_state.copy_(state[0]); self.rng_state.copy_(state[1])
+            self.G.zero_()
+            return False
         self._graph, self._static = g, (sx, sy)
+        return True
 
     def _iteration(self, x: torch.Tensor, y: torch.Tensor, on_device_adam: bool):
         flow, B = self.flow, x.shape[0]
@@ -319,11 +338,12 @@ class ConditionalFlowTrainer:
             if i > 0:
                 gy = gy @ flow.perm_y[i].W.t()
                 gx = gx @ flow.perm_x[i].W.t()
-        if on_device_adam:                      # one process: step factors come from opt_state (prologue above)
+        if on_device_adam:                      # step factors come from opt_state (prologue above): capturable
+            scale = self._dp.allreduce_sum_(self.G, self.group)       # (no-op without a process group)
             with torch.cuda.device(self.device):
                 st = self.lib.hint_adam_step_dev(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
                                                  self.n_floats, self.opt_state.data_ptr(), self.betas[0], self.betas[1],
-                                                 self.eps, self.wd, 1.0, self.grad_clamp, 1,
+                                                 self.eps, self.wd, scale, self.grad_clamp, 1,
                                                  torch.cuda.current_stream(self.device).cuda_stream)
             self._lib.check(st, "hint_adam_step_dev")
         else:

@@ -111,7 +111,22 @@ def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
             dist.all_reduce = real
         return tr, out
 
+    cflow0 = hint_amd.ConditionalHintFlow(10, 3, 2, 24).to(DEV)
+    for p in cflow0.parameters():
+        p.data.add_(0.02 * torch.randn_like(p))
+    cx = [torch.randn(128, 10, device=DEV) for _ in range(3)]
+    cy = [torch.randn(128, 3, device=DEV) for _ in range(3)]
+
+    def run_cond():
+        tr = hint_amd.ConditionalFlowTrainer(copy.deepcopy(cflow0), noise=0.0, use_graph=True)
+        out = []
+        for x, y in zip(cx, cy):
+            l0, l1 = tr.step(x, y)
+            out.append([float(l0), float(l1)])
+        return tr, out
+
     _, want = run(copy.deepcopy(flow0))                      # no process group at all
+    _, cwant = run_cond()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
@@ -120,7 +135,10 @@ def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
         assert tr1._allreduce_in_graph and tr1._adam_in_graph
         tr2, got2 = run(copy.deepcopy(flow0), break_capture=True)
         assert not tr2._allreduce_in_graph and not tr2._adam_in_graph
+        ctr, cgot = run_cond()                               # the conditional two-lane trainer: same capture
+        assert ctr._graph is not None
     finally:
         dist.destroy_process_group()
     assert np.allclose(got1, want, rtol=1e-5, atol=1e-6), (got1, want)
     assert np.allclose(got2, want, rtol=1e-5, atol=1e-6), (got2, want)
+    assert np.allclose(cgot, cwant, rtol=1e-5, atol=1e-6), (cgot, cwant)
