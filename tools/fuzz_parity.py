@@ -1,0 +1,80 @@
+"""Randomised parity sweep (GPU): random block shapes - lanes, hidden widths, conditions, batch sizes,
+max_splits / min_split_size - through forward, inverse and backward against the CPU oracle in float32
+(the arithmetic the reference runs in: against float64 a single row whose ReLU pre-activation sits at
+zero flips its subgradient and moves a weight gradient by 1e-2, in the oracle exactly as on the GPU).
+   python tools/fuzz_parity.py [n_cases] [seed]"""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import hint_amd
+from oracle import hint_oracle as orc
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = "cuda:0"
+worst = dict(z=0.0, J=0.0, gx=0.0, gw=0.0, rt=0.0)
+for case in range(n_cases):
+    d = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 21, 31, 43, 64])
+    depth = rng.randint(1, 4)
+    widths = [rng.choice([3, 8, 15, 16, 17, 24, 33, 48, 64, 70, 100, 128, 140]) for _ in range(depth)]
+    dc = rng.choice([0, 0, 0, 1, 3, 5])
+    B = rng.choice([1, 2, 15, 16, 17, 33, 100, 257, 1000])
+    max_splits = rng.choice([-1, -1, 0, 1, 2])
+    min_split = rng.choice([2, 2, 3])
+    clamp = rng.choice([4.0, 4.0, 2.0])
+    dims_c = [(dc,)] if dc else []
+    try:
+        nodes = orc.build_nodes(d, dims_c, widths, max_splits=max_splits, min_split_size=min_split)
+    except TypeError:
+        nodes = orc.build_nodes(d, dims_c, widths)
+        max_splits, min_split = -1, 2
+    P = orc.init_params(nodes, seed=case, scale=None)
+    gen = torch.Generator().manual_seed(1000 + case)
+    x = torch.randn(B, d, generator=gen)
+    cond = [torch.randn(B, dc, generator=gen)] if dc else []
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], dims_c=dims_c, c_internal=widths, clamp=clamp,
+                                                   max_splits=max_splits, min_split_size=min_split)
+    blk.load_state_dict({k: v.clone() for k, v in P.items()})
+    blk = blk.to(dev)
+    sc = lambda t: max(1.0, t.detach().abs().max().item())
+
+    def compare(x, cond):
+        Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        xo = x.clone().requires_grad_(True)
+        zo, Jo = orc.block_apply(nodes, Po, xo, cond, rev=False, clamp=clamp)
+        (0.5 * (zo ** 2).sum(1) - Jo).mean().backward()
+        blk.zero_grad()
+        xg = x.to(dev).requires_grad_(True)
+        cg = [c.to(dev) for c in cond]
+        (z,) = blk([xg], c=cg); J = blk.jacobian(None)
+        (0.5 * (z ** 2).sum(1) - J).mean().backward()
+        with torch.no_grad():
+            (xr,) = blk([z.detach()], c=cg, rev=True)
+        named = dict(blk.named_parameters())
+        row_err = (xg.grad.cpu() - xo.grad).abs().max(dim=1).values / (xo.grad.abs().max() + 1e-30)
+        return dict(z=(z.detach().cpu() - zo.detach()).abs().max().item() / sc(zo),
+                    J=(J.detach().cpu() - Jo.detach()).abs().max().item() / sc(Jo),
+                    gx=row_err.max().item(),
+                    # weight gradients: largest deviation in any tensor, relative to the largest gradient entry of
+                    # the block (per tensor, a tiny bias gradient makes one kink row look like a 1e-2 error)
+                    gw=max([(named[k].grad.cpu() - p.grad).abs().max().item()
+                            for k, p in Po.items() if p.grad is not None and p.numel() > 0] + [0.0])
+                       / max([p.grad.abs().max().item() for p in Po.values() if p.grad is not None and p.numel() > 0] + [1e-30]),
+                    rt=(xr.cpu() - x).abs().max().item() / sc(x)), row_err
+
+    e, row_err = compare(x, cond)
+    note = ""
+    if (e["gx"] > 1e-4 or e["gw"] > 2e-4) and e["z"] <= 1e-5 and e["J"] <= 1e-5:
+        # a row whose ReLU pre-activation rounds to the other side of zero on the GPU than in the oracle gets
+        # another subgradient: drop the (few) rows that differ and look again
+        keep = row_err <= 3e-5
+        if 0 < int((~keep).sum()) <= 3 and int(keep.sum()) > 0:
+            note = f" [{int((~keep).sum())} row(s) on a ReLU kink dropped]"
+            e, row_err = compare(x[keep], [c[keep] for c in cond])
+    bad = e["z"] > 1e-5 or e["J"] > 1e-5 or e["gx"] > 1e-4 or e["gw"] > 2e-4
+    for k in worst: worst[k] = max(worst[k], e[k])
+    if bad or note or case % 10 == 0:
+        print(("BAD " if bad else "ok  ") + note + f"case {case}: d={d} widths={widths} dc={dc} B={B} max_splits={max_splits} min_split={min_split} clamp={clamp} "
+              + " ".join(f"{k} {v:.1e}" for k, v in e.items()), flush=True)
+    assert not bad
+print("worst:", {k: f"{v:.1e}" for k, v in worst.items()})
