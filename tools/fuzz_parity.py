@@ -2,7 +2,7 @@
 max_splits / min_split_size - through forward, inverse and backward against the CPU oracle in float32
 (the arithmetic the reference runs in: against float64 a single row whose ReLU pre-activation sits at
 zero flips its subgradient and moves a weight gradient by 1e-2, in the oracle exactly as on the GPU).
-   python tools/fuzz_parity.py [n_cases] [seed]"""
+   python tools/fuzz_parity.py [n_cases] [seed] [wide]"""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,11 +14,13 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev = "cuda:0"
 worst = dict(z=0.0, J=0.0, gx=0.0, gw=0.0, rt=0.0)
 for case in range(n_cases):
-    d = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 21, 31, 43, 64])
-    depth = rng.randint(1, 4)
-    widths = [rng.choice([3, 8, 15, 16, 17, 24, 33, 48, 64, 70, 100, 128, 140]) for _ in range(depth)]
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"       # up to the limits: 128 lanes, split (h > 384) nodes
+    d = rng.choice([2, 6, 33, 100, 127, 128] if wide else [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 21, 31, 43, 64])
+    depth = rng.randint(1, 3 if wide else 4)
+    widths = [rng.choice([200, 224, 256, 385, 400, 512] if wide else [3, 8, 15, 16, 17, 24, 33, 48, 64, 70, 100, 128, 140])
+              for _ in range(depth)]
     dc = rng.choice([0, 0, 0, 1, 3, 5])
-    B = rng.choice([1, 2, 15, 16, 17, 33, 100, 257, 1000])
+    B = rng.choice([1, 17, 100, 257] if wide else [1, 2, 15, 16, 17, 33, 100, 257, 1000])
     max_splits = rng.choice([-1, -1, 0, 1, 2])
     min_split = rng.choice([2, 2, 3])
     clamp = rng.choice([4.0, 4.0, 2.0])
@@ -62,7 +64,13 @@ for case in range(n_cases):
                        / max([p.grad.abs().max().item() for p in Po.values() if p.grad is not None and p.numel() > 0] + [1e-30]),
                     rt=(xr.cpu() - x).abs().max().item() / sc(x)), row_err
 
-    e, row_err = compare(x, cond)
+    try:
+        e, row_err = compare(x, cond)
+    except hint_amd.HintAmdError as err:           # the documented limit: one net of a node must fit the 160 KiB LDS
+        if "LDS" in str(err):
+            print(f"limit case {case}: d={d} widths={widths} dc={dc}: {str(err)[-80:]}", flush=True)
+            continue
+        raise
     note = ""
     if (e["gx"] > 1e-4 or e["gw"] > 2e-4) and e["z"] <= 1e-5 and e["J"] <= 1e-5:
         # a row whose ReLU pre-activation rounds to the other side of zero on the GPU than in the oracle gets
