@@ -111,7 +111,7 @@ def kernel_legs(trainer, x, reps=200):
     stream = torch.cuda.current_stream().cuda_stream
     P, PK = eng.arena.data_ptr(), eng.packed.data_ptr()
     out["hint_pack_kernel"] = timed(lambda: lib.hint_block_pack(eng.plan, P, PK, stream))
-    out["hint_block_apply_kernel<fwd>"] = timed(
+    out["hint_apply_kernel<fwd>"] = timed(
         lambda: lib.hint_block_forward(eng.plan, P, PK, x.data_ptr(), None, z.data_ptr(), J.data_ptr(), tape.data_ptr(), B, stream))
     gz = torch.randn_like(x); gJ = torch.full((B,), -1.0 / B, device=x.device)
     gx = torch.empty_like(x); gp = torch.empty(eng.total, device=x.device)
@@ -121,27 +121,21 @@ def kernel_legs(trainer, x, reps=200):
     def bwd():
         return lib.hint_block_backward(eng.plan, P, PK, x.data_ptr(), tape.data_ptr(), None, gz.data_ptr(), gJ.data_ptr(),
                                        gx.data_ptr(), None, gp.data_ptr(), 1, ws.data_ptr(), nb, B, stream)
-    for mask, name in ((1, "hint_block_bwd_kernel"), (2, "hint_block_dw_kernel"), (3, "backward_total")):
-        lib.hint_debug_set_backward_stages(mask)
-        out[name] = timed(bwd)
-    lib.hint_debug_set_backward_stages(3)
+    out["backward_total"] = timed(bwd)
     # the launches the timed step actually makes: the whole flow per kernel (hint_chain_*)
     if trainer._chainable:
         chain = trainer._chain_for(B)
         n = len(trainer.engines)
         zc = torch.empty_like(x); Jc = torch.empty(B, device=x.device); gxc = torch.empty_like(x)
         acc = torch.zeros(64, 2, device=x.device)
-        out[f"chain{n}:hint_block_apply_kernel<fwd>"] = timed(
+        out[f"chain{n}:hint_apply_kernel<fwd>"] = timed(
             lambda: lib.hint_chain_forward(chain, x.data_ptr(), None, zc.data_ptr(), Jc.data_ptr(), None,
                                            acc.data_ptr(), stream))
 
-        def cbwd():
-            return lib.hint_chain_backward(chain, x.data_ptr(), None, zc.data_ptr(), None, gxc.data_ptr(), None,
-                                           1.0 / B, -1.0 / B, 1, stream)
-        for mask, name in ((1, "hint_block_bwd_kernel"), (2, "hint_block_dw_kernel"), (3, "backward_total")):
-            lib.hint_debug_set_backward_stages(mask)
-            out[f"chain{n}:{name}"] = timed(cbwd)
-        lib.hint_debug_set_backward_stages(3)
+        for parts, name in ((1, "hint_bwd_kernel"), (2, "hint_wgrad_kernel+hint_wreduce_kernel"), (3, "backward_total")):
+            out[f"chain{n}:{name}"] = timed(
+                lambda: lib.hint_chain_backward_parts(chain, x.data_ptr(), None, zc.data_ptr(), None, gxc.data_ptr(), None,
+                                                      1.0 / B, -1.0 / B, 1, parts, stream))
         trainer.G.zero_()                    # the timing launches accumulated into the gradient arena
     return out
 
@@ -254,7 +248,7 @@ def main():
             # dominant kernel = the row-parallel backward kernel (part A), one launch for all blocks:
             # dX through the three layers (F) + the thin weight gradients dW1, dW3 per sample and block
             # (nothing is recomputed: the hidden activations come from the forward's tape)
-            name = "hint_block_bwd_kernel"
+            name = "hint_bwd_kernel"
             nb = cfg["n_blocks"]                       # blocks one launch processes
             us = in_step[name]
             flops = (F + thin_flops_per_sample_block(d, cfg["c_internal"])) * B * nb
@@ -274,7 +268,7 @@ def main():
             res["kernels_in_step_us"] = in_step       # inside real steps (HIP events between the launches)
             # the element-wise view the north_star asks for: compulsory HBM bytes of the forward,
             # 4*(2d+1) B per sample and block, against 8 TB/s
-            fwd_us = in_step["hint_block_apply_kernel<fwd>"]
+            fwd_us = in_step["hint_apply_kernel<fwd>"]
             hbytes = 4.0 * (2 * d + 1) * B * nb
             hb = hbytes / (fwd_us * 1e-6) / 1e9
             res["hbm_view_fwd_kernel"] = {"achieved": hb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hb / PEAK_HBM_GBS,

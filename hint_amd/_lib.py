@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HINT_AMD_LIB") or os.path.join(_HERE, "lib", "libhint_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HintAmdError(RuntimeError):
@@ -60,8 +60,8 @@ _PROTOS = {
     "hint_chain_forward_noisy": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hint_chain_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "hint_chain_destroy": (None, [C.c_void_p]),
-    "hint_debug_set_backward_stages": (None, [C.c_int32]),
-    "hint_debug_set_stamp_buffer": (C.c_int, [C.c_void_p]),
+    "hint_chain_backward_parts": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "hint_chain_inverse": (C.c_int, [C.c_void_p] * 7),
     "hint_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_void_p] + [C.c_float] * 6 + [C.c_int32, C.c_void_p]),
     "hint_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32] + [C.c_float] * 7 + [C.c_int32,
                                                                                                  C.c_void_p]),

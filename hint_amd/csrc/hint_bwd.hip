@@ -1,0 +1,253 @@
+// Backward kernel, part A (row parallel; gfx950 / CDNA4 only): gradients with respect to the lanes
+// and the condition, and the per-row factors of every weight gradient.
+//
+// What autograd derives from /root/reference/hint.py:62-101 when the training loop calls
+// loss.backward() (train_unconditional.py:137), per node, root first:
+//   g_t = g_l' ; g_a = g_l'*exp(a)*l + g_J ; g_l = g_l'*exp(a) ; g_s = g_a*alpha/(1+s^2)
+//   g2 = (W3^T g_st) .* relu'(a2) ; g1 = (W2^T g2) .* relu'(a1) ; g_v = W1^T g1 ; g_u += g_v[:k], g_c += g_v[k:]
+// Nothing is recomputed: s, the lane tiles of every level and both hidden activations come from the
+// forward's tape (bit-identical ReLU masks by construction).  One workgroup carries the gradient
+// tile of 16 batch rows through all blocks of the chain, last to first.  Per group three phases:
+//   Q1  element-wise: add the g_v partials of the group before, coupling backward -> g_st (LDS + global)
+//   Q2  g2 fragment tiles (masked by a2) -> LDS + global                         (run_phase<K_G2>)
+//   Q3  g1 tiles (masked by a1) -> global, and straight from the accumulator the K-split partial
+//       of g_v into the wavefront's slab                                          (run_phase<K_G1>)
+// All weight gradients are batch reductions of (g1, g2, g_st) against (v, a1, a2): part B
+// (hint_wgrad.hip) computes them from the arrays written here.
+#include "hint_rows.hpp"
+
+using namespace hint;
+
+constexpr int LV_REGS = 4;      // floats per thread of a prefetched [16, d] tile: 16*d <= LV_REGS * threads
+
+struct LevelPrefetch { float x[LV_REGS], s[LV_REGS]; };
+__device__ __forceinline__ void level_issue(LevelPrefetch& p, const float* __restrict__ xsrc, const float* __restrict__ ssrc,
+                                            int d, int row0, int B, int tid, int nthreads) {
+    const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * d;
+    const size_t base = (size_t)row0 * d;
+#pragma unroll
+    for (int k = 0; k < LV_REGS; ++k) {
+        const int i = tid + k * nthreads;
+        const int ic = i < nvalid ? i : 0;
+        const float xv = xsrc[base + ic], sv = ssrc[base + ic];
+        p.x[k] = i < nvalid ? xv : 0.f;
+        p.s[k] = i < nvalid ? sv : 0.f;
+    }
+}
+__device__ __forceinline__ void level_commit(const LevelPrefetch& p, float* xs, float* sb, int ld, int d, int tid, int nthreads) {
+    const float inv = frcp(d);
+#pragma unroll
+    for (int k = 0; k < LV_REGS; ++k) {
+        const int i = tid + k * nthreads;
+        if (i < ROWS * d) {
+            const int r = fdiv(i, inv), j = i - r * d;
+            xs[r * ld + j] = p.x[k];
+            sb[r * ld + j] = p.s[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
+    KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
+    const float* __restrict__ x, const float* __restrict__ c,
+    const float* __restrict__ g_z, const float* __restrict__ g_J, float* __restrict__ g_x,
+    float* __restrict__ g_c, float gz_scale, float gJ_const) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const float inv_d = frcp(a.d);
+    const Tables T = make_tables(a, lds);
+    float* xs = lds + (a.meta_bytes >> 2);    // lane tile of the current level, as the forward pass saw it
+    float* gs = xs + ROWS * a.xld;            // gradient tile
+    float* sb = gs + ROWS * a.xld;            // s of the current level (tape)
+    float* cs = sb + ROWS * a.xld;
+    float* gcs = cs + ROWS * a.cld;
+    float* gst = gcs + ROWS * a.cld;          // [16][gld] coupling gradients of the group
+    float* abuf = gst + ROWS * a.gld;         // g2 fragment tiles
+    float* slab = abuf + a.abuf_tiles * 256;  // g_v partials
+    float* gj = slab + a.slab_floats;
+    const int ntiles = (a.B + ROWS - 1) / ROWS;
+    const size_t lvl = (size_t)a.B * a.d;     // floats of one [B, d] tape slice
+    copy_meta(a, lds, tid, nthreads);
+#define HINT_CB(I) chain_block(chain, one, I)
+    // input lanes of level LV of a block: x for the deepest level of the first block of a call without
+    // a fused permutation, the top tape slice (hint_apply_kernel stored it) for other deepest levels,
+    // tape[LV-1] otherwise
+#define LEVEL_SRC(TAPE, TOP, LV) ((LV) == 0 ? ((TOP) ? (TAPE) + (size_t)(a.n_levels - 1) * lvl : x) : (TAPE) + (size_t)((LV) - 1) * lvl)
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        load_tile(gs, a.xld, g_z, a.d, row0, a.B, tid, nthreads);
+        if (a.dc > 0) {
+            load_tile(cs, a.cld, c, a.dc, row0, a.B, tid, nthreads);
+            load_tile(gcs, a.cld, nullptr, a.dc, row0, a.B, tid, nthreads);
+        }
+        if (tid < ROWS) gj[tid] = (row0 + tid < a.B) ? (g_J != nullptr ? g_J[row0 + tid] : gJ_const) : 0.f;
+        {
+            const GBlock lb = HINT_CB(n_chain - 1);
+            const float* tape = (const float*)lb.tape;
+            const bool top = lb.perm != nullptr || n_chain > 1;
+            load_tile(xs, a.xld, LEVEL_SRC(tape, top, a.n_levels - 1), a.d, row0, a.B, tid, nthreads);
+            load_tile(sb, a.xld, tape + (size_t)(a.n_levels + a.n_levels - 1) * lvl, a.d, row0, a.B, tid, nthreads);
+        }
+        __syncthreads();
+        if (gz_scale != 1.f) {                 // loss gradient fused: g_z = z / B given z
+            for (int i = tid; i < ROWS * a.d; i += nthreads) { const int r = fdiv(i, inv_d); gs[r * a.xld + (i - r * a.d)] *= gz_scale; }
+            __syncthreads();
+        }
+
+        for (int cb = n_chain - 1; cb >= 0; --cb) {
+            const GBlock blk = HINT_CB(cb);
+            const GBlock nblk = HINT_CB(cb > 0 ? cb - 1 : 0);          // the block worked on after this one
+            const float* perm = (const float*)blk.perm;
+            const float* tape = (const float*)blk.tape;
+            const bool top = perm != nullptr || cb > 0;
+            float* wsGST = (float*)blk.wsGST;
+            PhaseCtx pc;
+            pc.packed = (const float*)blk.packed;
+            pc.abuf = abuf; pc.xs = xs; pc.cs = cs; pc.gst = gst; pc.slab = slab;
+            pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
+            pc.store = true;
+
+            for (int gi = a.n_groups; gi >= 0; --gi) {
+                // gi == 0 .. n_groups-1: the boundary in front of group gi (root first), then its GEMM phases;
+                // slot n_groups is used for the boundary BEHIND group 0 (scatter only), visited last
+                const int slot = gi > 0 ? gi - 1 : a.n_groups;
+                const bool tail_only = gi == 0;
+                const GroupU g = load_group(T.groups + (tail_only ? 0 : slot));
+                const int lop0 = tail_only ? a.n_groups * a.d : g.lop_begin;
+                // units of the group just finished (whose g_v partials wait in the slabs)
+                const bool has_prev = gi < a.n_groups;
+                const GroupU gp = load_group(T.groups + (has_prev ? (tail_only ? 0 : slot + 1) : 0));
+
+                // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
+                for (int idx = tid; idx < ROWS * a.d; idx += nthreads) {
+                    const int row = fdiv(idx, inv_d), col = idx - row * a.d;
+                    const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
+                    const unsigned w0 = (unsigned)lp[0], w1 = (unsigned)lp[1], w2 = (unsigned)lp[2];
+                    const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
+                    const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
+                    const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);
+                    float gval = gs[row * a.xld + col];
+                    if (sc_unit >= 0) {
+#pragma unroll
+                        for (int net = 0; net < 2; ++net) {
+                            const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + sc_unit + net);
+                            const int cin = up[15], sl_n = up[21], gv_off = up[22];
+                            const int stride = 64 * ((cin + 3) >> 2);
+                            const float* sp = slab + gv_off + ((sc_k >> 2) * 16 + row) * 4 + (sc_k & 3);
+                            for (int sl = 0; sl < sl_n; ++sl) gval += sp[sl * stride];
+                        }
+                    }
+                    if (!tail_only && cp_ls >= 0) {
+                        const float s = sb[row * a.xld + col];
+                        const float aa = a.alpha * atanf(s);
+                        const float ea = expf(aa);
+                        const float l = xs[row * a.xld + col];            // lower input of the node
+                        const float ga = gval * ea * l + gj[row];           // g_a (a feeds both l' and J)
+                        const float gsv = ga * a.alpha / (1.f + s * s);     // g_s
+                        gst[row * a.gld + cp_ls] = gsv;
+                        gst[row * a.gld + cp_lt] = gval;                    // g_t = g_l'
+                        float* go = wsGST + (size_t)(row0 + row) * a.ST;
+                        go[cp_gs] = gsv;
+                        go[cp_gt] = gval;
+                        gval *= ea;                                         // g_l
+                    }
+                    gs[row * a.xld + col] = gval;
+                }
+                if (a.dc > 0 && has_prev) {
+                    // condition columns: every unit of the previous group contributes (fixed order: deterministic)
+                    for (int idx = tid; idx < ROWS * a.dc; idx += nthreads) {
+                        const int row = idx / a.dc, cc = idx - row * a.dc;
+                        float acc = gcs[row * a.cld + cc];
+                        for (int u = gp.unit_begin; u < gp.unit_end; ++u) {
+                            const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + u);
+                            const int cin = up[15], ku = up[16], sl_n = up[21], gv_off = up[22];
+                            const int k = ku + cc;
+                            const int stride = 64 * ((cin + 3) >> 2);
+                            const float* sp = slab + gv_off + ((k >> 2) * 16 + row) * 4 + (k & 3);
+                            for (int sl = 0; sl < sl_n; ++sl) acc += sp[sl * stride];
+                        }
+                        gcs[row * a.cld + cc] = acc;
+                    }
+                }
+                lds_barrier();
+                if (tail_only) break;
+
+                // ---- lane tile and s of the level the NEXT boundary needs: global -> registers now,
+                //      registers -> LDS at the end of Q3 (xs / sb are not read by the GEMM phases) ----
+                LevelPrefetch lp;
+                bool lp_pending = false;
+                {
+                    const bool block_switch = slot == 0;                     // next: root level of the block before
+                    int nlevel = a.n_levels - 1;
+                    if (!block_switch) nlevel = lds_i32((const LDS_AS int32_t*)(T.groups + slot - 1) + 7);
+                    if (block_switch ? cb > 0 : nlevel != g.level) {
+                        const float* ntape = block_switch ? (const float*)nblk.tape : tape;
+                        const bool ntop = block_switch ? (nblk.perm != nullptr || cb > 1) : top;
+                        level_issue(lp, LEVEL_SRC(ntape, ntop, nlevel), ntape + (size_t)(a.n_levels + nlevel) * lvl, a.d, row0, a.B,
+                                    tid, nthreads);
+                        lp_pending = true;
+                    }
+                }
+                const LDS_AS int32_t* rng = T.rng + g.rng_begin;
+                // ---- Q2: g2 = (W3^T g_st) .* relu'(a2) ----
+                pc.mask = (const float*)blk.actA1 + a.act_stride;
+                pc.out1 = (float*)blk.wsG1 + a.act_stride;
+                run_phase<K_G2>(pc, T, g, lds_i32(rng + wave), lds_i32(rng + wave + 1), nullptr, lane);
+                lds_barrier();
+                // ---- Q3: g1 = (W2^T g2) .* relu'(a1);  g_v partial = W1^T g1 ----
+                pc.mask = (const float*)blk.actA1;
+                pc.out1 = (float*)blk.wsG1;
+                run_phase<K_G1>(pc, T, g, lds_i32(rng + a.nw + 1 + wave), lds_i32(rng + a.nw + 2 + wave),
+                                slab + lds_i32(rng + 3 * a.nw + 2 + wave), lane);
+                if (lp_pending) level_commit(lp, xs, sb, a.xld, a.d, tid, nthreads);
+                lds_barrier();
+            }
+            if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
+                // 16*d <= LV_REGS*threads (plan check): the products are held in registers across the
+                // barrier so that they can go back into gs
+                float pacc[LV_REGS];
+#pragma unroll
+                for (int q = 0; q < LV_REGS; ++q) {
+                    const int i = tid + q * nthreads;
+                    float acc = 0.f;
+                    if (i < ROWS * a.d) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        acc = perm_dot(gs + r * a.xld, perm + (size_t)j * a.d, 1, a.d);
+                    }
+                    pacc[q] = acc;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < LV_REGS; ++q) {
+                    const int i = tid + q * nthreads;
+                    if (i < ROWS * a.d) { const int r = fdiv(i, inv_d); gs[r * a.xld + (i - r * a.d)] = pacc[q]; }
+                }
+                __syncthreads();
+            }
+        }
+        store_tile(g_x, gs, a.xld, a.d, row0, a.B, tid, nthreads);
+        if (a.dc > 0 && g_c != nullptr) store_tile(g_c, gcs, a.cld, a.dc, row0, a.B, tid, nthreads);
+        __syncthreads();
+    }
+#undef HINT_CB
+#undef LEVEL_SRC
+}
+
+namespace hint {
+
+hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
+                      int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
+                      float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream) {
+    hipLaunchKernelGGL(hint_bwd_kernel, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, one, chain, n_chain, x, c,
+                       g_z, g_J, g_x, g_c, gz_scale, gJ_const);
+    return hipGetLastError();
+}
+
+hipError_t set_max_lds_bwd(int bytes) {
+    return hipFuncSetAttribute((const void*)hint_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace hint

@@ -1,54 +1,63 @@
-// Internal device-side plan layout shared by the plan builder (hint_plan.cpp) and the
-// kernels (hint_kernels.hip).  Not part of the public ABI (that is include/hint_amd.h).
+// Internal device-side plan layout shared by the plan builder (hint_plan.cpp) and the kernels
+// (hint_fwd.hip, hint_bwd.hip, hint_wgrad.hip, hint_pack.hip).  Not part of the public ABI (that
+// is include/hint_amd.h).
+//
+// Design in one paragraph (DESIGN.md has the long form).  A workgroup owns a tile of 16 batch rows
+// and carries it through every tree level of every block of a flow.  All subnet GEMMs are computed
+// TRANSPOSED, out^T[features x 16 rows] = W[features x K] * act^T[K x 16 rows], with
+// v_mfma_f32_16x16x4_f32: the weights are the A operand (pre-packed fragments streamed from L2), the
+// activations the B operand.  In that orientation the accumulator of one layer (lane l holds
+// features 4*(l>>4)+i of row l&15) IS the B operand of the next layer, so a "unit" (one subnet of
+// one node) runs layer 2 -> layer 3 (forward) or g1 -> g_v (backward) inside one wavefront with no
+// barrier; activations travel between wavefronts as 1 KiB "fragment tiles" in LDS (element
+// [lane*4+i]), written and read with one ds_*_b128 per lane.  The wavefronts of a workgroup split a
+// group's (unit, 16-feature tile) list into contiguous, cost-balanced ranges; a wavefront whose
+// range covers part of a unit contributes a K-split partial of the thin last layer to a slab.
 #pragma once
 #include <stdint.h>
 
 namespace hint {
 
-// Tuning knobs (compile-time; the plan builder and the kernels must agree):
-//   HINT_NWAVES  wavefronts per workgroup (8 or 16): with one 16-row tile per CU at B = 4096 the
-//                only latency hiding is between the wavefronts of the one resident workgroup
-#ifndef HINT_NWAVES
-#define HINT_NWAVES 8
-#endif
-constexpr int ROWS = 16;        // batch rows per workgroup tile = one MFMA M-tile
-constexpr int NWAVES = HINT_NWAVES;
-constexpr int NTHREADS = 64 * NWAVES;
+constexpr int ROWS = 16;        // batch rows per row tile = one MFMA N-tile of the transposed products
 constexpr int TILE = 16;        // MFMA 16x16x4 f32 tile edge
-constexpr int MAX_SLABS = 4;    // K-split partial-sum slabs of the thin (N <= 16) layers
+constexpr int MAX_NW = 16;      // wavefronts per workgroup (plan-time choice: 4, 8 or 16)
+constexpr int MAX_RT = 4;       // 16-wide tiles of a unit's output (r <= 64) and of its input (cin <= 64 + dc)
+constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (cin <= 192)
 
 // ---------------------------------------------------------------------------------------
-// Packed weights.  Every GEMM of the block reads its B operand from a buffer in MFMA
-// fragment order, zero padded in both dimensions: the 16x16 tile (n-tile nt, k-block kb) of a
-// logical matrix Wlog[N][K] is 256 consecutive floats, element [lane*4 + i] =
-// Wlog[nt*16 + (lane&15)][kb*16 + 4*(lane>>4) + i], tiles ordered kb-fastest.  A wavefront
-// fetches one tile with a single fully coalesced 1 KiB global_load_dwordx4.
+// Packed weights.  Every GEMM reads its weight operand from a buffer in MFMA fragment order, zero
+// padded in both dimensions: the 16x16 tile (n-tile nt, k-block kb) of a logical matrix
+// Wlog[N][K] is 256 consecutive floats, tiles ordered kb-fastest.  Element [lane*4 + i] is
+//   kmap 0 ("blocked"):      Wlog[nt*16 + (lane&15)][kb*16 + 4*(lane>>4) + i]
+//   kmap 1 ("interleaved"):  Wlog[nt*16 + (lane&15)][kb*16 + 4*i + (lane>>4)]
+// MFMA i of a k-block takes component i of the lane's float4 as its A operand.  Blocked is the
+// order in which an accumulator tile of the previous layer supplies the B operand; interleaved is
+// used where the B operand is read element-wise from a row-major LDS tile (first layer from the
+// lane tile, g2 from the coupling gradients): a K of 1..4 then costs ONE MFMA, not four.
 // ---------------------------------------------------------------------------------------
 struct PackSeg {
     int64_t dst;        // float offset of the segment in the packed buffer
-    int64_t src0, src1; // float offsets into the flat parameter buffer
+    int64_t src;        // float offset into the flat parameter buffer
     int32_t N, K;       // logical (unpadded) extents; tiles = ceil(N/16) x NB
     int32_t NB;         // k-blocks per n-tile
     int32_t ld;         // row stride of the source tensor
-    int32_t mode;       // 0: Wlog[n][k] = P[src0 + n*ld + k]           (forward layers)
-                        // 1: Wlog[n][k] = P[src0 + k*ld + n]           (transposed, backward)
-                        // 2: Wlog[n][k] = P[src(k/hp) + (k%hp)*ld + n], k%hp < h  (stacked s|t)
-    int32_t hp, h;
+    int32_t trans;      // 0: Wlog[n][k] = P[src + n*ld + k];  1: Wlog[n][k] = P[src + k*ld + n]
+    int32_t kmap;       // 0 blocked, 1 interleaved
     int32_t tile_begin; // index of this segment's first n-tile in the global n-tile list
+    int32_t pad;
 };
 
-// Per-block pointers of a chained launch (hint_chain_*): all blocks of a flow share one plan
-// shape, so the kernels loop over the blocks with the lane tile (forward) or the gradient tile
-// (backward) staying in LDS between blocks.
+// Per-block pointers of a launch (one block: passed by value; a chain: a device table).
 struct ChainBlock {
     const float* params;
     const float* packed;
     const float* perm;     // [d,d] permutation in front of the block, or nullptr
-    float* tape;           // forward tape of this block (or nullptr)
-    float* wsA1;           // hidden activations a1 [Bp][WT] inside the tape (a2 follows act_stride later); NULL = inference
-    float* wsG2;
-    float* wsT;
-    float* gparams;        // flat parameter gradient of this block (part B)
+    float* tape;           // forward tape of this block (or nullptr): [lane tiles L x B x d][s L x B x d] ...
+    float* actA1;          // hidden activations a1 [Bp][WT] inside the tape (a2 follows act_stride later); NULL = inference
+    float* wsG1;           // workspace: g1 [Bp][WT]; g2 follows act_stride later
+    float* wsGST;          // workspace: coupling gradients [Bp][ST] (g_s | g_t columns of every unit)
+    float* wsSlab;         // workspace: [splits][param_floats] partial weight gradients (part B)
+    float* gparams;        // flat parameter gradient of this block
 };
 
 // one block's share of a multi-block pack launch (hint_pack_group_*)
@@ -63,88 +72,70 @@ struct PackItem {
     int32_t grid_begin, pad;
 };
 
-// One job of a GEMM stage: nt (1..3) adjacent 16-column output tiles of one (node, net) that
-// share their A operand, over nb consecutive 16-wide k-blocks:
-//   out[16 rows][16*nt cols] (+)= A[16][16*nb] * Wlog^T.
-// The host cuts every stage into jobs and deals them to the 8 wavefronts so that the four SIMDs
-// (wavefronts w and w+4 share one) carry equal MFMA work; a wavefront's jobs form a list of
-// 16-byte records read from LDS with one ds_read_b128 each.
-struct TJob {
-    int32_t wtile;      // packed offset, in 256-float tiles, of (first n-tile, first k-block)
-    uint16_t acol;      // A column (floats) of the first k-block in the stage's LDS input
-    uint16_t ocol;      // first output column of the first tile in the stage's LDS output
-    uint8_t nb;         // k-blocks (0 only for K = 0 jobs: the tiles are bias-only)
-    uint8_t nt;         // n-tiles; 0 = nothing to do (the single record of an idle wavefront)
-    uint8_t nvalid;     // valid output columns of the LAST tile (the others are full; rest is written as 0)
-    uint8_t slab;       // K-split slab the partial result goes to
-    uint16_t tstride;   // distance, in tiles, between consecutive n-tiles in the packed buffer
-    uint16_t count;     // in the FIRST record of a wavefront's list: number of jobs in the list
+// One unit = one subnet (s: even index, t: odd index) of one node.  24 x int32 = 6 x 16 bytes.
+struct Unit {
+    int32_t f1, f2, f3, b3;         // first packed tile (offset / 256) of W1 [h x cin], W2 [h x h], W3 [r x h], W3^T [h x r]
+    int32_t b2, b1, bias1, bias2;   // ... W2^T [h x h], W1^T [cin x h]; float offsets of b1, b2 (zero padded to 16) in packed
+    int32_t bias3, wcol, tile0, gcol;   // b3; column in the [Bp][WT] arrays; first fragment tile inside the group; column in [Bp][ST]
+    int32_t NT, KB1, RT, cin;       // tiles of h, k-blocks of cin, tiles of r; subnet input width
+    int32_t ku, r, xoff, h;         // lanes among the inputs (the rest is the condition), outputs, first input lane, hidden width
+    int32_t sl_off, sl_n, gv_off, lcol; // first L3 slab (floats inside the slab buffer), slices; first g_v slab; gcol - group's gcol0
 };
-static_assert(sizeof(TJob) == 16, "TJob must be 16 bytes");
-// nt == TJOB_OUTER marks an outer-product tile of a thin weight gradient (dW1, dW3) that rides in
-// a GEMM stage's lists of the backward kernel:  T[m][n] = sum_rows A[row][acol+m] * B[row][ocol+n],
-// stored at slab[wtile + m*tstride + n] for m <= (nvalid & 15), n <= (nvalid >> 4); nb = 0.
-// A record covers a run of adjacent tiles (up to 127) that share one operand: slab = direction | tiles << 1, direction
-// 0 = along n (ocol += 16 per tile, A shared), 1 = along m (acol += 16, B shared); nvalid describes the
-// LAST tile (the others are full in the direction the record walks).
-constexpr int TJOB_OUTER = 0xff;
-typedef TJob GJob;      // the per-group lists hold TJob and OJob records, 16 B each
+static_assert(sizeof(Unit) == 96, "Unit must be 6 x 16 bytes");
 
-// A stage's lists sit at a fixed stride: wavefront w's list starts at record w*stride (the stage
-// descriptor packs offset and stride into one int, see STAGE_DESC).
-#define STAGE_DESC(OFF, STRIDE) (((OFF) & 0xffff) | ((STRIDE) << 16))
-
-struct Ent { int16_t xcol, scol, tcol, pad; };                  // one transformed lane of a group
-
-// A group = a set of same-depth nodes processed together by one workgroup pass.  28 int32
-// fields = 7 x 16 bytes, read from LDS in one burst (see load_group()).  The *_off fields are stage
-// descriptors (STAGE_DESC) into the group's job list (16-byte records from jl_begin): L1, L2, L3
-// of the forward pass, g2, g1, dv of the backward pass (the thin weight gradients' outer-product
-// tiles ride in g2's and dv's lists), o3_off: the dW3 tiles as a stage of their own (plans without
-// LDS for a separate g2 buffer, KArgs.split_o3).  o3_cnt, o1_off, o1_cnt are unused.
-// pad: 0 = whole nodes; 1 / 2 = the t / s unit of a node whose two nets run one at a time.
-struct DGroup {
-    int32_t node_begin, node_end, jl_begin, jl_count;
-    int32_t l1_off, l2_off, l3_off, g2_off;
-    int32_t g1_off, dv_off, o3_off, o3_cnt;
-    int32_t o1_off, o1_cnt, ent_begin, ent_cnt;
-    int32_t bmap_begin, bmap3_begin, aw, vw;
-    int32_t sw, l3_slabs, dv_slabs, wcol0;
-    int32_t level, level_last, vmap_begin, pad;
+// A group = a set of same-depth nodes processed together.  16 x int32.
+struct Group {
+    int32_t unit_begin, unit_end, ntiles, tmap_begin;   // tmap: uint16 per fragment tile = unit index inside the group
+    int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[ (nw+1) | (nw+1) | nw | nw ] = tile ranges of the two GEMM phases, first slab per wavefront (L3, g_v)
+    int32_t level_last, gcol0, gcols, lop_begin;        // first / number of [ST] columns; LaneOp[d] of the boundary in front of the group (backward)
+    int32_t level_first, cpad0, cpad1, cpad2;
 };
-static_assert(sizeof(DGroup) == 112, "DGroup must be 7 x 16 bytes");
+static_assert(sizeof(Group) == 64, "Group must be 4 x 16 bytes");
 
-// dW2 tile job of the weight-gradient kernel: C[m][n] = sum_b G2[b][col+m] * A1[b][col+n]
-// The tile spans mw x nw "virtual" 16x16 MFMA tiles (1..3 each way): lane l of virtual tile j
-// holds column m0 + mw*(l&15) + j, so one dwordx3 load per operand and k-step feeds up to three
-// MFMA tiles (the permutation of columns inside the 48-wide group is undone at write-out).
-struct DWJob {
-    int32_t col, H;     // workspace column of this (node, net); H = valid extent (h)
-    int32_t m0, n0;     // output tile origin
-    int32_t mw, nw;     // virtual tiles (= floats per lane and load) along m and n
-    int64_t wofs;       // offset of dW2 in the flat gradient buffer (row stride H)
+// One transformed lane of a group (coupling): 16 bytes.
+struct Ent {
+    int16_t xcol, nquad;    // lane column; ceil(r / 4) of the node: a slice's slab is 16 rows x 4*nquad floats
+    int16_t sl_ns, sl_nt;   // slices (slabs to add up) of the node's s / t subnet
+    int32_t s_off, t_off;   // float offset inside the slab buffer of element (quad j/4, row 0, j%4) of the first slice
 };
+static_assert(sizeof(Ent) == 16, "Ent must be 16 bytes");
+
+// Backward, per lane column at the boundary in front of a group (slot n_groups: behind the last one):
+// what to add from the group before (the g_v partials of the node whose input this lane is) and
+// where the coupling gradients of the coming group's node that transforms this lane go.  16 bytes.
+struct LaneOp {
+    int16_t sc_unit, sc_k;  // s unit (global index) of the node of the previous group that takes this lane as input k; -1: none
+    int16_t cp_ls, cp_lt;   // column of g_s / g_t of this lane in the LDS coupling-gradient buffer; cp_ls = -1: lane not transformed
+    int16_t cp_gs, cp_gt;   // the same columns in the global [Bp][ST] array
+    int32_t pad;
+};
+static_assert(sizeof(LaneOp) == 16, "LaneOp must be 16 bytes");
+
+// Weight-gradient job (part B): out[m][n] = sum_b P[b][pcol+m] * Q[b][qcol+n] for one tile of up to
+// 48 x 48 outputs of one parameter matrix; bofs >= 0: the job also sums P's columns (bias gradient).
+enum { WSRC_G1 = 0, WSRC_G2 = 1, WSRC_GST = 2, WSRC_A1 = 3, WSRC_A2 = 4, WSRC_X = 5, WSRC_C = 6 };
+struct WJob {
+    int32_t psrc, pcol, M, mw;      // operand array, first column, valid outputs (<= 16*mw), 16-wide tiles (1..3)
+    int32_t qsrc, qcol, N, nw;      // N may be 0 (bias only)
+    int32_t qlevel, ldo;            // WSRC_X: tree level whose input lanes are read; row stride of the output matrix
+    int32_t pmax, qmax;             // last readable column of either operand (loads are clamped to it)
+    int64_t wofs;                   // float offset of out[0][0] in the flat gradient layout
+    int64_t bofs;                   // float offset of the bias gradient's first element, or -1
+};
+static_assert(sizeof(WJob) == 64, "WJob must be 64 bytes");
 
 struct KArgs {
-    const void* meta;              // [groups | vmap | ents] contiguous, copied to LDS at kernel start
-    const GJob* jobs;              // all groups' job lists (GJob / OJob, 16 bytes each)
-    const int32_t* bmap;           // per LDS column: compact thin-gradient index of its bias, or -1
-    int32_t thin_total;            // floats of one row tile's thin-gradient slab
+    const void* meta;              // [groups | units | tmap | ents | ranges | laneops] contiguous, copied to LDS at kernel start
     int32_t meta_bytes;            // multiple of 16
-    int32_t vmap_off, ents_off;    // byte offsets inside meta (vmap: int16 per v column)
-    int32_t first[2][4];           // {jl_begin, jl_count, bmap_begin, nbias} of the first group: [0] forward order, [1] reverse
-    int32_t jmax;                  // capacity (jobs) of one LDS job buffer
-    int32_t bmax;                  // capacity (floats) of one LDS bias buffer
-    int64_t bias_off;              // float offset of the bias region inside the packed buffer
-    int64_t act_stride;            // floats between the a1 and a2 activation arrays of the tape (ChainBlock.wsA1)
-    int32_t n_groups, n_levels;
-    int32_t d, dc;
-    int32_t xld, cld, ald, vld, sld;   // LDS row strides (floats)
-    int32_t max_aw;                    // widest group's activation columns (a1 / a2 buffers)
-    int32_t perm_lds;                  // float offset in LDS of the chain's d x d permutation matrices ([n_chain][d][d]); 0: read them from global memory
-    int32_t s3, sv;                    // slab counts of the st / gv buffers
-    int32_t WT;                        // workspace row width (floats)
-    int32_t split_o3;                  // backward: no LDS for a separate g2 buffer -> dW3 tiles run as their own phase
+    int32_t units_off, tmap_off, ents_off, rng_off, lops_off;   // byte offsets inside meta
+    int32_t n_groups, n_levels, n_units, nw;
+    int32_t d, dc, xld, cld;       // lanes, condition width, LDS row strides of the lane / condition tiles
+    int32_t abuf_tiles;            // fragment tiles of the widest group (LDS activation buffer)
+    int32_t slab_floats;           // L3 slab buffer (forward) / g_v slab buffer (backward), floats
+    int32_t gld;                   // LDS row stride of the coupling-gradient buffer (backward)
+    int32_t WT, ST;                // row widths of the activation / coupling-gradient arrays
+    int32_t perm_lds;              // float offset in LDS of the chain's d x d permutation matrices; 0: read them from global memory
+    int64_t act_stride;            // floats between the a1 and a2 (g1 and g2) arrays
     float alpha;
     int32_t B;
 };

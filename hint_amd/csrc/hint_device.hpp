@@ -1,0 +1,194 @@
+// Device-side helpers shared by the block kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hint_dev.h"
+
+namespace hint {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Explicit address spaces.  A pointer that loses its address space is read with flat_load, which
+// counts against vmcnt AND lgkmcnt and so serialises LDS traffic with the weight prefetch.
+#define LDS_AS __attribute__((address_space(3)))
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() makes hipcc drain vmcnt(0) first,
+// which would retire the weight prefetch at every phase boundary.  Global stores issued before it
+// are never read back inside the kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// floor(i / d) for 0 <= i < 2^20 through the float unit (three instructions instead of ~25)
+__device__ __forceinline__ float frcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ int fdiv(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ float row16_sum(float v) {      // deterministic butterfly over 16 adjacent lanes
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+// ChainBlock with the pointers typed as global memory (pointers that arrive inside a by-value struct
+// or a device table are generic to the compiler).
+struct GBlock {
+    const GLOBAL_AS float* params;
+    const GLOBAL_AS float* packed;
+    const GLOBAL_AS float* perm;
+    GLOBAL_AS float* tape;
+    GLOBAL_AS float* actA1;
+    GLOBAL_AS float* wsG1;
+    GLOBAL_AS float* wsGST;
+    GLOBAL_AS float* wsSlab;
+    GLOBAL_AS float* gparams;
+};
+__device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ chain, const ChainBlock& one, int i) {
+    const ChainBlock b = (chain != nullptr) ? chain[i] : one;
+    GBlock g;
+    g.params = (const GLOBAL_AS float*)b.params;
+    g.packed = (const GLOBAL_AS float*)b.packed;
+    g.perm = (const GLOBAL_AS float*)b.perm;
+    g.tape = (GLOBAL_AS float*)b.tape;
+    g.actA1 = (GLOBAL_AS float*)b.actA1;
+    g.wsG1 = (GLOBAL_AS float*)b.wsG1;
+    g.wsGST = (GLOBAL_AS float*)b.wsGST;
+    g.wsSlab = (GLOBAL_AS float*)b.wsSlab;
+    g.gparams = (GLOBAL_AS float*)b.gparams;
+    return g;
+}
+
+// ---- wave-uniform reads of the plan tables staged in LDS ----
+struct UnitU {
+    int f1, f2, f3, b3, b2, b1, bias1, bias2, bias3, wcol, tile0, gcol, NT, KB1, RT, cin, ku, r, xoff, h, sl_off, sl_n,
+        gv_off, lcol;
+};
+__device__ __forceinline__ UnitU load_unit(const LDS_AS Unit* u) {
+    const LDS_AS i32x4* p = (const LDS_AS i32x4*)u;
+    const i32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+    UnitU r;
+    r.f1 = rfl(q0.x); r.f2 = rfl(q0.y); r.f3 = rfl(q0.z); r.b3 = rfl(q0.w);
+    r.b2 = rfl(q1.x); r.b1 = rfl(q1.y); r.bias1 = rfl(q1.z); r.bias2 = rfl(q1.w);
+    r.bias3 = rfl(q2.x); r.wcol = rfl(q2.y); r.tile0 = rfl(q2.z); r.gcol = rfl(q2.w);
+    r.NT = rfl(q3.x); r.KB1 = rfl(q3.y); r.RT = rfl(q3.z); r.cin = rfl(q3.w);
+    r.ku = rfl(q4.x); r.r = rfl(q4.y); r.xoff = rfl(q4.z); r.h = rfl(q4.w);
+    r.sl_off = rfl(q5.x); r.sl_n = rfl(q5.y); r.gv_off = rfl(q5.z); r.lcol = rfl(q5.w);
+    return r;
+}
+struct GroupU {
+    int unit_begin, unit_end, ntiles, tmap_begin, ent_begin, ent_cnt, rng_begin, level, level_last, gcol0, gcols,
+        lop_begin, level_first;
+};
+__device__ __forceinline__ GroupU load_group(const LDS_AS Group* g) {
+    const LDS_AS i32x4* p = (const LDS_AS i32x4*)g;
+    const i32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    GroupU r;
+    r.unit_begin = rfl(q0.x); r.unit_end = rfl(q0.y); r.ntiles = rfl(q0.z); r.tmap_begin = rfl(q0.w);
+    r.ent_begin = rfl(q1.x); r.ent_cnt = rfl(q1.y); r.rng_begin = rfl(q1.z); r.level = rfl(q1.w);
+    r.level_last = rfl(q2.x); r.gcol0 = rfl(q2.y); r.gcols = rfl(q2.z); r.lop_begin = rfl(q2.w);
+    r.level_first = rfl(q3.x);
+    return r;
+}
+__device__ __forceinline__ int lds_i32(const LDS_AS int32_t* p) { return rfl(*p); }
+__device__ __forceinline__ int lds_u16(const LDS_AS uint16_t* p) { return rfl((int)*p); }
+
+// ---- [16, width] tiles of row-major [B, width] tensors: one contiguous run of 16*width floats ----
+__device__ __forceinline__ void load_tile(float* dst, int ld, const float* __restrict__ src, int width, int row0,
+                                          int B, int tid, int nthreads) {
+    const float inv = frcp(width);
+    if (src == nullptr) {
+        for (int i = tid; i < ROWS * width; i += nthreads) { const int r = fdiv(i, inv); dst[r * ld + (i - r * width)] = 0.f; }
+        return;
+    }
+    const float* p = src + (size_t)row0 * width;
+    const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
+    for (int i = tid; i < ROWS * width; i += nthreads) {
+        const int r = fdiv(i, inv);
+        dst[r * ld + (i - r * width)] = (i < nvalid) ? p[i] : 0.f;
+    }
+}
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* src, int ld, int width, int row0,
+                                           int B, int tid, int nthreads) {
+    float* p = dst + (size_t)row0 * width;
+    const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
+    const float inv = frcp(width);
+    for (int i = tid; i < nvalid; i += nthreads) {
+        const int r = fdiv(i, inv);
+        p[i] = src[r * ld + (i - r * width)];
+    }
+}
+
+// sum_k row[k] * w[k * stride]: a row of the lane tile times a column (or row) of a fixed d x d matrix
+__device__ __forceinline__ float perm_dot(const float* row, const float* __restrict__ w, int stride, int d) {
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 8 <= d; k += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(row[k + u], wv[u], acc);
+    }
+    for (; k < d; ++k) acc = fmaf(row[k], w[(size_t)k * stride], acc);
+    return acc;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11) + Box-Muller: four standard normals per (key, counter).
+// Dequantisation noise of a training step (train_unconditional.py:121, x += 0.01*randn_like(x)),
+// drawn inside the forward kernel: no extra launch, no HBM round trip.
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long step, unsigned idx,
+                                               float (&out)[4]) {
+    unsigned c0 = idx, c1 = (unsigned)step, c2 = (unsigned)(step >> 32), c3 = 0x48494e54u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)c0 + 1.0f) * 2.3283064365386963e-10f;     // (0, 1]
+    const float u1 = (float)c1 * 2.3283064365386963e-10f;
+    const float u2 = ((float)c2 + 1.0f) * 2.3283064365386963e-10f;
+    const float u3 = (float)c3 * 2.3283064365386963e-10f;
+    // hardware transcendentals: v_log_f32 is log2, v_sin/v_cos take their argument in turns
+    const float r0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u0, 1.0f)));
+    const float r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u2, 1.0f)));
+    const float s0 = __builtin_amdgcn_sinf(u1), cs0 = __builtin_amdgcn_cosf(u1);
+    const float s1 = __builtin_amdgcn_sinf(u3), cs1 = __builtin_amdgcn_cosf(u3);
+    out[0] = r0 * cs0; out[1] = r0 * s0; out[2] = r1 * cs1; out[3] = r1 * s1;
+}
+
+// LDS carve-up shared by the block kernels: [meta blob][float buffers ...]
+struct Tables {
+    const LDS_AS Group* groups;
+    const LDS_AS Unit* units;
+    const LDS_AS uint16_t* tmap;
+    const LDS_AS Ent* ents;
+    const LDS_AS int32_t* rng;
+    const LDS_AS LaneOp* lops;
+};
+__device__ __forceinline__ Tables make_tables(const KArgs& a, float* lds) {
+    LDS_AS char* mbase = (LDS_AS char*)lds;
+    Tables t;
+    t.groups = (const LDS_AS Group*)mbase;
+    t.units = (const LDS_AS Unit*)(mbase + a.units_off);
+    t.tmap = (const LDS_AS uint16_t*)(mbase + a.tmap_off);
+    t.ents = (const LDS_AS Ent*)(mbase + a.ents_off);
+    t.rng = (const LDS_AS int32_t*)(mbase + a.rng_off);
+    t.lops = (const LDS_AS LaneOp*)(mbase + a.lops_off);
+    return t;
+}
+__device__ __forceinline__ void copy_meta(const KArgs& a, float* lds, int tid, int nthreads) {
+    const int n16 = a.meta_bytes >> 4;
+    LDS_AS i32x4* dst = (LDS_AS i32x4*)lds;
+    const i32x4* src = (const i32x4*)a.meta;
+    for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+}
+
+}  // namespace hint

@@ -1,0 +1,217 @@
+// Forward / inverse kernel (gfx950 / CDNA4 only) of HINT's recursive affine-coupling block.
+//
+// Arithmetic reproduced (reference, read-only): /root/reference/hint.py:62-101
+//   per node:  v = [u | c];  s = mlp_s(v), t = mlp_t(v)            (hint.py:76-77, :10-13)
+//              a = alpha*atan(s), alpha = clamp*0.636               (hint.py:56-60)
+//   forward    l' = exp(a)*l + t ;  J += sum a   (children first)   (hint.py:70-80,97-99)
+//   inverse    l  = (l' - t)/exp(a); J -= sum a  (root first)       (hint.py:82-88)
+//
+// One workgroup owns a tile of 16 batch rows and carries it through ALL tree levels of ALL blocks
+// of a flow inside one launch; the lane tile and the condition stay in LDS, HBM sees x once in and
+// z, J once out (plus the training tape).  Per group of same-depth nodes three phases:
+//   P1  first layer of every unit -> a1 fragment tiles in LDS            (run_phase<K_L1>)
+//   P2  second layer, and straight from its accumulator the third layer's K-split partial
+//       (+ bias) into the wavefront's slab                                (run_phase<K_L2>)
+//   P3  coupling: s, t = sum of the slabs; l' = exp(a) l + t; log-det
+#include "hint_rows.hpp"
+
+using namespace hint;
+
+template <bool REV>
+__global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
+    KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
+    const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
+    float* __restrict__ J, const float* __restrict__ J_in, float* __restrict__ loss_acc,
+    float noise, const unsigned long long* __restrict__ rng_state, float* __restrict__ x_noisy) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const float inv_d = frcp(a.d);
+    const Tables T = make_tables(a, lds);
+    float* t0 = lds + (a.meta_bytes >> 2);    // two lane tiles: a fused permutation ping-pongs between them
+    float* cs = t0 + 2 * ROWS * a.xld;
+    float* abuf = cs + ROWS * a.cld;
+    float* slab = abuf + a.abuf_tiles * 256;
+    float* jac = slab + a.slab_floats;
+    float* red = jac + ROWS;                  // MAX_NW floats: loss partials
+    const int ntiles = (a.B + ROWS - 1) / ROWS;
+    copy_meta(a, lds, tid, nthreads);
+    // the chain's fixed d x d permutation matrices, once per workgroup (when the launch found LDS for them)
+    float* ptab = lds + a.perm_lds;
+    const int pdd = a.d * a.d;
+    if (a.perm_lds > 0) {
+        for (int i = tid; i < n_chain * pdd; i += nthreads) {
+            const int cbi = fdiv(i, frcp(pdd));
+            const float* pp = (chain != nullptr) ? chain[cbi].perm : one.perm;
+            ptab[i] = pp != nullptr ? ((const GLOBAL_AS float*)pp)[i - cbi * pdd] : 0.f;
+        }
+    }
+#define HINT_CB(I) chain_block(chain, one, I)
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        // the current lane tile is t0 + xcur (an integer offset, not a swapped pointer: the compiler
+        // must keep seeing LDS addresses or it falls back to flat loads)
+        int xcur = 0;
+        const int xflip = ROWS * a.xld;
+#define XS (t0 + xcur)
+#define XO (t0 + (xflip - xcur))
+        load_tile(XS, a.xld, x, a.d, row0, a.B, tid, nthreads);
+        if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid, nthreads);
+        if (tid < ROWS) jac[tid] = 0.f;
+        __syncthreads();                      // meta and the lane tile visible
+        if (!REV && rng_state != nullptr) {
+            // x += noise * N(0,1), four values per Philox call, keyed by (seed, step, element group)
+            const unsigned long long seed = rng_state[0], step = rng_state[1];
+            const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
+            for (int q = tid; 4 * q < nvalid; q += nthreads) {
+                float nz[4];
+                philox_normal4(seed, step, (unsigned)(((size_t)row0 * a.d) / 4 + (size_t)q), nz);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    if (i < nvalid) { const int r = fdiv(i, inv_d); XS[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
+                }
+            }
+            __syncthreads();
+            if (x_noisy != nullptr) store_tile(x_noisy, XS, a.xld, a.d, row0, a.B, tid, nthreads);   // what the backward pass starts from
+        }
+
+        for (int cb = 0; cb < n_chain; ++cb) {
+            const int bi = REV ? n_chain - 1 - cb : cb;       // the inverse walks the chain last block first
+            const GBlock blk = HINT_CB(bi);
+            const float* perm = (const float*)blk.perm;
+            float* tape = (float*)blk.tape;
+            float* actA1 = (float*)blk.actA1;
+            const bool train = !REV && actA1 != nullptr;
+            if (!REV && perm != nullptr) {
+                // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
+                const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
+                for (int i = tid; i < ROWS * a.d; i += nthreads) {
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
+                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, w + j, a.d, a.d);
+                }
+                xcur = xflip - xcur;
+                __syncthreads();
+                if (tape != nullptr)      // the permuted input is what the backward pass starts from
+                    store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
+            } else if (!REV && cb > 0 && tape != nullptr) {
+                // inner block of a chain without a permutation: its input exists nowhere else
+                store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
+            }
+            PhaseCtx pc;
+            pc.packed = (const float*)blk.packed;
+            pc.abuf = abuf; pc.cs = cs; pc.gst = nullptr; pc.slab = slab;
+            pc.mask = nullptr;
+            pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
+            pc.store = train;
+
+            for (int gi = 0; gi < a.n_groups; ++gi) {
+                const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : gi));
+                const LDS_AS int32_t* rng = T.rng + g.rng_begin;
+                pc.xs = XS;
+                // ---- P1: first layer ----
+                pc.out1 = actA1;
+                run_phase<K_L1>(pc, T, g, lds_i32(rng + wave), lds_i32(rng + wave + 1), nullptr, lane);
+                lds_barrier();
+                // ---- P2: second layer + third layer partials ----
+                pc.out1 = train ? actA1 + a.act_stride : nullptr;
+                run_phase<K_L2>(pc, T, g, lds_i32(rng + a.nw + 1 + wave), lds_i32(rng + a.nw + 2 + wave),
+                                slab + lds_i32(rng + 2 * a.nw + 2 + wave), lane);
+                lds_barrier();
+                // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) ----
+                {
+                    const int sub = tid & 15, row = tid >> 4;
+                    float part = 0.f;
+                    if (row < ROWS) {
+                        for (int e = sub; e < g.ent_cnt; e += 16) {
+                            const LDS_AS int32_t* ep = (const LDS_AS int32_t*)(T.ents + g.ent_begin + e);
+                            const unsigned w0 = (unsigned)ep[0], w1 = (unsigned)ep[1];
+                            const int xcol = (int)(w0 & 0xffffu), sl_ns = (int)(w1 & 0xffffu), sl_nt = (int)(w1 >> 16);
+                            const int stride = 64 * (int)(w0 >> 16);             // floats per slice slab: 16 rows x pad4(r)
+                            const int s_off = ep[2], t_off = ep[3];
+                            float s = 0.f, t = 0.f;
+                            for (int sl = 0; sl < sl_ns; ++sl) s += slab[s_off + sl * stride + row * 4];
+                            for (int sl = 0; sl < sl_nt; ++sl) t += slab[t_off + sl * stride + row * 4];
+                            const float aa = a.alpha * atanf(s);
+                            float* px = XS + row * a.xld + xcol;
+                            // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it
+                            // scales): the backward pass needs no third-layer recompute
+                            if (!REV && tape != nullptr && row0 + row < a.B)
+                                tape[((size_t)(a.n_levels + g.level) * a.B + row0 + row) * a.d + xcol] = s;
+                            if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
+                            else      { *px = ((*px) - t) / expf(aa); part -= aa; }
+                        }
+                    }
+                    part = row16_sum(part);
+                    if (sub == 0 && row < ROWS) jac[row] += part;
+                }
+                lds_barrier();
+                // training: keep the lane tile as it stands after each level except the root's, so that
+                // the backward pass sees bit-identical subnet inputs (tape[level][B][d])
+                if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
+                    store_tile(tape + (size_t)g.level * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
+            }
+            if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
+                const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
+                for (int i = tid; i < ROWS * a.d; i += nthreads) {
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
+                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, w + (size_t)j * a.d, 1, a.d);
+                }
+                xcur = xflip - xcur;
+                __syncthreads();
+            }
+        }
+        store_tile(z, XS, a.xld, a.d, row0, a.B, tid, nthreads);
+        if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid] + (J_in != nullptr ? J_in[row0 + tid] : 0.f);
+        if (loss_acc != nullptr) {
+            // per-workgroup partial sums of the two loss terms (train_unconditional.py:128-129):
+            // slot[0] += sum_rows 0.5*|z|^2, slot[1] += sum_rows J_total
+            float zz = 0.f;
+            const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS);
+            for (int i = tid; i < nvalid * a.d; i += nthreads) { const int r = fdiv(i, inv_d); const float v = XS[r * a.xld + (i - r * a.d)]; zz += v * v; }
+            for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o, 64);
+            if (lane == 0) red[wave] = zz;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (int w = 0; w < a.nw; ++w) t += red[w];
+                float js = 0.f;
+                for (int r = 0; r < nvalid; ++r) js += jac[r] + (J_in != nullptr ? J_in[row0 + r] : 0.f);
+                // 64 slots of {sum 0.5|z|^2, sum J}: spreads the atomics of the workgroups
+                float* slot = loss_acc + 2 * (blockIdx.x & 63);
+                atomicAdd(slot, 0.5f * t);
+                atomicAdd(slot + 1, js);
+            }
+        }
+        __syncthreads();
+#undef XS
+#undef XO
+    }
+#undef HINT_CB
+}
+
+namespace hint {
+
+hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
+                        const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
+                        const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
+                        float* x_noisy, hipStream_t stream) {
+    if (rev)
+        hipLaunchKernelGGL(hint_apply_kernel<true>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, one, chain,
+                           n_chain, x, c, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr,
+                           (float*)nullptr);
+    else
+        hipLaunchKernelGGL(hint_apply_kernel<false>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, one, chain,
+                           n_chain, x, c, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
+    return hipGetLastError();
+}
+
+hipError_t set_max_lds_apply(int bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)hint_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)hint_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace hint

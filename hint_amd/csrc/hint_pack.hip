@@ -1,0 +1,120 @@
+// Weight packing (gfx950): flat torch-layout parameters -> MFMA fragment order (hint_dev.h), plus the
+// small streaming helpers of the C ABI.  Pure data movement: HBM / L2 bound, 16 bytes per lane.
+#include "hint_device.hpp"
+
+using namespace hint;
+
+__device__ __forceinline__ void pack_body(int bid, const PackSeg* __restrict__ segs,
+                                          const int2* __restrict__ ptiles, int n_tiles,
+                                          const int32_t* __restrict__ bmap, int n_bias, long bias_off,
+                                          const float* __restrict__ P, float* __restrict__ packed) {
+    if (bid >= n_tiles) {
+        // trailing workgroups: biases b1, b2 per unit, zero padded to 16
+        const int i = (bid - n_tiles) * 256 + (int)threadIdx.x;
+        if (i < n_bias) { const int off = bmap[i]; packed[bias_off + i] = off >= 0 ? P[off] : 0.f; }
+        return;
+    }
+    const int2 pt = ptiles[bid];
+    const PackSeg sg = segs[pt.x];
+    const int nt = pt.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = nt * 16 + (lane & 15), kq = lane >> 4;
+    for (int kb = wave; kb < sg.NB; kb += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float val = 0.f;
+            if (sg.trans == 2) {
+                // "bias tile" of a last layer: element [lane*4+i] = b[16 nt + 4 (lane>>4) + i] for every row
+                const int f = nt * 16 + 4 * kq + i;
+                if (f < sg.N) val = P[sg.src + f];
+            } else {
+                const int k = kb * 16 + (sg.kmap ? 4 * i + kq : 4 * kq + i);
+                if (n < sg.N && k < sg.K) val = sg.trans ? P[sg.src + (int64_t)k * sg.ld + n] : P[sg.src + (int64_t)n * sg.ld + k];
+            }
+            v[i] = val;
+        }
+        ((f32x4*)(packed + sg.dst + ((int64_t)nt * sg.NB + kb) * 256))[lane] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void hint_pack_kernel(const PackSeg* __restrict__ segs,
+                                                        const int2* __restrict__ ptiles, int n_tiles,
+                                                        const int32_t* __restrict__ bmap, int n_bias,
+                                                        long bias_off, const float* __restrict__ P,
+                                                        float* __restrict__ packed) {
+    pack_body((int)blockIdx.x, segs, ptiles, n_tiles, bmap, n_bias, bias_off, P, packed);
+}
+
+// all blocks of a flow in ONE launch (the trainer re-packs every block after each optimizer step)
+// The launch doubles as the prologue of a training step: one extra workgroup clears the loss sums
+// of the step before and advances the noise counter (hint_pack_group_run_ex).
+__global__ __launch_bounds__(256) void hint_pack_many_kernel(const PackItem* __restrict__ items, int n_items,
+                                                             int pack_grid, float* __restrict__ zero_buf, int zero_floats,
+                                                             unsigned long long* __restrict__ rng_state,
+                                                             float* __restrict__ opt_state) {
+    if ((int)blockIdx.x >= pack_grid) {
+        for (int i = threadIdx.x; i < zero_floats; i += 256) zero_buf[i] = 0.f;
+        if (rng_state != nullptr && threadIdx.x == 0) {
+            const unsigned long long step = rng_state[1] + 1ull;
+            rng_state[1] = step;
+            if (opt_state != nullptr) {
+                // Adam's bias corrections of this step (torch.optim.Adam evaluates them in double):
+                // opt_state = {lr, beta1, beta2, -> lr/(1-beta1^t), -> 1/sqrt(1-beta2^t)}
+                const double b1 = opt_state[1], b2 = opt_state[2], t = (double)step;
+                opt_state[3] = (float)((double)opt_state[0] / (1.0 - pow(b1, t)));
+                opt_state[4] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+            }
+        }
+        return;
+    }
+    // which item: one parallel look at every item's first workgroup instead of a chain of dependent loads
+    int it = 0;
+    for (int i0 = 0; i0 < n_items; i0 += 64) {
+        const int i = i0 + (int)(threadIdx.x & 63);
+        const bool ge = i < n_items && (int)blockIdx.x >= items[i].grid_begin;
+        it += __builtin_popcountll(__ballot(ge));
+    }
+    it = __builtin_amdgcn_readfirstlane(it - 1);
+    const PackItem q = items[it];
+    pack_body((int)blockIdx.x - q.grid_begin, q.segs, (const int2*)q.ptiles, q.n_tiles, q.bmap, q.n_bias, q.bias_off, q.params,
+              q.packed);
+}
+
+__global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, long n4, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) ((f32x4*)p)[i] = z;
+    const long t = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = 0.f;
+}
+
+namespace hint {
+
+hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
+                       long bias_off, const float* params, float* packed, hipStream_t stream) {
+    const int grid = n_tiles + (n_bias + 255) / 256;
+    if (grid > 0)
+        hipLaunchKernelGGL(hint_pack_kernel, dim3(grid), dim3(256), 0, stream, segs, ptiles, n_tiles, bmap, n_bias,
+                           bias_off, params, packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
+                            unsigned long long* rng_state, float* opt_state, hipStream_t stream) {
+    const int extra = (zero_floats > 0 || rng_state != nullptr) ? 1 : 0;
+    if (grid + extra > 0)
+        hipLaunchKernelGGL(hint_pack_many_kernel, dim3(grid + extra), dim3(256), 0, stream, items, n_items, grid, zero_buf,
+                           zero_floats, rng_state, opt_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream) {
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > (long)num_cu * 4 ? (long)num_cu * 4 : blocks);
+    hipLaunchKernelGGL(hint_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n4, n);
+    return hipGetLastError();
+}
+
+}  // namespace hint

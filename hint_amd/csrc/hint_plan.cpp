@@ -1,15 +1,18 @@
-// Host side of the C ABI (include/hint_amd.h): turns the node list of one coupling tree
-// (the structure /root/reference/hint.py:25-54 builds recursively) into a static level
-// schedule in device memory, and launches the kernels of hint_kernels.hip / hint_optim.hip.
+// Host side of the C ABI (include/hint_amd.h): turns the node list of one coupling tree (the
+// structure /root/reference/hint.py:25-54 builds recursively) into a static schedule in device
+// memory - groups of same-depth nodes, their units (one subnet of one node each), the split of every
+// group's fragment tiles over the wavefronts, the packed-weight layout, the weight-gradient jobs -
+// and launches the kernels of hint_fwd.hip / hint_bwd.hip / hint_wgrad.hip / hint_pack.hip /
+// hint_optim.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
-#include <tuple>
 #include <vector>
 
 #include "../../include/hint_amd.h"
@@ -28,11 +31,12 @@ hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
                       int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                       float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
-hipError_t launch_dw(const DWJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
-                     int n_chain, int WT, int Bp, int rows_per_wg, const int32_t* tmap, int thin_total, int ntiles,
-                     hipStream_t stream);
-hipError_t set_max_lds(int fwd_bytes, int bwd_bytes);
-hipError_t set_stamp_buffer(unsigned long long* p);
+hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
+                        int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
+                        int64_t act_stride, int64_t param_floats, const float* x, const float* c, const uint8_t* real,
+                        int accumulate, int num_cu, hipStream_t stream);
+hipError_t set_max_lds_apply(int bytes);
+hipError_t set_max_lds_bwd(int bytes);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
                        float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads,
                        int num_cu, const float* dev_state, hipStream_t stream);
@@ -58,71 +62,53 @@ static int fail(const char* fmt, ...) {
         if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-static inline int pad16(int v) { return (v + 15) & ~15; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int pad4(int v) { return (v + 3) & ~3; }
 
-// LDS row stride for a buffer read with ds_read_b128 by lanes (row = l&15, 16-byte column
-// slot = l>>4): stride = 8 (mod 64) floats makes each 16-lane group of the instruction hit 64
-// distinct banks (MI355X_MICROARCH.md §LDS).
-static inline int lds_stride(int width) {
-    int w = std::max(width, 16);
-    int ld = ((w + 63) / 64) * 64 + 8;
-    if (ld - 64 >= w) ld -= 64;
-    return ld;
-}
+static constexpr int LDS_LIMIT = 160 * 1024;
+static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
+static constexpr int WS_SLACK = 64;              // floats of slack behind every [Bp][W] array
+static constexpr int LV_REGS = 4;                // hint_bwd.hip: a [16, d] tile in <= 4 registers per thread
+static constexpr int MAX_TAIL = 8;               // hint_rows.hpp: tail accumulators
+static thread_local bool g_host_only = false;    // hint_plan_check: build and verify the plan, touch no device
 
 struct hint_plan {
     int device = -1;
-    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_dwjobs = 0, n_ptiles = 0;
+    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_units = 0, n_wjobs = 0, n_ptiles = 0, nw = 8;
     float alpha = 0.f;
     int64_t param_floats = 0, packed_floats = 0;
-    int WT = 0;
-    int xld = 0, cld = 0, ald = 0, vld = 0, sld = 0, max_aw = 0;
-    int s3 = 1, sv = 1;   // max K-split slabs of the layer-3 / dv stages
+    int WT = 0, ST = 0;
+    int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
-    int meta_bytes = 0, vmap_off = 0, ents_off = 0, jmax = 0, bmax = 0, n_bias = 0, split_o3 = 0;
-    int first[2][4] = {{0}};
-    int thin_total = 0;
-    int32_t* d_tmap = nullptr;
-    int32_t* d_tbmap = nullptr;
-    void* d_meta = nullptr;      // [groups | vnodes | ents]
-    GJob* d_jobs = nullptr;      // per-group job lists (GJob and OJob records, 16 bytes each)
+    int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
+    void* d_meta = nullptr;
     int32_t* d_bmap = nullptr;
-    DWJob* d_dwjobs = nullptr;
+    uint8_t* d_real = nullptr;
+    WJob* d_wjobs = nullptr;
     PackSeg* d_segs = nullptr;
     int2* d_ptiles = nullptr;
 };
 
-static constexpr int LDS_LIMIT = 160 * 1024;
-#ifndef HINT_JOB_OVERHEAD
-#define HINT_JOB_OVERHEAD 1200
-#endif
-static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
-static constexpr int WS_SLACK = 64;
-static thread_local bool g_host_only = false;   // hint_plan_check: build and verify the plan, touch no device   // floats of slack at the end of every workspace array
-static int g_bwd_stages = 3;          // profiling aid: bit0 = row-parallel part A, bit1 = weight-gradient part B
-
-static int fwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3) {
-    return 4 * ROWS * (2 * xld + cld + vld + 2 * ald + s3 * sld + 1);
-}
-static int bwd_lds_bytes(int xld, int cld, int vld, int ald, int sld, int s3, int sv, int n_abuf) {
-    (void)s3;
-    return 4 * ROWS * (3 * xld + 2 * cld + (1 + sv) * vld + n_abuf * ald + sld + 1);
-}
-static constexpr int JOBS_PER_GROUP_MAX = 2 * NTHREADS;   // what the in-kernel job prefetch moves
-static constexpr int SPLIT_HP = 384;   // nodes with pad16(h) beyond this are planned one net at a time
-
-// how many K-split slabs a thin stage gets: enough jobs to occupy the 8 wavefronts, each slab
-// at least 2 k-blocks deep
-static int pick_slabs(int n_tile_jobs, int min_nblk, int max_slabs) {
-    if (n_tile_jobs <= 0) return 1;
-    int s = NWAVES / n_tile_jobs;
-    s = std::min(s, min_nblk / 2);
-    return std::max(1, std::min(s, max_slabs));
+// cut `cost` (one entry per fragment tile) into nw contiguous ranges of about equal total
+static void balance(const std::vector<int>& cost, int nw, std::vector<int>& bounds) {
+    const int n = (int)cost.size();
+    std::vector<long> pre(n + 1, 0);
+    for (int i = 0; i < n; ++i) pre[i + 1] = pre[i] + cost[i];
+    bounds.assign(nw + 1, n);
+    bounds[0] = 0;
+    int t = 0;
+    for (int w = 1; w < nw; ++w) {
+        const double target = (double)pre[n] * w / nw;
+        while (t < n && std::fabs((double)pre[t + 1] - target) <= std::fabs((double)pre[t] - target)) ++t;
+        bounds[w] = t;
+    }
+    bounds[nw] = n;
 }
 
-static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
-                      int max_slabs, int cap_scale, bool use_a3, hint_plan** out, bool* retry_smaller) {
+// tile_cap: fragment tiles per group (1 KiB of LDS each), unless one node needs more
+static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int nw,
+                      int tile_cap, hint_plan** out, bool* retry_smaller) {
     *retry_smaller = false;
     int max_depth = 0;
     for (int i = 0; i < n_nodes; ++i) max_depth = std::max(max_depth, nodes[i].depth);
@@ -132,9 +118,10 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->dc = dc;
     P->n_nodes = n_nodes;
     P->n_levels = max_depth + 1;
+    P->nw = nw;
     P->alpha = (float)((double)clamp * 0.636);   // hint.py:57,60 (python float product, then fp32)
-    P->xld = pad16(d) + 4;
-    P->cld = dc > 0 ? pad16(dc) + 4 : 0;
+    P->xld = d | 1;                              // odd strides: 16 rows hit 16 different LDS banks
+    P->cld = dc > 0 ? (dc | 1) : 0;
 
     // ---- forward order: deepest level first (children before parents, hint.py:70-73) ----
     std::vector<int> order;
@@ -142,512 +129,271 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int i = 0; i < n_nodes; ++i)
             if (nodes[i].depth == dep) order.push_back(i);
 
-    // Every single node must fit the 160 KiB LDS of the backward kernel (that fixes minimum
-    // strides); groups then grow up to soft caps so that shallow-but-wide and deep-but-narrow
-    // levels end up with similar footprints.
-    int min_aw = 0, min_vw = 0, min_sw = 0;
-    for (int i = 0; i < n_nodes; ++i) {
-        min_aw = std::max(min_aw, (pad16(nodes[i].h) > SPLIT_HP ? 1 : 2) * pad16(nodes[i].h));
-        min_vw = std::max(min_vw, pad16(nodes[i].k + dc));
-        min_sw = std::max(min_sw, 2 * pad16(nodes[i].r));
-    }
-    const int cap_aw = std::max(min_aw, 512 / cap_scale), cap_vw = std::max(min_vw, 128 / cap_scale),
-              cap_sw = std::max(min_sw, 256 / cap_scale);
-    // rough size of what rides along in LDS besides the float buffers (group/node/lane tables)
-    const int meta_guess = 16 * n_nodes + 8 * d + 160 * (max_depth + 2);
-    auto bwd_bytes = [&](int aw_, int vw_, int sw_) {
-        return meta_guess + bwd_lds_bytes(P->xld, P->cld, lds_stride(vw_), lds_stride(aw_), lds_stride(sw_), 1, 1, 2);
-    };
-
-    // Host-side working copy of a node - or of ONE of its two nets: a node whose two nets do not fit
-    // the LDS side by side (h > 384) is planned as two units in two consecutive single-unit groups,
-    // the t net first (forward order), then the s net, which carries the coupling.  Both units keep
-    // the node's full [s | t] column layout in the s/t and g_st buffers (those are not cleared
-    // between the two groups), everything else is per net.
-    struct DNode {
-        int off, k, r, h, cin, hp, rp, cinp, acol, vcol, scol, wcol;
-        int net0, nn;         // nets of this unit: [net0, net0 + nn)
-        bool couples;         // this unit runs the node's coupling (false for the t-only unit)
-    };
-    auto has_net = [](const DNode& q, int net) { return net >= q.net0 && net < q.net0 + q.nn; };
-    auto acol_of = [](const DNode& q, int net) { return q.acol + (net - q.net0) * q.hp; };
-    std::vector<DNode> dn;
-    std::vector<const hint_node_desc*> src;   // parallel to dn
-    std::vector<DGroup> dg;
-    std::vector<GJob> jobs;                   // all groups' job lists (GJob and OJob records)
+    std::vector<Group> groups;
+    std::vector<Unit> units;
+    std::vector<int> unit_node;       // node index (into `nodes`) of every unit
+    std::vector<uint16_t> tmap;
     std::vector<Ent> ents;
-    std::vector<int16_t> vmap;
-    std::vector<int32_t> tmap;     // compact thin-gradient index -> offset in the flat gradient buffer
-    std::vector<int32_t> tbmap;    // like bmap, but compact thin indices (bias gradients)
-    std::vector<int32_t> bmap;
-    std::vector<DWJob> dwj;
+    std::vector<int32_t> rng;
     std::vector<PackSeg> segs;
     std::vector<int2> ptiles;
-    int wcol = 0;
-    int max_aw = 0, max_vw = 0, max_sw = 0;
+    std::vector<int32_t> bmap;
+    std::vector<WJob> wjobs;
     int64_t pmax = 0, packed = 0;
+    int wcol = 0, gcol = 0;
 
-    auto add_seg = [&](int N, int K, int NB, int ld, int mode, int64_t s0, int64_t s1, int hp, int h) -> int64_t {
+    auto add_seg = [&](int N, int K, int NB, int ld, int trans, int kmap, int64_t src) -> int {
         PackSeg sg{};
-        sg.dst = packed; sg.src0 = s0; sg.src1 = s1; sg.N = N; sg.K = K; sg.NB = NB; sg.ld = ld; sg.mode = mode;
-        sg.hp = hp; sg.h = h; sg.tile_begin = (int)ptiles.size();
-        const int NT = (N + 15) / 16;
-        for (int nt = 0; nt < NT; ++nt) ptiles.push_back(int2{(int)segs.size(), nt});
+        sg.dst = packed; sg.src = src; sg.N = N; sg.K = K; sg.NB = NB; sg.ld = ld; sg.trans = trans; sg.kmap = kmap;
+        sg.tile_begin = (int)ptiles.size();
+        const int NTn = std::max(1, cdiv(N, 16));
+        for (int nt = 0; nt < NTn; ++nt) ptiles.push_back(int2{(int)segs.size(), nt});
         segs.push_back(sg);
-        packed += (int64_t)NT * NB * 256;
-        return sg.dst;
+        const int first = (int)(packed / 256);
+        packed += (int64_t)NTn * NB * 256;
+        return first;
     };
 
+    // ---- groups, units, packed segments ----
     size_t pos = 0;
-    bool split_pending = false;       // the t unit of order[pos] is planned, its s unit comes next
     while (pos < order.size()) {
-        DGroup g{};
-        g.node_begin = (int)dn.size();
-        g.wcol0 = wcol;
-        int aw = 0, vw = 0, sw = 0;
+        Group g{};
+        g.unit_begin = (int)units.size();
+        g.tmap_begin = (int)tmap.size();
+        g.gcol0 = gcol;
         const int depth = nodes[order[pos]].depth;
+        int tiles = 0;
+        const size_t first_pos = pos;
         while (pos < order.size() && nodes[order[pos]].depth == depth) {
             const hint_node_desc& n = nodes[order[pos]];
-            const int hp = pad16(n.h), rp = pad16(n.r), cin = n.k + dc, cinp = pad16(cin);
-            const bool split = hp > SPLIT_HP;
-            const int unit_aw = split ? hp : 2 * hp;
-            if (bwd_bytes(unit_aw, cinp, 2 * rp) > LDS_LIMIT) {
+            const int NT = cdiv(n.h, 16);
+            if (tiles > 0 && tiles + 2 * NT > tile_cap) break;
+            const int cin = n.k + dc, KB1 = std::max(1, cdiv(cin, 16)), RT = cdiv(n.r, 16);
+            if (RT > MAX_TAIL || KB1 > MAX_TAIL) {
                 delete P;
-                return fail("hint_plan_create: a node with h=%d, cin=%d, r=%d does not fit the 160 KiB LDS", n.h, cin, n.r);
-            }
-            // start a new group at the same depth when this node would overflow the budget; the two
-            // units of a split node are single-unit groups
-            if (aw > 0 && (split || aw + unit_aw > cap_aw || vw + cinp > cap_vw || sw + 2 * rp > cap_sw ||
-                           bwd_bytes(std::max(min_aw, aw + unit_aw), std::max(min_vw, vw + cinp),
-                                     std::max(min_sw, sw + 2 * rp)) > LDS_LIMIT))
-                break;
-            DNode q{};
-            q.off = n.off; q.k = n.k; q.r = n.r; q.h = n.h; q.cin = cin;
-            q.hp = hp; q.rp = rp; q.cinp = cinp;
-            q.acol = aw; q.vcol = vw; q.scol = sw; q.wcol = wcol;
-            q.net0 = 0; q.nn = 2; q.couples = true;
-            if (split) {                     // t unit now, s unit (with the coupling) as the next group
-                q.net0 = split_pending ? 0 : 1; q.nn = 1; q.couples = split_pending;
+                return fail("hint_plan_create: a node with r=%d outputs / cin=%d inputs exceeds the kernels' limit of %d",
+                            n.r, cin, 16 * MAX_TAIL);
             }
             const int64_t sizes[6] = {(int64_t)n.h * cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
             for (int t = 0; t < 12; ++t) pmax = std::max(pmax, n.p_off[t] + sizes[t % 6]);
-            aw += unit_aw; vw += cinp; sw += 2 * rp; wcol += unit_aw;
-            dn.push_back(q);
-            src.push_back(&n);
-            if (split) {
-                if (!split_pending) { split_pending = true; break; }     // same node again: its s unit
-                split_pending = false;
-                ++pos;
-                break;
+            for (int net = 0; net < 2; ++net) {
+                const int64_t* po = n.p_off + net * 6;
+                Unit u{};
+                u.f1 = add_seg(n.h, cin, KB1, cin, 0, 1, po[HINT_W1]);          // v  -> a1   (interleaved k)
+                u.f2 = add_seg(n.h, n.h, NT, n.h, 0, 0, po[HINT_W2]);           // a1 -> a2
+                u.f3 = add_seg(n.r, n.h, NT, n.h, 0, 0, po[HINT_W3]);           // a2 -> s | t
+                (void)add_seg(n.r, 0, 1, 0, 2, 0, po[HINT_B3]);                 // b3 as "bias tiles" right behind W3
+                u.b3 = add_seg(n.h, n.r, RT, n.h, 1, 1, po[HINT_W3]);           // g_st -> g2 (interleaved k)
+                u.b2 = add_seg(n.h, n.h, NT, n.h, 1, 0, po[HINT_W2]);           // g2 -> g1
+                u.b1 = add_seg(cin, n.h, NT, cin, 1, 0, po[HINT_W1]);           // g1 -> g_v
+                u.bias1 = (int)bmap.size();                                     // (made absolute below)
+                for (int j = 0; j < 16 * NT; ++j) bmap.push_back(j < n.h ? (int32_t)(po[HINT_B1] + j) : -1);
+                u.bias2 = (int)bmap.size();
+                for (int j = 0; j < 16 * NT; ++j) bmap.push_back(j < n.h ? (int32_t)(po[HINT_B2] + j) : -1);
+                u.bias3 = 0;
+                u.wcol = wcol; u.tile0 = tiles; u.gcol = gcol;
+                u.NT = NT; u.KB1 = KB1; u.RT = RT; u.cin = cin;
+                u.ku = n.k; u.r = n.r; u.xoff = n.off; u.h = n.h;
+                u.lcol = gcol - g.gcol0;
+                for (int t = 0; t < NT; ++t) tmap.push_back((uint16_t)((int)units.size() - g.unit_begin));
+                units.push_back(u);
+                unit_node.push_back(order[pos]);
+                wcol += 16 * NT; gcol += pad4(n.r); tiles += NT;
             }
             ++pos;
         }
-        g.node_end = (int)dn.size();
-        g.aw = aw; g.vw = vw; g.sw = sw;
+        g.unit_end = (int)units.size();
+        g.ntiles = tiles;
+        g.gcols = gcol - g.gcol0;
         g.level = max_depth - depth;
-        g.level_last = (!split_pending && (pos >= order.size() || nodes[order[pos]].depth != depth)) ? 1 : 0;
-        // Units of a split node: the coupling needs s and t, so it runs in whichever unit comes second
-        // (forward: the s unit, inverse: the t unit); the backward pass, which only needs s, couples in
-        // the s unit (first in its order) and the t unit after it must keep the g_st columns written there.
-        g.pad = dn.back().nn == 2 ? 0 : (dn.back().net0 == 1 ? 1 : 2);      // 0 whole nodes, 1 t unit, 2 s unit
-        max_aw = std::max(max_aw, aw); max_vw = std::max(max_vw, vw); max_sw = std::max(max_sw, sw);
+        g.level_first = (first_pos == 0 || nodes[order[first_pos - 1]].depth != depth) ? 1 : 0;
+        g.level_last = (pos >= order.size() || nodes[order[pos]].depth != depth) ? 1 : 0;
+        P->abuf_tiles = std::max(P->abuf_tiles, tiles);
+        P->gld = std::max(P->gld, g.gcols | 1);
 
-        // ---- K-split factors of the thin stages of this group ----
-        int l3_tiles = 0, dv_tiles = 0, min_hb = 1 << 30;
-        for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-            l3_tiles += 2 * (dn[ni].rp / 16);        // (a split node's units use the slab count of the whole node)
-            dv_tiles += dn[ni].cinp / 16;
-            min_hb = std::min(min_hb, dn[ni].hp / 16);
+        // ---- the wavefronts' tile ranges of the two GEMM phases, slices and slabs ----
+        std::vector<int> c1(tiles), c2(tiles);
+        for (int t = 0; t < tiles; ++t) {
+            const Unit& u = units[g.unit_begin + tmap[g.tmap_begin + t]];
+            c1[t] = std::max(u.KB1, u.RT) + 2;                  // first layer / g2: one k-block or so per tile
+            c2[t] = u.NT + std::max(u.RT, u.KB1) + 1;           // second layer + tail steps
         }
-        g.l3_slabs = pick_slabs(l3_tiles, min_hb, max_slabs);
-        g.dv_slabs = pick_slabs(dv_tiles, (dn[g.node_begin].nn == 1 ? 1 : 2) * min_hb, max_slabs);
-        P->s3 = std::max(P->s3, g.l3_slabs);
-        P->sv = std::max(P->sv, g.dv_slabs);
+        std::vector<int> b1, b2;
+        balance(c1, nw, b1);
+        balance(c2, nw, b2);
+        g.rng_begin = (int)rng.size();
+        for (int w = 0; w <= nw; ++w) rng.push_back(b1[w]);
+        for (int w = 0; w <= nw; ++w) rng.push_back(b2[w]);
+        std::vector<int> sl3(nw, 0), slv(nw, 0);
+        int off3 = 0, offv = 0;
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) units[ui].sl_n = 0;
+        for (int w = 0; w < nw; ++w) {
+            sl3[w] = off3; slv[w] = offv;
+            int t = b2[w];
+            while (t < b2[w + 1]) {
+                const int ui = g.unit_begin + tmap[g.tmap_begin + t];
+                Unit& u = units[ui];
+                if (u.sl_n == 0) { u.sl_off = off3; u.gv_off = offv; }
+                ++u.sl_n;
+                off3 += 64 * cdiv(u.r, 4);
+                offv += 64 * cdiv(u.cin, 4);
+                t = std::min(b2[w + 1], u.tile0 + u.NT);
+            }
+        }
+        for (int w = 0; w < nw; ++w) rng.push_back(sl3[w]);
+        for (int w = 0; w < nw; ++w) rng.push_back(slv[w]);
+        P->slab_fwd = std::max(P->slab_fwd, off3);
+        P->slab_bwd = std::max(P->slab_bwd, offv);
 
-        // ---- packed weight segments + GEMM tile jobs ----
-        struct NodePack { int64_t f1[2], f2[2], f3[2], b3[2], b2[2], bdv; };
-        std::vector<NodePack> np(g.node_end - g.node_begin);
-        for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-            const DNode& q = dn[ni];
-            const hint_node_desc& n = *src[ni];
-            NodePack& k = np[ni - g.node_begin];
-            for (int net = 0; net < 2; ++net) {
-                if (!has_net(q, net)) continue;
-                const int64_t* po = n.p_off + net * 6;
-                k.f1[net] = add_seg(q.h, q.cin, q.cinp / 16, q.cin, 0, po[0], 0, q.hp, q.h);   // v  -> a1
-                k.f2[net] = add_seg(q.h, q.h, q.hp / 16, q.h, 0, po[2], 0, q.hp, q.h);         // a1 -> a2
-                k.f3[net] = add_seg(q.r, q.h, q.hp / 16, q.h, 0, po[4], 0, q.hp, q.h);         // a2 -> s|t
-                k.b3[net] = add_seg(q.h, q.r, q.rp / 16, q.h, 1, po[4], 0, q.hp, q.h);         // g_st -> g2
-                k.b2[net] = add_seg(q.h, q.h, q.hp / 16, q.h, 1, po[2], 0, q.hp, q.h);         // g2 -> g1
-            }
-            if (q.nn == 2)
-                k.bdv = add_seg(q.cin, 2 * q.hp, 2 * q.hp / 16, q.cin, 2, n.p_off[0], n.p_off[6], q.hp, q.h);   // g1 -> g_v
-            else        // one net: the "stack" is that net's W1 alone
-                k.bdv = add_seg(q.cin, q.hp, q.hp / 16, q.cin, 2, n.p_off[6 * q.net0], n.p_off[6 * q.net0], q.hp, q.h);
-        }
-        // ---- thin weight gradients done inside the row-parallel backward kernel: 16x16 outer-product
-        //      tiles  T[m][n] = sum_rows A[row][acol+m] * B[row][bcol+n]  of dW3 = g_st^T a2 (with the g2
-        //      stage) and dW1 = g1^T v (with the dv stage), stored at slab[goff + m*N + n] ----
-        struct OuterTile { int32_t goff; int acol, bcol, mvalid, nvalid, N, cnt, dir; };   // cnt tiles along dir (0: n, 1: m)
-        struct OuterMat { int base, acol, bcol, M, N; };       // one thin gradient matrix [M x N]
-        std::vector<OuterMat> outer3, outer1;
-        auto thin_alloc = [&](int64_t param_off, int count) {   // contiguous compact range mirroring a tensor
-            const int base = (int)tmap.size();
-            for (int i = 0; i < count; ++i) tmap.push_back((int32_t)(param_off + i));
-            return base;
-        };
-        // Records of adjacent tiles along a matrix's longer side (they share the other side's operand and
-        // one decode / baton hand-over): `per` evenly sized records per row of tiles.
-        auto outer_records = [&](const std::vector<OuterMat>& mats, int per, std::vector<OuterTile>& out) {
-            out.clear();
-            for (const OuterMat& m : mats) {
-                const int MT = (m.M + 15) / 16, NTl = (m.N + 15) / 16;
-                const int dir = MT > NTl ? 1 : 0, L = dir ? MT : NTl, O = dir ? NTl : MT;
-                const int nrec = std::max(std::min(L, per), (L + 126) / 127);
-                for (int o = 0; o < O; ++o)
-                    for (int rc = 0, l0 = 0; rc < nrec; ++rc) {
-                        const int cnt = (L - l0 + (nrec - rc) - 1) / (nrec - rc);
-                        const int mt = dir ? l0 : o, nt = dir ? o : l0;
-                        const int mlast = dir ? l0 + cnt - 1 : o, nlast = dir ? o : l0 + cnt - 1;
-                        out.push_back(OuterTile{m.base + 16 * mt * m.N + 16 * nt, m.acol + 16 * mt, m.bcol + 16 * nt,
-                                                std::min(16, m.M - 16 * mlast), std::min(16, m.N - 16 * nlast), m.N, cnt, dir});
-                        l0 += cnt;
-                    }
-            }
-        };
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net) {            // dW3[r][h] = g_st^T a2
-                const DNode& q = dn[ni];
-                if (!has_net(q, net)) continue;
-                outer3.push_back(OuterMat{thin_alloc(src[ni]->p_off[net * 6 + 4], q.r * q.h), q.scol + net * q.rp,
-                                          acol_of(q, net), q.r, q.h});
-            }
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net) {            // dW1[h][cin] = g1^T v
-                const DNode& q = dn[ni];
-                if (q.cin == 0 || !has_net(q, net)) continue;
-                outer1.push_back(OuterMat{thin_alloc(src[ni]->p_off[net * 6 + 0], q.h * q.cin), acol_of(q, net), q.vcol,
-                                          q.h, q.cin});
-            }
-        // one (slab, node, net) of a stage: NT adjacent output tiles over the same k-blocks
-        struct Segment { int64_t wtile; int NT, nb, tstride, acol, ocol, N, slab; };
-        auto emit_stage = [&](int which) -> int {
-            // which: 1 = L1, 2 = L2, 3 = L3, 4 = g2, 5 = g1, 6 = dv
-            std::vector<Segment> segs;
-            const int slabs = which == 3 ? g.l3_slabs : (which == 6 ? g.dv_slabs : 1);
-            for (int sl = 0; sl < slabs && which != 7; ++sl)
-                for (int ni = g.node_begin; ni < g.node_end; ++ni) {
-                    const DNode& q = dn[ni];
-                    const NodePack& k = np[ni - g.node_begin];
-                    const int nets = which == 6 ? 1 : 2;
-                    for (int net = 0; net < nets; ++net) {
-                        if (which != 6 && !has_net(q, net)) continue;
-                        int N, NB, acol, ocol0; int64_t wbase;
-                        const int ac = which == 6 ? q.acol : acol_of(q, net);
-                        switch (which) {
-                            case 1: N = q.h; NB = q.cinp / 16; acol = q.vcol; ocol0 = ac; wbase = k.f1[net]; break;
-                            case 2: N = q.h; NB = q.hp / 16; acol = ac; ocol0 = ac; wbase = k.f2[net]; break;
-                            case 3: N = q.r; NB = q.hp / 16; acol = ac; ocol0 = q.scol + net * q.rp; wbase = k.f3[net]; break;
-                            case 4: N = q.h; NB = q.rp / 16; acol = q.scol + net * q.rp; ocol0 = ac; wbase = k.b3[net]; break;
-                            case 5: N = q.h; NB = q.hp / 16; acol = ac; ocol0 = ac; wbase = k.b2[net]; break;
-                            default: N = q.cin; NB = q.nn * q.hp / 16; acol = q.acol; ocol0 = q.vcol; wbase = k.bdv; break;
-                        }
-                        // this slab's share of the k-blocks
-                        const int kb0 = (int)((int64_t)NB * sl / slabs), kb1 = (int)((int64_t)NB * (sl + 1) / slabs);
-                        Segment sg{};
-                        sg.NT = (N + 15) / 16;
-                        if (sg.NT == 0) continue;
-                        sg.N = N; sg.ocol = ocol0; sg.slab = sl; sg.tstride = std::max(NB, 1);
-                        if (kb1 > kb0) { sg.wtile = wbase / 256 + kb0; sg.nb = kb1 - kb0; sg.acol = acol + kb0 * 16; }
-                        else { sg.wtile = 0; sg.nb = 0; sg.acol = 0; sg.tstride = 0; }   // K = 0 (cin = 0) or empty slab
-                        segs.push_back(sg);
-                    }
-                }
-            // Cut the segments into jobs of <= 3 tiles and deal them to the wavefronts.  More, smaller
-            // jobs balance better, fewer, wider ones share more A reads and pay fewer prologues: try
-            // every total job count from the minimum up and keep the cheapest estimated makespan.
-            // Cost model (cycles, from in-kernel stamps): 128 per tile and k-block on the SIMD's matrix pipe,
-            // which the two wavefronts of a SIMD (w, w+4) share, plus a per-job prologue/epilogue - decode,
-            // dispatch, LDS round trips, the baton hand-over - that the partner hides only in part and that
-            // dwarfs the pipe time of a thin job; an outer-product record costs about as much plus 150 per tile.
-            const long JOB_OVERHEAD = HINT_JOB_OVERHEAD, OUTER_OVERHEAD = HINT_JOB_OVERHEAD, OUTER_TILE = 150;
-            struct Cut { int seg, t0, nt; long cost, overhead; };   // seg < 0: outer tile -1-seg
-            // which == 7: the dW3 tiles as a stage of their own (plans without LDS for the g2 buffer)
-            const std::vector<OuterMat>* outer_mats = (which == 4 && use_a3) || which == 7 ? &outer3 : (which == 6 ? &outer1 : nullptr);
-            std::vector<OuterTile> orec, best_orec;
-            auto cut_segments = [&](int extra, std::vector<Cut>& cuts) {
-                // segment s gets ceil(NT/3) jobs plus a share of `extra` (largest work per job first)
-                std::vector<int> cnt(segs.size());
-                for (size_t i = 0; i < segs.size(); ++i) cnt[i] = (segs[i].NT + 2) / 3;
-                for (int e = 0; e < extra; ++e) {
-                    int best = -1; double bw = 0;
-                    for (size_t i = 0; i < segs.size(); ++i) {
-                        if (cnt[i] >= segs[i].NT) continue;
-                        const double w = (double)segs[i].NT * std::max(segs[i].nb, 1) / cnt[i];
-                        if (w > bw) { bw = w; best = (int)i; }
-                    }
-                    if (best < 0) break;
-                    ++cnt[best];
-                }
-                cuts.clear();
-                for (size_t i = 0; i < segs.size(); ++i) {
-                    int t0 = 0;
-                    for (int c = 0; c < cnt[i]; ++c) {
-                        const int nt = (segs[i].NT - t0 + (cnt[i] - c) - 1) / (cnt[i] - c);
-                        cuts.push_back(Cut{(int)i, t0, nt, 128L * nt * std::max(segs[i].nb, 1), JOB_OVERHEAD});
-                        t0 += nt;
-                    }
-                }
-                for (size_t i = 0; i < orec.size(); ++i) cuts.push_back(Cut{-1 - (int)i, 0, 1, OUTER_TILE * orec[i].cnt, OUTER_OVERHEAD});
-            };
-            auto deal = [&](const std::vector<Cut>& cuts, std::vector<std::vector<int>>& per_wave) -> long {
-                std::vector<int> idx(cuts.size());
-                for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
-                    return cuts[x].cost + cuts[x].overhead > cuts[y].cost + cuts[y].overhead; });
-                per_wave.assign(NWAVES, {});
-                long wload[NWAVES] = {0}, sload[4] = {0};
-                for (int i : idx) {
-                    int w = 0;
-                    for (int v = 1; v < NWAVES; ++v) {
-                        const long sv = sload[v & 3], sw = sload[w & 3];
-                        if (sv < sw || (sv == sw && wload[v] < wload[w])) w = v;
-                    }
-                    per_wave[w].push_back(i);
-                    wload[w] += cuts[i].cost + cuts[i].overhead;
-                    sload[w & 3] += cuts[i].cost + cuts[i].overhead / 2;
-                }
-                long worst = 0;
-                for (int w = 0; w < NWAVES; ++w) worst = std::max(worst, std::max(wload[w], sload[w & 3]));
-                return worst;
-            };
-            std::vector<Cut> cuts, best_cuts;
-            std::vector<std::vector<int>> per_wave, best_pw(NWAVES);
-            long best_cost = -1;
-            int total_tiles = 0;
-            for (const Segment& sg : segs) total_tiles += sg.NT;
-            int max_run = 1;      // longest row of tiles of the stage's thin gradient matrices
-            if (outer_mats)
-                for (const OuterMat& m : *outer_mats) max_run = std::max(max_run, (std::max(m.M, m.N) + 15) / 16);
-            for (int per = 1; per <= std::min(max_run, 16); ++per) {     // records per row of outer-product tiles
-                if (outer_mats) outer_records(*outer_mats, per, orec);
-                for (int extra = 0; extra <= 2 * NWAVES; ++extra) {
-                    cut_segments(extra, cuts);
-                    const long c = deal(cuts, per_wave);
-                    if (best_cost < 0 || c < best_cost) { best_cost = c; best_cuts = cuts; best_pw = per_wave; best_orec = orec; }
-                    if ((int)cuts.size() >= total_tiles + (int)orec.size()) break;
-                }
-            }
-            const int hdr = (int)jobs.size() - g.jl_begin;
-            std::vector<std::vector<TJob>> lists(NWAVES);
-            size_t longest = 1;
-            for (int w = 0; w < NWAVES; ++w) {
-                for (int i : best_pw[w]) {
-                    const Cut& c = best_cuts[i];
-                    TJob t{};
-                    if (c.seg < 0) {                       // outer-product tile (see TJob)
-                        const OuterTile& o = best_orec[-1 - c.seg];
-                        if (o.N > 0xffff) return -1;
-                        t.wtile = o.goff;
-                        t.acol = (uint16_t)o.acol; t.ocol = (uint16_t)o.bcol;
-                        t.nb = 0; t.nt = TJOB_OUTER;
-                        t.slab = (uint8_t)(o.dir | (o.cnt << 1));
-                        t.nvalid = (uint8_t)((o.mvalid - 1) | ((o.nvalid - 1) << 4));
-                        t.tstride = (uint16_t)o.N;
-                        lists[w].push_back(t);
-                        continue;
-                    }
-                    const Segment& sg = segs[c.seg];
-                    const int64_t wt = sg.wtile + (int64_t)c.t0 * sg.tstride;
-                    if (wt > 0x7fffffff || sg.tstride > 0xffff) return -1;
-                    t.wtile = (int32_t)wt;
-                    t.acol = (uint16_t)sg.acol;
-                    t.ocol = (uint16_t)(sg.ocol + 16 * c.t0);
-                    t.nb = (uint8_t)sg.nb;
-                    t.nt = (uint8_t)c.nt;
-                    t.nvalid = (uint8_t)std::min(16, sg.N - 16 * (c.t0 + c.nt - 1));
-                    t.slab = (uint8_t)sg.slab;
-                    t.tstride = (uint16_t)sg.tstride;
-                    lists[w].push_back(t);
-                }
-                // an idle wavefront still has one record (nt = 0): it only hands the prefetch baton on
-                if (lists[w].empty()) lists[w].push_back(TJob{});
-                longest = std::max(longest, lists[w].size());
-            }
-            // ---- self-check (always on; also what hint_plan_check exists for): read the records back the
-            //      way the kernels do and make sure every output tile of the stage is produced exactly
-            //      once, by the right k-blocks, and every outer-product tile exactly once ----
-            {
-                std::vector<std::vector<int>> seen(segs.size());
-                for (size_t i = 0; i < segs.size(); ++i) seen[i].assign(segs[i].NT, 0);
-                std::vector<int64_t> outer_seen;
-                for (int w = 0; w < NWAVES; ++w)
-                    for (const TJob& t : lists[w]) {
-                        if (t.nt == 0) continue;
-                        if (t.nt == TJOB_OUTER) {
-                            const int dir = t.slab & 1, cnt = t.slab >> 1;
-                            if (cnt < 1) return -2;
-                            for (int k = 0; k < cnt; ++k) outer_seen.push_back((int64_t)t.wtile + (int64_t)k * (dir ? 16 * t.tstride : 16));
-                            continue;
-                        }
-                        bool found = false;
-                        for (size_t i = 0; i < segs.size() && !found; ++i) {
-                            const Segment& sg = segs[i];
-                            if (sg.slab != t.slab || t.ocol < sg.ocol || t.ocol >= sg.ocol + 16 * sg.NT || sg.nb != t.nb) continue;
-                            const int t0 = (t.ocol - sg.ocol) / 16;
-                            if ((t.ocol - sg.ocol) % 16 || t0 + t.nt > sg.NT || t.nt > 3) return -2;
-                            if (sg.nb > 0 && (t.wtile != sg.wtile + (int64_t)t0 * sg.tstride || t.acol != sg.acol || t.tstride != sg.tstride)) continue;
-                            const int want_valid = std::min(16, sg.N - 16 * (t0 + t.nt - 1));
-                            if (t.nvalid != want_valid) return -2;
-                            for (int k = 0; k < t.nt; ++k) ++seen[i][t0 + k];
-                            found = true;
-                        }
-                        if (!found) return -2;
-                    }
-                for (size_t i = 0; i < segs.size(); ++i)
-                    for (int c : seen[i]) if (c != 1) return -2;
-                std::vector<int64_t> outer_want;
-                if (outer_mats)
-                    for (const OuterMat& m : *outer_mats)
-                        for (int mt = 0; mt * 16 < m.M; ++mt)
-                            for (int nt = 0; nt * 16 < m.N; ++nt) outer_want.push_back((int64_t)m.base + 16 * mt * m.N + 16 * nt);
-                std::sort(outer_seen.begin(), outer_seen.end());
-                std::sort(outer_want.begin(), outer_want.end());
-                if (outer_seen != outer_want) return -2;
-            }
-            const int stride = (int)longest;
-            for (int w = 0; w < NWAVES; ++w) {
-                if (lists[w].size() > 0xffff) return -1;
-                lists[w][0].count = (uint16_t)lists[w].size();
-                lists[w].resize(stride, TJob{});
-                for (const TJob& c : lists[w]) jobs.push_back(c);
-            }
-            if (hdr > 0xffff || stride > 0x7fff) return -1;
-            return STAGE_DESC(hdr, stride);
-        };
-        g.jl_begin = (int)jobs.size();
-        g.l1_off = emit_stage(1);
-        g.l2_off = emit_stage(2);
-        g.l3_off = emit_stage(3);
-        g.g2_off = emit_stage(4);
-        g.g1_off = emit_stage(5);
-        g.dv_off = emit_stage(6);
-        g.o3_off = use_a3 ? 0 : emit_stage(7);
-        if (g.o3_off == -2 || g.l1_off == -2 || g.l2_off == -2 || g.l3_off == -2 || g.g2_off == -2 || g.g1_off == -2 ||
-            g.dv_off == -2) {
-            delete P;
-            return fail("hint_plan_create: internal error, a stage's job lists do not cover its tiles exactly once");
-        }
-        if (g.o3_off < 0 || g.l1_off < 0 || g.l2_off < 0 || g.l3_off < 0 || g.g2_off < 0 || g.g1_off < 0 || g.dv_off < 0) {
-            delete P;
-            if (cap_scale < 16) { *retry_smaller = true; return 1; }
-            return fail("hint_plan_create: a group's job lists exceed the 16-bit stage descriptor");
-        }
-        g.o3_cnt = g.o1_off = g.o1_cnt = 0;      // outer-product tiles ride in the g2 / dv stage lists (or o3_off's)
-        g.jl_count = (int)jobs.size() - g.jl_begin;
-        if (g.jl_count > JOBS_PER_GROUP_MAX) {
-            delete P;
-            if (cap_scale < 16) { *retry_smaller = true; return 1; }
-            return fail("hint_plan_create: a group needs %d tile jobs (max %d)", g.jl_count, JOBS_PER_GROUP_MAX);
-        }
-        P->jmax = std::max(P->jmax, g.jl_count);
-        P->bmax = std::max(P->bmax, 2 * aw + sw);
-        g.bmap_begin = (int)bmap.size();
-        for (int layer = 0; layer < 2; ++layer)          // b1 map, then b2 map, aw entries each
-            for (int ni = g.node_begin; ni < g.node_end; ++ni)
-                for (int net = 0; net < 2; ++net)
-                {
-                    if (!has_net(dn[ni], net)) continue;
-                    const int tb = thin_alloc(src[ni]->p_off[net * 6 + (layer ? 3 : 1)], dn[ni].h);
-                    for (int j = 0; j < dn[ni].hp; ++j) {
-                        bmap.push_back(j < dn[ni].h ? (int32_t)(src[ni]->p_off[net * 6 + (layer ? 3 : 1)] + j) : -1);
-                        tbmap.push_back(j < dn[ni].h ? tb + j : -1);
-                    }
-                }
-        g.bmap3_begin = (int)bmap.size();
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int net = 0; net < 2; ++net)
-            {
-                // (the [s | t] column layout is kept by both units of a split node; the absent net's
-                // columns carry no bias and no gradient slot)
-                const bool here = has_net(dn[ni], net);
-                const int tb = here ? thin_alloc(src[ni]->p_off[net * 6 + 5], dn[ni].r) : 0;
-                for (int j = 0; j < dn[ni].rp; ++j) {
-                    bmap.push_back(here && j < dn[ni].r ? (int32_t)(src[ni]->p_off[net * 6 + 5] + j) : -1);
-                    tbmap.push_back(here && j < dn[ni].r ? tb + j : -1);
-                }
-            }
-
-        g.vmap_begin = (int)vmap.size();
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int j = 0; j < dn[ni].cinp; ++j)
-                vmap.push_back(j < dn[ni].k ? (int16_t)(dn[ni].off + j)
-                                             : (j < dn[ni].cin ? (int16_t)(-2 - (j - dn[ni].k)) : (int16_t)-1));
+        // ---- coupling entries: one per transformed lane ----
         g.ent_begin = (int)ents.size();
-        for (int ni = g.node_begin; ni < g.node_end; ++ni)
-            for (int j = 0; j < dn[ni].r; ++j)       // (both units of a split node list the lanes: which one couples depends on the direction)
-                ents.push_back(Ent{(int16_t)(dn[ni].off + dn[ni].k + j), (int16_t)(dn[ni].scol + j),
-                                   (int16_t)(dn[ni].scol + dn[ni].rp + j), 0});
+        for (int ui = g.unit_begin; ui < g.unit_end; ui += 2) {
+            const Unit& us = units[ui];
+            const Unit& ut = units[ui + 1];
+            for (int j = 0; j < us.r; ++j) {
+                Ent e{};
+                e.xcol = (int16_t)(us.xoff + us.ku + j);
+                e.nquad = (int16_t)cdiv(us.r, 4);
+                e.sl_ns = (int16_t)us.sl_n; e.sl_nt = (int16_t)ut.sl_n;
+                e.s_off = us.sl_off + (j / 4) * 64 + (j % 4);
+                e.t_off = ut.sl_off + (j / 4) * 64 + (j % 4);
+                ents.push_back(e);
+            }
+        }
         g.ent_cnt = (int)ents.size() - g.ent_begin;
-        dg.push_back(g);
+        groups.push_back(g);
     }
-    if (pmax >= (int64_t)1 << 31 || packed >= (int64_t)1 << 31) {
-        delete P;
-        return fail("hint_plan_create: block too large (parameter offsets must fit 31 bits)");
-    }
-    P->n_groups = (int)dg.size();
+    P->n_groups = (int)groups.size();
+    P->n_units = (int)units.size();
     P->WT = wcol;
-    P->param_floats = pmax;
+    P->ST = gcol;
+    P->param_floats = (pmax + 3) / 4 * 4;
     P->packed_floats = packed;
-    P->ald = lds_stride(max_aw);
-    P->max_aw = max_aw;
-    P->vld = lds_stride(max_vw);
-    P->sld = lds_stride(max_sw);
-    // ---- meta blob staged in LDS by the kernels: [groups | vmap | ents] ----
-    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t groups_bytes = up16(dg.size() * sizeof(DGroup));
-    const size_t vmap_bytes = up16(vmap.size() * sizeof(int16_t));
-    const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
-    P->vmap_off = (int)groups_bytes;
-    P->ents_off = (int)(groups_bytes + vmap_bytes);
-    P->meta_bytes = (int)(groups_bytes + vmap_bytes + ents_bytes);
-    std::vector<char> meta(P->meta_bytes, 0);
-    std::memcpy(meta.data(), dg.data(), dg.size() * sizeof(DGroup));
-    if (!vmap.empty()) std::memcpy(meta.data() + P->vmap_off, vmap.data(), vmap.size() * sizeof(int16_t));
-    if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
-    for (int o = 0; o < 2; ++o) {
-        const DGroup& fg = o == 0 ? dg.front() : dg.back();
-        P->first[o][0] = fg.jl_begin; P->first[o][1] = fg.jl_count;
-        P->first[o][2] = fg.bmap_begin; P->first[o][3] = 2 * fg.aw + fg.sw;
-    }
     P->n_bias = (int)bmap.size();
-    P->split_o3 = use_a3 ? 0 : 1;
-    const int fixed = P->meta_bytes + 2 * P->jmax * (int)sizeof(GJob) + 4 * P->bmax * 4;   // [biases | bias-gradient map] x 2
-    P->lds_fwd = fixed + fwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3);
-    P->lds_bwd = fixed + bwd_lds_bytes(P->xld, P->cld, P->vld, P->ald, P->sld, P->s3, P->sv, use_a3 ? 3 : 2);
-    if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT || d + 16 > 32000 || max_aw > 60000 ||
-        P->bmax > 4 * NTHREADS) {
-        const int need = std::max(P->lds_bwd, P->lds_fwd);
-        const bool can_retry = use_a3 || max_slabs > 1 || cap_scale < 16;
+    if (pmax >= (int64_t)1 << 31 || packed + (int64_t)bmap.size() >= (int64_t)1 << 31 || units.size() > 32000 ||
+        gcol > 32000 || d > 32000) {
         delete P;
-        if (can_retry) { *retry_smaller = true; return 1; }   // rebuild with fewer slabs / smaller groups
+        return fail("hint_plan_create: block too large (offsets must fit 31 / 15 bits)");
+    }
+    for (Unit& u : units) { u.bias1 += (int)packed; u.bias2 += (int)packed; }   // the bias region follows the weight tiles
+
+    // ---- backward lane tables: per boundary (in front of group gi; slot n_groups: behind group 0) and lane ----
+    std::vector<LaneOp> lops((size_t)(P->n_groups + 1) * d);
+    for (int b = 0; b <= P->n_groups; ++b) {
+        const int cur = b < P->n_groups ? b : -1;                 // the group about to run (none for the last slot)
+        const int prev = b < P->n_groups ? (b + 1 < P->n_groups ? b + 1 : -1) : 0;   // the group that ran just before
+        for (int col = 0; col < d; ++col) {
+            LaneOp op{};
+            op.sc_unit = -1; op.sc_k = 0; op.cp_ls = -1; op.cp_lt = 0; op.cp_gs = 0; op.cp_gt = 0;
+            if (prev >= 0)
+                for (int ui = groups[prev].unit_begin; ui < groups[prev].unit_end; ui += 2) {
+                    const Unit& u = units[ui];
+                    if (col >= u.xoff && col < u.xoff + u.ku) { op.sc_unit = (int16_t)ui; op.sc_k = (int16_t)(col - u.xoff); }
+                }
+            if (cur >= 0)
+                for (int ui = groups[cur].unit_begin; ui < groups[cur].unit_end; ui += 2) {
+                    const Unit& us = units[ui];
+                    const Unit& ut = units[ui + 1];
+                    const int j = col - us.xoff - us.ku;
+                    if (j >= 0 && j < us.r) {
+                        op.cp_ls = (int16_t)(us.lcol + j); op.cp_lt = (int16_t)(ut.lcol + j);
+                        op.cp_gs = (int16_t)(us.gcol + j); op.cp_gt = (int16_t)(ut.gcol + j);
+                    }
+                }
+            lops[(size_t)b * d + col] = op;
+        }
+        if (b < P->n_groups) groups[b].lop_begin = b * d;
+    }
+
+    // ---- meta blob staged in LDS by the kernels ----
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t groups_bytes = up16(groups.size() * sizeof(Group));
+    const size_t units_bytes = up16(units.size() * sizeof(Unit));
+    const size_t tmap_bytes = up16(tmap.size() * sizeof(uint16_t));
+    const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
+    const size_t rng_bytes = up16(rng.size() * sizeof(int32_t));
+    const size_t lops_bytes = up16(lops.size() * sizeof(LaneOp));
+    P->units_off = (int)groups_bytes;
+    P->tmap_off = P->units_off + (int)units_bytes;
+    P->ents_off = P->tmap_off + (int)tmap_bytes;
+    P->rng_off = P->ents_off + (int)ents_bytes;
+    P->lops_off = P->rng_off + (int)rng_bytes;
+    P->meta_bytes = P->lops_off + (int)lops_bytes;
+    std::vector<char> meta(P->meta_bytes, 0);
+    std::memcpy(meta.data(), groups.data(), groups.size() * sizeof(Group));
+    std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
+    if (!tmap.empty()) std::memcpy(meta.data() + P->tmap_off, tmap.data(), tmap.size() * sizeof(uint16_t));
+    if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
+    std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
+    std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
+    P->lds_fwd = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW);
+    P->lds_bwd = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + P->abuf_tiles * 256 + P->slab_bwd + ROWS);
+    if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT) {
+        const int need = std::max(P->lds_bwd, P->lds_fwd);
+        const bool could_shrink = P->abuf_tiles > 0 && P->n_groups < (int)order.size();
+        delete P;
+        if (tile_cap > 8 && could_shrink) { *retry_smaller = true; return 1; }     // rebuild with smaller groups
         return fail("hint_plan_create: block needs %d bytes of LDS (> %d); d/dc/h too large", need, LDS_LIMIT);
     }
 
-    // ---- weight-gradient jobs: 48x48 output tiles of dW2 of every (node, net) ----
-    for (size_t ni = 0; ni < dn.size(); ++ni)
-        for (int net = 0; net < 2; ++net) {
-            if (!has_net(dn[ni], net)) continue;
-            const int T = dn[ni].hp / 16;          // padded extent in 16-wide tiles, cut into groups of <= 3
-            for (int mt = 0; mt < T; mt += 3)
-                for (int nt = 0; nt < T; nt += 3)
-                    dwj.push_back(DWJob{dn[ni].wcol + (net - dn[ni].net0) * dn[ni].hp, dn[ni].h, mt * 16, nt * 16, std::min(3, T - mt),
-                                        std::min(3, T - nt), src[ni]->p_off[net * 6 + 2]});
+    // ---- self-check: every fragment tile of every group lies in exactly one wavefront's range of either
+    //      phase, slices and slabs are consistent with the ranges, packed tiles are contiguous per unit ----
+    for (const Group& g : groups) {
+        const int32_t* r = rng.data() + g.rng_begin;
+        for (int ph = 0; ph < 2; ++ph) {
+            const int32_t* b = r + ph * (nw + 1);
+            if (b[0] != 0 || b[nw] != g.ntiles) { delete P; return fail("hint_plan_create: internal error (tile ranges)"); }
+            for (int w = 0; w < nw; ++w) if (b[w] > b[w + 1]) { delete P; return fail("hint_plan_create: internal error (tile ranges)"); }
         }
-    P->n_dwjobs = (int)dwj.size();
+        int slices = 0, want = 0;
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) slices += units[ui].sl_n;
+        const int32_t* b2 = r + (nw + 1);
+        for (int w = 0; w < nw; ++w) {
+            int t = b2[w];
+            while (t < b2[w + 1]) { const Unit& u = units[g.unit_begin + tmap[g.tmap_begin + t]]; ++want; t = std::min((int)b2[w + 1], u.tile0 + u.NT); }
+        }
+        if (slices != want) { delete P; return fail("hint_plan_create: internal error (slices)"); }
+    }
+
+    // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
+    std::vector<uint8_t> real((size_t)P->param_floats, 0);
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        const Unit& u = units[ui];
+        const hint_node_desc& n = nodes[unit_node[ui]];
+        const int net = (int)(ui & 1);
+        const int64_t* po = n.p_off + net * 6;
+        const int level = max_depth - n.depth;
+        const int64_t sizes[6] = {(int64_t)n.h * u.cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
+        for (int t = 0; t < 6; ++t)
+            for (int64_t i = 0; i < sizes[t]; ++i) real[(size_t)(po[t] + i)] = 1;
+        auto add_jobs = [&](int psrc, int pcol, int M, int pmaxc, int qsrc, int qcol, int N, int qmaxc, int qlevel, int ldo,
+                            int64_t wofs, int64_t bofs) {
+            // tiles of up to 48 x 48 outputs; the bias gradient rides with the first column group
+            const int MT = cdiv(M, 16), NTn = std::max(1, cdiv(N, 16));
+            for (int mt = 0; mt < MT; mt += 3)
+                for (int nt = 0; nt < NTn; nt += 3) {
+                    WJob j{};
+                    j.psrc = psrc; j.pcol = pcol + 16 * mt; j.M = std::min(48, M - 16 * mt); j.mw = std::min(3, MT - mt);
+                    j.qsrc = qsrc; j.qcol = qcol + 16 * nt; j.N = N > 0 ? std::min(48, N - 16 * nt) : 0;
+                    j.nw = N > 0 ? std::min(3, NTn - nt) : 0;
+                    j.qlevel = qlevel; j.ldo = ldo; j.pmax = pmaxc; j.qmax = qmaxc;
+                    j.wofs = wofs + (int64_t)16 * mt * ldo + 16 * nt;
+                    j.bofs = (bofs >= 0 && nt == 0) ? bofs + 16 * mt : -1;
+                    wjobs.push_back(j);
+                }
+        };
+        add_jobs(WSRC_G2, u.wcol, n.h, P->WT - 1, WSRC_A1, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W2], po[HINT_B2]);
+        add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
+        if (u.ku > 0)
+            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
+        if (dc > 0)
+            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_C, 0, dc, dc - 1, 0, u.cin, po[HINT_W1] + u.ku, u.ku > 0 ? -1 : po[HINT_B1]);
+        if (u.cin == 0)
+            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_A1, u.wcol, 0, P->WT - 1, 0, 1, po[HINT_W1], po[HINT_B1]);
+    }
+    P->n_wjobs = (int)wjobs.size();
     P->n_ptiles = (int)ptiles.size();
 
-    P->thin_total = (int)tmap.size();
     if (g_host_only) {           // hint_plan_check: everything above ran (and checked itself); no device
         P->num_cu = 256;
         *out = P;
@@ -665,21 +411,33 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
-    if (e == hipSuccess) e = upload((void**)&P->d_jobs, jobs.data(), jobs.size() * sizeof(GJob));
-    P->thin_total = (int)tmap.size();
-    if (e == hipSuccess) e = upload((void**)&P->d_tmap, tmap.data(), tmap.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = upload((void**)&P->d_tbmap, tbmap.data(), tbmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_bmap, bmap.data(), bmap.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = upload((void**)&P->d_dwjobs, dwj.data(), dwj.size() * sizeof(DWJob));
+    if (e == hipSuccess) e = upload((void**)&P->d_real, real.data(), real.size());
+    if (e == hipSuccess) e = upload((void**)&P->d_wjobs, wjobs.data(), wjobs.size() * sizeof(WJob));
     if (e == hipSuccess) e = upload((void**)&P->d_segs, segs.data(), segs.size() * sizeof(PackSeg));
     if (e == hipSuccess) e = upload((void**)&P->d_ptiles, ptiles.data(), ptiles.size() * sizeof(int2));
-    if (e == hipSuccess) e = set_max_lds(std::min(LDS_LIMIT, P->lds_fwd + PERM_LDS_MAX), std::min(LDS_LIMIT, P->lds_bwd + PERM_LDS_MAX));
+    // the kernels' dynamic-LDS ceiling is a per-kernel attribute: always the hardware limit, so that plans
+    // of different sizes created in any order (or on several devices) cannot lower it for each other
+    if (e == hipSuccess) e = set_max_lds_apply(LDS_LIMIT);
+    if (e == hipSuccess) e = set_max_lds_bwd(LDS_LIMIT);
     if (e != hipSuccess) {
         hint_plan_destroy(P);
         return fail("hint_plan_create: device setup failed: %s", hipGetErrorString(e));
     }
     *out = P;
     return 0;
+}
+
+// wavefronts per workgroup: HINT_NW (4, 8, 16) overrides; otherwise 8, or 16 when the block is too wide
+// for the backward kernel's register-held [16, d] tile at 8
+static int pick_nw(int d) {
+    int nw = 8;
+    if (const char* s = std::getenv("HINT_NW")) {
+        const int v = std::atoi(s);
+        if (v == 4 || v == 8 || v == 16) nw = v;
+    }
+    while (nw < MAX_NW && ROWS * d > LV_REGS * 64 * nw) nw *= 2;
+    return nw;
 }
 
 extern "C" {
@@ -691,8 +449,8 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
                      hint_plan** out) {
     if (!nodes || n_nodes <= 0 || d <= 0 || dc < 0 || !out) return fail("hint_plan_create: bad arguments");
     *out = nullptr;
-    if (d > 4 * NTHREADS / ROWS)      // TilePrefetch of the backward kernel holds 4 floats per thread
-        return fail("hint_plan_create: d = %d lanes exceeds the supported maximum %d", d, 4 * NTHREADS / ROWS);
+    if (ROWS * d > LV_REGS * 64 * MAX_NW)
+        return fail("hint_plan_create: d = %d lanes exceeds the supported maximum %d", d, LV_REGS * 64 * MAX_NW / ROWS);
     // ---- validate the tree: lane ranges inside [0,d), same-depth nodes disjoint ----
     for (int i = 0; i < n_nodes; ++i) {
         const hint_node_desc& n = nodes[i];
@@ -708,14 +466,12 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
             if (nodes[i].depth == nodes[j].depth && nodes[i].off < nodes[j].off + nodes[j].D &&
                 nodes[j].off < nodes[i].off + nodes[i].D)
                 return fail("hint_plan_create: nodes %d and %d of depth %d overlap", i, j, nodes[i].depth);
-    // first choice: full K-split and large groups; fall back to fewer slabs, then smaller groups
-    for (int cap_scale = 1; cap_scale <= 16; cap_scale *= 2)
-        for (int max_slabs = MAX_SLABS; max_slabs >= 1; max_slabs /= 2)
-            for (int use_a3 = 1; use_a3 >= 0; --use_a3) {
-            bool retry = false;
-            const int st = build_plan(nodes, n_nodes, d, dc, clamp, max_slabs, cap_scale, use_a3 != 0, out, &retry);
-            if (st == 0 || !retry) return st;
-        }
+    // large groups first (fewer phases per block); smaller ones when the block does not fit the LDS
+    for (int tile_cap = 72; tile_cap >= 8; tile_cap -= 16) {
+        bool retry = false;
+        const int st = build_plan(nodes, n_nodes, d, dc, clamp, pick_nw(d), tile_cap, out, &retry);
+        if (st == 0 || !retry) return st;
+    }
     return fail("hint_plan_create: could not fit the block into LDS");
 }
 
@@ -726,9 +482,9 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
     g_host_only = false;
     if (st != 0) return st;
     if (stats) {
-        stats[0] = P->n_groups; stats[1] = P->n_levels; stats[2] = P->WT; stats[3] = P->thin_total;
-        stats[4] = P->lds_fwd; stats[5] = P->lds_bwd; stats[6] = P->jmax; stats[7] = P->n_dwjobs;
-        stats[8] = P->param_floats; stats[9] = P->packed_floats; stats[10] = P->split_o3; stats[11] = P->max_aw;
+        stats[0] = P->n_groups; stats[1] = P->n_levels; stats[2] = P->WT; stats[3] = P->ST;
+        stats[4] = P->lds_fwd; stats[5] = P->lds_bwd; stats[6] = P->nw; stats[7] = P->n_wjobs;
+        stats[8] = P->param_floats; stats[9] = P->packed_floats; stats[10] = P->n_units; stats[11] = P->abuf_tiles;
     }
     delete P;                   // (host-only plans own no device memory)
     return 0;
@@ -737,20 +493,17 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
 void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
     (void)hipFree(P->d_meta);
-    (void)hipFree(P->d_jobs);
     (void)hipFree(P->d_bmap);
-    (void)hipFree(P->d_tmap);
-    (void)hipFree(P->d_tbmap);
-    (void)hipFree(P->d_dwjobs);
+    (void)hipFree(P->d_real);
+    (void)hipFree(P->d_wjobs);
     (void)hipFree(P->d_segs);
     (void)hipFree(P->d_ptiles);
     delete P;
 }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
-// +3 KiB of slack: the weight prefetch of the GEMM stages never reads past a job's last
-// k-block, but keeping a margin makes that robust against future tuning
-int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 3 * 256 : -1; }
+// + 1 KiB of slack behind the bias region
+int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 256 : -1; }
 
 static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
@@ -758,25 +511,38 @@ static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 static inline int64_t tape_act_off(const hint_plan* P, int B) {
     return (2 * (int64_t)P->n_levels * B * P->d + 3) / 4 * 4;
 }
-static inline int64_t tape_act_stride(const hint_plan* P, int B) {
-    return (int64_t)rows_padded(B) * P->WT + WS_SLACK;
-}
+static inline int64_t act_stride(const hint_plan* P, int B) { return (int64_t)rows_padded(B) * P->WT + WS_SLACK; }
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
-    // per level: the lane tile as the level saw it (the last slice: the block's permuted input) and
-    // the s values of the level's couplings, both [B, d]; then both hidden activations of every
-    // (node, net), [Bp, WT] each (the operand a1 of part B's dW2 = g2^T a1 lives here as well)
-    return tape_act_off(P, B) + 2 * tape_act_stride(P, B);
+    return tape_act_off(P, B) + 2 * act_stride(P, B);
+}
+
+// batch split of part B: a multiple of 8 splits (one XCD each), enough workgroups to cover the chip,
+// every workgroup reducing at least 128 rows
+static void wgrad_splits(const hint_plan* P, int B, int n_chain, int* splits_out, int* rows_out) {
+    const long Bp = rows_padded(B);
+    int splits = 8;
+    while ((long)splits * P->n_wjobs * n_chain < (long)P->num_cu && Bp / (splits * 2) >= 128) splits *= 2;
+    int rows_per_wg = (int)((Bp + splits - 1) / splits);
+    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+    if ((long)rows_per_wg * (splits - 1) >= Bp)   // tiny batches: fewer, non-empty splits
+        splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
+    *splits_out = splits;
+    *rows_out = rows_per_wg;
+}
+
+// Workspace layout (floats): [g1: Bp x WT + slack][g2: same][g_st: Bp x ST + slack, padded to 4][slabs: splits x param_floats]
+static inline int64_t ws_gst_off(const hint_plan* P, int B) { return 2 * act_stride(P, B); }
+static inline int64_t ws_slab_off(const hint_plan* P, int B) {
+    return ws_gst_off(P, B) + ((int64_t)rows_padded(B) * P->ST + WS_SLACK + 3) / 4 * 4;
 }
 
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
     if (!P || B <= 0) return 0;
-    const size_t Bp = rows_padded(B);
-    // [g2 rows][slack][thin-gradient slabs, one per row tile][one 64-float dump per row tile: where the
-    // backward kernel's branch-free outer-product stores put the elements that fall outside a matrix]
-    const size_t floats = (Bp * (size_t)P->WT + WS_SLACK) + (Bp / ROWS) * (size_t)P->thin_total + (Bp / ROWS) * (size_t)64 + WS_SLACK;
-    return floats * sizeof(float);
+    int splits, rows;
+    wgrad_splits(P, B, 1, &splits, &rows);        // (a chain never uses more splits than a single block)
+    return (size_t)(ws_slab_off(P, B) + (int64_t)splits * P->param_floats) * sizeof(float);
 }
 
 int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
@@ -791,17 +557,17 @@ static int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool a
     a->perm_lds = lds_plan / (int)sizeof(float);
     return lds_plan + (int)extra;
 }
-static KArgs make_args(const hint_plan* P, int B) {
+static KArgs make_args(const hint_plan* P, int B, bool backward) {
     KArgs a{};
-    a.meta = P->d_meta; a.jobs = P->d_jobs; a.bmap = P->d_tbmap; a.thin_total = P->thin_total;
-    a.meta_bytes = P->meta_bytes; a.vmap_off = P->vmap_off; a.ents_off = P->ents_off; a.jmax = P->jmax;
-    std::memcpy(a.first, P->first, sizeof a.first);
-    a.bmax = P->bmax; a.bias_off = P->packed_floats; a.act_stride = tape_act_stride(P, B);
-    a.s3 = P->s3; a.sv = P->sv;
-    a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.d = P->d; a.dc = P->dc;
-    a.xld = P->xld; a.cld = P->cld; a.ald = P->ald; a.vld = P->vld; a.sld = P->sld;
-    a.WT = P->WT;
-    a.alpha = P->alpha; a.B = B; a.split_o3 = P->split_o3; a.max_aw = P->max_aw;
+    a.meta = P->d_meta; a.meta_bytes = P->meta_bytes;
+    a.units_off = P->units_off; a.tmap_off = P->tmap_off; a.ents_off = P->ents_off; a.rng_off = P->rng_off;
+    a.lops_off = P->lops_off;
+    a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;
+    a.d = P->d; a.dc = P->dc; a.xld = P->xld; a.cld = P->cld;
+    a.abuf_tiles = P->abuf_tiles; a.slab_floats = backward ? P->slab_bwd : P->slab_fwd; a.gld = P->gld;
+    a.WT = P->WT; a.ST = P->ST; a.perm_lds = 0;
+    a.act_stride = act_stride(P, B);
+    a.alpha = P->alpha; a.B = B;
     return a;
 }
 
@@ -860,43 +626,38 @@ void hint_pack_group_destroy(hint_pack_group* G) {
 }
 
 static void split_workspace(const hint_plan* P, int B, void* workspace, ChainBlock* b) {
-    const size_t Bp = rows_padded(B);
-    b->wsG2 = (float*)workspace;
-    b->wsT = b->wsG2 + Bp * P->WT + WS_SLACK;       // [row tile][thin_total] partial thin gradients
+    b->wsG1 = (float*)workspace;
+    b->wsGST = b->wsG1 + ws_gst_off(P, B);
+    b->wsSlab = b->wsG1 + ws_slab_off(P, B);
 }
 
 // the hidden activations live inside the tape (the training forward writes them)
 static void bind_tape(const hint_plan* P, int B, float* tape, ChainBlock* b) {
     b->tape = tape;
-    b->wsA1 = tape ? tape + tape_act_off(P, B) : nullptr;
+    b->actA1 = tape ? tape + tape_act_off(P, B) : nullptr;
 }
 
-// part A (row-parallel) + part B (weight gradients) of the backward pass of one block or a chain
+static int grid_for(const hint_plan* P, int B) {
+    const int ntiles = (B + ROWS - 1) / ROWS;
+    return std::min(ntiles, P->num_cu * 8);
+}
+
+// part A (row-parallel, bit 0 of `parts`) and part B (weight gradients, bit 1) of the backward pass of
+// one block or a chain
 static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, int n_chain,
                         const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
-                        float gz_scale, float gJ_const, int B, hipStream_t s, bool any_perm) {
-    const size_t Bp = rows_padded(B);
-    const int ntiles = (B + ROWS - 1) / ROWS;
-    const int grid = std::min(ntiles, P->num_cu * 8);
-    const int stages = g_bwd_stages;
-    if (stages & 1) {
-        // (the permutation matrices stay in global memory here: the LDS table was measured +5 us in this
-        // kernel, which has no register to spare)
-        (void)any_perm;
-        HIP_TRY(launch_bwd(make_args(P, B), P->lds_bwd, grid, one, chain, n_chain, x, c, g_z, g_J, g_x, g_c,
-                           gz_scale, gJ_const, s));
+                        float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s) {
+    if (parts & 1) {
+        // (the permutation matrices stay in global memory here: one d x d product per block)
+        HIP_TRY(launch_bwd(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c, g_z, g_J, g_x,
+                           g_c, gz_scale, gJ_const, s));
     }
-    if (!(stages & 2)) return 0;
-    // batch split of the dW2 GEMMs: a multiple of 8 splits (one XCD each), enough workgroups
-    // to cover the chip, every workgroup reducing at least 128 rows
-    int splits = 8;
-    while ((long)splits * P->n_dwjobs * n_chain < (long)P->num_cu && (long)Bp / (splits * 2) >= 128) splits *= 2;
-    int rows_per_wg = (int)(((long)Bp + splits - 1) / splits);
-    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
-    if ((long)rows_per_wg * (splits - 1) >= (long)Bp)   // tiny batches: fewer, non-empty splits
-        splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
-    HIP_TRY(launch_dw(P->d_dwjobs, P->n_dwjobs, splits, one, chain, n_chain, P->WT, (int)Bp, rows_per_wg, P->d_tmap,
-                      P->thin_total, ntiles, s));
+    if (!(parts & 2)) return 0;
+    int splits, rows_per_wg;
+    wgrad_splits(P, B, n_chain, &splits, &rows_per_wg);
+    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, splits, one, chain, n_chain, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
+                         rows_padded(B), rows_per_wg, act_stride(P, B), P->param_floats, x, c, P->d_real, accumulate,
+                         P->num_cu, s));
     return 0;
 }
 
@@ -908,14 +669,12 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", what, P->dc);
     if (B < 0) return fail("negative batch");
     if (B == 0) return 0;
-    const int ntiles = (B + ROWS - 1) / ROWS;
-    const int grid = std::min(ntiles, P->num_cu * 8);
     ChainBlock one{};
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, rev ? nullptr : tape, &one);
-    KArgs a = make_args(P, B);
+    KArgs a = make_args(P, B, false);
     const int lds = lds_with_perms(P, P->lds_fwd, 1, perm != nullptr, &a);
-    HIP_TRY(launch_apply(rev, a, lds, grid, one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
+    HIP_TRY(launch_apply(rev, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
 }
@@ -958,26 +717,29 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
     if (!P || !params || !packed || (!x && !perm) || !g_x || !g_params) return fail("hint_block_backward: null argument");
     if (perm && !tape) return fail("hint_block_backward_ex: a fused permutation needs the tape of hint_block_forward_ex");
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
-    if (!tape && B > 0) return fail("hint_block_backward: tape is NULL (the backward pass reads the forward's lane tiles and s values from it)");
+    if (!tape && B > 0) return fail("hint_block_backward: tape is NULL (the backward pass reads the forward's lane tiles, s values and activations from it)");
     if (B < 0) return fail("negative batch");
     hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
-    if (B == 0) return 0;
+    if (B == 0) {
+        if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
+        return 0;
+    }
     if (!workspace || workspace_bytes < hint_plan_workspace_bytes(P, B))
         return fail("hint_block_backward: workspace too small (%zu < %zu)", workspace_bytes,
                     hint_plan_workspace_bytes(P, B));
     if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_backward: workspace must be 16-byte aligned");
+    if (((uintptr_t)g_params & 15) != 0) return fail("hint_block_backward: g_params must be 16-byte aligned");
     ChainBlock one{};
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, const_cast<float*>(tape), &one);
     one.gparams = g_params;
     split_workspace(P, B, workspace, &one);
-    return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, s, one.perm != nullptr);
+    return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, 3, s);
 }
 
 // ---------------------------------------------------------------------------------------
 // chained launches: the blocks of a flow (same plan, own parameters) in one kernel each for the
-// forward pass, backward part A and backward part B
+// forward pass, backward part A and backward part B (+ its slab reduction)
 // ---------------------------------------------------------------------------------------
 struct hint_chain {
     const hint_plan* plan = nullptr;
@@ -1024,6 +786,7 @@ int hint_chain_set_block(hint_chain* C, int32_t i, const float* params, const fl
             return fail("hint_chain_set_block: workspace too small (%zu < %zu)", workspace_bytes,
                         hint_plan_workspace_bytes(P, C->B));
         if (((uintptr_t)workspace & 15) != 0) return fail("hint_chain_set_block: workspace must be 16-byte aligned");
+        if (((uintptr_t)g_params & 15) != 0) return fail("hint_chain_set_block: g_params must be 16-byte aligned");
         split_workspace(P, C->B, workspace, &b);
     }
     C->host[i] = b;
@@ -1053,42 +816,51 @@ int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c
     if (!C->committed) return fail("hint_chain_forward: hint_chain_commit() has not been called");
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
-    const int ntiles = (C->B + ROWS - 1) / ROWS;
-    const int grid = std::min(ntiles, P->num_cu * 8);
-    KArgs a = make_args(P, C->B);
+    KArgs a = make_args(P, C->B, false);
     const int lds = lds_with_perms(P, P->lds_fwd, C->n, chain_any_perm(C), &a);
-    HIP_TRY(launch_apply(false, a, lds, grid, C->host[0], C->d_table, C->n, x, c, z, J,
+    HIP_TRY(launch_apply(false, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, c, z, J,
                          J_in, loss_acc, noise, (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
     return 0;
 }
 
-int hint_chain_backward(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
-                        float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate, void* stream) {
+int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, float* x, float* J, const float* J_in,
+                       void* stream) {
+    if (!C || !z || !x || !J) return fail("hint_chain_inverse: null argument");
+    if (!C->committed) return fail("hint_chain_inverse: hint_chain_commit() has not been called");
+    const hint_plan* P = C->plan;
+    if (P->dc > 0 && !c) return fail("hint_chain_inverse: plan has dc=%d but c is NULL", P->dc);
+    KArgs a = make_args(P, C->B, false);
+    const int lds = lds_with_perms(P, P->lds_fwd, C->n, chain_any_perm(C), &a);
+    HIP_TRY(launch_apply(true, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, c, x, J, J_in, nullptr, 0.f,
+                         nullptr, nullptr, (hipStream_t)stream));
+    return 0;
+}
+
+int hint_chain_backward_parts(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
+                              float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate,
+                              int32_t parts, void* stream) {
     if (!C || !g_z || !g_x) return fail("hint_chain_backward: null argument");
     if (!C->committed) return fail("hint_chain_backward: hint_chain_commit() has not been called");
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_backward: plan has dc=%d but c is NULL", P->dc);
     if (!x && !C->host[0].perm) return fail("hint_chain_backward: x is NULL but the first block has no fused permutation");
     for (int i = 0; i < C->n; ++i)
-        if (!C->host[i].wsG2 || !C->host[i].wsA1 || !C->host[i].gparams)
+        if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
             return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
-    hipStream_t s = (hipStream_t)stream;
-    if (!accumulate)
-        for (int i = 0; i < C->n; ++i) HIP_TRY(launch_zero(C->host[i].gparams, (long)P->param_floats, P->num_cu, s));
-    return run_backward(P, C->host[0], C->d_table, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, s, chain_any_perm(C));
+    if ((parts & 3) == 0) return fail("hint_chain_backward_parts: parts must select part A (1), part B (2) or both (3)");
+    return run_backward(P, C->host[0], C->d_table, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
+                        accumulate ? 1 : 0, parts & 3, (hipStream_t)stream);
+}
+
+int hint_chain_backward(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
+                        float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate, void* stream) {
+    return hint_chain_backward_parts(C, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, accumulate, 3, stream);
 }
 
 void hint_chain_destroy(hint_chain* C) {
     if (!C) return;
     (void)hipFree(C->d_table);
     delete C;
-}
-
-void hint_debug_set_backward_stages(int32_t mask) { g_bwd_stages = mask & 3; }
-
-int hint_debug_set_stamp_buffer(void* device_buffer) {
-    HIP_TRY(set_stamp_buffer((unsigned long long*)device_buffer));
-    return 0;
 }
 
 static int adam_num_cu() {

@@ -1,0 +1,232 @@
+// Backward, part B (gfx950 / CDNA4 only): every weight and bias gradient of a block is a reduction
+// over the batch of per-row factors that part A (hint_bwd.hip) and the forward tape left in HBM:
+//   dW1[f][k] = sum_b g1[b][f] v[b][k]      v = [lanes of the node's level | condition]
+//   dW2[m][n] = sum_b g2[b][m] a1[b][n]
+//   dW3[j][f] = sum_b g_st[b][j] a2[b][f]
+//   db1 = colsum g1, db2 = colsum g2, db3 = colsum g_st
+// i.e. GEMMs whose K dimension is the batch.  The OUTPUT is tiled (up to 48x48 per workgroup: 3x3
+// MFMA tiles fed by one 12-byte load per operand and k-step) and the batch is split over `splits`
+// workgroups and the 8 wavefronts of each.  Block ids are mapped so that all tiles of one batch split
+// run on the same XCD (blocks b, b+8, .. share one): the rows of a split are fetched from HBM /
+// Infinity Cache once and re-read from that XCD's L2 by the tiles that share them.
+// Deterministic: every (tile, split) writes its partial to the split's own slab with plain stores and
+// hint_wreduce_kernel adds the slabs in a fixed order - no float atomics anywhere.
+#include "hint_device.hpp"
+
+using namespace hint;
+
+constexpr int DW_WAVES = 8;
+
+struct SrcRef { const float* p; int ld; int rows; };
+
+__device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bool top, const float* __restrict__ x,
+                                       const float* __restrict__ c, int WT, int ST, int d, int dc, int n_levels, int B, int Bp,
+                                       int64_t act_stride) {
+    SrcRef r;
+    r.rows = Bp;
+    switch (src) {
+        case WSRC_G1: r.p = (const float*)blk.wsG1; r.ld = WT; break;
+        case WSRC_G2: r.p = (const float*)blk.wsG1 + act_stride; r.ld = WT; break;
+        case WSRC_GST: r.p = (const float*)blk.wsGST; r.ld = ST; break;
+        case WSRC_A1: r.p = (const float*)blk.actA1; r.ld = WT; break;
+        case WSRC_A2: r.p = (const float*)blk.actA1 + act_stride; r.ld = WT; break;
+        case WSRC_X: {
+            const float* tape = (const float*)blk.tape;
+            const size_t lvl = (size_t)B * d;
+            r.p = level == 0 ? (top ? tape + (size_t)(n_levels - 1) * lvl : x) : tape + (size_t)(level - 1) * lvl;
+            r.ld = d; r.rows = B;
+            break;
+        }
+        default: r.p = c; r.ld = dc; r.rows = B; break;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
+    const WJob* __restrict__ jobs, int n_jobs, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
+    int grid_pb, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
+    int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c) {
+    __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
+    __shared__ float bred[DW_WAVES][3][16];
+
+    // a chained launch holds grid_pb (a multiple of 8, so that the XCD mapping below holds for every
+    // block) workgroups per block of the chain, of which the first n_jobs * splits have work
+    const int cbi = (int)blockIdx.x / grid_pb;
+    const int bid = (int)blockIdx.x - cbi * grid_pb;
+    if (bid >= n_jobs * splits) return;
+    const GBlock blk = chain_block(chain, one, cbi);
+    const bool top = blk.perm != nullptr || cbi > 0;
+
+    int jidx, split;
+    if ((splits & 7) == 0) {          // XCD-aware: split s lives on XCD s % 8
+        const int xcd = bid & 7, t = bid >> 3;
+        split = xcd + 8 * (t / n_jobs);
+        jidx = t % n_jobs;
+    } else {
+        split = bid / n_jobs;
+        jidx = bid % n_jobs;
+    }
+    const WJob job = jobs[jidx];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int nl = lane & 15, kq = lane >> 4;
+    const int ntm = job.mw, ntn = job.nw;
+    const SrcRef ps = wsrc(job.psrc, 0, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride);
+    const SrcRef qs = wsrc(job.qsrc, job.qlevel, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride);
+    const int b_begin = split * rows_per_wg;
+    const int b_end = min(Bp, b_begin + rows_per_wg);
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = zero4();
+    float psum[3] = {0.f, 0.f, 0.f};
+
+    // lane nl holds columns col0 + w*nl + {0..w-1} of its operand (the permutation of columns inside
+    // the up-to-48-wide group is undone at write-out).  Full 48-column groups inside the array: one
+    // 12-byte load per k-step; otherwise element loads clamped to the operand's last column (products
+    // of clamped columns are never written).
+    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+    const int pc0 = job.pcol + ntm * nl, qc0 = job.qcol + ntn * nl;
+    const bool pvec = ntm == 3 && job.pcol + 47 <= job.pmax;
+    const bool qvec = ntn == 3 && job.qcol + 47 <= job.qmax;
+    int pcj[3], qcj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { pcj[j] = min(pc0 + j, job.pmax); qcj[j] = min(qc0 + j, max(job.qmax, 0)); }
+    const int prow_max = ps.rows - 1, qrow_max = qs.rows - 1;
+
+    f32x3u av[2][4], bv[2][4];
+#define DW_LOAD(BUF, BB)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+        const int row_ = (BB) + 4 * i + kq;                                                \
+        const size_t pr_ = (size_t)min(row_, prow_max) * ps.ld;                            \
+        const size_t qr_ = (size_t)min(row_, qrow_max) * qs.ld;                            \
+        if (pvec) av[BUF][i] = *(const f32x3u*)(ps.p + pr_ + pc0);                         \
+        else { av[BUF][i].x = ps.p[pr_ + pcj[0]]; av[BUF][i].y = ps.p[pr_ + pcj[1]]; av[BUF][i].z = ps.p[pr_ + pcj[2]]; } \
+        if (ntn > 0) {                                                                     \
+            if (qvec) bv[BUF][i] = *(const f32x3u*)(qs.p + qr_ + qc0);                     \
+            else { bv[BUF][i].x = qs.p[qr_ + qcj[0]]; bv[BUF][i].y = qs.p[qr_ + qcj[1]]; bv[BUF][i].z = qs.p[qr_ + qcj[2]]; } \
+        }                                                                                  \
+    }
+#define DW_MMA(BUF)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+        _Pragma("unroll") for (int tm = 0; tm < 3; ++tm) {                                 \
+            psum[tm] += av[BUF][i][tm];                                                    \
+            if (tm < ntm)                                                                  \
+                _Pragma("unroll") for (int tn = 0; tn < 3; ++tn)                           \
+                    if (tn < ntn) acc[tm][tn] = mfma4(av[BUF][i][tm], bv[BUF][i][tn], acc[tm][tn]); \
+        }                                                                                  \
+    }
+
+    // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs of block j
+    const int step = 16 * DW_WAVES;
+    int bb = b_begin + wave * 16;
+    if (bb < b_end) {
+        DW_LOAD(0, bb)
+        while (true) {
+            const int nb1 = bb + step;
+            const bool last1 = nb1 >= b_end;
+            if (!last1) { DW_LOAD(1, nb1) }
+            DW_MMA(0)
+            if (last1) break;
+            const int nb2 = nb1 + step;
+            const bool last2 = nb2 >= b_end;
+            if (!last2) { DW_LOAD(0, nb2) }
+            DW_MMA(1)
+            if (last2) break;
+            bb = nb2;
+        }
+    }
+#undef DW_LOAD
+#undef DW_MMA
+    // combine the wavefronts (fixed order)
+#pragma unroll
+    for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 3; ++tn) *(f32x4*)&red[wave][tm * 3 + tn][lane][0] = acc[tm][tn];
+    if (job.bofs >= 0) {
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) {
+            float v = psum[tm];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) bred[wave][tm][nl] = v;
+        }
+    }
+    __syncthreads();
+    float* slab = (float*)blk.wsSlab + (size_t)split * param_floats;
+    for (int idx = tid; idx < 9 * 64; idx += DW_WAVES * 64) {
+        const int t = idx >> 6, l = idx & 63;
+        const int tm = t / 3, tn = t - 3 * tm;
+        if (tm >= ntm || tn >= ntn) continue;
+        f32x4 v = *(f32x4*)&red[0][t][l][0];
+#pragma unroll
+        for (int w = 1; w < DW_WAVES; ++w) v += *(f32x4*)&red[w][t][l][0];
+        const int n = ntn * (l & 15) + tn;          // undo the column permutation of the loads
+        if (n >= job.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = ntm * (4 * (l >> 4) + i) + tm;
+            if (m < job.M) slab[job.wofs + (size_t)m * job.ldo + n] = v[i];
+        }
+    }
+    if (job.bofs >= 0 && tid < 48) {
+        const int tm = tid >> 4, l = tid & 15;
+        const int m = ntm * l + tm;
+        if (tm < ntm && m < job.M) {
+            float v = bred[0][tm][l];
+#pragma unroll
+            for (int w = 1; w < DW_WAVES; ++w) v += bred[w][tm][l];
+            slab[job.bofs + m] = v;
+        }
+    }
+}
+
+// g[i] (+)= sum over the splits' slabs, in split order, for every real parameter element i (the
+// padding between tensors stays untouched when accumulating and is cleared otherwise)
+__global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const ChainBlock* __restrict__ chain,
+                                                           const uint8_t* __restrict__ real, int64_t param_floats,
+                                                           int splits, int accumulate, int blocks_pb) {
+    const int cbi = (int)blockIdx.x / blocks_pb;
+    const int bid = (int)blockIdx.x - cbi * blocks_pb;
+    const GBlock blk = chain_block(chain, one, cbi);
+    const float* slab = (const float*)blk.wsSlab;
+    float* g = (float*)blk.gparams;
+    const int64_t n4 = param_floats >> 2;        // param_floats is a multiple of 4 (hint_plan_param_floats)
+    for (int64_t i4 = (int64_t)bid * 256 + threadIdx.x; i4 < n4; i4 += (int64_t)blocks_pb * 256) {
+        const uchar4 rl = ((const uchar4*)real)[i4];
+        f32x4 s = zero4();
+        for (int sp = 0; sp < splits; ++sp) s += ((const f32x4*)(slab + (size_t)sp * param_floats))[i4];
+        f32x4 o = accumulate ? ((const f32x4*)g)[i4] : zero4();
+        if (rl.x) o.x += s.x;
+        if (rl.y) o.y += s.y;
+        if (rl.z) o.z += s.z;
+        if (rl.w) o.w += s.w;
+        ((f32x4*)g)[i4] = o;
+    }
+}
+
+namespace hint {
+
+hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
+                        int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
+                        int64_t act_stride, int64_t param_floats, const float* x, const float* c, const uint8_t* real,
+                        int accumulate, int num_cu, hipStream_t stream) {
+    const int used = n_jobs * splits;
+    const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
+    if (used > 0)
+        hipLaunchKernelGGL(hint_wgrad_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs,
+                           splits, one, chain, grid_pb, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
+                           param_floats, x, c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int blocks_pb = (int)((param_floats / 4 + 255) / 256);
+    const int cap = num_cu * 4 / (n_chain > 0 ? n_chain : 1);
+    blocks_pb = blocks_pb < 1 ? 1 : (blocks_pb > cap && cap >= 1 ? cap : blocks_pb);
+    hipLaunchKernelGGL(hint_wreduce_kernel, dim3(blocks_pb * n_chain), dim3(256), 0, stream, one, chain, real,
+                       param_floats, splits, accumulate, blocks_pb);
+    return hipGetLastError();
+}
+
+}  // namespace hint

@@ -64,6 +64,13 @@ class FlowTrainer:
             e.bind_external_arena(self.P[a:b])
             e.ensure_arena()
             e.pack()
+        if dp.world_info(group)[1] > 1:
+            # data-parallel replicas must start from the same weights (the reference idiom
+            # p.data = init_scale*randn_like(p) draws per-process values): rank 0's win; M and V are zero
+            src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
+            torch.distributed.broadcast(self.P, src=src, group=group)
+            for e in self.engines:
+                e.pack()
         self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)   # per-slot partial loss sums
         self._loss_single = self.loss_acc      # (step_many points loss_acc at its last iteration's sums)
         self._pack_group, self._pack_key = None, None
@@ -75,7 +82,9 @@ class FlowTrainer:
         # identical blocks (the configs stack copies of one block) run as ONE forward launch and
         # TWO backward launches for the whole flow (hint_chain_*)
         self._chainable = use_chain and all(e.shape_key == self.engines[0].shape_key for e in self.engines)
-        self._chain, self._chain_key, self._chain_bufs = None, None, None
+        # one chain (handle, tapes, workspaces) per batch size: a captured graph keeps raw pointers into
+        # its chain's buffers, so a chain is never destroyed while a graph that used it is alive
+        self._chains = {}
         # state of the in-kernel noise generator (hint_chain_forward_noisy): {seed, step}; every rank
         # of a data-parallel job draws its own stream
         if seed is None:
@@ -102,9 +111,10 @@ class FlowTrainer:
 
     def __del__(self):
         try:
-            if getattr(self, "_chain", None):
-                self.lib.hint_chain_destroy(self._chain)
-                self._chain = None
+            self._graph = self._graph_many = None
+            for handle, _, _ in getattr(self, "_chains", {}).values():
+                self.lib.hint_chain_destroy(handle)
+            self._chains = {}
             if getattr(self, "_pack_group", None):
                 self.lib.hint_pack_group_destroy(self._pack_group)
                 self._pack_group = None
@@ -122,11 +132,25 @@ class FlowTrainer:
         perms = [e.compose_perm(f) for e, f in zip(self.engines, front)]
         key = (B,) + tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) \
             + tuple(p.data_ptr() if p is not None else 0 for p in perms) + (self.G.data_ptr(),)
-        if self._chain_key == key:
-            return self._chain
-        if self._chain:
-            self.lib.hint_chain_destroy(self._chain)
-            self._chain, self._chain_key = None, None
+        have = self._chains.get(B)
+        if have is not None and have[1] == key:
+            return have[0]
+        if have is not None:
+            # an arena, packed buffer or permutation moved: every captured graph may point at the old
+            # addresses - drop them all (they are re-captured on their next use), then the stale chain
+            self._graph = self._graph_many = None
+            self._static = None
+            self.lib.hint_chain_destroy(have[0])
+            del self._chains[B]
+        elif len(self._chains) >= 8:
+            # many batch sizes (ragged data): forget the chains no live graph was captured on
+            keep = {self._static["x"].shape[0]} if self._graph is not None and self._static is not None else set()
+            st = getattr(self, "_static_many", None)
+            if getattr(self, "_graph_many", None) is not None and st is not None:
+                keep.add(st["x"].shape[1])
+            for b in [b for b in self._chains if b not in keep]:
+                self.lib.hint_chain_destroy(self._chains[b][0])
+                del self._chains[b]
         e0, n = self.engines[0], len(self.engines)
         tape_floats = max(self.lib.hint_plan_tape_floats(e0.plan, B), 1)
         ws_bytes = (self.lib.hint_plan_workspace_bytes(e0.plan, B) + 255) // 256 * 256
@@ -142,7 +166,7 @@ class FlowTrainer:
                     perms[i].data_ptr() if perms[i] is not None else None, tapes[i].data_ptr(),
                     ws[i].data_ptr(), ws_bytes, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
             _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
-        self._chain, self._chain_key, self._chain_bufs = handle, key, (tapes, ws, perms)
+        self._chains[B] = (handle, key, (tapes, ws, perms))
         return handle
 
     # ---- the un-captured step body ----------------------------------------------------
@@ -267,6 +291,8 @@ class FlowTrainer:
             self._check_arenas()
             self._fwd_bwd(x, c)
         else:
+            if self._graph is not None and any(e.params[0].data_ptr() != e._ptrs[0] for e in self.engines):
+                self._graph = None             # parameters were rebound from outside (p.data = ..., .to()): re-capture
             if self._graph is None or self._static["x"].shape != x.shape:
                 self._capture(x, c)
             # (a batch that already sits in the graph's input buffers - input_buffers() - is not copied again)
@@ -402,18 +428,16 @@ class FlowTrainer:
                 self.rng_state.data_ptr() if noisy else None, xn.data_ptr() if noisy else None, stream), "forward")
             ev[2].record()
             xin = xn if noisy else x
-            for k, mask in ((3, 1), (4, 2)):          # part A (row-parallel), then part B (weight gradients)
-                self.lib.hint_debug_set_backward_stages(mask)
-                _lib.check(self.lib.hint_chain_backward(chain, xin.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(), None,
-                                                        1.0 / B, -1.0 / B, 1, stream), "backward")
+            for k, parts in ((3, 1), (4, 2)):         # part A (row-parallel), then part B (weight gradients)
+                _lib.check(self.lib.hint_chain_backward_parts(chain, xin.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
+                                                              None, 1.0 / B, -1.0 / B, 1, parts, stream), "backward")
                 ev[k].record()
-            self.lib.hint_debug_set_backward_stages(3)
             self._last_B = B
             scale = dp.allreduce_sum_(self.G, self.group)
             self._optimizer(scale)
             ev[5].record()
         torch.cuda.synchronize(self.device)
-        names = ["hint_pack_many_kernel", "hint_block_apply_kernel<fwd>", "hint_block_bwd_kernel", "hint_block_dw_kernel",
+        names = ["hint_pack_many_kernel", "hint_apply_kernel<fwd>", "hint_bwd_kernel", "hint_wgrad_kernel+hint_wreduce_kernel",
                  "allreduce+hint_adam_kernel"]
         return {n: ev[i].elapsed_time(ev[i + 1]) * 1e3 for i, n in enumerate(names)}
 

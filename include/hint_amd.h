@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HINT_AMD_ABI_VERSION 1
+#define HINT_AMD_ABI_VERSION 2
 
 /* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
  * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],
@@ -61,16 +61,16 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
                      float clamp, hint_plan** out);
 
 /* Host-only dry run of hint_plan_create (no device needed, nothing uploaded): builds the plan, lets the
- * planner verify its own job lists (every output tile of every GEMM stage produced exactly once, every
- * outer-product tile of the thin weight gradients exactly once) and reports what it came to:
- * stats[12] = { groups, levels, WT (activation columns), thin-gradient slab floats, LDS bytes forward,
- * LDS bytes backward, longest per-group job list, part-B tile jobs, parameter floats, packed floats,
- * split_o3, widest group }.  For tests and tools; same return convention as hint_plan_create. */
+ * planner verify its own schedule (every fragment tile of every group in exactly one wavefront's range of
+ * either GEMM phase, slices and slabs consistent with the ranges) and reports what it came to:
+ * stats[12] = { groups, levels, WT (activation columns), ST (coupling-gradient columns), LDS bytes forward,
+ * LDS bytes backward, wavefronts per workgroup, part-B tile jobs, parameter floats, packed floats, units,
+ * fragment tiles of the widest group }.  For tests and tools; same return convention as hint_plan_create. */
 int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
                     int64_t* stats);
 void hint_plan_destroy(hint_plan* plan);
 
-/* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size). */
+/* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size), rounded up to 4. */
 int64_t hint_plan_param_floats(const hint_plan* plan);
 /* floats of the packed-weight buffer (both subnets of every node, forward and transposed
  * copies, in MFMA fragment order, zero padded). */
@@ -81,9 +81,11 @@ int64_t hint_plan_packed_floats(const hint_plan* plan);
  * of the level's coupling arguments s (indexed by the lane each one scales), then both hidden
  * activations of every subnet, [B rounded up to 16, sum of 2*pad16(h)] each.  The backward pass
  * recomputes nothing (what autograd keeps for hint.py:77, minus the pre-activations), and the
- * weight-gradient kernel takes its a1 operand from here. */
+ * weight-gradient kernel takes its a1 / a2 / lane operands from here. */
 int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
-/* bytes of scratch hint_block_backward needs for a batch of B rows. */
+/* bytes of scratch hint_block_backward needs for a batch of B rows: the per-row gradient factors g1, g2
+ * ([B rounded up to 16, sum of 2*pad16(h)] each) and g_s | g_t, and one partial-gradient slab per batch
+ * split of the weight-gradient kernel. */
 size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
 /* dynamic LDS bytes per workgroup of the forward / backward kernels (informational). */
 int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
@@ -124,9 +126,9 @@ int hint_block_inverse(const hint_plan* plan, const float* params, const float* 
  * g_J [B] (either may be NULL = zeros).  Writes g_x [B,d], g_c [B,dc] (may be NULL) and the
  * flat parameter gradient g_params (same layout as params): overwritten when accumulate == 0,
  * added to when accumulate != 0 (the caller then owns zeroing, e.g. hint_adam_step's
- * zero_grads).  Parameter gradients are reduced with float atomics, so their last bits can
- * differ from run to run.  workspace: hint_plan_workspace_bytes(plan, B) bytes, 16-byte
- * aligned device scratch. */
+ * zero_grads); 16-byte aligned.  Every gradient is reduced in a fixed order (per-split slabs, then one
+ * reduction pass; no float atomics): the same inputs give bit-identical gradients.  workspace:
+ * hint_plan_workspace_bytes(plan, B) bytes, 16-byte aligned device scratch. */
 int hint_block_backward(const hint_plan* plan, const float* params, const float* packed,
                         const float* x, const float* tape, const float* c, const float* g_z,
                         const float* g_J, float* g_x, float* g_c, float* g_params,
@@ -195,6 +197,17 @@ int hint_chain_forward_noisy(const hint_chain* chain, const float* x, const floa
 int hint_chain_backward(const hint_chain* chain, const float* x, const float* c, const float* g_z,
                         const float* g_J, float* g_x, float* g_c, float gz_scale, float gJ_const,
                         int32_t accumulate, void* stream);
+/* The same with the two halves of the backward pass selectable per call (profiling, or overlapping
+ * part B with other work): parts bit 0 = the row-parallel kernel (g_x, g_c and the per-row factors in
+ * the workspace), bit 1 = the weight-gradient kernels (read what bit 0 left in the workspace). */
+int hint_chain_backward_parts(const hint_chain* chain, const float* x, const float* c, const float* g_z,
+                              const float* g_J, float* g_x, float* g_c, float gz_scale, float gJ_const,
+                              int32_t accumulate, int32_t parts, void* stream);
+/* Sampling direction (train_unconditional.py:152-153, rev=True through the whole graph): the blocks
+ * of the chain last to first in ONE launch, x = chain^-1(z), J = J_in - sum of the blocks' log-dets
+ * (the reference's rev=True sign, hint.py:83).  x may alias z. */
+int hint_chain_inverse(const hint_chain* chain, const float* z, const float* c, float* x, float* J,
+                       const float* J_in, void* stream);
 void hint_chain_destroy(hint_chain* chain);
 
 /* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces
@@ -215,15 +228,6 @@ int hint_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_a
                        const float* opt_state, float beta1, float beta2, float eps,
                        float weight_decay, float grad_scale, float grad_clamp, int32_t zero_grads,
                        void* stream);
-
-/* Profiling aid (process-global, not for production use): restrict hint_block_backward to its
- * row-parallel kernel (mask 1), its weight-gradient kernel (mask 2, reuses whatever the
- * workspace holds) or both (3, the default), so each can be timed on its own. */
-void hint_debug_set_backward_stages(int32_t mask);
-/* Diagnostic builds only (-DHINT_STAMPS): workgroup 0 of the block kernels writes shader-clock
- * stamps of its stage boundaries into device_buffer (8 waves x 128 uint64).  Returns non-zero
- * in a normal build. */
-int hint_debug_set_stamp_buffer(void* device_buffer);
 
 int hint_abi_version(void);
 const char* hint_last_error(void);

@@ -1,8 +1,8 @@
 """Planner (hint_amd/csrc/hint_plan.cpp) without a GPU: hint_plan_check builds the launch plan of a block
-on the host, lets the planner verify its own job lists (every output tile of every GEMM stage of the
-forward and backward kernels produced exactly once, every outer-product tile of the thin weight
-gradients exactly once) and reports the plan's figures.  Covers the BASELINE configs' block shapes
-(SURVEY.md §8a/d), the conditional lanes, split (h > 384) nodes and ragged widths."""
+on the host, lets the planner verify its own schedule (every fragment tile of every group in exactly one
+wavefront's range of either GEMM phase, slices consistent with the ranges) and reports the plan's
+figures.  Covers the BASELINE configs' block shapes, the conditional lanes, wide
+(h = 512) nodes and ragged widths."""
 import ctypes as C
 
 import pytest
@@ -12,7 +12,7 @@ import hint_amd
 from hint_amd import _lib
 from hint_amd.hint import node_descs
 
-STAT = ["groups", "levels", "WT", "thin", "lds_fwd", "lds_bwd", "jmax", "dwjobs", "params", "packed", "split_o3", "max_aw"]
+STAT = ["groups", "levels", "WT", "ST", "lds_fwd", "lds_bwd", "nw", "wjobs", "params", "packed", "units", "abuf_tiles"]
 
 
 def check(tree, d, dc, clamp=4.0):
@@ -33,7 +33,7 @@ def check(tree, d, dc, clamp=4.0):
     (100, 4, [224, 112, 56], 71, 7),         # conditional_recursive_cinn_4.py style
     (43, 0, [67, 33, 16, 8], 31, 5),         # cfg 5 as BASELINE words it
     (42, 0, [67, 33, 16, 8], 31, 5),         # the reference's MINIBOONE width (data.py:423)
-    (6, 0, [512, 256, 128], 3, 2),           # *_big: h > 384, nets planned one at a time
+    (6, 0, [512, 256, 128], 3, 2),           # *_big: h = 512
     (5, 0, [385], None, None),
     (1, 0, [8], 1, 1),
     (2, 3, [7, 5], 1, 1),
@@ -51,18 +51,20 @@ def test_planner_covers_every_tile_exactly_once(d, dc, widths, n_nodes, n_levels
     assert total - 4 < st["params"] <= total          # (the last tensor's padding is not part of the plan)
     assert 0 < st["lds_fwd"] <= 160 * 1024 and 0 < st["lds_bwd"] <= 160 * 1024
     assert st["groups"] >= st["levels"]
-    # activation columns: every (node, net) once, h padded to 16 (split nodes: two units)
-    want_wt = sum(2 * ((n.s[0].out_features + 15) // 16 * 16) for n, _, _ in nodes)
-    assert st["WT"] == want_wt
-    # thin-gradient slab: dW1, dW3 and the three biases of every net
-    thin = 0
+    assert st["units"] == 2 * len(nodes) and st["nw"] in (4, 8, 16)
+    # activation columns: every (node, net) once, h padded to 16; coupling-gradient columns: r padded to 4
+    assert st["WT"] == sum(2 * ((n.s[0].out_features + 15) // 16 * 16) for n, _, _ in nodes)
+    assert st["ST"] == sum(2 * ((n.s[4].out_features + 3) // 4 * 4) for n, _, _ in nodes)
+    # part B: tiles of up to 48 x 48 outputs of every weight matrix (dW1 in a lane part and a condition part)
+    t3 = lambda v: ((v + 15) // 16 + 2) // 3
+    jobs = 0
     for n, _, _ in nodes:
-        for net in (n.s, n.t):
-            thin += net[0].weight.numel() + net[4].weight.numel() + net[0].bias.numel() + net[2].bias.numel() + net[4].bias.numel()
-    assert st["thin"] == thin
-    # part B: 48x48 tiles of every dW2
-    dw = sum(2 * (((n.s[0].out_features + 15) // 16 + 2) // 3) ** 2 for n, _, _ in nodes)
-    assert st["dwjobs"] == dw
+        h, r, k = n.s[0].out_features, n.s[4].out_features, n.split_idx
+        per = t3(h) * t3(h) + t3(r) * t3(h) + (t3(h) * t3(k) if k else 0) + (t3(h) * t3(dc) if dc else 0)
+        per += t3(h) if (k + dc) == 0 else 0
+        jobs += 2 * per
+    assert st["wjobs"] == jobs
+    assert st["abuf_tiles"] >= max(2 * ((n.s[0].out_features + 15) // 16) for n, _, _ in nodes)
 
 
 def test_planner_accepts_the_conditional_lane_couplings():
