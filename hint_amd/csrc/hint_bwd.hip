@@ -7,11 +7,11 @@
 //   g2 = (W3^T g_st) .* relu'(a2) ; g1 = (W2^T g2) .* relu'(a1) ; g_v = W1^T g1 ; g_u += g_v[:k], g_c += g_v[k:]
 // Nothing is recomputed: s, the lane tiles of every level and both hidden activations come from the
 // forward's tape (bit-identical ReLU masks by construction).  One workgroup carries the gradient
-// tile of 16 batch rows through all blocks of the chain, last to first.  Per group three phases:
+// tile of 16 batch rows through all blocks of the chain, last to first.  Per group two phases:
 //   Q1  element-wise: add the g_v partials of the group before, coupling backward -> g_st (LDS + global)
-//   Q2  g2 fragment tiles (masked by a2) -> LDS + global                         (run_phase<K_G2>)
-//   Q3  g1 tiles (masked by a1) -> global, and straight from the accumulator the K-split partial
-//       of g_v into the wavefront's slab                                          (run_phase<K_G1>)
+//   Q3  every wavefront runs its rows of the group: the unit's g2 tiles (masked by a2) on the vector
+//       ALU -> LDS + global, g1 tiles (masked by a1) on the matrix pipe -> global, and straight from
+//       the accumulator the K-split partial of g_v into the row's slab            (run_rows<K_BWD>)
 // All weight gradients are batch reductions of (g1, g2, g_st) against (v, a1, a2): part B
 // (hint_wgrad.hip) computes them from the arrays written here.
 #include "hint_rows.hpp"
@@ -67,8 +67,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
     float* abuf = gst + ROWS * a.gld;         // g2 fragment tiles
     float* slab = abuf + a.abuf_tiles * 256;  // g_v partials
     float* gj = slab + a.slab_floats;
+    float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
     const size_t lvl = (size_t)a.B * a.d;     // floats of one [B, d] tape slice
+    STAMP_DECL()
     copy_meta(a, lds, tid, nthreads);
 #define HINT_CB(I) chain_block(chain, one, I)
     // input lanes of level LV of a block: x for the deepest level of the first block of a call without
@@ -104,9 +106,20 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             const float* tape = (const float*)blk.tape;
             const bool top = perm != nullptr || cb > 0;
             float* wsGST = (float*)blk.wsGST;
+            if (a.thin_lds > 0) {
+                const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
+                for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
+                __syncthreads();
+            }
             PhaseCtx pc;
-            pc.packed = (const float*)blk.packed;
-            pc.abuf = abuf; pc.xs = xs; pc.cs = cs; pc.gst = gst; pc.slab = slab;
+            pc.packed = blk.packed;
+            pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
+            pc.thin_g = blk.packed + a.thin_off;
+            pc.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
+            pc.abuf = (LDS_AS float*)abuf; pc.slab = (LDS_AS float*)slab;
+            pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
+            pc.out_thin = blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1;
+            pc.mask_thin = blk.actA1 + a.act_stride; pc.mask_main = blk.actA1;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
             pc.store = true;
 
@@ -121,6 +134,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 const bool has_prev = gi < a.n_groups;
                 const GroupU gp = load_group(T.groups + (has_prev ? (tail_only ? 0 : slot + 1) : 0));
 
+                const int sid = ((n_chain - 1 - cb) * (a.n_groups + 1) + (a.n_groups - gi)) * 16;
+                (void)sid;
+                pc.sid = sid;
+                STAMP(sid + 0)
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
                 for (int idx = tid; idx < ROWS * a.d; idx += nthreads) {
                     const int row = fdiv(idx, inv_d), col = idx - row * a.d;
@@ -172,7 +189,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         gcs[row * a.cld + cc] = acc;
                     }
                 }
+                STAMP(sid + 1)
                 lds_barrier();
+                STAMP(sid + 2)
                 if (tail_only) break;
 
                 // ---- lane tile and s of the level the NEXT boundary needs: global -> registers now,
@@ -192,18 +211,14 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     }
                 }
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
-                // ---- Q2: g2 = (W3^T g_st) .* relu'(a2) ----
-                pc.mask = (const float*)blk.actA1 + a.act_stride;
-                pc.out1 = (float*)blk.wsG1 + a.act_stride;
-                run_phase<K_G2>(pc, T, g, lds_i32(rng + wave), lds_i32(rng + wave + 1), nullptr, lane);
-                lds_barrier();
-                // ---- Q3: g1 = (W2^T g2) .* relu'(a1);  g_v partial = W1^T g1 ----
-                pc.mask = (const float*)blk.actA1;
-                pc.out1 = (float*)blk.wsG1;
-                run_phase<K_G1>(pc, T, g, lds_i32(rng + a.nw + 1 + wave), lds_i32(rng + a.nw + 2 + wave),
-                                slab + lds_i32(rng + 3 * a.nw + 2 + wave), lane);
+                STAMP(sid + 3)
+                STAMP(sid + 4)
+                // ---- Q3: g2 = (W3^T g_st) .* relu'(a2) (VALU);  g1 = (W2^T g2) .* relu'(a1);  g_v partial = W1^T g1 ----
+                run_rows<K_BWD>(pc, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
+                STAMP(sid + 5)
                 if (lp_pending) level_commit(lp, xs, sb, a.xld, a.d, tid, nthreads);
                 lds_barrier();
+                STAMP(sid + 6)
             }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
                 // 16*d <= LV_REGS*threads (plan check): the products are held in registers across the
@@ -232,6 +247,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
         if (a.dc > 0 && g_c != nullptr) store_tile(g_c, gcs, a.cld, a.dc, row0, a.B, tid, nthreads);
         __syncthreads();
     }
+    STAMP_FLUSH(a.stamps)
 #undef HINT_CB
 #undef LEVEL_SRC
 }

@@ -3,16 +3,17 @@
 // is include/hint_amd.h).
 //
 // Design in one paragraph (DESIGN.md has the long form).  A workgroup owns a tile of 16 batch rows
-// and carries it through every tree level of every block of a flow.  All subnet GEMMs are computed
-// TRANSPOSED, out^T[features x 16 rows] = W[features x K] * act^T[K x 16 rows], with
-// v_mfma_f32_16x16x4_f32: the weights are the A operand (pre-packed fragments streamed from L2), the
-// activations the B operand.  In that orientation the accumulator of one layer (lane l holds
-// features 4*(l>>4)+i of row l&15) IS the B operand of the next layer, so a "unit" (one subnet of
-// one node) runs layer 2 -> layer 3 (forward) or g1 -> g_v (backward) inside one wavefront with no
-// barrier; activations travel between wavefronts as 1 KiB "fragment tiles" in LDS (element
-// [lane*4+i]), written and read with one ds_*_b128 per lane.  The wavefronts of a workgroup split a
-// group's (unit, 16-feature tile) list into contiguous, cost-balanced ranges; a wavefront whose
-// range covers part of a unit contributes a K-split partial of the thin last layer to a slab.
+// and carries it through every tree level of every block of a flow.  The wide subnet GEMMs (second
+// layer forward, g1 backward) are computed TRANSPOSED, out^T[features x 16 rows] = W[features x K] *
+// act^T[K x 16 rows], with v_mfma_f32_16x16x4_f32: the weights are the A operand (pre-packed
+// fragments streamed from L2), the activations the B operand.  In that orientation the accumulator of
+// one layer (lane l holds features 4*(l>>4)+i of row l&15) IS the B operand of the next layer, so
+// the thin last layer (forward) / g_v (backward) is multiplied straight out of the accumulator, and
+// activations travel between wavefronts as 1 KiB "fragment tiles" in LDS (element [lane*4+i]),
+// written and read with one ds_*_b128 per lane.  The thin first layer (K = a few lanes) and g2
+// (K = r) are plain FMAs on the vector ALU in the same lane layout.  The unit of work is a ROW: up to
+// three adjacent 16-feature tiles of one unit (one subnet of one node) that share every B fragment;
+// the plan deals a group's rows to the wavefronts (balanced per SIMD) as per-wavefront record lists.
 #pragma once
 #include <stdint.h>
 
@@ -20,20 +21,22 @@ namespace hint {
 
 constexpr int ROWS = 16;        // batch rows per row tile = one MFMA N-tile of the transposed products
 constexpr int TILE = 16;        // MFMA 16x16x4 f32 tile edge
-constexpr int MAX_NW = 16;      // wavefronts per workgroup (plan-time choice: 4, 8 or 16)
+constexpr int MAX_NW = 8;       // wavefronts per workgroup (plan-time choice: 4 or 8)
 constexpr int MAX_RT = 4;       // 16-wide tiles of a unit's output (r <= 64) and of its input (cin <= 64 + dc)
 constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (cin <= 192)
 
 // ---------------------------------------------------------------------------------------
-// Packed weights.  Every GEMM reads its weight operand from a buffer in MFMA fragment order, zero
-// padded in both dimensions: the 16x16 tile (n-tile nt, k-block kb) of a logical matrix
-// Wlog[N][K] is 256 consecutive floats, tiles ordered kb-fastest.  Element [lane*4 + i] is
-//   kmap 0 ("blocked"):      Wlog[nt*16 + (lane&15)][kb*16 + 4*(lane>>4) + i]
-//   kmap 1 ("interleaved"):  Wlog[nt*16 + (lane&15)][kb*16 + 4*i + (lane>>4)]
-// MFMA i of a k-block takes component i of the lane's float4 as its A operand.  Blocked is the
-// order in which an accumulator tile of the previous layer supplies the B operand; interleaved is
-// used where the B operand is read element-wise from a row-major LDS tile (first layer from the
-// lane tile, g2 from the coupling gradients): a K of 1..4 then costs ONE MFMA, not four.
+// Packed weights.  The GEMMs read their weight operand from a buffer in MFMA fragment order, zero
+// padded in both dimensions: the 16x16 tile (n-tile nt, k-block kb) of a logical matrix Wlog[N][K] is
+// 256 consecutive floats, tiles ordered kb-fastest; element [lane*4 + i] is
+//   layout 0 ("fragment"):  Wlog[nt*16 + (lane&15)][kb*16 + 4*(lane>>4) + i]
+// and MFMA i of a k-block takes component i of the lane's float4 as its A operand (the order in which
+// an accumulator tile of the previous layer supplies the B operand).  The thin layers' weights are
+// stored for the vector ALU instead:
+//   layout 2 ("vector"):    dst[(nt*KV + k)*16 + f] = Wlog[nt*16 + f][k]   (KV = K, or K + 1 with the layer's bias as vector K)
+// so that the lane that owns features 4*(l>>4)..+3 reads the four weights of input k with one float4.  The
+// vector-layout segments of a block form two contiguous "thin blobs" (forward, backward) at the start of
+// the packed buffer, small enough to be staged in LDS once per block.
 // ---------------------------------------------------------------------------------------
 struct PackSeg {
     int64_t dst;        // float offset of the segment in the packed buffer
@@ -42,9 +45,10 @@ struct PackSeg {
     int32_t NB;         // k-blocks per n-tile
     int32_t ld;         // row stride of the source tensor
     int32_t trans;      // 0: Wlog[n][k] = P[src + n*ld + k];  1: Wlog[n][k] = P[src + k*ld + n]
-    int32_t kmap;       // 0 blocked, 1 interleaved
+    int32_t kmap;       // layout: 0 fragment, 2 vector
     int32_t tile_begin; // index of this segment's first n-tile in the global n-tile list
     int32_t pad;
+    int64_t src2;       // vector layout: float offset of a bias tensor stored as vector K of every tile, or -1
 };
 
 // Per-block pointers of a launch (one block: passed by value; a chain: a device table).
@@ -74,19 +78,19 @@ struct PackItem {
 
 // One unit = one subnet (s: even index, t: odd index) of one node.  24 x int32 = 6 x 16 bytes.
 struct Unit {
-    int32_t f1, f2, f3, b3;         // first packed tile (offset / 256) of W1 [h x cin], W2 [h x h], W3 [r x h], W3^T [h x r]
-    int32_t b2, b1, bias1, bias2;   // ... W2^T [h x h], W1^T [cin x h]; float offsets of b1, b2 (zero padded to 16) in packed
+    int32_t w1v, f2, f3, w3v;       // float offset of W1 (vector layout); first packed tile (offset / 256) of W2 [h x h], W3 [r x h]; float offset of W3^T (vector layout)
+    int32_t b2, b1, bias1, bias2;   // first packed tile of W2^T [h x h], W1^T [cin x h]; float offsets of b1, b2 (zero padded to 16) in packed
     int32_t bias3, wcol, tile0, gcol;   // b3; column in the [Bp][WT] arrays; first fragment tile inside the group; column in [Bp][ST]
     int32_t NT, KB1, RT, cin;       // tiles of h, k-blocks of cin, tiles of r; subnet input width
     int32_t ku, r, xoff, h;         // lanes among the inputs (the rest is the condition), outputs, first input lane, hidden width
-    int32_t sl_off, sl_n, gv_off, lcol; // first L3 slab (floats inside the slab buffer), slices; first g_v slab; gcol - group's gcol0
+    int32_t sl_off, sl_n, gv_off, lcol; // first L3 slab (floats inside the slab buffer), rows (= slabs); first g_v slab; gcol - group's gcol0
 };
 static_assert(sizeof(Unit) == 96, "Unit must be 6 x 16 bytes");
 
 // A group = a set of same-depth nodes processed together.  16 x int32.
 struct Group {
-    int32_t unit_begin, unit_end, ntiles, tmap_begin;   // tmap: uint16 per fragment tile = unit index inside the group
-    int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[ (nw+1) | (nw+1) | nw | nw ] = tile ranges of the two GEMM phases, first slab per wavefront (L3, g_v)
+    int32_t unit_begin, unit_end, ntiles, row_begin;    // row_begin: the group's first row record (both directions)
+    int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[nw+1] = the wavefronts' ranges in the group's record list
     int32_t level_last, gcol0, gcols, lop_begin;        // first / number of [ST] columns; LaneOp[d] of the boundary in front of the group (backward)
     int32_t level_first, cpad0, cpad1, cpad2;
 };
@@ -124,8 +128,33 @@ struct WJob {
 };
 static_assert(sizeof(WJob) == 64, "WJob must be 64 bytes");
 
+// Row record: everything a wavefront needs to know about one row - up to three adjacent fragment tiles
+// [tb, tb+ntt) of one unit - in one direction; 16 x int32, read with one scalar load.  The steps of a
+// row, every one `ntt` elements wide: n1 main steps (weight tiles base1 + j*n1 + kb), one aux step (bias
+// vectors at packed + aux + 16 j, or the forward activation tiles at column ocol + 16 j), n2 tail steps
+// (weight tiles base2 + q*n1 + j), n3 steps of the last layer's bias (packed + bias3 + 16 q).  A record
+// with the `thin` flag first runs the unit's thin layer (first layer / g2) for all NT tiles of the unit.
+struct RowRec {
+    int32_t base1, base2;
+    int32_t counts;     // n1 | n2 << 8 | n3 << 16 | ntt << 24
+    int32_t aux;        // float offset of the row's first bias vector in the packed buffer (forward)
+    int32_t ocol;       // column of the row's first tile in the [Bp][WT] arrays
+    int32_t tile;       // first fragment tile of the unit inside the group | ceil(W/4) << 16 (W = r forward, cin backward)
+    int32_t slab;       // float offset of the row's slab inside the slab buffer
+    int32_t bias3;      // float offset of the unit's b3 (zero padded to 16) in the packed buffer
+    int32_t thin_w;     // float offset of the unit's thin-layer vectors inside the direction's thin blob
+    int32_t thin_b;     // (unused)
+    int32_t thin_k;     // forward: cin | ku << 8 | xoff << 16;  backward: r | lcol << 16
+    int32_t flags;      // NT | thin << 8 (run the thin layer before this row) | first << 9 (the row holds the unit's tile 0: it stores the thin layer's tiles and adds b3)
+    int32_t wcol;       // column of the unit's tile 0 in the [Bp][WT] arrays
+    int32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(RowRec) == 64, "RowRec must be 64 bytes");
+
 struct KArgs {
     const void* meta;              // [groups | units | tmap | ents | ranges | laneops] contiguous, copied to LDS at kernel start
+    const void* recs;              // RowRec[2][total_rows]: forward records, then backward records, rows in (group, wavefront, unit) order
+    int32_t total_rows;
     int32_t meta_bytes;            // multiple of 16
     int32_t units_off, tmap_off, ents_off, rng_off, lops_off;   // byte offsets inside meta
     int32_t n_groups, n_levels, n_units, nw;
@@ -134,10 +163,13 @@ struct KArgs {
     int32_t slab_floats;           // L3 slab buffer (forward) / g_v slab buffer (backward), floats
     int32_t gld;                   // LDS row stride of the coupling-gradient buffer (backward)
     int32_t WT, ST;                // row widths of the activation / coupling-gradient arrays
+    int32_t thin_off, thin_floats; // the direction's thin blob: float offset in the packed buffer, size (multiple of 4)
+    int32_t thin_lds;              // float offset in LDS where the kernel stages it per block; 0: read it from global memory
     int32_t perm_lds;              // float offset in LDS of the chain's d x d permutation matrices; 0: read them from global memory
     int64_t act_stride;            // floats between the a1 and a2 (g1 and g2) arrays
     float alpha;
     int32_t B;
+    unsigned long long* stamps;    // diagnostic builds (-DHINT_STAMPS): where workgroup 0 leaves its phase stamps; else unused
 };
 
 }  // namespace hint

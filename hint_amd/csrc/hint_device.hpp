@@ -65,14 +65,14 @@ __device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ cha
 
 // ---- wave-uniform reads of the plan tables staged in LDS ----
 struct UnitU {
-    int f1, f2, f3, b3, b2, b1, bias1, bias2, bias3, wcol, tile0, gcol, NT, KB1, RT, cin, ku, r, xoff, h, sl_off, sl_n,
+    int w1v, f2, f3, w3v, b2, b1, bias1, bias2, bias3, wcol, tile0, gcol, NT, KB1, RT, cin, ku, r, xoff, h, sl_off, sl_n,
         gv_off, lcol;
 };
 __device__ __forceinline__ UnitU load_unit(const LDS_AS Unit* u) {
     const LDS_AS i32x4* p = (const LDS_AS i32x4*)u;
     const i32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
     UnitU r;
-    r.f1 = rfl(q0.x); r.f2 = rfl(q0.y); r.f3 = rfl(q0.z); r.b3 = rfl(q0.w);
+    r.w1v = rfl(q0.x); r.f2 = rfl(q0.y); r.f3 = rfl(q0.z); r.w3v = rfl(q0.w);
     r.b2 = rfl(q1.x); r.b1 = rfl(q1.y); r.bias1 = rfl(q1.z); r.bias2 = rfl(q1.w);
     r.bias3 = rfl(q2.x); r.wcol = rfl(q2.y); r.tile0 = rfl(q2.z); r.gcol = rfl(q2.w);
     r.NT = rfl(q3.x); r.KB1 = rfl(q3.y); r.RT = rfl(q3.z); r.cin = rfl(q3.w);
@@ -81,14 +81,14 @@ __device__ __forceinline__ UnitU load_unit(const LDS_AS Unit* u) {
     return r;
 }
 struct GroupU {
-    int unit_begin, unit_end, ntiles, tmap_begin, ent_begin, ent_cnt, rng_begin, level, level_last, gcol0, gcols,
+    int unit_begin, unit_end, ntiles, row_begin, ent_begin, ent_cnt, rng_begin, level, level_last, gcol0, gcols,
         lop_begin, level_first;
 };
 __device__ __forceinline__ GroupU load_group(const LDS_AS Group* g) {
     const LDS_AS i32x4* p = (const LDS_AS i32x4*)g;
     const i32x4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
     GroupU r;
-    r.unit_begin = rfl(q0.x); r.unit_end = rfl(q0.y); r.ntiles = rfl(q0.z); r.tmap_begin = rfl(q0.w);
+    r.unit_begin = rfl(q0.x); r.unit_end = rfl(q0.y); r.ntiles = rfl(q0.z); r.row_begin = rfl(q0.w);
     r.ent_begin = rfl(q1.x); r.ent_cnt = rfl(q1.y); r.rng_begin = rfl(q1.z); r.level = rfl(q1.w);
     r.level_last = rfl(q2.x); r.gcol0 = rfl(q2.y); r.gcols = rfl(q2.z); r.lop_begin = rfl(q2.w);
     r.level_first = rfl(q3.x);
@@ -163,6 +163,23 @@ __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned
     const float s1 = __builtin_amdgcn_sinf(u3), cs1 = __builtin_amdgcn_cosf(u3);
     out[0] = r0 * cs0; out[1] = r0 * s0; out[2] = r1 * cs1; out[3] = r1 * s1;
 }
+
+// Diagnostic build only (-DHINT_STAMPS): shader-clock stamps of workgroup 0 at phase boundaries, one row
+// of STAMP_IDS per wavefront, collected in LDS (a global store per stamp would sit in the vmcnt queue in
+// front of the weight loads and distort what it measures) and flushed when the kernel ends.
+#ifdef HINT_STAMPS
+constexpr int STAMP_IDS = 512;
+static __shared__ unsigned long long hint_stamp_lds[MAX_NW * STAMP_IDS];
+#define STAMP_DECL() { for (int i_ = threadIdx.x; i_ < MAX_NW * STAMP_IDS; i_ += blockDim.x) hint_stamp_lds[i_] = 0ull; __syncthreads(); }
+#define STAMP(ID) { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (ID) < STAMP_IDS) \
+    hint_stamp_lds[(threadIdx.x >> 6) * STAMP_IDS + (ID)] = __builtin_amdgcn_s_memtime(); }
+#define STAMP_FLUSH(BUF) { __syncthreads(); if ((BUF) != nullptr && blockIdx.x == 0) \
+    for (int i_ = threadIdx.x; i_ < MAX_NW * STAMP_IDS; i_ += blockDim.x) (BUF)[i_] = hint_stamp_lds[i_]; }
+#else
+#define STAMP_DECL() {}
+#define STAMP(ID) {}
+#define STAMP_FLUSH(BUF) {}
+#endif
 
 // LDS carve-up shared by the block kernels: [meta blob][float buffers ...]
 struct Tables {

@@ -8,10 +8,10 @@
 //
 // One workgroup owns a tile of 16 batch rows and carries it through ALL tree levels of ALL blocks
 // of a flow inside one launch; the lane tile and the condition stay in LDS, HBM sees x once in and
-// z, J once out (plus the training tape).  Per group of same-depth nodes three phases:
-//   P1  first layer of every unit -> a1 fragment tiles in LDS            (run_phase<K_L1>)
-//   P2  second layer, and straight from its accumulator the third layer's K-split partial
-//       (+ bias) into the wavefront's slab                                (run_phase<K_L2>)
+// z, J once out (plus the training tape).  Per group of same-depth nodes two phases:
+//   P2  every wavefront runs its rows of the group: the unit's first layer on the vector ALU (a1
+//       fragment tiles in LDS), the second layer on the matrix pipe and, straight from its
+//       accumulator, the third layer's K-split partial (+ bias) into the row's slab   (run_rows<K_FWD>)
 //   P3  coupling: s, t = sum of the slabs; l' = exp(a) l + t; log-det
 #include "hint_rows.hpp"
 
@@ -35,7 +35,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
     float* slab = abuf + a.abuf_tiles * 256;
     float* jac = slab + a.slab_floats;
     float* red = jac + ROWS;                  // MAX_NW floats: loss partials
+    float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
+    STAMP_DECL()
     copy_meta(a, lds, tid, nthreads);
     // the chain's fixed d x d permutation matrices, once per workgroup (when the launch found LDS for them)
     float* ptab = lds + a.perm_lds;
@@ -100,26 +102,39 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 // inner block of a chain without a permutation: its input exists nowhere else
                 store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
             }
+            if (a.thin_lds > 0) {
+                // this block's thin-layer weights (vector layout, a few KiB) into LDS: every wavefront re-reads them
+                // for its units, and all workgroups asking L2 for the same few lines at once is what made them slow
+                const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
+                for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
+                __syncthreads();
+            }
             PhaseCtx pc;
-            pc.packed = (const float*)blk.packed;
-            pc.abuf = abuf; pc.cs = cs; pc.gst = nullptr; pc.slab = slab;
-            pc.mask = nullptr;
+            pc.packed = blk.packed;
+            pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
+            pc.thin_g = blk.packed + a.thin_off;
+            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.slab = (LDS_AS float*)slab;
+            pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
+            pc.out_thin = blk.actA1; pc.out_main = train ? blk.actA1 + a.act_stride : nullptr;
+            pc.mask_thin = nullptr; pc.mask_main = nullptr;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
             pc.store = train;
 
             for (int gi = 0; gi < a.n_groups; ++gi) {
                 const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : gi));
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
-                pc.xs = XS;
-                // ---- P1: first layer ----
-                pc.out1 = actA1;
-                run_phase<K_L1>(pc, T, g, lds_i32(rng + wave), lds_i32(rng + wave + 1), nullptr, lane);
+                pc.xs = (const LDS_AS float*)(XS);
+                const int sid = (cb * a.n_groups + gi) * 16;
+                (void)sid;
+                pc.sid = sid;
+                STAMP(sid + 0)
+                STAMP(sid + 1)
+                STAMP(sid + 2)
+                // ---- P2: first layer (VALU), second layer, third layer partials ----
+                run_rows<K_FWD>(pc, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
+                STAMP(sid + 3)
                 lds_barrier();
-                // ---- P2: second layer + third layer partials ----
-                pc.out1 = train ? actA1 + a.act_stride : nullptr;
-                run_phase<K_L2>(pc, T, g, lds_i32(rng + a.nw + 1 + wave), lds_i32(rng + a.nw + 2 + wave),
-                                slab + lds_i32(rng + 2 * a.nw + 2 + wave), lane);
-                lds_barrier();
+                STAMP(sid + 4)
                 // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) ----
                 {
                     const int sub = tid & 15, row = tid >> 4;
@@ -147,7 +162,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                     part = row16_sum(part);
                     if (sub == 0 && row < ROWS) jac[row] += part;
                 }
+                STAMP(sid + 5)
                 lds_barrier();
+                STAMP(sid + 6)
                 // training: keep the lane tile as it stands after each level except the root's, so that
                 // the backward pass sees bit-identical subnet inputs (tape[level][B][d])
                 if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
 #undef XS
 #undef XO
     }
+    STAMP_FLUSH(a.stamps)
 #undef HINT_CB
 }
 

@@ -9,7 +9,7 @@ __device__ __forceinline__ void pack_body(int bid, const PackSeg* __restrict__ s
                                           const int32_t* __restrict__ bmap, int n_bias, long bias_off,
                                           const float* __restrict__ P, float* __restrict__ packed) {
     if (bid >= n_tiles) {
-        // trailing workgroups: biases b1, b2 per unit, zero padded to 16
+        // trailing workgroups: biases b1, b2, b3 per unit, zero padded to 16
         const int i = (bid - n_tiles) * 256 + (int)threadIdx.x;
         if (i < n_bias) { const int off = bmap[i]; packed[bias_off + i] = off >= 0 ? P[off] : 0.f; }
         return;
@@ -17,6 +17,20 @@ __device__ __forceinline__ void pack_body(int bid, const PackSeg* __restrict__ s
     const int2 pt = ptiles[bid];
     const PackSeg sg = segs[pt.x];
     const int nt = pt.y;
+    if (sg.kmap == 2) {
+        // vector layout (thin layers): dst[(nt*KV + k)*16 + f] = Wlog[nt*16 + f][k]; vector K: the bias
+        const int KV = sg.K + (sg.src2 >= 0 ? 1 : 0);
+        for (int idx = (int)threadIdx.x; idx < 16 * KV; idx += 256) {
+            const int k = idx >> 4, f = idx & 15, n = nt * 16 + f;
+            float val = 0.f;
+            if (n < sg.N) {
+                if (k < sg.K) val = sg.trans ? P[sg.src + (int64_t)k * sg.ld + n] : P[sg.src + (int64_t)n * sg.ld + k];
+                else val = P[sg.src2 + n];
+            }
+            packed[sg.dst + (int64_t)nt * KV * 16 + idx] = val;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = nt * 16 + (lane & 15), kq = lane >> 4;
     for (int kb = wave; kb < sg.NB; kb += 4) {
@@ -24,14 +38,8 @@ __device__ __forceinline__ void pack_body(int bid, const PackSeg* __restrict__ s
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float val = 0.f;
-            if (sg.trans == 2) {
-                // "bias tile" of a last layer: element [lane*4+i] = b[16 nt + 4 (lane>>4) + i] for every row
-                const int f = nt * 16 + 4 * kq + i;
-                if (f < sg.N) val = P[sg.src + f];
-            } else {
-                const int k = kb * 16 + (sg.kmap ? 4 * i + kq : 4 * kq + i);
-                if (n < sg.N && k < sg.K) val = sg.trans ? P[sg.src + (int64_t)k * sg.ld + n] : P[sg.src + (int64_t)n * sg.ld + k];
-            }
+            const int k = kb * 16 + 4 * kq + i;
+            if (n < sg.N && k < sg.K) val = sg.trans ? P[sg.src + (int64_t)k * sg.ld + n] : P[sg.src + (int64_t)n * sg.ld + k];
             v[i] = val;
         }
         ((f32x4*)(packed + sg.dst + ((int64_t)nt * sg.NB + kb) * 256))[lane] = v;

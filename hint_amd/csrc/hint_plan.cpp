@@ -66,10 +66,17 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int pad4(int v) { return (v + 3) & ~3; }
 
 static constexpr int LDS_LIMIT = 160 * 1024;
+#ifdef HINT_STAMPS
+static constexpr int LDS_ATTR = LDS_LIMIT - 33 * 1024;   // the diagnostic build's static stamp array shares the 160 KiB
+#else
+static constexpr int LDS_ATTR = LDS_LIMIT;
+#endif
+static constexpr int THIN_LDS_MAX = 24 * 1024;   // a block's thin-layer vectors are staged in LDS up to this size
 static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
 static constexpr int WS_SLACK = 64;              // floats of slack behind every [Bp][W] array
 static constexpr int LV_REGS = 4;                // hint_bwd.hip: a [16, d] tile in <= 4 registers per thread
 static constexpr int MAX_TAIL = 8;               // hint_rows.hpp: tail accumulators
+static unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only (hint_debug_set_stamp_buffer)
 static thread_local bool g_host_only = false;    // hint_plan_check: build and verify the plan, touch no device
 
 struct hint_plan {
@@ -79,32 +86,19 @@ struct hint_plan {
     int64_t param_floats = 0, packed_floats = 0;
     int WT = 0, ST = 0;
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
+    int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
+    RowRec* d_recs = nullptr;
+    int total_rows = 0;
     int32_t* d_bmap = nullptr;
     uint8_t* d_real = nullptr;
     WJob* d_wjobs = nullptr;
     PackSeg* d_segs = nullptr;
     int2* d_ptiles = nullptr;
 };
-
-// cut `cost` (one entry per fragment tile) into nw contiguous ranges of about equal total
-static void balance(const std::vector<int>& cost, int nw, std::vector<int>& bounds) {
-    const int n = (int)cost.size();
-    std::vector<long> pre(n + 1, 0);
-    for (int i = 0; i < n; ++i) pre[i + 1] = pre[i] + cost[i];
-    bounds.assign(nw + 1, n);
-    bounds[0] = 0;
-    int t = 0;
-    for (int w = 1; w < nw; ++w) {
-        const double target = (double)pre[n] * w / nw;
-        while (t < n && std::fabs((double)pre[t + 1] - target) <= std::fabs((double)pre[t] - target)) ++t;
-        bounds[w] = t;
-    }
-    bounds[nw] = n;
-}
 
 // tile_cap: fragment tiles per group (1 KiB of LDS each), unless one node needs more
 static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int nw,
@@ -132,7 +126,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<Group> groups;
     std::vector<Unit> units;
     std::vector<int> unit_node;       // node index (into `nodes`) of every unit
-    std::vector<uint16_t> tmap;
+    std::vector<RowRec> recs_f, recs_b;   // row records in (group, wavefront, unit) order
     std::vector<Ent> ents;
     std::vector<int32_t> rng;
     std::vector<PackSeg> segs;
@@ -142,9 +136,21 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     int64_t pmax = 0, packed = 0;
     int wcol = 0, gcol = 0;
 
-    auto add_seg = [&](int N, int K, int NB, int ld, int trans, int kmap, int64_t src) -> int {
+    // the thin layers' vectors form two contiguous blobs at the start of the packed buffer (forward: W1 and b1 of
+    // every unit; backward: W3^T), each padded to whole 256-float tiles; the fragment tiles follow
+    int64_t blob_f = 0, blob_b = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        const int NT = cdiv(nodes[i].h, 16);
+        blob_f += 2 * (int64_t)NT * (nodes[i].k + dc + 1) * 16;
+        blob_b += 2 * (int64_t)NT * nodes[i].r * 16;
+    }
+    const int64_t blob_f_pad = (blob_f + 255) / 256 * 256, blob_b_pad = (blob_b + 255) / 256 * 256;
+    int64_t cur_f = 0, cur_b = blob_f_pad;
+    packed = blob_f_pad + blob_b_pad;
+    // fragment-layout segment: returns its first packed tile (offset / 256)
+    auto add_seg = [&](int N, int K, int NB, int ld, int trans, int64_t src) -> int {
         PackSeg sg{};
-        sg.dst = packed; sg.src = src; sg.N = N; sg.K = K; sg.NB = NB; sg.ld = ld; sg.trans = trans; sg.kmap = kmap;
+        sg.dst = packed; sg.src = src; sg.src2 = -1; sg.N = N; sg.K = K; sg.NB = NB; sg.ld = ld; sg.trans = trans; sg.kmap = 0;
         sg.tile_begin = (int)ptiles.size();
         const int NTn = std::max(1, cdiv(N, 16));
         for (int nt = 0; nt < NTn; ++nt) ptiles.push_back(int2{(int)segs.size(), nt});
@@ -153,13 +159,24 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         packed += (int64_t)NTn * NB * 256;
         return first;
     };
+    // vector-layout segment (thin layers) inside a blob: returns its float offset inside that blob
+    auto add_vec = [&](int64_t& cur, int64_t blob0, int N, int K, int ld, int trans, int64_t src, int64_t src2) -> int {
+        PackSeg sg{};
+        sg.dst = cur; sg.src = src; sg.src2 = src2; sg.N = N; sg.K = K; sg.NB = 0; sg.ld = ld; sg.trans = trans; sg.kmap = 2;
+        sg.tile_begin = (int)ptiles.size();
+        const int NTn = std::max(1, cdiv(N, 16));
+        for (int nt = 0; nt < NTn; ++nt) ptiles.push_back(int2{(int)segs.size(), nt});
+        segs.push_back(sg);
+        const int first = (int)(cur - blob0);
+        cur += (int64_t)NTn * (K + (src2 >= 0 ? 1 : 0)) * 16;
+        return first;
+    };
 
     // ---- groups, units, packed segments ----
     size_t pos = 0;
     while (pos < order.size()) {
         Group g{};
         g.unit_begin = (int)units.size();
-        g.tmap_begin = (int)tmap.size();
         g.gcol0 = gcol;
         const int depth = nodes[order[pos]].depth;
         int tiles = 0;
@@ -179,23 +196,22 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             for (int net = 0; net < 2; ++net) {
                 const int64_t* po = n.p_off + net * 6;
                 Unit u{};
-                u.f1 = add_seg(n.h, cin, KB1, cin, 0, 1, po[HINT_W1]);          // v  -> a1   (interleaved k)
-                u.f2 = add_seg(n.h, n.h, NT, n.h, 0, 0, po[HINT_W2]);           // a1 -> a2
-                u.f3 = add_seg(n.r, n.h, NT, n.h, 0, 0, po[HINT_W3]);           // a2 -> s | t
-                (void)add_seg(n.r, 0, 1, 0, 2, 0, po[HINT_B3]);                 // b3 as "bias tiles" right behind W3
-                u.b3 = add_seg(n.h, n.r, RT, n.h, 1, 1, po[HINT_W3]);           // g_st -> g2 (interleaved k)
-                u.b2 = add_seg(n.h, n.h, NT, n.h, 1, 0, po[HINT_W2]);           // g2 -> g1
-                u.b1 = add_seg(cin, n.h, NT, cin, 1, 0, po[HINT_W1]);           // g1 -> g_v
+                u.w1v = add_vec(cur_f, 0, n.h, cin, cin, 0, po[HINT_W1], po[HINT_B1]);       // v  -> a1 (vector ALU; b1 as vector cin)
+                u.f2 = add_seg(n.h, n.h, NT, n.h, 0, po[HINT_W2]);           // a1 -> a2
+                u.f3 = add_seg(n.r, n.h, NT, n.h, 0, po[HINT_W3]);           // a2 -> s | t
+                u.w3v = add_vec(cur_b, blob_f_pad, n.h, n.r, n.h, 1, po[HINT_W3], -1);       // g_st -> g2 (vector ALU)
+                u.b2 = add_seg(n.h, n.h, NT, n.h, 1, po[HINT_W2]);           // g2 -> g1
+                u.b1 = add_seg(cin, n.h, NT, cin, 1, po[HINT_W1]);           // g1 -> g_v
                 u.bias1 = (int)bmap.size();                                     // (made absolute below)
                 for (int j = 0; j < 16 * NT; ++j) bmap.push_back(j < n.h ? (int32_t)(po[HINT_B1] + j) : -1);
                 u.bias2 = (int)bmap.size();
                 for (int j = 0; j < 16 * NT; ++j) bmap.push_back(j < n.h ? (int32_t)(po[HINT_B2] + j) : -1);
-                u.bias3 = 0;
+                u.bias3 = (int)bmap.size();
+                for (int j = 0; j < 16 * RT; ++j) bmap.push_back(j < n.r ? (int32_t)(po[HINT_B3] + j) : -1);
                 u.wcol = wcol; u.tile0 = tiles; u.gcol = gcol;
                 u.NT = NT; u.KB1 = KB1; u.RT = RT; u.cin = cin;
                 u.ku = n.k; u.r = n.r; u.xoff = n.off; u.h = n.h;
                 u.lcol = gcol - g.gcol0;
-                for (int t = 0; t < NT; ++t) tmap.push_back((uint16_t)((int)units.size() - g.unit_begin));
                 units.push_back(u);
                 unit_node.push_back(order[pos]);
                 wcol += 16 * NT; gcol += pad4(n.r); tiles += NT;
@@ -211,39 +227,100 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->abuf_tiles = std::max(P->abuf_tiles, tiles);
         P->gld = std::max(P->gld, g.gcols | 1);
 
-        // ---- the wavefronts' tile ranges of the two GEMM phases, slices and slabs ----
-        std::vector<int> c1(tiles), c2(tiles);
-        for (int t = 0; t < tiles; ++t) {
-            const Unit& u = units[g.unit_begin + tmap[g.tmap_begin + t]];
-            c1[t] = std::max(u.KB1, u.RT) + 2;                  // first layer / g2: one k-block or so per tile
-            c2[t] = u.NT + std::max(u.RT, u.KB1) + 1;           // second layer + tail steps
-        }
-        std::vector<int> b1, b2;
-        balance(c1, nw, b1);
-        balance(c2, nw, b2);
-        g.rng_begin = (int)rng.size();
-        for (int w = 0; w <= nw; ++w) rng.push_back(b1[w]);
-        for (int w = 0; w <= nw; ++w) rng.push_back(b2[w]);
-        std::vector<int> sl3(nw, 0), slv(nw, 0);
+        // ---- rows: up to three adjacent tiles of a unit; every row has its own slab for the K-split
+        //      partial of the tail product ----
+        struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
+        std::vector<Row> rows;
         int off3 = 0, offv = 0;
-        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) units[ui].sl_n = 0;
-        for (int w = 0; w < nw; ++w) {
-            sl3[w] = off3; slv[w] = offv;
-            int t = b2[w];
-            while (t < b2[w + 1]) {
-                const int ui = g.unit_begin + tmap[g.tmap_begin + t];
-                Unit& u = units[ui];
-                if (u.sl_n == 0) { u.sl_off = off3; u.gv_off = offv; }
-                ++u.sl_n;
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+            Unit& u = units[ui];
+            const int nr = cdiv(u.NT, 3);
+            u.sl_off = off3; u.gv_off = offv; u.sl_n = nr;
+            int tb = 0;
+            for (int ri = 0; ri < nr; ++ri) {
+                const int ntt = (u.NT - tb + (nr - ri) - 1) / (nr - ri);
+                // matrix-pipe time of the row (main + tail steps) plus what its bookkeeping costs in the same unit
+                const long cost = (long)u.NT * ntt * 4 + std::max(u.RT, u.KB1) * ntt * 4 + 24;
+                rows.push_back(Row{ui, tb, ntt, off3, offv, cost});
                 off3 += 64 * cdiv(u.r, 4);
                 offv += 64 * cdiv(u.cin, 4);
-                t = std::min(b2[w + 1], u.tile0 + u.NT);
+                tb += ntt;
             }
         }
-        for (int w = 0; w < nw; ++w) rng.push_back(sl3[w]);
-        for (int w = 0; w < nw; ++w) rng.push_back(slv[w]);
         P->slab_fwd = std::max(P->slab_fwd, off3);
         P->slab_bwd = std::max(P->slab_bwd, offv);
+        // ---- deal the rows to the wavefronts: longest first, to the wavefront whose SIMD (wavefronts w and
+        //      w + 4 share one: its matrix pipe and its issue slots) is least loaded; a wavefront's first row
+        //      of a unit also pays for the unit's thin layer ----
+        std::vector<std::vector<int>> wave_rows(nw);
+        {
+            std::vector<int> idx(rows.size());
+            for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return rows[x].cost > rows[y].cost; });
+            std::vector<long> wload(nw, 0), sload(4, 0);
+            for (int i : idx) {
+                const Unit& u = units[rows[i].unit];
+                const long thin = (long)u.NT * (std::max(u.cin, u.r) + 3) / 2;
+                int best = 0;
+                long best_s = -1, best_w = -1;
+                for (int w = 0; w < nw; ++w) {
+                    bool has = false;
+                    for (int r : wave_rows[w]) has = has || rows[r].unit == rows[i].unit;
+                    const long add = rows[i].cost + (has ? 0 : thin);
+                    // (the two wavefronts of a SIMD interleave: what one wavefront runs back to back counts as well)
+                    const long sl = sload[w & 3] + wload[w] + 2 * add, wl = wload[w] + add;
+                    if (best_s < 0 || sl < best_s || (sl == best_s && wl < best_w)) { best = w; best_s = sl; best_w = wl; }
+                }
+                bool has = false;
+                for (int r : wave_rows[best]) has = has || rows[r].unit == rows[i].unit;
+                const long add = rows[i].cost + (has ? 0 : thin);
+                wave_rows[best].push_back(i);
+                wload[best] += add; sload[best & 3] += add;
+            }
+            for (int w = 0; w < nw; ++w) std::sort(wave_rows[w].begin(), wave_rows[w].end());   // unit order, then tile order
+        }
+        if (std::getenv("HINT_PLAN_DUMP")) {
+            std::fprintf(stderr, "[hint plan] group %d level %d: %d units, %d tiles, %d rows\n", (int)groups.size(), g.level,
+                         g.unit_end - g.unit_begin, tiles, (int)rows.size());
+            for (int w = 0; w < nw; ++w) {
+                std::fprintf(stderr, "   wave %d:", w);
+                for (int ri : wave_rows[w]) std::fprintf(stderr, " (u%d t%d+%d)", rows[ri].unit - g.unit_begin, rows[ri].tb, rows[ri].ntt);
+                std::fprintf(stderr, "\n");
+            }
+        }
+        // ---- the wavefronts' record lists, forward and backward ----
+        g.row_begin = (int)recs_f.size();
+        g.rng_begin = (int)rng.size();
+        for (int w = 0; w < nw; ++w) {
+            rng.push_back((int)recs_f.size() - g.row_begin);
+            int last_unit = -1;
+            for (int ri : wave_rows[w]) {
+                const Row& rw = rows[ri];
+                const Unit& u = units[rw.unit];
+                if (u.NT > 255 || u.cin > 255 || u.ku > 255 || u.r > 255 || u.tile0 > 0xffff) {
+                    delete P;
+                    return fail("hint_plan_create: a node is too wide for the row records (h <= 4080, cin <= 255)");
+                }
+                const int thin = rw.unit != last_unit ? 1 : 0, first = rw.tb == 0 ? 1 : 0;
+                last_unit = rw.unit;
+                RowRec r{};
+                r.ocol = u.wcol + 16 * rw.tb; r.bias3 = u.bias3; r.wcol = u.wcol;
+                r.flags = u.NT | (thin << 8) | (first << 9);
+                // forward: second layer + third layer partials (+ b3 with the unit's first row)
+                r.base1 = u.f2 + rw.tb * u.NT; r.base2 = u.f3 + rw.tb;
+                r.counts = u.NT | (u.RT << 8) | ((first ? u.RT : 0) << 16) | (rw.ntt << 24);
+                r.aux = u.bias2 + 16 * rw.tb; r.tile = u.tile0 | (cdiv(u.r, 4) << 16); r.slab = rw.slab3;
+                r.thin_w = u.w1v; r.thin_b = 0; r.thin_k = u.cin | (u.ku << 8) | (u.xoff << 16);
+                recs_f.push_back(r);
+                // backward: g1 + g_v partials
+                r.base1 = u.b2 + rw.tb * u.NT; r.base2 = u.b1 + rw.tb;
+                r.counts = u.NT | (u.KB1 << 8) | (rw.ntt << 24);
+                r.aux = 0; r.tile = u.tile0 | (cdiv(u.cin, 4) << 16); r.slab = rw.slabv;
+                r.thin_w = u.w3v; r.thin_b = 0; r.thin_k = u.r | (u.lcol << 16);
+                recs_b.push_back(r);
+            }
+        }
+        rng.push_back((int)recs_f.size() - g.row_begin);
 
         // ---- coupling entries: one per transformed lane ----
         g.ent_begin = (int)ents.size();
@@ -275,7 +352,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         delete P;
         return fail("hint_plan_create: block too large (offsets must fit 31 / 15 bits)");
     }
-    for (Unit& u : units) { u.bias1 += (int)packed; u.bias2 += (int)packed; }   // the bias region follows the weight tiles
+    for (Unit& u : units) { u.bias1 += (int)packed; u.bias2 += (int)packed; u.bias3 += (int)packed; }   // the bias region follows the weight tiles
+    for (RowRec& r : recs_f) { r.aux += (int)packed; r.bias3 += (int)packed; }
 
     // ---- backward lane tables: per boundary (in front of group gi; slot n_groups: behind group 0) and lane ----
     std::vector<LaneOp> lops((size_t)(P->n_groups + 1) * d);
@@ -309,25 +387,36 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t groups_bytes = up16(groups.size() * sizeof(Group));
     const size_t units_bytes = up16(units.size() * sizeof(Unit));
-    const size_t tmap_bytes = up16(tmap.size() * sizeof(uint16_t));
     const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
     const size_t rng_bytes = up16(rng.size() * sizeof(int32_t));
     const size_t lops_bytes = up16(lops.size() * sizeof(LaneOp));
     P->units_off = (int)groups_bytes;
     P->tmap_off = P->units_off + (int)units_bytes;
-    P->ents_off = P->tmap_off + (int)tmap_bytes;
+    P->ents_off = P->tmap_off;
     P->rng_off = P->ents_off + (int)ents_bytes;
     P->lops_off = P->rng_off + (int)rng_bytes;
     P->meta_bytes = P->lops_off + (int)lops_bytes;
     std::vector<char> meta(P->meta_bytes, 0);
     std::memcpy(meta.data(), groups.data(), groups.size() * sizeof(Group));
     std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
-    if (!tmap.empty()) std::memcpy(meta.data() + P->tmap_off, tmap.data(), tmap.size() * sizeof(uint16_t));
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
     std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
     P->lds_fwd = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW);
     P->lds_bwd = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + P->abuf_tiles * 256 + P->slab_bwd + ROWS);
+    P->lds_fwd = (P->lds_fwd + 15) / 16 * 16;
+    P->lds_bwd = (P->lds_bwd + 15) / 16 * 16;
+    // the thin blobs ride in LDS (staged once per block) when they are small
+    P->thin_f_off = 0; P->thin_f_floats = (int)((blob_f + 3) / 4 * 4);
+    P->thin_b_off = (int)blob_f_pad; P->thin_b_floats = (int)((blob_b + 3) / 4 * 4);
+    if (P->thin_f_floats * 4 <= THIN_LDS_MAX && P->lds_fwd + P->thin_f_floats * 4 <= LDS_LIMIT) {
+        P->thin_lds_f = P->lds_fwd / 4;
+        P->lds_fwd += P->thin_f_floats * 4;
+    }
+    if (P->thin_b_floats * 4 <= THIN_LDS_MAX && P->lds_bwd + P->thin_b_floats * 4 <= LDS_LIMIT) {
+        P->thin_lds_b = P->lds_bwd / 4;
+        P->lds_bwd += P->thin_b_floats * 4;
+    }
     if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT) {
         const int need = std::max(P->lds_bwd, P->lds_fwd);
         const bool could_shrink = P->abuf_tiles > 0 && P->n_groups < (int)order.size();
@@ -336,23 +425,34 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return fail("hint_plan_create: block needs %d bytes of LDS (> %d); d/dc/h too large", need, LDS_LIMIT);
     }
 
-    // ---- self-check: every fragment tile of every group lies in exactly one wavefront's range of either
-    //      phase, slices and slabs are consistent with the ranges, packed tiles are contiguous per unit ----
+    // ---- self-check: the record lists of every group cover every fragment tile of every unit exactly once,
+    //      in both directions, every wavefront runs a unit's thin layer before its first row of the unit,
+    //      and exactly one row per unit stores the thin layer's tiles ----
     for (const Group& g : groups) {
         const int32_t* r = rng.data() + g.rng_begin;
-        for (int ph = 0; ph < 2; ++ph) {
-            const int32_t* b = r + ph * (nw + 1);
-            if (b[0] != 0 || b[nw] != g.ntiles) { delete P; return fail("hint_plan_create: internal error (tile ranges)"); }
-            for (int w = 0; w < nw; ++w) if (b[w] > b[w + 1]) { delete P; return fail("hint_plan_create: internal error (tile ranges)"); }
+        const int nrows = r[nw];
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<RowRec>& rc = dir ? recs_b : recs_f;
+            std::vector<int> seen(g.ntiles, 0), firsts(g.unit_end - g.unit_begin, 0);
+            for (int w = 0; w < nw; ++w) {
+                if (r[w] > r[w + 1] || r[w + 1] > nrows) { delete P; return fail("hint_plan_create: internal error (record ranges)"); }
+                int have_thin_for = -1;
+                for (int i = r[w]; i < r[w + 1]; ++i) {
+                    const RowRec& q = rc[g.row_begin + i];
+                    const int tile0 = q.tile & 0xffff, ntt = (q.counts >> 24) & 0xff, NT = q.flags & 0xff;
+                    const int tb = (q.ocol - q.wcol) / 16;
+                    int ui = -1;
+                    for (int u = g.unit_begin; u < g.unit_end; ++u) if (units[u].tile0 == tile0) ui = u;
+                    if (ui < 0 || units[ui].NT != NT || ntt < 1 || ntt > 3 || tb < 0 || tb + ntt > NT) { delete P; return fail("hint_plan_create: internal error (row record)"); }
+                    if ((q.flags >> 8) & 1) have_thin_for = ui;
+                    if (have_thin_for != ui) { delete P; return fail("hint_plan_create: internal error (thin layer missing)"); }
+                    if ((q.flags >> 9) & 1) ++firsts[ui - g.unit_begin];
+                    for (int j = 0; j < ntt; ++j) ++seen[tile0 + tb + j];
+                }
+            }
+            for (int c : seen) if (c != 1) { delete P; return fail("hint_plan_create: internal error (tiles not covered exactly once)"); }
+            for (int c : firsts) if (c != 1) { delete P; return fail("hint_plan_create: internal error (first rows)"); }
         }
-        int slices = 0, want = 0;
-        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) slices += units[ui].sl_n;
-        const int32_t* b2 = r + (nw + 1);
-        for (int w = 0; w < nw; ++w) {
-            int t = b2[w];
-            while (t < b2[w + 1]) { const Unit& u = units[g.unit_begin + tmap[g.tmap_begin + t]]; ++want; t = std::min((int)b2[w + 1], u.tile0 + u.NT); }
-        }
-        if (slices != want) { delete P; return fail("hint_plan_create: internal error (slices)"); }
     }
 
     // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
@@ -392,6 +492,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_A1, u.wcol, 0, P->WT - 1, 0, 1, po[HINT_W1], po[HINT_B1]);
     }
     P->n_wjobs = (int)wjobs.size();
+    P->total_rows = (int)recs_f.size();
     P->n_ptiles = (int)ptiles.size();
 
     if (g_host_only) {           // hint_plan_check: everything above ran (and checked itself); no device
@@ -411,6 +512,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
+    if (e == hipSuccess) {
+        std::vector<RowRec> both(recs_f);
+        both.insert(both.end(), recs_b.begin(), recs_b.end());
+        e = upload((void**)&P->d_recs, both.data(), both.size() * sizeof(RowRec));
+    }
     if (e == hipSuccess) e = upload((void**)&P->d_bmap, bmap.data(), bmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_real, real.data(), real.size());
     if (e == hipSuccess) e = upload((void**)&P->d_wjobs, wjobs.data(), wjobs.size() * sizeof(WJob));
@@ -418,8 +524,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (e == hipSuccess) e = upload((void**)&P->d_ptiles, ptiles.data(), ptiles.size() * sizeof(int2));
     // the kernels' dynamic-LDS ceiling is a per-kernel attribute: always the hardware limit, so that plans
     // of different sizes created in any order (or on several devices) cannot lower it for each other
-    if (e == hipSuccess) e = set_max_lds_apply(LDS_LIMIT);
-    if (e == hipSuccess) e = set_max_lds_bwd(LDS_LIMIT);
+    if (e == hipSuccess) e = set_max_lds_apply(LDS_ATTR);
+    if (e == hipSuccess) e = set_max_lds_bwd(LDS_ATTR);
     if (e != hipSuccess) {
         hint_plan_destroy(P);
         return fail("hint_plan_create: device setup failed: %s", hipGetErrorString(e));
@@ -428,13 +534,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     return 0;
 }
 
-// wavefronts per workgroup: HINT_NW (4, 8, 16) overrides; otherwise 8, or 16 when the block is too wide
-// for the backward kernel's register-held [16, d] tile at 8
+// wavefronts per workgroup: HINT_NW (4 or 8) overrides; otherwise 8 (4 only for blocks narrow enough
+// for the backward kernel's register-held [16, d] tile)
 static int pick_nw(int d) {
     int nw = 8;
     if (const char* s = std::getenv("HINT_NW")) {
         const int v = std::atoi(s);
-        if (v == 4 || v == 8 || v == 16) nw = v;
+        if (v == 4 || v == 8) nw = v;
     }
     while (nw < MAX_NW && ROWS * d > LV_REGS * 64 * nw) nw *= 2;
     return nw;
@@ -493,6 +599,7 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
 void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
     (void)hipFree(P->d_meta);
+    (void)hipFree(P->d_recs);
     (void)hipFree(P->d_bmap);
     (void)hipFree(P->d_real);
     (void)hipFree(P->d_wjobs);
@@ -502,8 +609,8 @@ void hint_plan_destroy(hint_plan* P) {
 }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
-// + 1 KiB of slack behind the bias region
-int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 256 : -1; }
+// + 4 KiB of slack behind the bias region (a padded row's dummy steps load up to three tiles past its last)
+int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 1024 : -1; }
 
 static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
@@ -559,15 +666,18 @@ static int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool a
 }
 static KArgs make_args(const hint_plan* P, int B, bool backward) {
     KArgs a{};
-    a.meta = P->d_meta; a.meta_bytes = P->meta_bytes;
+    a.meta = P->d_meta; a.meta_bytes = P->meta_bytes; a.recs = P->d_recs; a.total_rows = P->total_rows;
     a.units_off = P->units_off; a.tmap_off = P->tmap_off; a.ents_off = P->ents_off; a.rng_off = P->rng_off;
     a.lops_off = P->lops_off;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;
     a.d = P->d; a.dc = P->dc; a.xld = P->xld; a.cld = P->cld;
     a.abuf_tiles = P->abuf_tiles; a.slab_floats = backward ? P->slab_bwd : P->slab_fwd; a.gld = P->gld;
     a.WT = P->WT; a.ST = P->ST; a.perm_lds = 0;
+    a.thin_off = backward ? P->thin_b_off : P->thin_f_off;
+    a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
+    a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;
     a.act_stride = act_stride(P, B);
-    a.alpha = P->alpha; a.B = B;
+    a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
     return a;
 }
 
@@ -862,6 +972,12 @@ void hint_chain_destroy(hint_chain* C) {
     (void)hipFree(C->d_table);
     delete C;
 }
+
+#ifdef HINT_STAMPS
+// diagnostic builds only (make stamps): device buffer of MAX_NW x 256 uint64 that workgroup 0 of the block
+// kernels fills with shader-clock stamps of its phase boundaries; not part of the shipped ABI
+int hint_debug_set_stamp_buffer(void* device_buffer) { g_stamp_buf = (unsigned long long*)device_buffer; return 0; }
+#endif
 
 static int adam_num_cu() {
     static int num_cu = 0;

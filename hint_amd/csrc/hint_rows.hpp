@@ -1,260 +1,315 @@
-// The GEMM engine of the block kernels: one wavefront walks a contiguous range of a group's
-// fragment tiles (a fragment tile = 16 output features x 16 batch rows of one unit) and, per tile,
-// streams that tile's "row" of packed weight tiles from L2 through a register ring:
+// The GEMM engine of the block kernels.  One wavefront executes its list of ROWS of a group; a row
+// is up to three adjacent fragment tiles (16 output features x 16 batch rows each) of one unit
+// that share every B fragment:
 //
-//   phase    main steps (A = weight tile kb)            B operand                tail steps
-//   K_L1     KB1 tiles of W1   [h x cin], interleaved   lane tile / condition    -
-//   K_L2     NT  tiles of W2   [h x h],   blocked       a1 fragment tiles (LDS)  RT tiles of W3 (B = the a2 tile just
-//                                                                                 finished, in registers) [+ RT bias tiles]
-//                                                                                 accumulated in the wavefront's LDS slab
-//   K_G2     RT  tiles of W3^T [h x r],   interleaved   coupling gradients (LDS) -
-//   K_G1     NT  tiles of W2^T [h x h],   blocked       g2 fragment tiles (LDS)  CT tiles of W1^T (B = the g1 tile just finished)
+//   direction  thin layer (VALU, per unit)      main steps (A = weight tiles)   B operand      aux step            tail steps
+//   forward    a1 = relu(W1 v + b1)             n1 = NT k-blocks of W2          a1 tiles (LDS)  + b2, ReLU -> a2    RT x W3 tiles (B = a2, registers) [+ b3]
+//   backward   g2' = W3^T g_st (unmasked)       n1 = NT k-blocks of W2^T        g2' tiles (LDS) .* relu'(a1) -> g1  CT x W1^T tiles (B = g1)
+//                                                                               .* relu'(a2 tile kb), which rides in the ring
 //
 // Every product is transposed (out^T = W * act^T), so the accumulator of the main steps - lane l
 // holds features 4*(l>>4)+i of batch row l&15 - is exactly the B operand of the tail steps, and
-// what a wavefront stores as a fragment tile (ds_write_b128 at lane*16) is what another one reads
-// as its B operand (ds_read_b128): no transposes, no per-layer barrier inside a unit.
-// The ring holds the next RING weight tiles (1 KiB, one global_load_dwordx4 per lane, fully
-// coalesced); a second iterator runs RING steps ahead of the consuming one, across tiles and units.
+// what a wavefront stores as a fragment tile (ds_write_b128 at lane*16) is what it (or another
+// wavefront) reads as a B operand (ds_read_b128): no transposes.  The thin layer of a unit (K = the
+// few lanes feeding the subnet, or its r outputs) is recomputed by every wavefront that holds rows
+// of the unit - identical values land in the same LDS tiles - so a group needs no barrier between
+// its layers.  The K-split partial of a row's tail product goes to the row's own LDS slab.
+//
+// The weight stream runs through a register ring of RING slots x 3 elements: every step consumes one
+// slot and issues its 16-byte-per-lane global loads for the step RING ahead (a row's body is compiled
+// for its tile count; the hand-over to the next row always loads three elements, a narrower row's last
+// tile again: an L1 hit) - weight tiles, bias vectors and the forward activations whose
+// sign masks the backward tiles all travel the same way.  That regularity is what lets hipcc keep the
+// loads in flight (counted vmcnt waits): a load under a branch makes its wait-count analysis assume
+// the worst on every path.  A row's stream is [main steps, padded with dummies to a multiple of
+// RING][extra steps: aux, tail, last-layer bias]; position p lives in slot p % RING, so the loops
+// are plain unrolled-by-RING loops with static slots.  Per-row bookkeeping is one 64-byte record,
+// fetched with a scalar load one row ahead.
 #pragma once
 #include "hint_device.hpp"
 
 namespace hint {
 
-enum { K_L1 = 0, K_L2 = 1, K_G2 = 2, K_G1 = 3 };
+enum { K_FWD = 0, K_BWD = 1 };
 #ifndef HINT_RING
 #define HINT_RING 4
 #endif
 constexpr int RING = HINT_RING;
+constexpr int NTT = 3;          // tiles per row
+constexpr int NEL = NTT + 1;    // ring elements per slot: the row's weight tiles + (backward) the a2 tile that masks the step's B fragment
 
-// wave-uniform position in the stream of weight tiles
-struct RowIt {
-    int t, kb;                  // fragment tile, step inside its row
-    int n1, n2, n3;             // main / tail / bias-tile steps of the row
-    int base1, base2, base3, stride2;   // packed tile index of step kb: see row_tile()
-    int tile0, NT;              // fragment tiles [tile0, tile0 + NT) belong to the iterator's current unit
-    int ui;                     // that unit
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+#define CONST_AS __attribute__((address_space(4)))
+__device__ __forceinline__ i32x16 load_rec(const void* recs, int idx) {
+    const CONST_AS i32x16* p = (const CONST_AS i32x16*)(unsigned long long)recs;
+    return p[idx];
+}
+struct RowU {           // decoded record (all wave-uniform)
+    int base1, base2, n1, n2, n3, ntt, aux, ocol, tile0, nquad, slab, bias3;
+    int thin_w, thin_b, thin_k, NT, thin, first, wcol;
 };
-__device__ __forceinline__ int row_tile(const RowIt& it) {
-    if (it.kb < it.n1) return it.base1 + it.kb;
-    if (it.kb < it.n1 + it.n2) return it.base2 + (it.kb - it.n1) * it.stride2;
-    return it.base3 + (it.kb - it.n1 - it.n2);
+__device__ __forceinline__ RowU decode_rec(const i32x16 r) {
+    RowU u;
+    u.base1 = r[0]; u.base2 = r[1];
+    u.n1 = r[2] & 0xff; u.n2 = (r[2] >> 8) & 0xff; u.n3 = (r[2] >> 16) & 0xff; u.ntt = (r[2] >> 24) & 0xff;
+    u.aux = r[3]; u.ocol = r[4];
+    u.tile0 = r[5] & 0xffff; u.nquad = (r[5] >> 16) & 0xff;
+    u.slab = r[6]; u.bias3 = r[7];
+    u.thin_w = r[8]; u.thin_b = r[9]; u.thin_k = r[10];
+    u.NT = r[11] & 0xff; u.thin = (r[11] >> 8) & 1; u.first = (r[11] >> 9) & 1;
+    u.wcol = r[12];
+    return u;
 }
 
-template <int KIND>
-__device__ __forceinline__ void row_setup(RowIt& it, const Tables& T, const GroupU& g, int t, bool force) {
-    it.t = t;
-    it.kb = 0;
-    if (force || t >= it.tile0 + it.NT) {
-        it.ui = g.unit_begin + lds_u16(T.tmap + g.tmap_begin + t);
-        const LDS_AS int32_t* u = (const LDS_AS int32_t*)(T.units + it.ui);
-        it.tile0 = lds_i32(u + 10);
-        it.NT = lds_i32(u + 12);
-    }
-    const LDS_AS int32_t* u = (const LDS_AS int32_t*)(T.units + it.ui);
-    const int nt = t - it.tile0;
-    if (KIND == K_L1) {
-        const int KB1 = lds_i32(u + 13);
-        it.n1 = KB1; it.n2 = 0; it.n3 = 0;
-        it.base1 = lds_i32(u + 0) + nt * KB1;
-        it.base2 = it.base3 = it.stride2 = 0;
-    } else if (KIND == K_L2) {
-        const int RT = lds_i32(u + 14);
-        it.n1 = it.NT; it.n2 = RT; it.n3 = nt == 0 ? RT : 0;
-        it.base1 = lds_i32(u + 1) + nt * it.NT;
-        it.base2 = lds_i32(u + 2) + nt; it.stride2 = it.NT;
-        it.base3 = lds_i32(u + 2) + RT * it.NT;          // the unit's b3 "bias tiles" follow its W3 tiles
-    } else if (KIND == K_G2) {
-        const int RT = lds_i32(u + 14);
-        it.n1 = RT; it.n2 = 0; it.n3 = 0;
-        it.base1 = lds_i32(u + 3) + nt * RT;
-        it.base2 = it.base3 = it.stride2 = 0;
-    } else {
-        const int CT = lds_i32(u + 13);
-        it.n1 = it.NT; it.n2 = CT; it.n3 = 0;
-        it.base1 = lds_i32(u + 4) + nt * it.NT;
-        it.base2 = lds_i32(u + 5) + nt; it.stride2 = it.NT;
-        it.base3 = 0;
-    }
-}
-
-// advance to the next step; returns false when the range [.., t1) is exhausted
-template <int KIND>
-__device__ __forceinline__ bool row_advance(RowIt& it, const Tables& T, const GroupU& g, int t1) {
-    ++it.kb;
-    if (it.kb < it.n1 + it.n2 + it.n3) return true;
-    if (it.t + 1 >= t1) { it.t = t1; return false; }
-    row_setup<KIND>(it, T, g, it.t + 1, false);
-    return true;
-}
-
-// What the phases need besides the tables: pointers and strides of the workgroup's LDS buffers and
-// of the block's global arrays.
+// What the phases need besides the records: pointers and strides of the workgroup's LDS buffers and
+// of the block's global arrays.  (Explicit address spaces: a generic pointer is read with flat_load,
+// which counts against vmcnt AND lgkmcnt and turns every wait into vmcnt(0) lgkmcnt(0).)
 struct PhaseCtx {
-    const float* packed;        // packed weights of the block (global)
-    float* abuf;                // fragment tiles of the group (LDS): a1 (forward), g2 (backward)
-    const float* xs;            // lane tile [16][xld] (LDS)
-    const float* cs;            // condition tile [16][cld] (LDS)
-    const float* gst;           // coupling gradients [16][gld] (LDS, backward)
-    float* slab;                // partial-sum slabs of the tail products (LDS)
-    float* out1;                // global [Bp][WT]: a1 (K_L1, forward training), g2 (K_G2), g1 (K_G1); a2 for K_L2
-    const float* mask;          // global [Bp][WT]: a2 (K_G2) / a1 (K_G1): relu'() of the forward activation
+    const GLOBAL_AS float* packed;   // packed weights of the block
+    const void* recs;                // row records of the plan (global, constant), this direction's
+    LDS_AS float* abuf;              // fragment tiles of the group: a1 (forward), g2 (backward)
+    LDS_AS float* slab;              // the rows' slabs
+    const LDS_AS float* xs;          // lane tile [16][xld]
+    const LDS_AS float* cs;          // condition tile [16][cld]
+    const LDS_AS float* gst;         // coupling gradients [16][gld] (backward)
+    const LDS_AS float* thin_l;      // the direction's thin blob staged in LDS, or nullptr
+    const GLOBAL_AS float* thin_g;   // ... in the packed buffer
+    GLOBAL_AS float* out_thin;       // [Bp][WT]: a1 (training forward) / g2 (backward)
+    GLOBAL_AS float* out_main;       // [Bp][WT]: a2 (training forward) / g1 (backward)
+    const GLOBAL_AS float* mask_thin;    // [Bp][WT] a2: relu'() for g2 (backward)
+    const GLOBAL_AS float* mask_main;    // [Bp][WT] a1: relu'() for g1 (backward)
     int xld, cld, gld, WT, row0;
-    bool store;                 // write out1 (training forward / always in the backward pass)
+    int sid;                         // diagnostic builds: stamp id base of the phase
+    bool store;                      // write out_thin / out_main (training forward; always in the backward pass)
 };
 
-// One phase of one wavefront: fragment tiles [t0, t1) of group g; `slabp` is where the wavefront's
-// first tail slab goes (K_L2 / K_G1).
-template <int KIND>
-__device__ __forceinline__ void run_phase(const PhaseCtx& c, const Tables& T, const GroupU& g, int t0, int t1,
-                                          float* slabp, int lane) {
-    if (t0 >= t1) return;
+#ifdef HINT_ABLATE_STORE      // diagnostic: no activation / gradient rows leave the kernel
+#define HINT_STORE_ON false
+#else
+#define HINT_STORE_ON c.store
+#endif
+
+// Byte offsets of a lane inside the three kinds of stream elements.
+struct LaneOff { unsigned w, b, m; };    // lane*16 (weight tiles), kq*16 (bias vectors), (m*WT + 4 kq)*4 (activation tiles)
+
+// the first N weight elements of main step kb of row r (tile j of a narrower row: its last tile again); backward:
+// also the a2 tile of k-block kb (element NTT), whose sign masks the step's B fragment
+template <int KIND, int N>
+__device__ __forceinline__ void load_main3(f32x4 (&dst)[NEL], const PhaseCtx& c, const RowU& r, int kb, const LaneOff& lo) {
+    const GLOBAL_AS char* p = (const GLOBAL_AS char*)c.packed + lo.w;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int jj = j < r.ntt ? j : r.ntt - 1;
+        dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj * r.n1 + kb) * 1024);
+    }
+    if (KIND == K_BWD) {
+        const int kc = kb < r.n1 ? kb : r.n1 - 1;
+        dst[NTT] = *(const GLOBAL_AS f32x4*)((const GLOBAL_AS char*)c.mask_thin + ((size_t)c.row0 * c.WT + r.wcol + 16 * kc) * 4 + lo.m);
+    }
+}
+// the first N elements of extra step e: 0 = aux (bias vectors / forward activation tiles), 1 .. n2 = tail
+// weight tiles, then n3 bias vectors of the last layer; anything beyond re-loads the aux elements
+template <int KIND, int N>
+__device__ __forceinline__ void load_extra3(f32x4 (&dst)[NTT], const PhaseCtx& c, const RowU& r, int e, const LaneOff& lo) {
+    const GLOBAL_AS char* base;
+    unsigned off, step;
+    if (e >= 1 && e <= r.n2) {
+        base = (const GLOBAL_AS char*)c.packed + (size_t)(r.base2 + (e - 1) * r.n1) * 1024; off = lo.w; step = 1024;
+    } else if (e > r.n2 && e <= r.n2 + r.n3) {
+        base = (const GLOBAL_AS char*)c.packed + (size_t)(r.bias3 + 16 * (e - 1 - r.n2)) * 4; off = lo.b; step = 0;
+    } else if (KIND == K_FWD) {
+        base = (const GLOBAL_AS char*)c.packed + (size_t)r.aux * 4; off = lo.b; step = 64;
+    } else {
+        base = (const GLOBAL_AS char*)c.mask_main + ((size_t)c.row0 * c.WT + r.ocol) * 4; off = lo.m; step = 64;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int jj = j < r.ntt ? j : r.ntt - 1;
+        dst[j] = *(const GLOBAL_AS f32x4*)(base + (size_t)(jj * step) + off);
+    }
+}
+
+// The thin layer of a unit on the vector ALU, all NT tiles, into the group's LDS fragment tiles:
+//   forward   a1[f]  = relu(b1[f] + sum_k W1[f][k] v[k]),  v = [lanes xoff .. xoff+ku | condition]
+//   backward  g2'[f] = sum_j W3[j][f] g_st[j]              (relu'(a2) is applied where the tiles are consumed)
+// Lane l owns features 4*(l>>4)..+3 of row l&15 of every tile; the weights come as one float4 per input from the
+// direction's thin blob (vector layout), staged in LDS once per block when it is small enough (STAGED).
+template <int KIND, bool STAGED>
+__device__ __forceinline__ void thin_layer(const PhaseCtx& c, const RowU& r, int lane) {
     const int m = lane & 15, kq = lane >> 4;
-    const f32x4* wp4 = (const f32x4*)c.packed + lane;
-    const f32x4* abuf4 = (const f32x4*)c.abuf + lane;
-
-    RowIt pit;
-    pit.tile0 = 0; pit.NT = 0; pit.ui = 0;
-    row_setup<KIND>(pit, T, g, t0, true);
-    RowIt cit = pit;
-    UnitU U = load_unit(T.units + cit.ui);
-    bool pmore = true;
-    f32x4 ring[RING];
+    const int K = r.thin_k & 0xff;
+    const int KV = KIND == K_FWD ? K + 1 : K;            // vectors per tile (forward: the bias is vector K)
+    const bool st = KIND == K_FWD && HINT_STORE_ON && r.first;
+    const int vbase = r.thin_w + 4 * kq;                 // vector (nt, k) of this lane: float offset vbase + (nt*KV + k)*16
+    auto vec = [&](int nt, int k) -> f32x4 {
+        const int o = vbase + (nt * KV + k) * 16;
+        if (STAGED) return *(const LDS_AS f32x4*)(c.thin_l + o);
+        return *(const GLOBAL_AS f32x4*)(c.thin_g + o);
+    };
+    auto input = [&](int k) -> float {
+        if (KIND == K_FWD) {
+            const int ku = (r.thin_k >> 8) & 0xff, xoff = r.thin_k >> 16;
+            return k < ku ? c.xs[m * c.xld + xoff + k] : c.cs[m * c.cld + (k - ku)];
+        }
+        return c.gst[m * c.gld + (r.thin_k >> 16) + k];
+    };
+    // inputs of the unit for this lane's batch row, the first four in registers (more: re-read per tile)
+    float vin[4];
 #pragma unroll
-    for (int j = 0; j < RING; ++j) {
-        ring[j] = zero4();
-        if (pmore) {
-            ring[j] = wp4[(size_t)row_tile(pit) * 64];
-            pmore = row_advance<KIND>(pit, T, g, t1);
+    for (int k = 0; k < 4; ++k) vin[k] = k < K ? input(k) : 0.f;
+    for (int nt = 0; nt < r.NT; ++nt) {
+        f32x4 acc = KIND == K_FWD ? vec(nt, K) : zero4();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < K) acc += vec(nt, k) * vin[k];
+        for (int k = 4; k < K; ++k) acc += vec(nt, k) * input(k);
+        if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        ((LDS_AS f32x4*)c.abuf)[(r.tile0 + nt) * 64 + lane] = acc;
+        if (st) {
+            GLOBAL_AS float* op = c.out_thin + ((size_t)c.row0 * c.WT + r.wcol + 16 * nt) + (m * c.WT + 4 * kq);
+            __builtin_nontemporal_store(acc, (GLOBAL_AS f32x4*)op);
         }
     }
-    f32x4 acc0 = zero4(), acc1 = zero4();
-    bool slice_first = true;    // no row of the wavefront's current slice has reached its slab yet
-    f32x4 aux = zero4();        // bias of the row (K_L1, K_L2) / the forward activation whose sign masks it (K_G2, K_G1)
-    f32x4 act = zero4();        // the finished main tile (B operand of the tail steps)
-    f32x4 bnext = zero4();      // next B fragment (K_L2, K_G1)
+}
 
-#define HINT_ROW_BEGIN()                                                                                      \
-    {                                                                                                         \
-        const int nt_ = cit.t - U.tile0;                                                                      \
-        const size_t go_ = (size_t)(c.row0 + m) * c.WT + U.wcol + 16 * nt_ + 4 * kq;                           \
-        if (KIND == K_L1) aux = *(const f32x4*)(c.packed + U.bias1 + 16 * nt_ + 4 * kq);                       \
-        else if (KIND == K_L2) aux = *(const f32x4*)(c.packed + U.bias2 + 16 * nt_ + 4 * kq);                  \
-        else aux = *(const f32x4*)(c.mask + go_);                                                             \
-        if (KIND == K_L2 || KIND == K_G1) bnext = abuf4[(size_t)U.tile0 * 64];                                \
-        acc0 = zero4(); acc1 = zero4();                                                                       \
+// One row with NA tiles (compile-time: a run-time tile count would put a branch around every MFMA).  On entry the
+// ring holds the row's first RING main steps; on exit the first RING main steps of row `nr`.  The row's first
+// extra elements - bias vectors / forward activation tiles, the tail product's first weight tiles, the first
+// last-layer bias vector - are fetched when the row starts and wait in registers of their own; further tail
+// steps (r or cin beyond 16) fetch theirs when they run.
+template <int KIND, int NA>
+__device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, const RowU& nr, f32x4 (&ring)[RING][NEL],
+                                         const LaneOff& lo, int lane) {
+    const int m = lane & 15, kq = lane >> 4;
+    const LDS_AS f32x4* abuf4 = (const LDS_AS f32x4*)c.abuf + lane;
+    const int n1 = cr.n1;
+    const int n1p = (n1 + RING - 1) / RING * RING;
+    f32x4 xaux[NTT], xtail[NTT], xb3[NTT];
+    load_extra3<KIND, NA>(xaux, c, cr, 0, lo);
+    load_extra3<KIND, NA>(xtail, c, cr, 1, lo);
+    load_extra3<KIND, 1>(xb3, c, cr, 1 + cr.n2, lo);
+    f32x4 acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = zero4();
+    f32x4 bb[2];
+    bb[0] = abuf4[cr.tile0 * 64];
+    bb[1] = zero4();
+
+    // one main step: k-block KB, the slot's weight fragments W (backward: W[NTT] = the a2 tile of the k-block), static slot S
+    const bool stg2 = KIND == K_BWD && HINT_STORE_ON && cr.first;      // this row also writes the unit's masked g2 tiles
+#define HINT_MAIN_STEP(KB, W, S)                                                                        \
+    {                                                                                                   \
+        f32x4 b4 = bb[(S) & 1];                                                                         \
+        const int kn = (KB) + 1 < n1 ? (KB) + 1 : (KB);                                                 \
+        bb[((S) + 1) & 1] = abuf4[(cr.tile0 + kn) * 64];                                                \
+        if (KIND == K_BWD) {                                                                            \
+            b4.x = (W)[NTT].x > 0.f ? b4.x : 0.f; b4.y = (W)[NTT].y > 0.f ? b4.y : 0.f;                 \
+            b4.z = (W)[NTT].z > 0.f ? b4.z : 0.f; b4.w = (W)[NTT].w > 0.f ? b4.w : 0.f;                 \
+            if (stg2) *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + cr.wcol + 16 * (KB)) + (m * c.WT + 4 * kq)) = b4; \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+            _Pragma("unroll") for (int j = 0; j < NA; ++j) acc[j] = mfma4((W)[j][i], b4[i], acc[j]);    \
     }
-    HINT_ROW_BEGIN()
 
-    bool more = true;
-    while (more) {
+    // ---- main steps: all chunks but the last (no dummies in them) ----
+    int k0 = 0;
+    for (; k0 + RING < n1p; k0 += RING) {
 #pragma unroll
-        for (int j = 0; j < RING; ++j) {
-            if (more) {
-                const f32x4 w4 = ring[j];
-                const int kb = cit.kb;
-                if (kb < cit.n1) {
-                    // ---- main step ----
-                    if (KIND == K_L2 || KIND == K_G1) {
-                        const f32x4 b4 = bnext;
-                        const int kn = kb + 1 < cit.n1 ? kb + 1 : kb;
-                        bnext = abuf4[(size_t)(U.tile0 + kn) * 64];
-                        acc0 = mfma4(w4.x, b4.x, acc0);
-                        acc1 = mfma4(w4.y, b4.y, acc1);
-                        acc0 = mfma4(w4.z, b4.z, acc0);
-                        acc1 = mfma4(w4.w, b4.w, acc1);
-                    } else {
-                        // B read element-wise (interleaved k order: MFMA i covers k = 16 kb + 4 i + kq)
-                        const int K = KIND == K_L1 ? U.cin : U.r;
-                        const int rem = K - 16 * kb;
+        for (int s = 0; s < RING; ++s) {
+            f32x4 w[NEL];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (4 * i < rem) {
-                                const int k = 16 * kb + 4 * i + kq;
-                                float b = 0.f;
-                                if (KIND == K_L1) {
-                                    if (k < U.ku) b = c.xs[m * c.xld + U.xoff + k];
-                                    else if (k < U.cin) b = c.cs[m * c.cld + (k - U.ku)];
-                                } else {
-                                    if (k < U.r) b = c.gst[m * c.gld + U.lcol + k];
-                                }
-                                if (i & 1) acc1 = mfma4(w4[i], b, acc1);
-                                else acc0 = mfma4(w4[i], b, acc0);
-                            }
-                        }
-                    }
-                } else {
-                    // ---- tail step q: slab[q] (+)= Wtail(q, this tile) * act, the K-split partial of the thin
-                    //      product, kept in the wavefront's own LDS slab (compact: quad q4 = 4 q + kq holds
-                    //      features 4 q4 .. +3 of rows m); behind the tail steps of a unit's first tile come
-                    //      the last layer's bias tiles, added the same way ----
-                    const bool is_bias = kb >= cit.n1 + cit.n2;
-                    const int q = kb - cit.n1 - (is_bias ? cit.n2 : 0);
-                    f32x4 s = w4;
-                    if (!is_bias) {
-                        s = mfma4(w4.x, act.x, zero4());
-                        s = mfma4(w4.y, act.y, s);
-                        s = mfma4(w4.z, act.z, s);
-                        s = mfma4(w4.w, act.w, s);
-                    }
-                    const int W = KIND == K_L2 ? U.r : U.cin;
-                    const int q4 = 4 * q + kq;
-                    if (q4 < ((W + 3) >> 2)) {
-                        f32x4* sp = (f32x4*)(slabp + (q4 * 16 + m) * 4);
-                        if (is_bias || !slice_first) s += *sp;
-                        *sp = s;
-                    }
-                }
-                // ---- refill the slot RING steps ahead ----
-                if (pmore) {
-                    ring[j] = wp4[(size_t)row_tile(pit) * 64];
-                    pmore = row_advance<KIND>(pit, T, g, t1);
-                }
-                // ---- consumer bookkeeping ----
-                ++cit.kb;
-                if (cit.kb == cit.n1) {
-                    // main tile finished: epilogue
-                    const int nt = cit.t - U.tile0;
-                    f32x4 v = acc0 + acc1;
-                    if (KIND == K_L1 || KIND == K_L2) {
-                        v += aux;
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    } else {
-                        v.x = aux.x > 0.f ? v.x : 0.f; v.y = aux.y > 0.f ? v.y : 0.f;
-                        v.z = aux.z > 0.f ? v.z : 0.f; v.w = aux.w > 0.f ? v.w : 0.f;
-                    }
-                    act = v;
-                    if (KIND == K_L1 || KIND == K_G2) ((f32x4*)c.abuf)[(size_t)cit.t * 64 + lane] = v;
-                    if (c.store) {
-                        float* o = c.out1 + (size_t)(c.row0 + m) * c.WT + U.wcol + 16 * nt + 4 * kq;
-                        if (KIND == K_L1 || KIND == K_L2) __builtin_nontemporal_store(v, (f32x4*)o);
-                        else *(f32x4*)o = v;
-                    }
-                }
-                if (cit.kb == cit.n1 + cit.n2 + cit.n3) {
-                    // row finished
-                    const int tn = cit.t + 1;
-                    const bool unit_end = tn >= U.tile0 + U.NT;
-                    if (KIND == K_L2 || KIND == K_G1) {
-                        slice_first = false;
-                        if (tn >= t1 || unit_end) {      // the wavefront's slice of this unit ends: next slab
-                            const int W = KIND == K_L2 ? U.r : U.cin;
-                            slabp += 64 * ((W + 3) >> 2);
-                            slice_first = true;
-                        }
-                    }
-                    if (tn >= t1) {
-                        more = false;
-                    } else {
-                        row_setup<KIND>(cit, T, g, tn, false);
-                        if (unit_end) U = load_unit(T.units + cit.ui);
-                        HINT_ROW_BEGIN()
-                    }
-                }
-            }
+            for (int j = 0; j < NA; ++j) w[j] = ring[s][j];
+            w[NTT] = ring[s][NTT];
+            load_main3<KIND, NA>(ring[s], c, cr, k0 + s + RING, lo);
+            HINT_MAIN_STEP(k0 + s, w, s)
         }
     }
-#undef HINT_ROW_BEGIN
+    STAMP(c.sid + 10)
+    // ---- last main chunk: its loads fetch the next row's first main steps ----
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+        f32x4 w[NEL];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) w[j] = ring[s][j];
+        w[NTT] = ring[s][NTT];
+        load_main3<KIND, NTT>(ring[s], c, nr, s, lo);
+        if (k0 + s < n1) HINT_MAIN_STEP(k0 + s, w, s)
+    }
+#undef HINT_MAIN_STEP
+
+    STAMP(c.sid + 11)
+    // ---- aux step: the main tiles are finished ----
+    f32x4 act[NA];           // (B operands of the tail steps)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        f32x4 v = acc[j];
+        if (KIND == K_FWD) {
+            v += xaux[j];                                                            // bias
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else {                                                                     // relu'() of the forward activation
+            v.x = xaux[j].x > 0.f ? v.x : 0.f; v.y = xaux[j].y > 0.f ? v.y : 0.f;
+            v.z = xaux[j].z > 0.f ? v.z : 0.f; v.w = xaux[j].w > 0.f ? v.w : 0.f;
+        }
+        act[j] = v;
+        if (HINT_STORE_ON) {
+            GLOBAL_AS float* o = c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq);
+            if (KIND == K_FWD) __builtin_nontemporal_store(v, (GLOBAL_AS f32x4*)o);
+            else *(GLOBAL_AS f32x4*)o = v;
+        }
+    }
+    // ---- tail steps: slab[q] = sum over the row's tiles of Wtail(q, tile) * act, the K-split partial of the thin
+    //      product (compact: quad q4 = 4 q + kq holds features 4 q4 .. +3 of rows m); then, with a unit's first row,
+    //      the last layer's bias vectors are added to the same slab ----
+    LDS_AS float* slabp = c.slab + cr.slab;
+    for (int q = 0; q < cr.n2; ++q) {
+        if (q > 0) load_extra3<KIND, NA>(xtail, c, cr, 1 + q, lo);
+        f32x4 sv = zero4();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) sv = mfma4(xtail[j][i], act[j][i], sv);
+        const int q4 = 4 * q + kq;
+        if (q4 < cr.nquad) *(LDS_AS f32x4*)(slabp + (q4 * 16 + m) * 4) = sv;
+    }
+    for (int q = 0; q < cr.n3; ++q) {
+        if (q > 0) load_extra3<KIND, 1>(xb3, c, cr, 1 + cr.n2 + q, lo);
+        const int q4 = 4 * q + kq;
+        if (q4 < cr.nquad) {
+            LDS_AS f32x4* sp = (LDS_AS f32x4*)(slabp + (q4 * 16 + m) * 4);
+            *sp = *sp + xb3[0];
+        }
+    }
+    STAMP(c.sid + 12)
+}
+
+// One GEMM phase of one wavefront: records [r0, r1) of this direction's record list.
+template <int KIND>
+__device__ __forceinline__ void run_rows(const PhaseCtx& c, int r0, int r1, int lane) {
+    if (r0 >= r1) return;
+    const int m = lane & 15, kq = lane >> 4;
+    LaneOff lo;
+    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.m = (unsigned)(m * c.WT + 4 * kq) * 4u;
+
+    RowU cr = decode_rec(load_rec(c.recs, r0));
+    i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : r0);               // next row's record, one row ahead
+    f32x4 ring[RING][NEL];
+#pragma unroll
+    for (int s = 0; s < RING; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
+
+    for (int t = r0; t < r1; ++t) {
+        const RowU nr = decode_rec(nrec);                                      // (the last row: its own record again)
+        nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : r1 - 1);
+        if (t == r0) { STAMP(c.sid + 8) }
+        if (cr.thin) {                                                         // the unit's a1 / g2' tiles: the B operand below
+            if (c.thin_l != nullptr) thin_layer<KIND, true>(c, cr, lane);
+            else thin_layer<KIND, false>(c, cr, lane);
+        }
+        if (t == r0) { STAMP(c.sid + 9) }
+        if (cr.ntt >= 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
+        else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
+        else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+        cr = nr;
+    }
 }
 
 }  // namespace hint

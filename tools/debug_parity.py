@@ -15,6 +15,7 @@ torch.manual_seed(0)
 CASES = [
     (2, [16], 0, 16), (2, [20], 0, 5), (3, [40, 24], 0, 33), (6, [140, 70, 35, 17], 0, 100), (8, [128, 64, 32, 16], 0, 50),
     (6, [32, 16], 3, 40), (1, [8], 0, 7), (43, [67, 33, 16, 8], 0, 48), (100, [224, 112, 56], 4, 20), (6, [512, 256], 0, 20),
+    (2, [200], 0, 20), (2, [512], 0, 20), (40, [24], 0, 20),
 ]
 only = os.environ.get("CASE")
 stages = os.environ.get("STAGES", "fib")

@@ -1,0 +1,89 @@
+"""Phase stamps of workgroup 0 of the forward and backward kernels inside a chained launch (diagnostic build):
+   make -C hint_amd/csrc stamps && HINT_AMD_LIB=hint_amd/lib/libhint_amd_stamps.so python tools/stamps.py [workload]
+Prints, per group of the tree, the cycles every wavefront spent in each phase (GEMM phases: busy time of
+the wavefront; barriers: wait for the slowest one) for a block in the middle of the chain."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import hint_amd
+from hint_amd import _lib
+from bench import WORKLOADS
+
+name = sys.argv[1] if len(sys.argv) > 1 else "power_hint_8"
+cfg = WORKLOADS[name]
+dev = torch.device("cuda:0")
+lib = _lib.load()
+lib.hint_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+torch.manual_seed(0)
+flow = hint_amd.HintFlow(cfg["d"], cfg["n_blocks"], cfg["c_internal"]).to(dev)
+with torch.no_grad():
+    for p in flow.parameters():
+        p.data = 0.005 * torch.randn_like(p)
+tr = hint_amd.FlowTrainer(flow, use_graph=False)
+x = torch.randn(cfg["batch"], cfg["d"], device=dev)
+for _ in range(3):
+    tr.step(x)
+torch.cuda.synchronize()
+NW, IDS = 8, 512
+buf = torch.zeros(NW * IDS, dtype=torch.int64, device=dev)
+chain = tr._chain_for(x.shape[0])
+B = x.shape[0]
+z = torch.empty_like(x); J = torch.empty(B, device=dev); gx = torch.empty_like(x)
+stream = torch.cuda.current_stream().cuda_stream
+n_groups = None
+
+
+def show(title, st, per_block, labels, blocks):
+    st = st.reshape(NW, IDS)
+    nw = int((st[:, 0] != 0).sum())
+    print(f"== {title}: {nw} wavefronts; cycles per phase, wave 0..{nw - 1} (block {blocks})")
+    t_first = st[:nw][st[:nw] != 0].min(); t_last = st[:nw].max()
+    print(f"   whole kernel (workgroup 0): {t_last - t_first} cycles")
+    for cb in blocks:
+        for gi in range(per_block):
+            base = (cb * per_block + gi) * 16
+            row = st[:nw, base:base + 7]
+            if (row == 0).all():
+                continue
+            for k, lab in enumerate(labels):
+                d = row[:, k + 1] - row[:, k]
+                if (row[:, k + 1] == 0).any() or (row[:, k] == 0).any():
+                    continue
+                print(f"   blk {cb} grp {gi} {lab:22s} " + " ".join(f"{int(v):6d}" for v in d))
+            # inside the first row of the GEMM phase: thin layer, main chunks, last chunk, extra steps
+            inner = st[:nw, base + 8:base + 13]
+            for k, lab in enumerate(["  row0 thin layer", "  row0 main chunks", "  row0 last chunk", "  row0 extra steps"]):
+                if (inner[:, k] == 0).all() or (inner[:, k + 1] == 0).all():
+                    continue
+                d = np.where((inner[:, k] != 0) & (inner[:, k + 1] != 0), inner[:, k + 1] - inner[:, k], 0)
+                print(f"   blk {cb} grp {gi} {lab:22s} " + " ".join(f"{int(v):6d}" for v in d))
+        tb = st[:nw, cb * per_block * 16]
+        te = st[:nw, (cb + 1) * per_block * 16] if (cb + 1) * per_block * 16 < IDS else None
+        if te is not None and (te != 0).all():
+            print(f"   blk {cb} total {int((te - tb).max())} cycles")
+
+
+lib.hint_debug_set_stamp_buffer(buf.data_ptr())
+_lib.check(lib.hint_chain_forward(chain, x.data_ptr(), None, z.data_ptr(), J.data_ptr(), None, None, stream), "fwd")
+torch.cuda.synchronize()
+fw = buf.cpu().numpy().copy()
+buf.zero_()
+_lib.check(lib.hint_chain_backward_parts(chain, x.data_ptr(), None, z.data_ptr(), None, gx.data_ptr(), None, 1.0 / B, -1.0 / B,
+                                         1, 1, stream), "bwd")
+torch.cuda.synchronize()
+bw = buf.cpu().numpy().copy()
+lib.hint_debug_set_stamp_buffer(None)
+stats = (C.c_int64 * 12)()
+from hint_amd.hint import node_descs
+nodes = flow.blocks[0].tree._flat_nodes()
+descs, _, _, _ = node_descs(nodes)
+lib.hint_plan_check(descs, len(nodes), cfg["d"], 0, 4.0, stats)
+ng = int(stats[0])
+print("groups per block:", ng)
+show("forward", fw, ng, ["-", "-", "P2 rows (L1 L2 L3)", "barrier", "P3 coupling", "barrier"], [3])
+show("backward A", bw, ng + 1, ["Q1 couple/scatter", "barrier", "prefetch issue", "-", "Q3 rows (g2 g1 gv)", "commit+barrier"], [3])
