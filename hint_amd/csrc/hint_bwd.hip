@@ -123,6 +123,12 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
             pc.store = true;
 
+            f32x4 ring[RING][NEL];
+            {   // the weight stream (and the a2 tiles) of the root group's first row: started before its coupling phase
+                const GroupU g0 = load_group(T.groups + (a.n_groups - 1));
+                const LDS_AS int32_t* rng0 = T.rng + g0.rng_begin;
+                rows_begin<K_BWD>(pc, ring, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
+            }
             for (int gi = a.n_groups; gi >= 0; --gi) {
                 // gi == 0 .. n_groups-1: the boundary in front of group gi (root first), then its GEMM phases;
                 // slot n_groups is used for the boundary BEHIND group 0 (scatter only), visited last
@@ -214,7 +220,12 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 STAMP(sid + 3)
                 STAMP(sid + 4)
                 // ---- Q3: g2 = (W3^T g_st) .* relu'(a2) (VALU);  g1 = (W2^T g2) .* relu'(a1);  g_v partial = W1^T g1 ----
-                run_rows<K_BWD>(pc, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
+                rows_run<K_BWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
+                if (slot > 0) {             // the next group's first row: its loads fly across the coupling phase
+                    const GroupU gn = load_group(T.groups + (slot - 1));
+                    const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
+                    rows_begin<K_BWD>(pc, ring, gn.row_begin + lds_i32(rngn + wave), gn.row_begin + lds_i32(rngn + wave + 1), lane);
+                }
                 STAMP(sid + 5)
                 if (lp_pending) level_commit(lp, xs, sb, a.xld, a.d, tid, nthreads);
                 lds_barrier();

@@ -120,6 +120,14 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
             pc.store = train;
 
+            // the weight stream of a group's first row starts one phase early: before the block's first group
+            // here, for the later ones right behind the rows of the group before (i.e. across its coupling phase)
+            f32x4 ring[RING][NEL];
+            {
+                const GroupU g0 = load_group(T.groups + (REV ? a.n_groups - 1 : 0));
+                const LDS_AS int32_t* rng0 = T.rng + g0.rng_begin;
+                rows_begin<K_FWD>(pc, ring, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
+            }
             for (int gi = 0; gi < a.n_groups; ++gi) {
                 const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : gi));
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
@@ -131,7 +139,12 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 STAMP(sid + 1)
                 STAMP(sid + 2)
                 // ---- P2: first layer (VALU), second layer, third layer partials ----
-                run_rows<K_FWD>(pc, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
+                rows_run<K_FWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
+                if (gi + 1 < a.n_groups) {
+                    const GroupU gn = load_group(T.groups + (REV ? a.n_groups - 2 - gi : gi + 1));
+                    const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
+                    rows_begin<K_FWD>(pc, ring, gn.row_begin + lds_i32(rngn + wave), gn.row_begin + lds_i32(rngn + wave + 1), lane);
+                }
                 STAMP(sid + 3)
                 lds_barrier();
                 STAMP(sid + 4)

@@ -89,6 +89,13 @@ struct PhaseCtx {
 #define HINT_STORE_ON c.store
 #endif
 
+// tape rows are written once and read by a later kernel: plain stores retire sooner than non-temporal ones, and the weight stream waits behind them (HINT_NT_STORES: experiment)
+#ifndef HINT_NT_STORES
+#define HINT_TAPE_STORE(V, P) (*(P) = (V))
+#else
+#define HINT_TAPE_STORE(V, P) __builtin_nontemporal_store((V), (P))
+#endif
+
 // Byte offsets of a lane inside the three kinds of stream elements.
 struct LaneOff { unsigned w, b, m; };    // lane*16 (weight tiles), kq*16 (bias vectors), (m*WT + 4 kq)*4 (activation tiles)
 
@@ -139,7 +146,6 @@ __device__ __forceinline__ void thin_layer(const PhaseCtx& c, const RowU& r, int
     const int m = lane & 15, kq = lane >> 4;
     const int K = r.thin_k & 0xff;
     const int KV = KIND == K_FWD ? K + 1 : K;            // vectors per tile (forward: the bias is vector K)
-    const bool st = KIND == K_FWD && HINT_STORE_ON && r.first;
     const int vbase = r.thin_w + 4 * kq;                 // vector (nt, k) of this lane: float offset vbase + (nt*KV + k)*16
     auto vec = [&](int nt, int k) -> f32x4 {
         const int o = vbase + (nt * KV + k) * 16;
@@ -165,10 +171,6 @@ __device__ __forceinline__ void thin_layer(const PhaseCtx& c, const RowU& r, int
         for (int k = 4; k < K; ++k) acc += vec(nt, k) * input(k);
         if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         ((LDS_AS f32x4*)c.abuf)[(r.tile0 + nt) * 64 + lane] = acc;
-        if (st) {
-            GLOBAL_AS float* op = c.out_thin + ((size_t)c.row0 * c.WT + r.wcol + 16 * nt) + (m * c.WT + 4 * kq);
-            __builtin_nontemporal_store(acc, (GLOBAL_AS f32x4*)op);
-        }
     }
 }
 
@@ -253,7 +255,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         act[j] = v;
         if (HINT_STORE_ON) {
             GLOBAL_AS float* o = c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq);
-            if (KIND == K_FWD) __builtin_nontemporal_store(v, (GLOBAL_AS f32x4*)o);
+            if (KIND == K_FWD) HINT_TAPE_STORE(v, (GLOBAL_AS f32x4*)o);
             else *(GLOBAL_AS f32x4*)o = v;
         }
     }
@@ -282,9 +284,20 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     STAMP(c.sid + 12)
 }
 
-// One GEMM phase of one wavefront: records [r0, r1) of this direction's record list.
+// One GEMM phase of one wavefront: records [r0, r1) of this direction's record list, in two calls so that the
+// first row's weight stream can be started a phase early (its loads do not depend on the element-wise phase
+// in between): rows_begin() primes the ring, rows_run() executes the rows.
 template <int KIND>
-__device__ __forceinline__ void run_rows(const PhaseCtx& c, int r0, int r1, int lane) {
+__device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int lane) {
+    if (r0 >= r1) return;
+    LaneOff lo;
+    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.m = (unsigned)((lane & 15) * c.WT + 4 * (lane >> 4)) * 4u;
+    const RowU cr = decode_rec(load_rec(c.recs, r0));
+#pragma unroll
+    for (int s = 0; s < RING; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
+}
+template <int KIND>
+__device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int lane) {
     if (r0 >= r1) return;
     const int m = lane & 15, kq = lane >> 4;
     LaneOff lo;
@@ -292,10 +305,6 @@ __device__ __forceinline__ void run_rows(const PhaseCtx& c, int r0, int r1, int 
 
     RowU cr = decode_rec(load_rec(c.recs, r0));
     i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : r0);               // next row's record, one row ahead
-    f32x4 ring[RING][NEL];
-#pragma unroll
-    for (int s = 0; s < RING; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
-
     for (int t = r0; t < r1; ++t) {
         const RowU nr = decode_rec(nrec);                                      // (the last row: its own record again)
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : r1 - 1);
@@ -309,6 +318,19 @@ __device__ __forceinline__ void run_rows(const PhaseCtx& c, int r0, int r1, int 
         else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
         else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
         cr = nr;
+    }
+    if (KIND == K_FWD && HINT_STORE_ON) {
+        // training: the a1 tiles of the units whose first row ran here go to the tape now, from LDS, behind
+        // everything the rows had to wait for (stores retire in order with the loads of the weight stream)
+        const LDS_AS f32x4* abuf4 = (const LDS_AS f32x4*)c.abuf + lane;
+        for (int t = r0; t < r1; ++t) {
+            const RowU r = decode_rec(load_rec(c.recs, t));
+            if (!r.first) continue;
+            for (int nt = 0; nt < r.NT; ++nt) {
+                GLOBAL_AS float* op = c.out_thin + ((size_t)c.row0 * c.WT + r.wcol + 16 * nt) + (m * c.WT + 4 * kq);
+                HINT_TAPE_STORE(abuf4[(r.tile0 + nt) * 64], (GLOBAL_AS f32x4*)op);
+            }
+        }
     }
 }
 
