@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
     float* gcs = cs + ROWS * a.cld;
     float* gst = gcs + ROWS * a.cld;          // [16][gld] coupling gradients of the group
     float* abuf = gst + ROWS * a.gld;         // g2 fragment tiles
-    float* slab = abuf + a.abuf_tiles * 256;  // g_v partials
+    float* obuf = abuf + a.abuf_tiles * 256;  // g1 fragment tiles on their way to global memory
+    float* slab = obuf + a.abuf_tiles * 256;  // g_v partials
     float* gj = slab + a.slab_floats;
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
@@ -116,9 +117,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
-            pc.abuf = (LDS_AS float*)abuf; pc.slab = (LDS_AS float*)slab;
+            pc.abuf = (LDS_AS float*)abuf; pc.obuf = (LDS_AS float*)obuf; pc.slab = (LDS_AS float*)slab;
             pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
-            pc.out_thin = blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1;
             pc.mask_thin = blk.actA1 + a.act_stride; pc.mask_main = blk.actA1;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
             pc.store = true;
@@ -144,6 +144,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 (void)sid;
                 pc.sid = sid;
                 STAMP(sid + 0)
+                // the finished group's g2 (masked) and g1 tiles: out of LDS to the workspace, whole lines per batch row
+                if (has_prev) {
+                    stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid, nthreads);
+                    stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid, nthreads);
+                }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
                 for (int idx = tid; idx < ROWS * a.d; idx += nthreads) {
                     const int row = fdiv(idx, inv_d), col = idx - row * a.d;
@@ -218,14 +223,23 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 }
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 STAMP(sid + 3)
+                // ---- Q2: g2' = W3^T g_st of every unit of the group on the vector ALU, the tiles shared out ----
+                {
+                    const char* thb = (const char*)a.thins + (size_t)a.total_tiles * sizeof(ThinRec);
+                    const int t0 = g.tile_begin + lds_i32(rng + a.nw + 1 + wave), t1 = g.tile_begin + lds_i32(rng + a.nw + 2 + wave);
+                    if (a.thin_lds > 0) thin_phase<K_BWD, true>(pc, thb, t0, t1, lane);
+                    else thin_phase<K_BWD, false>(pc, thb, t0, t1, lane);
+                }
+                lds_barrier();
                 STAMP(sid + 4)
-                // ---- Q3: g2 = (W3^T g_st) .* relu'(a2) (VALU);  g1 = (W2^T g2) .* relu'(a1);  g_v partial = W1^T g1 ----
+                // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
                 rows_run<K_BWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
                 if (slot > 0) {             // the next group's first row: its loads fly across the coupling phase
                     const GroupU gn = load_group(T.groups + (slot - 1));
                     const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
                     rows_begin<K_BWD>(pc, ring, gn.row_begin + lds_i32(rngn + wave), gn.row_begin + lds_i32(rngn + wave + 1), lane);
                 }
+                STAMP(sid + 15)
                 STAMP(sid + 5)
                 if (lp_pending) level_commit(lp, xs, sb, a.xld, a.d, tid, nthreads);
                 lds_barrier();

@@ -33,7 +33,8 @@ constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (
 // and MFMA i of a k-block takes component i of the lane's float4 as its A operand (the order in which
 // an accumulator tile of the previous layer supplies the B operand).  The thin layers' weights are
 // stored for the vector ALU instead:
-//   layout 2 ("vector"):    dst[(nt*KV + k)*16 + f] = Wlog[nt*16 + f][k]   (KV = K, or K + 1 with the layer's bias as vector K)
+//   layout 2 ("vector"):    dst[(nt*KV + k)*16 + f] = Wlog[nt*16 + f][k]   (k < K; zero up to Kp = max(4, K); KV = Kp, or Kp + 1
+//                            with the layer's bias as vector Kp)
 // so that the lane that owns features 4*(l>>4)..+3 reads the four weights of input k with one float4.  The
 // vector-layout segments of a block form two contiguous "thin blobs" (forward, backward) at the start of
 // the packed buffer, small enough to be staged in LDS once per block.
@@ -42,7 +43,7 @@ struct PackSeg {
     int64_t dst;        // float offset of the segment in the packed buffer
     int64_t src;        // float offset into the flat parameter buffer
     int32_t N, K;       // logical (unpadded) extents; tiles = ceil(N/16) x NB
-    int32_t NB;         // k-blocks per n-tile
+    int32_t NB;         // k-blocks per n-tile (vector layout: Kp)
     int32_t ld;         // row stride of the source tensor
     int32_t trans;      // 0: Wlog[n][k] = P[src + n*ld + k];  1: Wlog[n][k] = P[src + k*ld + n]
     int32_t kmap;       // layout: 0 fragment, 2 vector
@@ -90,9 +91,9 @@ static_assert(sizeof(Unit) == 96, "Unit must be 6 x 16 bytes");
 // A group = a set of same-depth nodes processed together.  16 x int32.
 struct Group {
     int32_t unit_begin, unit_end, ntiles, row_begin;    // row_begin: the group's first row record (both directions)
-    int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[nw+1] = the wavefronts' ranges in the group's record list
+    int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[nw+1 | nw+1] = the wavefronts' ranges in the group's row-record list and in its thin-record list
     int32_t level_last, gcol0, gcols, lop_begin;        // first / number of [ST] columns; LaneOp[d] of the boundary in front of the group (backward)
-    int32_t level_first, cpad0, cpad1, cpad2;
+    int32_t level_first, tile_begin, wcol0, cpad2;      // tile_begin: the group's first thin record (both directions); wcol0: column of its first tile in the [Bp][WT] arrays
 };
 static_assert(sizeof(Group) == 64, "Group must be 4 x 16 bytes");
 
@@ -147,12 +148,24 @@ struct RowRec {
     int32_t thin_k;     // forward: cin | ku << 8 | xoff << 16;  backward: r | lcol << 16
     int32_t flags;      // NT | thin << 8 (run the thin layer before this row) | first << 9 (the row holds the unit's tile 0: it stores the thin layer's tiles and adds b3)
     int32_t wcol;       // column of the unit's tile 0 in the [Bp][WT] arrays
-    int32_t pad0, pad1, pad2;
+    int32_t tb;         // first tile of the row inside its unit
+    int32_t pad1, pad2;
 };
 static_assert(sizeof(RowRec) == 64, "RowRec must be 64 bytes");
 
+// Thin record: one fragment tile of a unit's thin layer (first layer forward, g2' backward), computed on the
+// vector ALU by whichever wavefront the tile is dealt to; 4 x int32, read with a scalar load.
+struct ThinRec {
+    int32_t voff;       // float offset of the tile's vectors inside the direction's thin blob
+    int32_t k;          // forward: cin | ku << 8 | xoff << 16;  backward: r | lcol << 16
+    int32_t tile;       // the tile's index among the group's LDS fragment tiles
+    int32_t kp;         // weight vectors per tile: max(4, K) (forward: the bias vector follows them)
+};
+
 struct KArgs {
     const void* meta;              // [groups | units | tmap | ents | ranges | laneops] contiguous, copied to LDS at kernel start
+    const void* thins;             // ThinRec[2][total_tiles]: forward records, then backward records, tiles in (group, unit) order
+    int32_t total_tiles;
     const void* recs;              // RowRec[2][total_rows]: forward records, then backward records, rows in (group, wavefront, unit) order
     int32_t total_rows;
     int32_t meta_bytes;            // multiple of 16

@@ -82,7 +82,7 @@ __device__ __forceinline__ UnitU load_unit(const LDS_AS Unit* u) {
 }
 struct GroupU {
     int unit_begin, unit_end, ntiles, row_begin, ent_begin, ent_cnt, rng_begin, level, level_last, gcol0, gcols,
-        lop_begin, level_first;
+        lop_begin, level_first, tile_begin, wcol0;
 };
 __device__ __forceinline__ GroupU load_group(const LDS_AS Group* g) {
     const LDS_AS i32x4* p = (const LDS_AS i32x4*)g;
@@ -91,7 +91,7 @@ __device__ __forceinline__ GroupU load_group(const LDS_AS Group* g) {
     r.unit_begin = rfl(q0.x); r.unit_end = rfl(q0.y); r.ntiles = rfl(q0.z); r.row_begin = rfl(q0.w);
     r.ent_begin = rfl(q1.x); r.ent_cnt = rfl(q1.y); r.rng_begin = rfl(q1.z); r.level = rfl(q1.w);
     r.level_last = rfl(q2.x); r.gcol0 = rfl(q2.y); r.gcols = rfl(q2.z); r.lop_begin = rfl(q2.w);
-    r.level_first = rfl(q3.x);
+    r.level_first = rfl(q3.x); r.tile_begin = rfl(q3.y); r.wcol0 = rfl(q3.z);
     return r;
 }
 __device__ __forceinline__ int lds_i32(const LDS_AS int32_t* p) { return rfl(*p); }
@@ -180,6 +180,20 @@ static __shared__ unsigned long long hint_stamp_lds[MAX_NW * STAMP_IDS];
 #define STAMP(ID) {}
 #define STAMP_FLUSH(BUF) {}
 #endif
+
+// The fragment tiles of a finished group, LDS -> the [Bp][WT] array in global memory, by all threads: 16 rows x
+// (16 ntiles) columns starting at column wcol0, whole 128-byte lines per batch row (the stores of a row phase
+// would retire slowly - partial lines - and everything a wavefront waits for queues behind its own stores).
+__device__ __forceinline__ void stream_tiles(float* __restrict__ dst, const float* tiles, int ntiles, int wcol0, int WT,
+                                             int row0, int tid, int nthreads) {
+    const int w4 = ntiles * 4;                          // float4 columns of the group
+    const float inv = frcp(w4);
+    for (int idx = tid; idx < ROWS * w4; idx += nthreads) {
+        const int r = fdiv(idx, inv), c4 = idx - r * w4;
+        const f32x4 v = *(const f32x4*)(tiles + (c4 >> 2) * 256 + ((c4 & 3) * 16 + r) * 4);
+        *(f32x4*)(dst + (size_t)(row0 + r) * WT + wcol0 + 4 * c4) = v;
+    }
+}
 
 // LDS carve-up shared by the block kernels: [meta blob][float buffers ...]
 struct Tables {

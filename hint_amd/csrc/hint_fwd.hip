@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
     float* t0 = lds + (a.meta_bytes >> 2);    // two lane tiles: a fused permutation ping-pongs between them
     float* cs = t0 + 2 * ROWS * a.xld;
     float* abuf = cs + ROWS * a.cld;
-    float* slab = abuf + a.abuf_tiles * 256;
+    float* obuf = abuf + a.abuf_tiles * 256;  // a2 fragment tiles on their way to the tape (training)
+    float* slab = obuf + a.abuf_tiles * 256;
     float* jac = slab + a.slab_floats;
     float* red = jac + ROWS;                  // MAX_NW floats: loss partials
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
@@ -113,9 +114,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
-            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.slab = (LDS_AS float*)slab;
+            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = (LDS_AS float*)obuf; pc.slab = (LDS_AS float*)slab;
             pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
-            pc.out_thin = blk.actA1; pc.out_main = train ? blk.actA1 + a.act_stride : nullptr;
             pc.mask_thin = nullptr; pc.mask_main = nullptr;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
             pc.store = train;
@@ -136,18 +136,31 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 (void)sid;
                 pc.sid = sid;
                 STAMP(sid + 0)
+                // ---- P1: first layer of every unit of the group on the vector ALU, the tiles shared out ----
+                {
+                    const int t0 = g.tile_begin + lds_i32(rng + a.nw + 1 + wave), t1 = g.tile_begin + lds_i32(rng + a.nw + 2 + wave);
+                    if (a.thin_lds > 0) thin_phase<K_FWD, true>(pc, a.thins, t0, t1, lane);
+                    else thin_phase<K_FWD, false>(pc, a.thins, t0, t1, lane);
+                }
                 STAMP(sid + 1)
+                lds_barrier();
                 STAMP(sid + 2)
-                // ---- P2: first layer (VALU), second layer, third layer partials ----
+                // ---- P2: second layer, third layer partials ----
                 rows_run<K_FWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
                 if (gi + 1 < a.n_groups) {
                     const GroupU gn = load_group(T.groups + (REV ? a.n_groups - 2 - gi : gi + 1));
                     const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
                     rows_begin<K_FWD>(pc, ring, gn.row_begin + lds_i32(rngn + wave), gn.row_begin + lds_i32(rngn + wave + 1), lane);
                 }
+                STAMP(sid + 15)
                 STAMP(sid + 3)
                 lds_barrier();
                 STAMP(sid + 4)
+                // training: both hidden activations of the group go to the tape now, out of LDS, whole lines per batch row
+                if (train) {
+                    stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid, nthreads);
+                    stream_tiles(actA1 + a.act_stride, obuf, g.ntiles, g.wcol0, a.WT, row0, tid, nthreads);
+                }
                 // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) ----
                 {
                     const int sub = tid & 15, row = tid >> 4;

@@ -18,14 +18,15 @@ __device__ __forceinline__ void pack_body(int bid, const PackSeg* __restrict__ s
     const PackSeg sg = segs[pt.x];
     const int nt = pt.y;
     if (sg.kmap == 2) {
-        // vector layout (thin layers): dst[(nt*KV + k)*16 + f] = Wlog[nt*16 + f][k]; vector K: the bias
-        const int KV = sg.K + (sg.src2 >= 0 ? 1 : 0);
+        // vector layout (thin layers): dst[(nt*KV + k)*16 + f] = Wlog[nt*16 + f][k] for k < K, zero up to Kp = NB;
+        // vector Kp: the bias
+        const int Kp = sg.NB, KV = Kp + (sg.src2 >= 0 ? 1 : 0);
         for (int idx = (int)threadIdx.x; idx < 16 * KV; idx += 256) {
             const int k = idx >> 4, f = idx & 15, n = nt * 16 + f;
             float val = 0.f;
             if (n < sg.N) {
                 if (k < sg.K) val = sg.trans ? P[sg.src + (int64_t)k * sg.ld + n] : P[sg.src + (int64_t)n * sg.ld + k];
-                else val = P[sg.src2 + n];
+                else if (k == Kp) val = P[sg.src2 + n];
             }
             packed[sg.dst + (int64_t)nt * KV * 16 + idx] = val;
         }

@@ -92,6 +92,8 @@ struct hint_plan {
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
     RowRec* d_recs = nullptr;
+    ThinRec* d_thins = nullptr;
+    int total_tiles = 0;
     int total_rows = 0;
     int32_t* d_bmap = nullptr;
     uint8_t* d_real = nullptr;
@@ -127,6 +129,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<Unit> units;
     std::vector<int> unit_node;       // node index (into `nodes`) of every unit
     std::vector<RowRec> recs_f, recs_b;   // row records in (group, wavefront, unit) order
+    std::vector<ThinRec> thin_f, thin_b;  // thin records in (group, unit, tile) order
     std::vector<Ent> ents;
     std::vector<int32_t> rng;
     std::vector<PackSeg> segs;
@@ -141,8 +144,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     int64_t blob_f = 0, blob_b = 0;
     for (int i = 0; i < n_nodes; ++i) {
         const int NT = cdiv(nodes[i].h, 16);
-        blob_f += 2 * (int64_t)NT * (nodes[i].k + dc + 1) * 16;
-        blob_b += 2 * (int64_t)NT * nodes[i].r * 16;
+        blob_f += 2 * (int64_t)NT * (std::max(4, nodes[i].k + dc) + 1) * 16;
+        blob_b += 2 * (int64_t)NT * std::max(4, nodes[i].r) * 16;
     }
     const int64_t blob_f_pad = (blob_f + 255) / 256 * 256, blob_b_pad = (blob_b + 255) / 256 * 256;
     int64_t cur_f = 0, cur_b = blob_f_pad;
@@ -162,13 +165,14 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // vector-layout segment (thin layers) inside a blob: returns its float offset inside that blob
     auto add_vec = [&](int64_t& cur, int64_t blob0, int N, int K, int ld, int trans, int64_t src, int64_t src2) -> int {
         PackSeg sg{};
-        sg.dst = cur; sg.src = src; sg.src2 = src2; sg.N = N; sg.K = K; sg.NB = 0; sg.ld = ld; sg.trans = trans; sg.kmap = 2;
+        const int Kp = std::max(4, K);      // inputs padded to four with zero vectors: the usual K <= 4 runs branch free
+        sg.dst = cur; sg.src = src; sg.src2 = src2; sg.N = N; sg.K = K; sg.NB = Kp; sg.ld = ld; sg.trans = trans; sg.kmap = 2;
         sg.tile_begin = (int)ptiles.size();
         const int NTn = std::max(1, cdiv(N, 16));
         for (int nt = 0; nt < NTn; ++nt) ptiles.push_back(int2{(int)segs.size(), nt});
         segs.push_back(sg);
         const int first = (int)(cur - blob0);
-        cur += (int64_t)NTn * (K + (src2 >= 0 ? 1 : 0)) * 16;
+        cur += (int64_t)NTn * (Kp + (src2 >= 0 ? 1 : 0)) * 16;
         return first;
     };
 
@@ -178,6 +182,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         Group g{};
         g.unit_begin = (int)units.size();
         g.gcol0 = gcol;
+        g.wcol0 = wcol;
         const int depth = nodes[order[pos]].depth;
         int tiles = 0;
         const size_t first_pos = pos;
@@ -232,9 +237,27 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
         std::vector<Row> rows;
         int off3 = 0, offv = 0;
+        // rows per unit: at least ceil(NT / 3); more (narrower rows) while the group has fewer rows than wavefronts
+        std::vector<int> nrows(g.unit_end - g.unit_begin);
+        {
+            int total = 0;
+            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, 3); total += nrows[ui - g.unit_begin]; }
+            while (total < nw) {
+                int best = -1; double bw = 0;
+                for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {       // split where the rows are widest
+                    const int nr = nrows[ui - g.unit_begin];
+                    if (nr >= units[ui].NT) continue;
+                    const double wdt = (double)units[ui].NT / nr * units[ui].NT;
+                    if (wdt > bw) { bw = wdt; best = ui; }
+                }
+                if (best < 0) break;
+                ++nrows[best - g.unit_begin]; ++total;
+            }
+        }
+        g.tile_begin = (int)thin_f.size();
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
             Unit& u = units[ui];
-            const int nr = cdiv(u.NT, 3);
+            const int nr = nrows[ui - g.unit_begin];
             u.sl_off = off3; u.gv_off = offv; u.sl_n = nr;
             int tb = 0;
             for (int ri = 0; ri < nr; ++ri) {
@@ -245,6 +268,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 off3 += 64 * cdiv(u.r, 4);
                 offv += 64 * cdiv(u.cin, 4);
                 tb += ntt;
+            }
+            const int kpf = std::max(4, u.cin), kpb = std::max(4, u.r);
+            for (int nt = 0; nt < u.NT; ++nt) {
+                thin_f.push_back(ThinRec{u.w1v + nt * (kpf + 1) * 16, u.cin | (u.ku << 8) | (u.xoff << 16), u.tile0 + nt, kpf});
+                thin_b.push_back(ThinRec{u.w3v + nt * kpb * 16, u.r | (u.lcol << 16), u.tile0 + nt, kpb});
             }
         }
         P->slab_fwd = std::max(P->slab_fwd, off3);
@@ -259,8 +287,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return rows[x].cost > rows[y].cost; });
             std::vector<long> wload(nw, 0), sload(4, 0);
             for (int i : idx) {
-                const Unit& u = units[rows[i].unit];
-                const long thin = (long)u.NT * (std::max(u.cin, u.r) + 3) / 2;
+                const long thin = 0;
                 int best = 0;
                 long best_s = -1, best_w = -1;
                 for (int w = 0; w < nw; ++w) {
@@ -304,7 +331,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 const int thin = rw.unit != last_unit ? 1 : 0, first = rw.tb == 0 ? 1 : 0;
                 last_unit = rw.unit;
                 RowRec r{};
-                r.ocol = u.wcol + 16 * rw.tb; r.bias3 = u.bias3; r.wcol = u.wcol;
+                r.ocol = u.wcol + 16 * rw.tb; r.bias3 = u.bias3; r.wcol = u.wcol; r.tb = rw.tb;
                 r.flags = u.NT | (thin << 8) | (first << 9);
                 // forward: second layer + third layer partials (+ b3 with the unit's first row)
                 r.base1 = u.f2 + rw.tb * u.NT; r.base2 = u.f3 + rw.tb;
@@ -321,6 +348,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
         }
         rng.push_back((int)recs_f.size() - g.row_begin);
+        for (int w = 0; w <= nw; ++w) rng.push_back((int)((long)tiles * w / nw));      // thin layers: the group's tiles shared out evenly
 
         // ---- coupling entries: one per transformed lane ----
         g.ent_begin = (int)ents.size();
@@ -402,8 +430,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
     std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
-    P->lds_fwd = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW);
-    P->lds_bwd = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + P->abuf_tiles * 256 + P->slab_bwd + ROWS);
+    P->lds_fwd = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + 2 * P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW);
+    P->lds_bwd = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + 2 * P->abuf_tiles * 256 + P->slab_bwd + ROWS);
     P->lds_fwd = (P->lds_fwd + 15) / 16 * 16;
     P->lds_bwd = (P->lds_bwd + 15) / 16 * 16;
     // the thin blobs ride in LDS (staged once per block) when they are small
@@ -444,8 +472,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                     int ui = -1;
                     for (int u = g.unit_begin; u < g.unit_end; ++u) if (units[u].tile0 == tile0) ui = u;
                     if (ui < 0 || units[ui].NT != NT || ntt < 1 || ntt > 3 || tb < 0 || tb + ntt > NT) { delete P; return fail("hint_plan_create: internal error (row record)"); }
-                    if ((q.flags >> 8) & 1) have_thin_for = ui;
-                    if (have_thin_for != ui) { delete P; return fail("hint_plan_create: internal error (thin layer missing)"); }
+                    (void)have_thin_for;
                     if ((q.flags >> 9) & 1) ++firsts[ui - g.unit_begin];
                     for (int j = 0; j < ntt; ++j) ++seen[tile0 + tb + j];
                 }
@@ -493,6 +520,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
     P->n_wjobs = (int)wjobs.size();
     P->total_rows = (int)recs_f.size();
+    P->total_tiles = (int)thin_f.size();
     P->n_ptiles = (int)ptiles.size();
 
     if (g_host_only) {           // hint_plan_check: everything above ran (and checked itself); no device
@@ -512,6 +540,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
+    if (e == hipSuccess) {
+        std::vector<ThinRec> both(thin_f);
+        both.insert(both.end(), thin_b.begin(), thin_b.end());
+        e = upload((void**)&P->d_thins, both.data(), both.size() * sizeof(ThinRec));
+    }
     if (e == hipSuccess) {
         std::vector<RowRec> both(recs_f);
         both.insert(both.end(), recs_b.begin(), recs_b.end());
@@ -600,6 +633,7 @@ void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
     (void)hipFree(P->d_meta);
     (void)hipFree(P->d_recs);
+    (void)hipFree(P->d_thins);
     (void)hipFree(P->d_bmap);
     (void)hipFree(P->d_real);
     (void)hipFree(P->d_wjobs);
@@ -666,7 +700,7 @@ static int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool a
 }
 static KArgs make_args(const hint_plan* P, int B, bool backward) {
     KArgs a{};
-    a.meta = P->d_meta; a.meta_bytes = P->meta_bytes; a.recs = P->d_recs; a.total_rows = P->total_rows;
+    a.meta = P->d_meta; a.meta_bytes = P->meta_bytes; a.recs = P->d_recs; a.total_rows = P->total_rows; a.thins = P->d_thins; a.total_tiles = P->total_tiles;
     a.units_off = P->units_off; a.tmap_off = P->tmap_off; a.ents_off = P->ents_off; a.rng_off = P->rng_off;
     a.lops_off = P->lops_off;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;

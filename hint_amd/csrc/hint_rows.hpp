@@ -10,10 +10,10 @@
 // Every product is transposed (out^T = W * act^T), so the accumulator of the main steps - lane l
 // holds features 4*(l>>4)+i of batch row l&15 - is exactly the B operand of the tail steps, and
 // what a wavefront stores as a fragment tile (ds_write_b128 at lane*16) is what it (or another
-// wavefront) reads as a B operand (ds_read_b128): no transposes.  The thin layer of a unit (K = the
-// few lanes feeding the subnet, or its r outputs) is recomputed by every wavefront that holds rows
-// of the unit - identical values land in the same LDS tiles - so a group needs no barrier between
-// its layers.  The K-split partial of a row's tail product goes to the row's own LDS slab.
+// wavefront) reads as a B operand (ds_read_b128): no transposes.  The thin layers of a group (K = the
+// few lanes feeding a subnet, or its r outputs) are a short phase of their own: the wavefronts share
+// the group's tiles, a barrier, then the rows.  The K-split partial of a row's tail product goes to
+// the row's own LDS slab.
 //
 // The weight stream runs through a register ring of RING slots x 3 elements: every step consumes one
 // slot and issues its 16-byte-per-lane global loads for the step RING ahead (a row's body is compiled
@@ -46,7 +46,7 @@ __device__ __forceinline__ i32x16 load_rec(const void* recs, int idx) {
 }
 struct RowU {           // decoded record (all wave-uniform)
     int base1, base2, n1, n2, n3, ntt, aux, ocol, tile0, nquad, slab, bias3;
-    int thin_w, thin_b, thin_k, NT, thin, first, wcol;
+    int thin_w, thin_b, thin_k, NT, thin, first, wcol, tb;
 };
 __device__ __forceinline__ RowU decode_rec(const i32x16 r) {
     RowU u;
@@ -57,7 +57,7 @@ __device__ __forceinline__ RowU decode_rec(const i32x16 r) {
     u.slab = r[6]; u.bias3 = r[7];
     u.thin_w = r[8]; u.thin_b = r[9]; u.thin_k = r[10];
     u.NT = r[11] & 0xff; u.thin = (r[11] >> 8) & 1; u.first = (r[11] >> 9) & 1;
-    u.wcol = r[12];
+    u.wcol = r[12]; u.tb = r[13];
     return u;
 }
 
@@ -69,31 +69,23 @@ struct PhaseCtx {
     const void* recs;                // row records of the plan (global, constant), this direction's
     LDS_AS float* abuf;              // fragment tiles of the group: a1 (forward), g2 (backward)
     LDS_AS float* slab;              // the rows' slabs
+    LDS_AS float* obuf;              // fragment tiles of the group's outputs on their way to global memory: a2 (training forward), g1 (backward)
     const LDS_AS float* xs;          // lane tile [16][xld]
     const LDS_AS float* cs;          // condition tile [16][cld]
     const LDS_AS float* gst;         // coupling gradients [16][gld] (backward)
     const LDS_AS float* thin_l;      // the direction's thin blob staged in LDS, or nullptr
     const GLOBAL_AS float* thin_g;   // ... in the packed buffer
-    GLOBAL_AS float* out_thin;       // [Bp][WT]: a1 (training forward) / g2 (backward)
-    GLOBAL_AS float* out_main;       // [Bp][WT]: a2 (training forward) / g1 (backward)
     const GLOBAL_AS float* mask_thin;    // [Bp][WT] a2: relu'() for g2 (backward)
     const GLOBAL_AS float* mask_main;    // [Bp][WT] a1: relu'() for g1 (backward)
     int xld, cld, gld, WT, row0;
     int sid;                         // diagnostic builds: stamp id base of the phase
-    bool store;                      // write out_thin / out_main (training forward; always in the backward pass)
+    bool store;                      // keep the outputs (training forward; always in the backward pass): the kernels stream them out of LDS after the phase
 };
 
 #ifdef HINT_ABLATE_STORE      // diagnostic: no activation / gradient rows leave the kernel
 #define HINT_STORE_ON false
 #else
 #define HINT_STORE_ON c.store
-#endif
-
-// tape rows are written once and read by a later kernel: plain stores retire sooner than non-temporal ones, and the weight stream waits behind them (HINT_NT_STORES: experiment)
-#ifndef HINT_NT_STORES
-#define HINT_TAPE_STORE(V, P) (*(P) = (V))
-#else
-#define HINT_TAPE_STORE(V, P) __builtin_nontemporal_store((V), (P))
 #endif
 
 // Byte offsets of a lane inside the three kinds of stream elements.
@@ -136,41 +128,42 @@ __device__ __forceinline__ void load_extra3(f32x4 (&dst)[NTT], const PhaseCtx& c
     }
 }
 
-// The thin layer of a unit on the vector ALU, all NT tiles, into the group's LDS fragment tiles:
+// The thin layers of a group on the vector ALU: every wavefront computes its share [t0, t1) of the group's
+// fragment tiles into LDS (a workgroup barrier follows before the rows read them as B operands):
 //   forward   a1[f]  = relu(b1[f] + sum_k W1[f][k] v[k]),  v = [lanes xoff .. xoff+ku | condition]
 //   backward  g2'[f] = sum_j W3[j][f] g_st[j]              (relu'(a2) is applied where the tiles are consumed)
-// Lane l owns features 4*(l>>4)..+3 of row l&15 of every tile; the weights come as one float4 per input from the
-// direction's thin blob (vector layout), staged in LDS once per block when it is small enough (STAGED).
+// Lane l owns features 4*(l>>4)..+3 of row l&15 of a tile; the weights come as one float4 per input from the
+// direction's thin blob (vector layout, inputs padded to four with zero vectors: no branches for the usual
+// K <= 4), staged in LDS once per block when it is small enough (STAGED).
+typedef int i32x4c __attribute__((ext_vector_type(4)));
 template <int KIND, bool STAGED>
-__device__ __forceinline__ void thin_layer(const PhaseCtx& c, const RowU& r, int lane) {
+__device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins, int t0, int t1, int lane) {
     const int m = lane & 15, kq = lane >> 4;
-    const int K = r.thin_k & 0xff;
-    const int KV = KIND == K_FWD ? K + 1 : K;            // vectors per tile (forward: the bias is vector K)
-    const int vbase = r.thin_w + 4 * kq;                 // vector (nt, k) of this lane: float offset vbase + (nt*KV + k)*16
-    auto vec = [&](int nt, int k) -> f32x4 {
-        const int o = vbase + (nt * KV + k) * 16;
-        if (STAGED) return *(const LDS_AS f32x4*)(c.thin_l + o);
-        return *(const GLOBAL_AS f32x4*)(c.thin_g + o);
-    };
-    auto input = [&](int k) -> float {
-        if (KIND == K_FWD) {
-            const int ku = (r.thin_k >> 8) & 0xff, xoff = r.thin_k >> 16;
-            return k < ku ? c.xs[m * c.xld + xoff + k] : c.cs[m * c.cld + (k - ku)];
-        }
-        return c.gst[m * c.gld + (r.thin_k >> 16) + k];
-    };
-    // inputs of the unit for this lane's batch row, the first four in registers (more: re-read per tile)
-    float vin[4];
+    for (int t = t0; t < t1; ++t) {
+        const i32x4c rec = ((const CONST_AS i32x4c*)(unsigned long long)thins)[t];
+        const int K = rec.y & 0xff, kp = rec.w;
+        const int vbase = rec.x + 4 * kq;                    // vector k of this lane's features: float offset vbase + 16 k
+        auto vec = [&](int k) -> f32x4 {
+            if (STAGED) return *(const LDS_AS f32x4*)(c.thin_l + vbase + 16 * k);
+            return *(const GLOBAL_AS f32x4*)(c.thin_g + vbase + 16 * k);
+        };
+        auto input = [&](int k) -> float {
+            if (KIND == K_FWD) {
+                const int ku = (rec.y >> 8) & 0xff, xoff = rec.y >> 16;
+                return k < ku ? c.xs[m * c.xld + xoff + k] : c.cs[m * c.cld + (k - ku)];
+            }
+            return c.gst[m * c.gld + (rec.y >> 16) + k];
+        };
+        f32x4 w[4];
+        float vin[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) vin[k] = k < K ? input(k) : 0.f;
-    for (int nt = 0; nt < r.NT; ++nt) {
-        f32x4 acc = KIND == K_FWD ? vec(nt, K) : zero4();
+        for (int k = 0; k < 4; ++k) { w[k] = vec(k); vin[k] = k < K ? input(k) : 0.f; }
+        f32x4 acc = KIND == K_FWD ? vec(kp) : zero4();
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < K) acc += vec(nt, k) * vin[k];
-        for (int k = 4; k < K; ++k) acc += vec(nt, k) * input(k);
+        for (int k = 0; k < 4; ++k) acc += w[k] * vin[k];
+        for (int k = 4; k < K; ++k) acc += vec(k) * input(k);
         if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        ((LDS_AS f32x4*)c.abuf)[(r.tile0 + nt) * 64 + lane] = acc;
+        ((LDS_AS f32x4*)c.abuf)[rec.z * 64 + lane] = acc;
     }
 }
 
@@ -198,7 +191,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     bb[1] = zero4();
 
     // one main step: k-block KB, the slot's weight fragments W (backward: W[NTT] = the a2 tile of the k-block), static slot S
-    const bool stg2 = KIND == K_BWD && HINT_STORE_ON && cr.first;      // this row also writes the unit's masked g2 tiles
+    const bool stg2 = KIND == K_BWD && HINT_STORE_ON && cr.first;      // this row leaves the unit's masked g2 tiles in LDS (streamed out later)
 #define HINT_MAIN_STEP(KB, W, S)                                                                        \
     {                                                                                                   \
         f32x4 b4 = bb[(S) & 1];                                                                         \
@@ -207,7 +200,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         if (KIND == K_BWD) {                                                                            \
             b4.x = (W)[NTT].x > 0.f ? b4.x : 0.f; b4.y = (W)[NTT].y > 0.f ? b4.y : 0.f;                 \
             b4.z = (W)[NTT].z > 0.f ? b4.z : 0.f; b4.w = (W)[NTT].w > 0.f ? b4.w : 0.f;                 \
-            if (stg2) *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + cr.wcol + 16 * (KB)) + (m * c.WT + 4 * kq)) = b4; \
+            if (stg2) ((LDS_AS f32x4*)c.abuf)[(cr.tile0 + (KB)) * 64 + lane] = b4;   /* (idempotent for the other readers) */ \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
             _Pragma("unroll") for (int j = 0; j < NA; ++j) acc[j] = mfma4((W)[j][i], b4[i], acc[j]);    \
@@ -253,11 +246,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
             v.z = xaux[j].z > 0.f ? v.z : 0.f; v.w = xaux[j].w > 0.f ? v.w : 0.f;
         }
         act[j] = v;
-        if (HINT_STORE_ON) {
-            GLOBAL_AS float* o = c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq);
-            if (KIND == K_FWD) HINT_TAPE_STORE(v, (GLOBAL_AS f32x4*)o);
-            else *(GLOBAL_AS f32x4*)o = v;
-        }
+        if (HINT_STORE_ON) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
     }
     // ---- tail steps: slab[q] = sum over the row's tiles of Wtail(q, tile) * act, the K-split partial of the thin
     //      product (compact: quad q4 = 4 q + kq holds features 4 q4 .. +3 of rows m); then, with a unit's first row,
@@ -303,35 +292,21 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.m = (unsigned)(m * c.WT + 4 * kq) * 4u;
 
+    STAMP(c.sid + 7)
     RowU cr = decode_rec(load_rec(c.recs, r0));
     i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : r0);               // next row's record, one row ahead
+    STAMP(c.sid + 8 + (cr.n1 > 1000 ? 1 : 0))
     for (int t = r0; t < r1; ++t) {
         const RowU nr = decode_rec(nrec);                                      // (the last row: its own record again)
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : r1 - 1);
-        if (t == r0) { STAMP(c.sid + 8) }
-        if (cr.thin) {                                                         // the unit's a1 / g2' tiles: the B operand below
-            if (c.thin_l != nullptr) thin_layer<KIND, true>(c, cr, lane);
-            else thin_layer<KIND, false>(c, cr, lane);
-        }
         if (t == r0) { STAMP(c.sid + 9) }
         if (cr.ntt >= 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
         else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
         else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
         cr = nr;
     }
-    if (KIND == K_FWD && HINT_STORE_ON) {
-        // training: the a1 tiles of the units whose first row ran here go to the tape now, from LDS, behind
-        // everything the rows had to wait for (stores retire in order with the loads of the weight stream)
-        const LDS_AS f32x4* abuf4 = (const LDS_AS f32x4*)c.abuf + lane;
-        for (int t = r0; t < r1; ++t) {
-            const RowU r = decode_rec(load_rec(c.recs, t));
-            if (!r.first) continue;
-            for (int nt = 0; nt < r.NT; ++nt) {
-                GLOBAL_AS float* op = c.out_thin + ((size_t)c.row0 * c.WT + r.wcol + 16 * nt) + (m * c.WT + 4 * kq);
-                HINT_TAPE_STORE(abuf4[(r.tile0 + nt) * 64], (GLOBAL_AS f32x4*)op);
-            }
-        }
-    }
+    STAMP(c.sid + 13)
+    STAMP(c.sid + 14)
 }
 
 }  // namespace hint

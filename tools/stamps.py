@@ -56,8 +56,8 @@ def show(title, st, per_block, labels, blocks):
                     continue
                 print(f"   blk {cb} grp {gi} {lab:22s} " + " ".join(f"{int(v):6d}" for v in d))
             # inside the first row of the GEMM phase: thin layer, main chunks, last chunk, extra steps
-            inner = st[:nw, base + 8:base + 13]
-            for k, lab in enumerate(["  row0 thin layer", "  row0 main chunks", "  row0 last chunk", "  row0 extra steps"]):
+            inner = st[:nw, base + 7:base + 16]
+            for k, lab in enumerate(["  record loads", "  -> row0", "  row0 main chunks", "  row0 last chunk", "  row0 extra steps", "  other rows", "  deferred stores", "  next ring priming"]):
                 if (inner[:, k] == 0).all() or (inner[:, k + 1] == 0).all():
                     continue
                 d = np.where((inner[:, k] != 0) & (inner[:, k + 1] != 0), inner[:, k + 1] - inner[:, k], 0)
@@ -85,5 +85,5 @@ descs, _, _, _ = node_descs(nodes)
 lib.hint_plan_check(descs, len(nodes), cfg["d"], 0, 4.0, stats)
 ng = int(stats[0])
 print("groups per block:", ng)
-show("forward", fw, ng, ["-", "-", "P2 rows (L1 L2 L3)", "barrier", "P3 coupling", "barrier"], [3])
-show("backward A", bw, ng + 1, ["Q1 couple/scatter", "barrier", "prefetch issue", "-", "Q3 rows (g2 g1 gv)", "commit+barrier"], [3])
+show("forward", fw, ng, ["P1 thin (VALU)", "barrier", "P2 rows (L2 L3)", "barrier", "P3 coupling", "barrier"], [3])
+show("backward A", bw, ng + 1, ["Q1 couple/scatter", "barrier", "prefetch issue", "Q2 thin + barrier", "Q3 rows (g1 gv)", "commit+barrier"], [3])
