@@ -145,12 +145,19 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 pc.sid = sid;
                 STAMP(sid + 0)
                 // the finished group's g2 (masked) and g1 tiles: out of LDS to the workspace, whole lines per batch row
+                // (by the wavefronts the element-wise work below does not need)
+                int qthreads = nthreads;                            // threads of the element-wise phase
                 if (has_prev) {
-                    stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid, nthreads);
-                    stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid, nthreads);
+                    const int need = (ROWS * a.d + 63) & ~63;
+                    const int soff = need < nthreads ? need : 0;
+                    if (soff > 0) qthreads = soff;
+                    if (tid >= soff) {
+                        stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                    }
                 }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
-                for (int idx = tid; idx < ROWS * a.d; idx += nthreads) {
+                for (int idx = tid; idx < ROWS * a.d && tid < qthreads; idx += qthreads) {
                     const int row = fdiv(idx, inv_d), col = idx - row * a.d;
                     const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
                     const unsigned w0 = (unsigned)lp[0], w1 = (unsigned)lp[1], w2 = (unsigned)lp[2];
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 }
                 if (a.dc > 0 && has_prev) {
                     // condition columns: every unit of the previous group contributes (fixed order: deterministic)
-                    for (int idx = tid; idx < ROWS * a.dc; idx += nthreads) {
+                    for (int idx = tid; idx < ROWS * a.dc && tid < qthreads; idx += qthreads) {
                         const int row = idx / a.dc, cc = idx - row * a.dc;
                         float acc = gcs[row * a.cld + cc];
                         for (int u = gp.unit_begin; u < gp.unit_end; ++u) {
@@ -233,11 +240,15 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 lds_barrier();
                 STAMP(sid + 4)
                 // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
-                rows_run<K_BWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
-                if (slot > 0) {             // the next group's first row: its loads fly across the coupling phase
-                    const GroupU gn = load_group(T.groups + (slot - 1));
-                    const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
-                    rows_begin<K_BWD>(pc, ring, gn.row_begin + lds_i32(rngn + wave), gn.row_begin + lds_i32(rngn + wave + 1), lane);
+                {
+                    int rnext = -1;         // the last row hands the weight ring to the wavefront's first row of the next group
+                    if (slot > 0) {
+                        const GroupU gn = load_group(T.groups + (slot - 1));
+                        const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
+                        const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
+                        if (n0 < n1) rnext = gn.row_begin + n0;
+                    }
+                    rows_run<K_BWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 5)

@@ -188,10 +188,19 @@ __device__ __forceinline__ void stream_tiles(float* __restrict__ dst, const floa
                                              int row0, int tid, int nthreads) {
     const int w4 = ntiles * 4;                          // float4 columns of the group
     const float inv = frcp(w4);
-    for (int idx = tid; idx < ROWS * w4; idx += nthreads) {
-        const int r = fdiv(idx, inv), c4 = idx - r * w4;
-        const f32x4 v = *(const f32x4*)(tiles + (c4 >> 2) * 256 + ((c4 & 3) * 16 + r) * 4);
-        *(f32x4*)(dst + (size_t)(row0 + r) * WT + wcol0 + 4 * c4) = v;
+    const int n = ROWS * w4;
+    for (int i0 = tid; i0 < n; i0 += 4 * nthreads) {    // four elements per thread in flight: reads first, then the stores
+        f32x4 v[4];
+        int r[4], c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = min(i0 + u * nthreads, n - 1);
+            r[u] = fdiv(idx, inv); c4[u] = idx - r[u] * w4;
+            v[u] = *(const f32x4*)(tiles + (c4[u] >> 2) * 256 + ((c4[u] & 3) * 16 + r[u]) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * nthreads < n) *(f32x4*)(dst + (size_t)(row0 + r[u]) * WT + wcol0 + 4 * c4[u]) = v[u];
     }
 }
 

@@ -145,48 +145,60 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 STAMP(sid + 1)
                 lds_barrier();
                 STAMP(sid + 2)
-                // ---- P2: second layer, third layer partials ----
-                rows_run<K_FWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), lane);
-                if (gi + 1 < a.n_groups) {
-                    const GroupU gn = load_group(T.groups + (REV ? a.n_groups - 2 - gi : gi + 1));
-                    const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
-                    rows_begin<K_FWD>(pc, ring, gn.row_begin + lds_i32(rngn + wave), gn.row_begin + lds_i32(rngn + wave + 1), lane);
+                // ---- P2: second layer, third layer partials; the last row hands the weight ring to the wavefront's
+                //      first row of the next group (its loads fly across the coupling and thin phases) ----
+                {
+                    int rnext = -1;
+                    if (gi + 1 < a.n_groups) {
+                        const GroupU gn = load_group(T.groups + (REV ? a.n_groups - 2 - gi : gi + 1));
+                        const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
+                        const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
+                        if (n0 < n1) rnext = gn.row_begin + n0;
+                    }
+                    rows_run<K_FWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 3)
                 lds_barrier();
                 STAMP(sid + 4)
-                // training: both hidden activations of the group go to the tape now, out of LDS, whole lines per batch row
+                // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) on the first wavefront(s):
+                //      16 rows x nsub lanes; the others meanwhile send both hidden activations of the group to the
+                //      tape (training), out of LDS, whole lines per batch row ----
+                const int nsub = g.ent_cnt <= 4 ? 4 : 16;
+                const int ncpl = ROWS * nsub;                     // threads of the coupling
                 if (train) {
-                    stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid, nthreads);
-                    stream_tiles(actA1 + a.act_stride, obuf, g.ntiles, g.wcol0, a.WT, row0, tid, nthreads);
-                }
-                // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) ----
-                {
-                    const int sub = tid & 15, row = tid >> 4;
-                    float part = 0.f;
-                    if (row < ROWS) {
-                        for (int e = sub; e < g.ent_cnt; e += 16) {
-                            const LDS_AS int32_t* ep = (const LDS_AS int32_t*)(T.ents + g.ent_begin + e);
-                            const unsigned w0 = (unsigned)ep[0], w1 = (unsigned)ep[1];
-                            const int xcol = (int)(w0 & 0xffffu), sl_ns = (int)(w1 & 0xffffu), sl_nt = (int)(w1 >> 16);
-                            const int stride = 64 * (int)(w0 >> 16);             // floats per slice slab: 16 rows x pad4(r)
-                            const int s_off = ep[2], t_off = ep[3];
-                            float s = 0.f, t = 0.f;
-                            for (int sl = 0; sl < sl_ns; ++sl) s += slab[s_off + sl * stride + row * 4];
-                            for (int sl = 0; sl < sl_nt; ++sl) t += slab[t_off + sl * stride + row * 4];
-                            const float aa = a.alpha * atanf(s);
-                            float* px = XS + row * a.xld + xcol;
-                            // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it
-                            // scales): the backward pass needs no third-layer recompute
-                            if (!REV && tape != nullptr && row0 + row < a.B)
-                                tape[((size_t)(a.n_levels + g.level) * a.B + row0 + row) * a.d + xcol] = s;
-                            if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
-                            else      { *px = ((*px) - t) / expf(aa); part -= aa; }
-                        }
+                    const int soff = nthreads > ncpl ? ncpl : 0;   // (a workgroup of one coupling's size does both in turn)
+                    if (tid >= soff) {
+                        stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        stream_tiles(actA1 + a.act_stride, obuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                     }
-                    part = row16_sum(part);
-                    if (sub == 0 && row < ROWS) jac[row] += part;
+                }
+                if (tid < ncpl) {
+                    const int sub = tid & (nsub - 1), row = nsub == 4 ? tid >> 2 : tid >> 4;
+                    float part = 0.f;
+                    for (int e = sub; e < g.ent_cnt; e += nsub) {
+                        const LDS_AS int32_t* ep = (const LDS_AS int32_t*)(T.ents + g.ent_begin + e);
+                        const unsigned w0 = (unsigned)ep[0], w1 = (unsigned)ep[1];
+                        const int xcol = (int)(w0 & 0xffffu), sl_ns = (int)(w1 & 0xffffu), sl_nt = (int)(w1 >> 16);
+                        const int stride = 64 * (int)(w0 >> 16);             // floats per slice slab: 16 rows x pad4(r)
+                        const int s_off = ep[2], t_off = ep[3];
+                        float s = 0.f, t = 0.f;
+                        for (int sl = 0; sl < sl_ns; ++sl) s += slab[s_off + sl * stride + row * 4];
+                        for (int sl = 0; sl < sl_nt; ++sl) t += slab[t_off + sl * stride + row * 4];
+                        const float aa = a.alpha * atanf(s);
+                        float* px = XS + row * a.xld + xcol;
+                        // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it
+                        // scales): the backward pass needs no third-layer recompute
+                        if (!REV && tape != nullptr && row0 + row < a.B)
+                            tape[((size_t)(a.n_levels + g.level) * a.B + row0 + row) * a.d + xcol] = s;
+                        if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
+                        else      { *px = ((*px) - t) / expf(aa); part -= aa; }
+                    }
+                    // deterministic butterfly over the nsub adjacent lanes that share a batch row
+                    if (nsub == 16) { part += __shfl_xor(part, 8, 16); part += __shfl_xor(part, 4, 16); }
+                    part += __shfl_xor(part, 2, 16);
+                    part += __shfl_xor(part, 1, 16);
+                    if (sub == 0) jac[row] += part;
                 }
                 STAMP(sid + 5)
                 lds_barrier();

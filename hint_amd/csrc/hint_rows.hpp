@@ -32,7 +32,7 @@ namespace hint {
 
 enum { K_FWD = 0, K_BWD = 1 };
 #ifndef HINT_RING
-#define HINT_RING 4
+#define HINT_RING 2
 #endif
 constexpr int RING = HINT_RING;
 constexpr int NTT = 3;          // tiles per row
@@ -285,20 +285,26 @@ __device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING
 #pragma unroll
     for (int s = 0; s < RING; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
 }
+// rnext: the record whose first main steps the LAST row hands the ring over to - the wavefront's first row of the
+// next group of the block - or -1 (then it re-loads its own: never used)
 template <int KIND>
-__device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int lane) {
-    if (r0 >= r1) return;
+__device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int rnext, int lane) {
+    if (r0 >= r1) {
+        if (rnext >= 0) rows_begin<KIND>(c, ring, rnext, rnext + 1, lane);     // nothing to do here, but the next group has work
+        return;
+    }
     const int m = lane & 15, kq = lane >> 4;
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.m = (unsigned)(m * c.WT + 4 * kq) * 4u;
 
     STAMP(c.sid + 7)
     RowU cr = decode_rec(load_rec(c.recs, r0));
-    i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : r0);               // next row's record, one row ahead
+    const int rlast = rnext >= 0 ? rnext : r1 - 1;                            // what follows the last row
+    i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);            // next row's record, one row ahead
     STAMP(c.sid + 8 + (cr.n1 > 1000 ? 1 : 0))
     for (int t = r0; t < r1; ++t) {
-        const RowU nr = decode_rec(nrec);                                      // (the last row: its own record again)
-        nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : r1 - 1);
+        const RowU nr = decode_rec(nrec);
+        nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
         if (t == r0) { STAMP(c.sid + 9) }
         if (cr.ntt >= 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
         else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
