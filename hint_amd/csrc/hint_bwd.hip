@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
     float* gst = gcs + ROWS * a.cld;          // [16][gld] coupling gradients of the group
     float* abuf = gst + ROWS * a.gld;         // g2 fragment tiles
     float* obuf = abuf + a.abuf_tiles * 256;  // g1 fragment tiles on their way to global memory
-    float* slab = obuf + a.abuf_tiles * 256;  // g_v partials
+    float* slab = obuf + (a.stage_out ? a.abuf_tiles * 256 : 0);  // g_v partials
     float* gj = slab + a.slab_floats;
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
-            pc.abuf = (LDS_AS float*)abuf; pc.obuf = (LDS_AS float*)obuf; pc.slab = (LDS_AS float*)slab;
+            pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
+            pc.out_thin = blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1; pc.wcol0 = 0;
             pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
             pc.mask_thin = blk.actA1 + a.act_stride; pc.mask_main = blk.actA1;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 // the finished group's g2 (masked) and g1 tiles: out of LDS to the workspace, whole lines per batch row
                 // (by the wavefronts the element-wise work below does not need)
                 int qthreads = nthreads;                            // threads of the element-wise phase
-                if (has_prev) {
+                if (has_prev && a.stage_out) {
                     const int need = (ROWS * a.d + 63) & ~63;
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
@@ -159,8 +160,14 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
                 for (int idx = tid; idx < ROWS * a.d && tid < qthreads; idx += qthreads) {
                     const int row = fdiv(idx, inv_d), col = idx - row * a.d;
-                    const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
-                    const unsigned w0 = (unsigned)lp[0], w1 = (unsigned)lp[1], w2 = (unsigned)lp[2];
+                    unsigned w0, w1, w2;
+                    if (a.lops_off >= 0) {
+                        const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
+                        w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
+                    } else {                                    // (large trees: the table stays in global memory)
+                        const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + col];
+                        w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
+                    }
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
                     const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);

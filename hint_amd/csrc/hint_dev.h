@@ -164,6 +164,7 @@ struct ThinRec {
 
 struct KArgs {
     const void* meta;              // [groups | units | tmap | ents | ranges | laneops] contiguous, copied to LDS at kernel start
+    const void* lops;              // LaneOp[(n_groups + 1) * d] in global memory (used when lops_off < 0: table too big for LDS)
     const void* thins;             // ThinRec[2][total_tiles]: forward records, then backward records, tiles in (group, unit) order
     int32_t total_tiles;
     const void* recs;              // RowRec[2][total_rows]: forward records, then backward records, rows in (group, wavefront, unit) order
@@ -176,6 +177,7 @@ struct KArgs {
     int32_t slab_floats;           // L3 slab buffer (forward) / g_v slab buffer (backward), floats
     int32_t gld;                   // LDS row stride of the coupling-gradient buffer (backward)
     int32_t WT, ST;                // row widths of the activation / coupling-gradient arrays
+    int32_t stage_out;             // 1: the rows leave their output tiles in LDS (obuf) and the element-wise phase streams them out; 0: no LDS for that, they store them themselves
     int32_t thin_off, thin_floats; // the direction's thin blob: float offset in the packed buffer, size (multiple of 4)
     int32_t thin_lds;              // float offset in LDS where the kernel stages it per block; 0: read it from global memory
     int32_t perm_lds;              // float offset in LDS of the chain's d x d permutation matrices; 0: read them from global memory

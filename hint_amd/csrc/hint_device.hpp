@@ -221,7 +221,7 @@ __device__ __forceinline__ Tables make_tables(const KArgs& a, float* lds) {
     t.tmap = (const LDS_AS uint16_t*)(mbase + a.tmap_off);
     t.ents = (const LDS_AS Ent*)(mbase + a.ents_off);
     t.rng = (const LDS_AS int32_t*)(mbase + a.rng_off);
-    t.lops = (const LDS_AS LaneOp*)(mbase + a.lops_off);
+    t.lops = (const LDS_AS LaneOp*)(mbase + (a.lops_off >= 0 ? a.lops_off : 0));
     return t;
 }
 __device__ __forceinline__ void copy_meta(const KArgs& a, float* lds, int tid, int nthreads) {

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
     float* cs = t0 + 2 * ROWS * a.xld;
     float* abuf = cs + ROWS * a.cld;
     float* obuf = abuf + a.abuf_tiles * 256;  // a2 fragment tiles on their way to the tape (training)
-    float* slab = obuf + a.abuf_tiles * 256;
+    float* slab = obuf + (a.stage_out ? a.abuf_tiles * 256 : 0);
     float* jac = slab + a.slab_floats;
     float* red = jac + ROWS;                  // MAX_NW floats: loss partials
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
-            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = (LDS_AS float*)obuf; pc.slab = (LDS_AS float*)slab;
+            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
+            pc.out_thin = blk.actA1; pc.out_main = train ? blk.actA1 + a.act_stride : nullptr;
             pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
             pc.mask_thin = nullptr; pc.mask_main = nullptr;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : gi));
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 pc.xs = (const LDS_AS float*)(XS);
+                pc.wcol0 = g.wcol0;
                 const int sid = (cb * a.n_groups + gi) * 16;
                 (void)sid;
                 pc.sid = sid;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 //      tape (training), out of LDS, whole lines per batch row ----
                 const int nsub = g.ent_cnt <= 4 ? 4 : 16;
                 const int ncpl = ROWS * nsub;                     // threads of the coupling
-                if (train) {
+                if (train && a.stage_out) {
                     const int soff = nthreads > ncpl ? ncpl : 0;   // (a workgroup of one coupling's size does both in turn)
                     if (tid >= soff) {
                         stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);

@@ -86,11 +86,13 @@ struct hint_plan {
     int64_t param_floats = 0, packed_floats = 0;
     int WT = 0, ST = 0;
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
+    int stage_out = 1;
     int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
+    LaneOp* d_lops = nullptr;
     RowRec* d_recs = nullptr;
     ThinRec* d_thins = nullptr;
     int total_tiles = 0;
@@ -417,21 +419,26 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     const size_t units_bytes = up16(units.size() * sizeof(Unit));
     const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
     const size_t rng_bytes = up16(rng.size() * sizeof(int32_t));
-    const size_t lops_bytes = up16(lops.size() * sizeof(LaneOp));
+    const bool lops_lds = lops.size() * sizeof(LaneOp) <= 16 * 1024;     // larger tables stay in global memory
+    const size_t lops_bytes = lops_lds ? up16(lops.size() * sizeof(LaneOp)) : 0;
     P->units_off = (int)groups_bytes;
     P->tmap_off = P->units_off + (int)units_bytes;
     P->ents_off = P->tmap_off;
     P->rng_off = P->ents_off + (int)ents_bytes;
-    P->lops_off = P->rng_off + (int)rng_bytes;
-    P->meta_bytes = P->lops_off + (int)lops_bytes;
+    P->lops_off = lops_lds ? P->rng_off + (int)rng_bytes : -1;
+    P->meta_bytes = P->rng_off + (int)rng_bytes + (int)lops_bytes;
     std::vector<char> meta(P->meta_bytes, 0);
     std::memcpy(meta.data(), groups.data(), groups.size() * sizeof(Group));
     std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
-    std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
-    P->lds_fwd = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + 2 * P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW);
-    P->lds_bwd = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + 2 * P->abuf_tiles * 256 + P->slab_bwd + ROWS);
+    if (lops_lds) std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
+    // the rows' output tiles wait in LDS for the element-wise phase to stream them out - when there is room for that
+    auto lds_f = [&](int nbuf) { return P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + nbuf * P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW); };
+    auto lds_b = [&](int nbuf) { return P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + nbuf * P->abuf_tiles * 256 + P->slab_bwd + ROWS); };
+    P->stage_out = (lds_f(2) <= LDS_LIMIT && lds_b(2) <= LDS_LIMIT) ? 1 : 0;
+    P->lds_fwd = lds_f(1 + P->stage_out);
+    P->lds_bwd = lds_b(1 + P->stage_out);
     P->lds_fwd = (P->lds_fwd + 15) / 16 * 16;
     P->lds_bwd = (P->lds_bwd + 15) / 16 * 16;
     // the thin blobs ride in LDS (staged once per block) when they are small
@@ -540,6 +547,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
+    if (e == hipSuccess) e = upload((void**)&P->d_lops, lops.data(), lops.size() * sizeof(LaneOp));
     if (e == hipSuccess) {
         std::vector<ThinRec> both(thin_f);
         both.insert(both.end(), thin_b.begin(), thin_b.end());
@@ -632,6 +640,7 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
 void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
     (void)hipFree(P->d_meta);
+    (void)hipFree(P->d_lops);
     (void)hipFree(P->d_recs);
     (void)hipFree(P->d_thins);
     (void)hipFree(P->d_bmap);
@@ -702,11 +711,11 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     KArgs a{};
     a.meta = P->d_meta; a.meta_bytes = P->meta_bytes; a.recs = P->d_recs; a.total_rows = P->total_rows; a.thins = P->d_thins; a.total_tiles = P->total_tiles;
     a.units_off = P->units_off; a.tmap_off = P->tmap_off; a.ents_off = P->ents_off; a.rng_off = P->rng_off;
-    a.lops_off = P->lops_off;
+    a.lops_off = P->lops_off; a.lops = P->d_lops;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;
     a.d = P->d; a.dc = P->dc; a.xld = P->xld; a.cld = P->cld;
     a.abuf_tiles = P->abuf_tiles; a.slab_floats = backward ? P->slab_bwd : P->slab_fwd; a.gld = P->gld;
-    a.WT = P->WT; a.ST = P->ST; a.perm_lds = 0;
+    a.WT = P->WT; a.ST = P->ST; a.perm_lds = 0; a.stage_out = P->stage_out;
     a.thin_off = backward ? P->thin_b_off : P->thin_f_off;
     a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
     a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;

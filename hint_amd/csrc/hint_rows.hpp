@@ -69,7 +69,10 @@ struct PhaseCtx {
     const void* recs;                // row records of the plan (global, constant), this direction's
     LDS_AS float* abuf;              // fragment tiles of the group: a1 (forward), g2 (backward)
     LDS_AS float* slab;              // the rows' slabs
-    LDS_AS float* obuf;              // fragment tiles of the group's outputs on their way to global memory: a2 (training forward), g1 (backward)
+    LDS_AS float* obuf;              // fragment tiles of the group's outputs on their way to global memory: a2 (training forward), g1 (backward);
+                                     // nullptr: no LDS for them, the rows store to out_thin / out_main themselves
+    GLOBAL_AS float* out_thin;       // [Bp][WT]: a1 (training forward) / g2 (backward)
+    GLOBAL_AS float* out_main;       // [Bp][WT]: a2 (training forward) / g1 (backward)
     const LDS_AS float* xs;          // lane tile [16][xld]
     const LDS_AS float* cs;          // condition tile [16][cld]
     const LDS_AS float* gst;         // coupling gradients [16][gld] (backward)
@@ -78,6 +81,7 @@ struct PhaseCtx {
     const GLOBAL_AS float* mask_thin;    // [Bp][WT] a2: relu'() for g2 (backward)
     const GLOBAL_AS float* mask_main;    // [Bp][WT] a1: relu'() for g1 (backward)
     int xld, cld, gld, WT, row0;
+    int wcol0;                       // column of the group's first tile in the [Bp][WT] arrays
     int sid;                         // diagnostic builds: stamp id base of the phase
     bool store;                      // keep the outputs (training forward; always in the backward pass): the kernels stream them out of LDS after the phase
 };
@@ -164,6 +168,8 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
         for (int k = 4; k < K; ++k) acc += vec(k) * input(k);
         if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         ((LDS_AS f32x4*)c.abuf)[rec.z * 64 + lane] = acc;
+        if (KIND == K_FWD && HINT_STORE_ON && c.obuf == nullptr)      // (no LDS staging: the tile goes to the tape from here)
+            *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + c.wcol0 + 16 * rec.z) + (m * c.WT + 4 * kq)) = acc;
     }
 }
 
@@ -200,7 +206,10 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         if (KIND == K_BWD) {                                                                            \
             b4.x = (W)[NTT].x > 0.f ? b4.x : 0.f; b4.y = (W)[NTT].y > 0.f ? b4.y : 0.f;                 \
             b4.z = (W)[NTT].z > 0.f ? b4.z : 0.f; b4.w = (W)[NTT].w > 0.f ? b4.w : 0.f;                 \
-            if (stg2) ((LDS_AS f32x4*)c.abuf)[(cr.tile0 + (KB)) * 64 + lane] = b4;   /* (idempotent for the other readers) */ \
+            if (stg2) {                                                                                 \
+                if (c.obuf != nullptr) ((LDS_AS f32x4*)c.abuf)[(cr.tile0 + (KB)) * 64 + lane] = b4;   /* (idempotent for the other readers) */ \
+                else *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + cr.wcol + 16 * (KB)) + (m * c.WT + 4 * kq)) = b4; \
+            }                                                                                           \
         }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
             _Pragma("unroll") for (int j = 0; j < NA; ++j) acc[j] = mfma4((W)[j][i], b4[i], acc[j]);    \
@@ -246,7 +255,10 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
             v.z = xaux[j].z > 0.f ? v.z : 0.f; v.w = xaux[j].w > 0.f ? v.w : 0.f;
         }
         act[j] = v;
-        if (HINT_STORE_ON) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
+        if (HINT_STORE_ON) {
+            if (c.obuf != nullptr) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
+            else *(GLOBAL_AS f32x4*)(c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq)) = v;
+        }
     }
     // ---- tail steps: slab[q] = sum over the row's tiles of Wtail(q, tile) * act, the K-split partial of the thin
     //      product (compact: quad q4 = 4 q + kq holds features 4 q4 .. +3 of rows m); then, with a unit's first row,
