@@ -4,11 +4,14 @@ training samples/s + mean NLL, UCI POWER d=6, batch 4096 per GPU, 1/2/4/8 GPUs).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
 
-A "step" = noise + forward + backward of the 8-block flow on this rank's 4096-row shard, one
-all-reduce of the flat gradient arena, fused clamp + Adam (train_unconditional.py:114-144).
-Inputs are synthetic N(0,1) rows already resident in HBM.  Rank 0 prints ONE JSON line.
+A "step" = noise + forward + backward of the 8-block flow on this rank's shard, one all-reduce of the
+flat gradient arena, fused clamp + Adam (train_unconditional.py:114-144).  --scaling weak (default):
+every rank has the workload's batch (4096 rows); --scaling strong: the workload's batch is the GLOBAL
+batch, split over the ranks.  Inputs are synthetic N(0,1) rows already resident in HBM.  Rank 0 prints
+ONE JSON line; it also carries the sampling direction (`inverse_samples_per_sec`, the whole chain
+x = f^-1(z) in one launch), the roofline of the step's dominant kernel and the CPU baseline.
 """
 import argparse
 import json
@@ -42,14 +45,6 @@ def flops_per_sample_block(d, widths, dc=0):
     from oracle import hint_oracle as orc   # only for the node list (bench-side bookkeeping)
     nodes = orc.build_nodes(d, [(dc,)] if dc else [], widths)
     return sum(2 * 2 * (n.cin * n.h + n.h * n.h + n.h * n.r) for n in nodes)
-
-
-def thin_flops_per_sample_block(d, widths, dc=0):
-    """FLOPs per sample of the weight gradients the row-parallel backward kernel computes itself
-    (dW1 and dW3 of both subnets; dW2 is part B's)"""
-    from oracle import hint_oracle as orc
-    nodes = orc.build_nodes(d, [(dc,)] if dc else [], widths)
-    return sum(2 * 2 * (n.cin * n.h + n.h * n.r) for n in nodes)
 
 
 def cpu_baseline(cfg, budget_s=12.0, max_steps=200):
@@ -150,6 +145,8 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="training iterations per hipGraph replay (FlowTrainer.step_many; one process only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch per rank; strong: the workload's batch is the global batch")
     ap.add_argument("--legs", action="store_true",
                     help="also time every kernel in a hot back-to-back loop (single-block and chained launches)")
     args = ap.parse_args()
@@ -173,6 +170,10 @@ def main():
     import hint_amd
     cfg = WORKLOADS[args.workload]
     d, B = cfg["d"], cfg["batch"]
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"--scaling strong: the global batch {B} does not divide over {world} ranks")
+        B //= world
     torch.manual_seed(0)                                     # identical weights on every rank
     flow = hint_amd.HintFlow(d, cfg["n_blocks"], cfg["c_internal"]).to(dev)
     with torch.no_grad():
@@ -231,49 +232,89 @@ def main():
                 for n_, v_ in t.items():
                     in_step[n_] = in_step.get(n_, 0.0) + v_ / 20
 
+    # the sampling direction: x = f^-1(z) through the whole chain, one launch (hint_chain_inverse), on the same
+    # resident rows; HIP events on the launch stream
+    inv_us = None
+    if trainer._chainable:
+        from hint_amd import _lib
+        lib = _lib.load()
+        chain = trainer._chain_for(B)
+        zi = torch.randn(B, d, device=dev)
+        xi, Ji = torch.empty_like(zi), torch.empty(B, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        run_inv = lambda: _lib.check(lib.hint_chain_inverse(chain, zi.data_ptr(), None, xi.data_ptr(), Ji.data_ptr(), None,
+                                                            stream), "hint_chain_inverse")
+        for _ in range(5):
+            run_inv()
+        reps = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record()
+        for _ in range(reps):
+            run_inv()
+        e1.record()
+        torch.cuda.synchronize()
+        inv_us = e0.elapsed_time(e1) * 1e3 / reps
+        if use_dist:
+            t = torch.tensor([inv_us], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            inv_us = float(t.item())
+
     if rank == 0:
         F = flops_per_sample_block(d, cfg["c_internal"])
+        nb = cfg["n_blocks"]                           # blocks one launch processes
         legs = kernel_legs(trainer, x) if args.legs else {}
         res = {
             "metric": "train_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: d={d}, {cfg['n_blocks']} recursive coupling blocks, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: d={d}, {nb} recursive coupling blocks, "
                                    f"c_internal={cfg['c_internal']}, batch {B} per GPU",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "steps_per_graph": spg,
                        "input": "batch resident in the captured step's input buffer (no per-step copy)"},
             "mean_nll_nats": nll, "last_step_loss": loss_last,
         }
-        if in_step:
-            # dominant kernel = the row-parallel backward kernel (part A), one launch for all blocks:
-            # dX through the three layers (F) + the thin weight gradients dW1, dW3 per sample and block
-            # (nothing is recomputed: the hidden activations come from the forward's tape)
-            name = "hint_bwd_kernel"
-            nb = cfg["n_blocks"]                       # blocks one launch processes
-            us = in_step[name]
-            flops = (F + thin_flops_per_sample_block(d, cfg["c_internal"])) * B * nb
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        if os.path.exists(pmc_path) and args.workload == "power_hint_8" and B == 4096:
+            try:
+                pmc = json.load(open(pmc_path))
+            except Exception:
+                pmc = {}
+
+        def hbm_traffic(kernel):           # PMC bytes per launch (profiles/README.md), the 8-block launches of this workload
+            return next((v.get("hbm_bytes_per_launch") for k, v in pmc.items() if k.startswith(kernel)), None)
+
+        def mfma_roofline(kernel, us, flops):
             ach = flops / (us * 1e-6) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-            if os.path.exists(pmc) and args.workload == "power_hint_8":
-                try:
-                    summary = json.load(open(pmc))       # (the kernel is a template: "hint_block_bwd_kernel<3>")
-                    traffic = next((v.get("hbm_bytes_per_launch") for k, v in summary.items() if k.startswith(name)), None)
-                except Exception:
-                    traffic = None
-            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                               "avg_launch_us": us, "algorithmic_flops_per_launch": flops,
-                               "blocks_per_launch": nb}
-            res["kernels_in_step_us"] = in_step       # inside real steps (HIP events between the launches)
+            return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": hbm_traffic(kernel), "avg_launch_us": us,
+                    "algorithmic_flops_per_launch": flops, "blocks_per_launch": nb}
+
+        if in_step:
+            # dominant kernel = the row-parallel backward kernel, one launch for all blocks: dX through the three
+            # layers of every subnet = the forward's MAC count F per sample and block (the hidden activations come
+            # from the forward's tape, nothing is recomputed; the weight gradients are the wgrad kernel's)
+            res["roofline"] = mfma_roofline("hint_bwd_kernel", in_step["hint_bwd_kernel"], F * B * nb)
+            res["kernels_in_step_us"] = in_step       # inside real (un-captured) steps, HIP events between the launches
+            fwd_us = in_step["hint_apply_kernel<fwd>"]
+            wg_us = in_step.get("hint_wgrad_kernel+hint_wreduce_kernel")
+            res["roofline_other_kernels"] = {
+                "hint_apply_kernel<fwd>": mfma_roofline("hint_apply_kernel<false>", fwd_us, F * B * nb),
+            }
+            if wg_us:
+                # weight gradients: every weight matrix once, 2*B MACs per element -> F per sample and block as well
+                res["roofline_other_kernels"]["hint_wgrad_kernel+hint_wreduce_kernel"] = mfma_roofline("hint_wgrad_kernel", wg_us, F * B * nb)
             # the element-wise view the north_star asks for: compulsory HBM bytes of the forward,
             # 4*(2d+1) B per sample and block, against 8 TB/s
-            fwd_us = in_step["hint_apply_kernel<fwd>"]
             hbytes = 4.0 * (2 * d + 1) * B * nb
             hb = hbytes / (fwd_us * 1e-6) / 1e9
             res["hbm_view_fwd_kernel"] = {"achieved": hb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hb / PEAK_HBM_GBS,
                                           "bytes_per_launch": hbytes}
-            res["mfma_view_fwd_kernel_tflops"] = F * B * nb / (fwd_us * 1e-6) / 1e12
+        if inv_us is not None:
+            res["inverse_samples_per_sec"] = B * world / (inv_us * 1e-6)
+            res["inverse"] = {"what": f"x = f^-1(z), {nb} blocks in one launch of hint_apply_kernel<true>, {B} rows per GPU, no tape",
+                              "avg_launch_us": inv_us, "roofline": mfma_roofline("hint_apply_kernel<true>", inv_us, F * B * nb)}
         if legs:
             res["kernels_hot_loop_us"] = legs         # back-to-back loops of one kernel (caches hot)
         if world == 1 and not args.no_cpu_baseline:

@@ -105,8 +105,10 @@ struct hint_plan {
 };
 
 // tile_cap: fragment tiles per group (1 KiB of LDS each), unless one node needs more
+// unit_waves: how many wavefronts may share the rows of one unit (each of them keeps a slab for it)
+// returns 0, 1 (error) or 2 (the block does not fit the LDS with these two settings; *retry_smaller: smaller groups exist)
 static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int nw,
-                      int tile_cap, hint_plan** out, bool* retry_smaller) {
+                      int tile_cap, int unit_waves, hint_plan** out, bool* retry_smaller) {
     *retry_smaller = false;
     int max_depth = 0;
     for (int i = 0; i < n_nodes; ++i) max_depth = std::max(max_depth, nodes[i].depth);
@@ -234,8 +236,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->abuf_tiles = std::max(P->abuf_tiles, tiles);
         P->gld = std::max(P->gld, g.gcols | 1);
 
-        // ---- rows: up to three adjacent tiles of a unit; every row has its own slab for the K-split
-        //      partial of the tail product ----
+        // ---- rows: up to three adjacent tiles of a unit; the rows of a unit that one wavefront runs share a slab
+        //      for the K-split partial of the tail product (the first writes it, the others add) ----
         struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
         std::vector<Row> rows;
         int off3 = 0, offv = 0;
@@ -260,15 +262,12 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
             Unit& u = units[ui];
             const int nr = nrows[ui - g.unit_begin];
-            u.sl_off = off3; u.gv_off = offv; u.sl_n = nr;
             int tb = 0;
             for (int ri = 0; ri < nr; ++ri) {
                 const int ntt = (u.NT - tb + (nr - ri) - 1) / (nr - ri);
                 // matrix-pipe time of the row (main + tail steps) plus what its bookkeeping costs in the same unit
                 const long cost = (long)u.NT * ntt * 4 + std::max(u.RT, u.KB1) * ntt * 4 + 24;
-                rows.push_back(Row{ui, tb, ntt, off3, offv, cost});
-                off3 += 64 * cdiv(u.r, 4);
-                offv += 64 * cdiv(u.cin, 4);
+                rows.push_back(Row{ui, tb, ntt, 0, 0, cost});
                 tb += ntt;
             }
             const int kpf = std::max(4, u.cin), kpb = std::max(4, u.r);
@@ -277,8 +276,6 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 thin_b.push_back(ThinRec{u.w3v + nt * kpb * 16, u.r | (u.lcol << 16), u.tile0 + nt, kpb});
             }
         }
-        P->slab_fwd = std::max(P->slab_fwd, off3);
-        P->slab_bwd = std::max(P->slab_bwd, offv);
         // ---- deal the rows to the wavefronts: longest first, to the wavefront whose SIMD (wavefronts w and
         //      w + 4 share one: its matrix pipe and its issue slots) is least loaded; a wavefront's first row
         //      of a unit also pays for the unit's thin layer ----
@@ -292,9 +289,16 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 const long thin = 0;
                 int best = 0;
                 long best_s = -1, best_w = -1;
+                int holders = 0;
                 for (int w = 0; w < nw; ++w) {
                     bool has = false;
                     for (int r : wave_rows[w]) has = has || rows[r].unit == rows[i].unit;
+                    holders += has ? 1 : 0;
+                }
+                for (int w = 0; w < nw; ++w) {
+                    bool has = false;
+                    for (int r : wave_rows[w]) has = has || rows[r].unit == rows[i].unit;
+                    if (!has && holders >= unit_waves) continue;           // (no further slab for this unit)
                     const long add = rows[i].cost + (has ? 0 : thin);
                     // (the two wavefronts of a SIMD interleave: what one wavefront runs back to back counts as well)
                     const long sl = sload[w & 3] + wload[w] + 2 * add, wl = wload[w] + add;
@@ -308,6 +312,19 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             for (int w = 0; w < nw; ++w) std::sort(wave_rows[w].begin(), wave_rows[w].end());   // unit order, then tile order
         }
+        // slabs: one per (unit, wavefront that has rows of it), a unit's slabs adjacent
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+            Unit& u = units[ui];
+            u.sl_off = off3; u.gv_off = offv; u.sl_n = 0;
+            for (int w = 0; w < nw; ++w) {
+                bool has = false;
+                for (int ri : wave_rows[w])
+                    if (rows[ri].unit == ui) { rows[ri].slab3 = off3; rows[ri].slabv = offv; has = true; }
+                if (has) { off3 += 64 * cdiv(u.r, 4); offv += 64 * cdiv(u.cin, 4); ++u.sl_n; }
+            }
+        }
+        P->slab_fwd = std::max(P->slab_fwd, off3);
+        P->slab_bwd = std::max(P->slab_bwd, offv);
         if (std::getenv("HINT_PLAN_DUMP")) {
             std::fprintf(stderr, "[hint plan] group %d level %d: %d units, %d tiles, %d rows\n", (int)groups.size(), g.level,
                          g.unit_end - g.unit_begin, tiles, (int)rows.size());
@@ -456,8 +473,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         const int need = std::max(P->lds_bwd, P->lds_fwd);
         const bool could_shrink = P->abuf_tiles > 0 && P->n_groups < (int)order.size();
         delete P;
-        if (tile_cap > 8 && could_shrink) { *retry_smaller = true; return 1; }     // rebuild with smaller groups
-        return fail("hint_plan_create: block needs %d bytes of LDS (> %d); d/dc/h too large", need, LDS_LIMIT);
+        *retry_smaller = tile_cap > 8 && could_shrink;
+        fail("hint_plan_create: block needs %d bytes of LDS (> %d); d/dc/h too large", need, LDS_LIMIT);
+        return 2;
     }
 
     // ---- self-check: the record lists of every group cover every fragment tile of every unit exactly once,
@@ -614,12 +632,16 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
                 nodes[j].off < nodes[i].off + nodes[i].D)
                 return fail("hint_plan_create: nodes %d and %d of depth %d overlap", i, j, nodes[i].depth);
     // large groups first (fewer phases per block); smaller ones when the block does not fit the LDS
-    for (int tile_cap = 72; tile_cap >= 8; tile_cap -= 16) {
-        bool retry = false;
-        const int st = build_plan(nodes, n_nodes, d, dc, clamp, pick_nw(d), tile_cap, out, &retry);
-        if (st == 0 || !retry) return st;
-    }
-    return fail("hint_plan_create: could not fit the block into LDS");
+    // and when the smallest groups do not fit either, fewer wavefronts per unit (fewer slabs)
+    const int nw = pick_nw(d);
+    for (int unit_waves = nw; unit_waves >= 1; unit_waves /= 2)
+        for (int tile_cap = 72; tile_cap >= 8; tile_cap -= 16) {
+            bool retry = false;
+            const int st = build_plan(nodes, n_nodes, d, dc, clamp, nw, tile_cap, unit_waves, out, &retry);
+            if (st != 2) return st;
+            if (!retry) break;
+        }
+    return 1;          // (the last attempt's message stands)
 }
 
 int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int64_t* stats) {

@@ -13,7 +13,7 @@
 // wavefront) reads as a B operand (ds_read_b128): no transposes.  The thin layers of a group (K = the
 // few lanes feeding a subnet, or its r outputs) are a short phase of their own: the wavefronts share
 // the group's tiles, a barrier, then the rows.  The K-split partial of a row's tail product goes to
-// the row's own LDS slab.
+// the LDS slab the wavefront keeps for the unit.
 //
 // The weight stream runs through a register ring of RING slots x 3 elements: every step consumes one
 // slot and issues its 16-byte-per-lane global loads for the step RING ahead (a row's body is compiled
@@ -272,7 +272,10 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
 #pragma unroll
             for (int j = 0; j < NA; ++j) sv = mfma4(xtail[j][i], act[j][i], sv);
         const int q4 = 4 * q + kq;
-        if (q4 < cr.nquad) *(LDS_AS f32x4*)(slabp + (q4 * 16 + m) * 4) = sv;
+        if (q4 < cr.nquad) {
+            LDS_AS f32x4* sp = (LDS_AS f32x4*)(slabp + (q4 * 16 + m) * 4);
+            if (cr.thin) *sp = sv; else *sp = *sp + sv;             // (the wavefront's first row of the unit starts the slab)
+        }
     }
     for (int q = 0; q < cr.n3; ++q) {
         if (q > 0) load_extra3<KIND, 1>(xb3, c, cr, 1 + cr.n2 + q, lo);

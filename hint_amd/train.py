@@ -500,6 +500,29 @@ class FlowTrainer:
         return s[0] / self._last_B, -s[1] / self._last_B
 
     @torch.no_grad()
+    def sample(self, z: torch.Tensor, c: Optional[torch.Tensor] = None):
+        """x = f^-1(z) and the log-determinant of that map per row (train_unconditional.py:152-153,
+        rev=True through the whole graph; hint.py:83 sign) - every block of the flow in ONE launch
+        (hint_chain_inverse), on the weights as they are now."""
+        if not self._chainable:
+            x = self.flow(z, c=c, rev=True)
+            return x, self.flow.log_jacobian(rev=True, run_forward=False)
+        z = z.contiguous().float()
+        B = z.shape[0]
+        x = torch.empty_like(z)
+        J = torch.empty(B, dtype=torch.float32, device=z.device)
+        if B == 0:
+            return x, J
+        self._check_arenas()
+        self._pack_all()
+        chain = self._chain_for(B)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.hint_chain_inverse(chain, z.data_ptr(), c.data_ptr() if c is not None else None, x.data_ptr(),
+                                                   J.data_ptr(), None, torch.cuda.current_stream(self.device).cuda_stream),
+                       "hint_chain_inverse")
+        return x, J
+
+    @torch.no_grad()
     def nll(self, x: torch.Tensor, c: Optional[torch.Tensor] = None) -> float:
         """mean negative log-likelihood in nats incl. the Gaussian constant
         (run_uci_experiments.py:71-72)"""

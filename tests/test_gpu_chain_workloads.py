@@ -1,0 +1,124 @@
+"""Chain-level parity at the BASELINE workloads' shapes (cfg 3 = gas_hint_8, cfg 4 =
+the d = 100 lane of conditional_hint_4_full.py with and without a condition, cfg 5 = miniboone_hint_10, and
+the *_big width h = 512): the whole flow per launch (hint_chain_forward / hint_chain_backward /
+hint_chain_inverse) against oracle/hint_oracle.py's OracleFlow evaluated in float64 on the same weights and
+rows.  Bars: NLL within 1e-4 relative (north_star), the flat gradient within 1e-4 relative (norm-wise; the
+element-wise deviation of single ReLU-kink rows is reported by tools/fuzz_parity.py), inverse round trip
+within 1e-4 absolute.  Plus the determinism of the weight gradients (two runs bit-identical)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import hint_amd
+from oracle import hint_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+WORKLOADS = [
+    # name, d, dc, n_blocks, widths, rows, weight scale (randn * scale: log-dets of a few nats, z of order 1..10 -
+    # the reference's own 0.005 (train_unconditional.py:165-167) would leave s and t next to zero)
+    ("cfg2_power_hint_8", 6, 0, 8, [140, 70, 35, 17], 1024, 0.06),
+    ("cfg3_gas_hint_8", 8, 0, 8, [128, 64, 32, 16], 512, 0.06),
+    ("cfg4_plus_x_lane", 100, 0, 4, [224, 112, 56], 160, 0.03),
+    ("cfg4_plus_x_lane_cond", 100, 4, 4, [224, 112, 56], 96, 0.03),
+    ("cfg5_miniboone_hint_10", 43, 0, 10, [67, 33, 16, 8], 200, 0.06),
+    ("plus_hint_4_big", 100, 0, 2, [512, 256, 128, 64], 48, 0.03),
+]
+
+
+def make_pair(d, dc, n_blocks, widths, scale, seed=0):
+    """OracleFlow in float64 and the same flow (same float32 weights) on the GPU"""
+    dims_c = [(dc,)] if dc else ()
+    ref = orc.OracleFlow(d, n_blocks, widths, dims_c=dims_c, seed=seed, init_scale=scale, dtype=torch.float64)
+    flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc)
+    for i, blk in enumerate(flow.blocks):
+        blk.load_state_dict({k: v.float() for k, v in ref.params[i].items()})
+        if ref.perms[i] is not None:
+            flow.perms[i].W.copy_(ref.perms[i].float())
+        # the oracle sees exactly the float32 weights the GPU has
+        ref.params[i] = {k: v.float().double() for k, v in ref.params[i].items()}
+    ref.perms = [None if p is None else p.float().double() for p in ref.perms]
+    return ref, flow.to(DEV)
+
+
+def flat_grads(tr, flow):
+    out = {}
+    for bi, ((a, b), eng) in enumerate(zip(tr.slices, tr.engines)):
+        for p, g in zip(eng.params, eng.split_flat(tr.G[a:b])):
+            name = [n for n, q in flow.blocks[bi].named_parameters() if q is p][0]
+            out[(bi, name)] = g.detach().double().cpu()
+    return out
+
+
+@pytest.mark.parametrize("name,d,dc,n_blocks,widths,B,scale", WORKLOADS, ids=[w[0] for w in WORKLOADS])
+def test_chain_nll_gradient_and_inverse_match_oracle(name, d, dc, n_blocks, widths, B, scale):
+    ref, flow = make_pair(d, dc, n_blocks, widths, scale)
+    g = torch.Generator().manual_seed(7)
+    x64 = torch.randn(B, d, generator=g, dtype=torch.float64).float().double()
+    c64 = torch.randn(B, dc, generator=g, dtype=torch.float64).float().double() if dc else None
+    cr = (c64,) if dc else ()
+    for p in ref.parameters():
+        p.requires_grad_(True)
+    z_ref, J_ref = ref.forward(x64, cr)
+    l0, l1 = ref.loss_terms(z_ref, J_ref)
+    (l0 + l1).backward()
+    nll_ref = float(l0 + l1) + 0.5 * d * math.log(2 * math.pi)
+
+    x = x64.float().to(DEV)
+    c = c64.float().to(DEV) if dc else None
+    tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
+    assert tr._chainable
+    tr._check_arenas()
+    tr.G.zero_()
+    tr._fwd_bwd(x, c)
+    torch.cuda.synchronize()
+    s = tr.loss_acc.double().sum(dim=0).cpu()
+    nll = float(s[0] / B - s[1] / B) + 0.5 * d * math.log(2 * math.pi)
+    assert abs(nll - nll_ref) <= 1e-4 * abs(nll_ref), (nll, nll_ref)
+
+    grads = flat_grads(tr, flow)
+    num = den = 0.0
+    for (bi, k), gg in grads.items():
+        r = ref.params[bi][k].grad
+        num += float(((gg - r) ** 2).sum()); den += float((r ** 2).sum())
+    assert math.sqrt(num / den) <= 1e-4, (name, math.sqrt(num / den))
+
+    # sampling direction: the whole chain in one launch
+    with torch.no_grad():
+        z = flow(x, c=c)
+        xr, Jr = tr.sample(z, c)
+        zi = torch.randn(B, d, generator=g, dtype=torch.float64).float()
+        xs, Js = tr.sample(zi.to(DEV), c)
+        xs_ref, Js_ref = ref.inverse(zi.double(), cr)
+    assert (xr - x).abs().max().item() < 1e-4 * max(1.0, x.abs().max().item())
+    np.testing.assert_allclose(Jr.double().cpu().numpy(), -J_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    scale = max(1.0, float(xs_ref.abs().max()))
+    assert float((xs.double().cpu() - xs_ref).abs().max()) < 1e-4 * scale
+    np.testing.assert_allclose(Js.double().cpu().numpy(), Js_ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("d,dc,n_blocks,widths,B", [
+    (6, 0, 8, [140, 70, 35, 17], 4096),            # the bench workload: 64 row splits of 4096 rows
+    (8, 3, 3, [64, 32, 16], 1000),
+    (43, 0, 2, [67, 33, 16, 8], 333),
+])
+def test_weight_gradients_are_deterministic(d, dc, n_blocks, widths, B):
+    """the K-split of the weight-gradient GEMMs is summed in a fixed order (slabs + hint_wreduce_kernel, no
+    atomics): two backward passes over the same tape give bit-identical gradients, overwrite and accumulate"""
+    torch.manual_seed(3)
+    flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc).to(DEV)
+    x = torch.randn(B, d, device=DEV)
+    c = torch.randn(B, dc, device=DEV) if dc else None
+    tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
+    tr._check_arenas()
+    runs = []
+    for _ in range(3):
+        tr.G.zero_()
+        tr._fwd_bwd(x, c)
+        torch.cuda.synchronize()
+        runs.append(tr.G.clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2])
+    assert runs[0].abs().sum().item() > 0

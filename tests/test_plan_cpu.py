@@ -34,6 +34,7 @@ def check(tree, d, dc, clamp=4.0):
     (43, 0, [67, 33, 16, 8], 31, 5),         # cfg 5 as BASELINE words it
     (42, 0, [67, 33, 16, 8], 31, 5),         # the reference's MINIBOONE width (data.py:423)
     (6, 0, [512, 256, 128], 3, 2),           # *_big: h = 512
+    (100, 0, [512, 256, 128, 64], None, None),   # plus_hint_4_big (bench.py): the widest root of the workloads
     (5, 0, [385], None, None),
     (1, 0, [8], 1, 1),
     (2, 3, [7, 5], 1, 1),

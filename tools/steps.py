@@ -19,5 +19,8 @@ tr = hint_amd.FlowTrainer(flow, use_graph=False, seed=1)     # no graph: the pro
 x = torch.randn(cfg["batch"], cfg["d"], device=dev)
 for _ in range(steps):
     tr.step(x)
+z = torch.randn(cfg["batch"], cfg["d"], device=dev)
+for _ in range(10):                                           # and the sampling direction (hint_apply_kernel<true>)
+    tr.sample(z)
 torch.cuda.synchronize()
 print("ok", name, steps, [float(v) for v in tr.last_losses()])
