@@ -120,7 +120,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
             pc.out_thin = blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1; pc.wcol0 = 0;
             pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
-            pc.mask_thin = blk.actA1 + a.act_stride; pc.mask_main = blk.actA1;
+            pc.bits_a1 = (GLOBAL_AS uint8_t*)(blk.actA1 + 2 * a.act_stride) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
+            pc.bits_a2 = pc.bits_a1 + a.bits_stride;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
             pc.store = true;
 

@@ -21,7 +21,14 @@ namespace hint {
 
 constexpr int ROWS = 16;        // batch rows per row tile = one MFMA N-tile of the transposed products
 constexpr int TILE = 16;        // MFMA 16x16x4 f32 tile edge
-constexpr int MAX_NW = 8;       // wavefronts per workgroup (plan-time choice: 4 or 8)
+#ifndef HINT_MAX_NW
+#define HINT_MAX_NW 8
+#endif
+#ifndef HINT_NTT
+#define HINT_NTT 3
+#endif
+constexpr int MAX_NW = HINT_MAX_NW;   // wavefronts per workgroup (plan-time choice: 4, 8, ...)
+constexpr int NTT = HINT_NTT;         // fragment tiles per row (hint_rows.hpp)
 constexpr int MAX_RT = 4;       // 16-wide tiles of a unit's output (r <= 64) and of its input (cin <= 64 + dc)
 constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (cin <= 192)
 
@@ -177,6 +184,7 @@ struct KArgs {
     int32_t slab_floats;           // L3 slab buffer (forward) / g_v slab buffer (backward), floats
     int32_t gld;                   // LDS row stride of the coupling-gradient buffer (backward)
     int32_t WT, ST;                // row widths of the activation / coupling-gradient arrays
+    int64_t bits_stride;           // bytes between the a1 and the a2 sign bytes of a block's tape
     int32_t stage_out;             // 1: the rows leave their output tiles in LDS (obuf) and the element-wise phase streams them out; 0: no LDS for that, they store them themselves
     int32_t thin_off, thin_floats; // the direction's thin blob: float offset in the packed buffer, size (multiple of 4)
     int32_t thin_lds;              // float offset in LDS where the kernel stages it per block; 0: read it from global memory

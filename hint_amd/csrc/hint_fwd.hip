@@ -116,8 +116,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
             pc.out_thin = blk.actA1; pc.out_main = train ? blk.actA1 + a.act_stride : nullptr;
+            pc.bits_a1 = train ? (GLOBAL_AS uint8_t*)(blk.actA1 + 2 * a.act_stride) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64 : nullptr;
+            pc.bits_a2 = train ? pc.bits_a1 + a.bits_stride : nullptr;
             pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
-            pc.mask_thin = nullptr; pc.mask_main = nullptr;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
             pc.store = train;
 

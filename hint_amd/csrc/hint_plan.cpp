@@ -245,7 +245,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         std::vector<int> nrows(g.unit_end - g.unit_begin);
         {
             int total = 0;
-            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, 3); total += nrows[ui - g.unit_begin]; }
+            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, NTT); total += nrows[ui - g.unit_begin]; }
             while (total < nw) {
                 int best = -1; double bw = 0;
                 for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {       // split where the rows are widest
@@ -599,7 +599,8 @@ static int pick_nw(int d) {
     int nw = 8;
     if (const char* s = std::getenv("HINT_NW")) {
         const int v = std::atoi(s);
-        if (v == 4 || v == 8) nw = v;
+        if (v == 4 || v == 8 || v == 16) nw = v;
+        if (nw > MAX_NW) nw = MAX_NW;
     }
     while (nw < MAX_NW && ROWS * d > LV_REGS * 64 * nw) nw *= 2;
     return nw;
@@ -680,14 +681,16 @@ int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_float
 static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
 // Tape layout (floats): [lane tiles: L x B x d][s: L x B x d][pad to 4][a1: Bp x WT + slack][a2: same]
+//                       [sign bytes of a1: Bp/16 x WT/16 x 64 bytes][of a2: same]
 static inline int64_t tape_act_off(const hint_plan* P, int B) {
     return (2 * (int64_t)P->n_levels * B * P->d + 3) / 4 * 4;
 }
 static inline int64_t act_stride(const hint_plan* P, int B) { return (int64_t)rows_padded(B) * P->WT + WS_SLACK; }
+static inline int64_t bits_stride(const hint_plan* P, int B) { return (int64_t)rows_padded(B) / ROWS * (P->WT / 16) * 64; }   // bytes
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
-    return tape_act_off(P, B) + 2 * act_stride(P, B);
+    return tape_act_off(P, B) + 2 * act_stride(P, B) + 2 * bits_stride(P, B) / 4;
 }
 
 // batch split of part B: a multiple of 8 splits (one XCD each), enough workgroups to cover the chip,
@@ -741,7 +744,7 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.thin_off = backward ? P->thin_b_off : P->thin_f_off;
     a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
     a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;
-    a.act_stride = act_stride(P, B);
+    a.act_stride = act_stride(P, B); a.bits_stride = bits_stride(P, B);
     a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
     return a;
 }

@@ -35,7 +35,6 @@ enum { K_FWD = 0, K_BWD = 1 };
 #define HINT_RING 2
 #endif
 constexpr int RING = HINT_RING;
-constexpr int NTT = 3;          // tiles per row
 constexpr int NEL = NTT + 1;    // ring elements per slot: the row's weight tiles + (backward) the a2 tile that masks the step's B fragment
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -78,8 +77,11 @@ struct PhaseCtx {
     const LDS_AS float* gst;         // coupling gradients [16][gld] (backward)
     const LDS_AS float* thin_l;      // the direction's thin blob staged in LDS, or nullptr
     const GLOBAL_AS float* thin_g;   // ... in the packed buffer
-    const GLOBAL_AS float* mask_thin;    // [Bp][WT] a2: relu'() for g2 (backward)
-    const GLOBAL_AS float* mask_main;    // [Bp][WT] a1: relu'() for g1 (backward)
+    // relu'() of the forward activations as one byte per lane and fragment tile (bit i: element i of the lane's
+    // float4 is positive), [tile of the block][64], of this workgroup's rows: written by the training forward next
+    // to the activation tiles, all the backward kernel reads of them (1/16 of the bytes)
+    GLOBAL_AS uint8_t* bits_a1;
+    GLOBAL_AS uint8_t* bits_a2;
     int xld, cld, gld, WT, row0;
     int wcol0;                       // column of the group's first tile in the [Bp][WT] arrays
     int sid;                         // diagnostic builds: stamp id base of the phase
@@ -93,10 +95,17 @@ struct PhaseCtx {
 #endif
 
 // Byte offsets of a lane inside the three kinds of stream elements.
-struct LaneOff { unsigned w, b, m; };    // lane*16 (weight tiles), kq*16 (bias vectors), (m*WT + 4 kq)*4 (activation tiles)
+struct LaneOff { unsigned w, b, l; };    // lane*16 (weight tiles), kq*16 (bias vectors), lane (sign bytes)
+
+__device__ __forceinline__ int sign_bits(const f32x4& v) {
+    return (v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0);
+}
+__device__ __forceinline__ void mask_by_bits(f32x4& v, int bits) {
+    v.x = (bits & 1) ? v.x : 0.f; v.y = (bits & 2) ? v.y : 0.f; v.z = (bits & 4) ? v.z : 0.f; v.w = (bits & 8) ? v.w : 0.f;
+}
 
 // the first N weight elements of main step kb of row r (tile j of a narrower row: its last tile again); backward:
-// also the a2 tile of k-block kb (element NTT), whose sign masks the step's B fragment
+// also the sign byte of the a2 tile of k-block kb (element NTT, in .x), which masks the step's B fragment
 template <int KIND, int N>
 __device__ __forceinline__ void load_main3(f32x4 (&dst)[NEL], const PhaseCtx& c, const RowU& r, int kb, const LaneOff& lo) {
     const GLOBAL_AS char* p = (const GLOBAL_AS char*)c.packed + lo.w;
@@ -107,7 +116,7 @@ __device__ __forceinline__ void load_main3(f32x4 (&dst)[NEL], const PhaseCtx& c,
     }
     if (KIND == K_BWD) {
         const int kc = kb < r.n1 ? kb : r.n1 - 1;
-        dst[NTT] = *(const GLOBAL_AS f32x4*)((const GLOBAL_AS char*)c.mask_thin + ((size_t)c.row0 * c.WT + r.wcol + 16 * kc) * 4 + lo.m);
+        dst[NTT].x = __int_as_float((int)c.bits_a2[((r.wcol >> 4) + kc) * 64 + lo.l]);
     }
 }
 // the first N elements of extra step e: 0 = aux (bias vectors / forward activation tiles), 1 .. n2 = tail
@@ -122,8 +131,13 @@ __device__ __forceinline__ void load_extra3(f32x4 (&dst)[NTT], const PhaseCtx& c
         base = (const GLOBAL_AS char*)c.packed + (size_t)(r.bias3 + 16 * (e - 1 - r.n2)) * 4; off = lo.b; step = 0;
     } else if (KIND == K_FWD) {
         base = (const GLOBAL_AS char*)c.packed + (size_t)r.aux * 4; off = lo.b; step = 64;
-    } else {
-        base = (const GLOBAL_AS char*)c.mask_main + ((size_t)c.row0 * c.WT + r.ocol) * 4; off = lo.m; step = 64;
+    } else {            // backward aux: the sign bytes of the row's a1 tiles (in .x)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int jj = j < r.ntt ? j : r.ntt - 1;
+            dst[j].x = __int_as_float((int)c.bits_a1[((r.ocol >> 4) + jj) * 64 + lo.l]);
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -168,8 +182,11 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
         for (int k = 4; k < K; ++k) acc += vec(k) * input(k);
         if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         ((LDS_AS f32x4*)c.abuf)[rec.z * 64 + lane] = acc;
-        if (KIND == K_FWD && HINT_STORE_ON && c.obuf == nullptr)      // (no LDS staging: the tile goes to the tape from here)
-            *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + c.wcol0 + 16 * rec.z) + (m * c.WT + 4 * kq)) = acc;
+        if (KIND == K_FWD && HINT_STORE_ON) {
+            c.bits_a1[((c.wcol0 >> 4) + rec.z) * 64 + lane] = (uint8_t)sign_bits(acc);
+            if (c.obuf == nullptr)      // (no LDS staging: the tile goes to the tape from here)
+                *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + c.wcol0 + 16 * rec.z) + (m * c.WT + 4 * kq)) = acc;
+        }
     }
 }
 
@@ -204,8 +221,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         const int kn = (KB) + 1 < n1 ? (KB) + 1 : (KB);                                                 \
         bb[((S) + 1) & 1] = abuf4[(cr.tile0 + kn) * 64];                                                \
         if (KIND == K_BWD) {                                                                            \
-            b4.x = (W)[NTT].x > 0.f ? b4.x : 0.f; b4.y = (W)[NTT].y > 0.f ? b4.y : 0.f;                 \
-            b4.z = (W)[NTT].z > 0.f ? b4.z : 0.f; b4.w = (W)[NTT].w > 0.f ? b4.w : 0.f;                 \
+            mask_by_bits(b4, __float_as_int((W)[NTT].x));                                               \
             if (stg2) {                                                                                 \
                 if (c.obuf != nullptr) ((LDS_AS f32x4*)c.abuf)[(cr.tile0 + (KB)) * 64 + lane] = b4;   /* (idempotent for the other readers) */ \
                 else *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + cr.wcol + 16 * (KB)) + (m * c.WT + 4 * kq)) = b4; \
@@ -251,10 +267,10 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
             v += xaux[j];                                                            // bias
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else {                                                                     // relu'() of the forward activation
-            v.x = xaux[j].x > 0.f ? v.x : 0.f; v.y = xaux[j].y > 0.f ? v.y : 0.f;
-            v.z = xaux[j].z > 0.f ? v.z : 0.f; v.w = xaux[j].w > 0.f ? v.w : 0.f;
+            mask_by_bits(v, __float_as_int(xaux[j].x));
         }
         act[j] = v;
+        if (KIND == K_FWD && HINT_STORE_ON) c.bits_a2[((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
         if (HINT_STORE_ON) {
             if (c.obuf != nullptr) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
             else *(GLOBAL_AS f32x4*)(c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq)) = v;
@@ -295,7 +311,7 @@ template <int KIND>
 __device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int lane) {
     if (r0 >= r1) return;
     LaneOff lo;
-    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.m = (unsigned)((lane & 15) * c.WT + 4 * (lane >> 4)) * 4u;
+    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
     const RowU cr = decode_rec(load_rec(c.recs, r0));
 #pragma unroll
     for (int s = 0; s < RING; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
@@ -310,7 +326,7 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
     }
     const int m = lane & 15, kq = lane >> 4;
     LaneOff lo;
-    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.m = (unsigned)(m * c.WT + 4 * kq) * 4u;
+    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.l = (unsigned)lane;
 
     STAMP(c.sid + 7)
     RowU cr = decode_rec(load_rec(c.recs, r0));
@@ -321,9 +337,16 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
         const RowU nr = decode_rec(nrec);
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
         if (t == r0) { STAMP(c.sid + 9) }
-        if (cr.ntt >= 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
-        else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
-        else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+        if constexpr (NTT >= 3) {
+            if (cr.ntt >= 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
+            else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
+            else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+        } else if constexpr (NTT == 2) {
+            if (cr.ntt >= 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
+            else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+        } else {
+            row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+        }
         cr = nr;
     }
     STAMP(c.sid + 13)

@@ -280,8 +280,9 @@ class _Engine:
 
 
 class _CouplingFn(torch.autograd.Function):
-    """autograd node of one block forward.  Saves the input and the (levels-1)x[B,d] lane tape;
-    the backward kernel recomputes the subnet activations from them."""
+    """autograd node of one block forward.  Saves the input and the tape the forward kernel wrote (the lanes
+    at every level, s, and the hidden activations a1, a2 of every subnet); the backward kernels read the
+    activations from it, nothing is recomputed."""
 
     @staticmethod
     def forward(ctx, engine, x, c, *params):
@@ -372,6 +373,27 @@ class HierarchicalAffineCouplingTree(nn.Module):
         else:
             self.leaf = True
         self._engine: Optional[_Engine] = None
+
+    # the engine (plan handle, device arenas: raw pointers) belongs to this object on its device: copies and
+    # pickles of the module (copy.deepcopy for an EMA / best-checkpoint copy, torch.save(model)) leave it behind
+    # and build their own on first use
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        eng, self._engine = self._engine, None
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                setattr(new, k, copy.deepcopy(v, memo))
+        finally:
+            self._engine = eng
+        return new
 
     # same closed forms as hint.py:56-60, kept for API parity (not used by the kernels)
     def e(self, s):

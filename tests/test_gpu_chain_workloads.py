@@ -2,9 +2,11 @@
 the d = 100 lane of conditional_hint_4_full.py with and without a condition, cfg 5 = miniboone_hint_10, and
 the *_big width h = 512): the whole flow per launch (hint_chain_forward / hint_chain_backward /
 hint_chain_inverse) against oracle/hint_oracle.py's OracleFlow evaluated in float64 on the same weights and
-rows.  Bars: NLL within 1e-4 relative (north_star), the flat gradient within 1e-4 relative (norm-wise; the
-element-wise deviation of single ReLU-kink rows is reported by tools/fuzz_parity.py), inverse round trip
-within 1e-4 absolute.  Plus the determinism of the weight gradients (two runs bit-identical)."""
+rows.  Bars: NLL within 1e-4 relative (north_star), the flat gradient within 1e-4 relative (norm-wise),
+inverse round trip within 1e-4 absolute.  Rows with a hidden pre-activation within KINK = 5e-7 (of its layer's
+largest one in that row) of zero in the float64 oracle are left out beforehand (and counted): float32 summation order decides on which side of the ReLU
+kink such a row lands, and either subgradient is a correct answer (tools/fuzz_parity.py shows the effect on
+single rows).  Plus the determinism of the weight gradients (runs bit-identical)."""
 import math
 
 import numpy as np
@@ -44,6 +46,29 @@ def make_pair(d, dc, n_blocks, widths, scale, seed=0):
     return ref, flow.to(DEV)
 
 
+KINK = 5e-7
+
+
+def rows_off_the_kinks(ref, x64, cr):
+    """mask of the rows none of whose hidden pre-activations (whole chain, float64) lies within KINK of zero"""
+    dist = torch.full((x64.shape[0],), float("inf"), dtype=torch.float64)
+    relu = torch.relu
+
+    def spy(t):
+        nonlocal dist
+        if t.numel() > 0:
+            a = t.detach().abs().reshape(t.shape[0], -1)
+            dist = torch.minimum(dist, a.min(dim=1).values / a.max(dim=1).values.clamp(min=1e-3))
+        return relu(t)
+    torch.relu = spy
+    try:
+        with torch.no_grad():
+            ref.forward(x64, cr)
+    finally:
+        torch.relu = relu
+    return dist > KINK
+
+
 def flat_grads(tr, flow):
     out = {}
     for bi, ((a, b), eng) in enumerate(zip(tr.slices, tr.engines)):
@@ -60,6 +85,13 @@ def test_chain_nll_gradient_and_inverse_match_oracle(name, d, dc, n_blocks, widt
     x64 = torch.randn(B, d, generator=g, dtype=torch.float64).float().double()
     c64 = torch.randn(B, dc, generator=g, dtype=torch.float64).float().double() if dc else None
     cr = (c64,) if dc else ()
+    keep = rows_off_the_kinks(ref, x64, cr)
+    assert int(keep.sum()) >= 0.5 * B, f"{B - int(keep.sum())} of {B} rows next to a ReLU kink"
+    x64 = x64[keep]
+    if dc:
+        c64 = c64[keep]
+        cr = (c64,)
+    B = x64.shape[0]
     for p in ref.parameters():
         p.requires_grad_(True)
     z_ref, J_ref = ref.forward(x64, cr)

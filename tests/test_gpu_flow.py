@@ -267,3 +267,25 @@ def test_step_many_equals_single_steps():
         assert rel_err(p2.detach().cpu().numpy(), p1.detach().cpu().numpy()) < 1e-4
     t2.step(xs[0])                                    # the single-step path still works afterwards
     assert np.isfinite(float(t2.last_losses()[0]))
+
+
+def test_module_copies_and_pickles_after_first_use(tmp_path):
+    """a module that already ran (it owns a plan handle and device arenas) can be deep-copied (EMA / best-checkpoint
+    copies mid-training) and saved whole; the copy builds its own engine and computes the same thing"""
+    import copy
+    torch.manual_seed(0)
+    flow = hint_amd.HintFlow(6, 2, [32, 16]).to(DEV)
+    x = torch.randn(50, 6, device=DEV)
+    with torch.no_grad():
+        z = flow(x)
+        J = flow.log_jacobian(run_forward=False)
+        twin = copy.deepcopy(flow)
+        assert twin.blocks[0].tree._engine is None and flow.blocks[0].tree._engine is not None
+        assert torch.equal(twin(x), z) and torch.equal(twin.log_jacobian(run_forward=False), J)
+        torch.save(flow, tmp_path / "flow.pt")
+        back = torch.load(tmp_path / "flow.pt", weights_only=False)
+        assert torch.equal(back(x), z)
+        # the copies own their weights
+        for p in twin.parameters():
+            p.mul_(0.5)
+        assert torch.equal(flow(x), z) and not torch.equal(twin(x), z)

@@ -3,8 +3,8 @@ the module mirror, against (1) the golden vectors of the real reference, (2) the
 fresh seeded inputs, (3) size-independent properties at the BASELINE sizes.
 
 Tolerances (fp32; north_star: log-likelihood within 1e-4 relative): z, J rtol 1e-5 / atol 1e-5
-scaled by the tensor's magnitude; gradients 1e-4 relative to the tensor's max-abs (they are
-recomputed through the block inverse)."""
+scaled by the tensor's magnitude; gradients 1e-4 relative to the tensor's max-abs (the backward kernels
+read the forward's taped activations)."""
 import numpy as np
 import pytest
 import torch

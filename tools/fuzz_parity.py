@@ -2,12 +2,39 @@
 max_splits / min_split_size - through forward, inverse and backward against the CPU oracle in float32
 (the arithmetic the reference runs in: against float64 a single row whose ReLU pre-activation sits at
 zero flips its subgradient and moves a weight gradient by 1e-2, in the oracle exactly as on the GPU).
+
+Rows on a ReLU kink: when forward and log-det agree to 1e-5 but a gradient does not, the rows whose input
+gradient deviates are looked up in the oracle: a row is ACCEPTED as a kink row only if one of its hidden
+pre-activations lies within KINK_EPS = 1e-5 (x the row's largest pre-activation, at least 1) of zero - the
+distance float32 summation order can move it across.  Such rows are printed (index, the pre-activation,
+its deviation) and dropped, at most KINK_ROWS = 3 per case; anything else fails the sweep.
    python tools/fuzz_parity.py [n_cases] [seed] [wide]"""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import hint_amd
 from oracle import hint_oracle as orc
+
+KINK_EPS, KINK_ROWS = 1e-5, 3
+
+
+def kink_distance(nodes, P, x, cond, clamp):
+    """per row: the hidden pre-activation of the oracle closest to zero, relative to the row's largest one"""
+    pre = []
+    relu = torch.relu
+
+    def spy(t):
+        pre.append(t.detach().abs())
+        return relu(t)
+    torch.relu = spy
+    try:
+        with torch.no_grad():
+            orc.block_apply(nodes, P, x, cond, rev=False, clamp=clamp)
+    finally:
+        torch.relu = relu
+    allp = torch.cat([p.reshape(p.shape[0], -1) for p in pre if p.numel() > 0], dim=1)
+    return allp.min(dim=1).values / allp.max(dim=1).values.clamp(min=1.0)
+
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -76,9 +103,16 @@ for case in range(n_cases):
         # a row whose ReLU pre-activation rounds to the other side of zero on the GPU than in the oracle gets
         # another subgradient: drop the (few) rows that differ and look again
         keep = row_err <= 3e-5
-        if 0 < int((~keep).sum()) <= 3 and int(keep.sum()) > 0:
-            note = f" [{int((~keep).sum())} row(s) on a ReLU kink dropped]"
-            e, row_err = compare(x[keep], [c[keep] for c in cond])
+        if 0 < int((~keep).sum()) <= KINK_ROWS and int(keep.sum()) > 0:
+            dist = kink_distance(nodes, P, x, cond, clamp)
+            rows = [int(i) for i in torch.nonzero(~keep).flatten()]
+            print(f"    case {case}: rows off in g_x: " + ", ".join(
+                f"row {i} (g_x dev {row_err[i].item():.1e}, nearest pre-activation {dist[i].item():.1e})" for i in rows), flush=True)
+            if all(dist[i].item() <= KINK_EPS for i in rows):
+                note = f" [{len(rows)} row(s) on a ReLU kink dropped: {rows}]"
+                e, row_err = compare(x[keep], [c[keep] for c in cond])
+            else:
+                note = " [deviating rows are NOT on a ReLU kink]"
     bad = e["z"] > 1e-5 or e["J"] > 1e-5 or e["gx"] > 1e-4 or e["gw"] > 2e-4
     for k in worst: worst[k] = max(worst[k], e[k])
     if bad or note or case % 10 == 0:
