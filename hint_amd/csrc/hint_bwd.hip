@@ -118,9 +118,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
             pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
-            pc.out_thin = blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1; pc.wcol0 = 0;
+            pc.out_thin = a.lean ? nullptr : blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1; pc.wcol0 = 0;      // (lean plans keep no g2)
             pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
-            pc.bits_a1 = (GLOBAL_AS uint8_t*)(blk.actA1 + 2 * a.act_stride) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
+            pc.bits_a1 = (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
             pc.bits_a2 = pc.bits_a1 + a.bits_stride;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
             pc.store = true;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
                     if (tid >= soff) {
-                        stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        if (!a.lean) stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                     }
                 }

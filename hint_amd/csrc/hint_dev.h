@@ -125,7 +125,10 @@ static_assert(sizeof(LaneOp) == 16, "LaneOp must be 16 bytes");
 
 // Weight-gradient job (part B): out[m][n] = sum_b P[b][pcol+m] * Q[b][qcol+n] for one tile of up to
 // 48 x 48 outputs of one parameter matrix; bofs >= 0: the job also sums P's columns (bias gradient).
-enum { WSRC_G1 = 0, WSRC_G2 = 1, WSRC_GST = 2, WSRC_A1 = 3, WSRC_A2 = 4, WSRC_X = 5, WSRC_C = 6 };
+// Lean plans (every unit has 1..4 inputs, no condition, and at most 4 outputs) keep neither a1 nor g2 in HBM: the
+// dW2 jobs rebuild their operands from what feeds the thin layers (WSRC_A1R: relu(W1 v + b1) from the level's lanes;
+// WSRC_G2R: relu'(a2) (W3^T g_st) from a2 and the coupling gradients) - a few FMAs per element instead of 4 bytes.
+enum { WSRC_G1 = 0, WSRC_G2 = 1, WSRC_GST = 2, WSRC_A1 = 3, WSRC_A2 = 4, WSRC_X = 5, WSRC_C = 6, WSRC_A1R = 7, WSRC_G2R = 8 };
 struct WJob {
     int32_t psrc, pcol, M, mw;      // operand array, first column, valid outputs (<= 16*mw), 16-wide tiles (1..3)
     int32_t qsrc, qcol, N, nw;      // N may be 0 (bias only)
@@ -133,8 +136,15 @@ struct WJob {
     int32_t pmax, qmax;             // last readable column of either operand (loads are clamped to it)
     int64_t wofs;                   // float offset of out[0][0] in the flat gradient layout
     int64_t bofs;                   // float offset of the bias gradient's first element, or -1
+    // operands rebuilt on the fly (WSRC_A1R / WSRC_G2R): the unit's thin layers in the flat parameter layout
+    int32_t r_w1, r_b1;             // W1 [h][cin], b1 [h]
+    int32_t r_w3;                   // W3 [r][h]
+    int32_t r_cin, r_xoff;          // inputs: lanes xoff .. xoff+cin of level qlevel
+    int32_t r_r, r_gcol;            // outputs: columns gcol .. gcol+r of the coupling gradients [Bp][ST]
+    int32_t r_h, r_wcol;            // hidden width (row stride of W3); the unit's first column in the [Bp][WT] arrays
+    int32_t pad_[7];
 };
-static_assert(sizeof(WJob) == 64, "WJob must be 64 bytes");
+static_assert(sizeof(WJob) == 128, "WJob must be 128 bytes");
 
 // Row record: everything a wavefront needs to know about one row - up to three adjacent fragment tiles
 // [tb, tb+ntt) of one unit - in one direction; 16 x int32, read with one scalar load.  The steps of a
@@ -184,6 +194,9 @@ struct KArgs {
     int32_t slab_floats;           // L3 slab buffer (forward) / g_v slab buffer (backward), floats
     int32_t gld;                   // LDS row stride of the coupling-gradient buffer (backward)
     int32_t WT, ST;                // row widths of the activation / coupling-gradient arrays
+    int32_t lean;                  // 1: a1 is not kept on the tape and g2 not in the workspace (the a2 / g1 arrays come first)
+    int32_t pad_lean;
+    int64_t a2_off, bits_off;      // floats from a block's a1 array (ChainBlock::actA1) to its a2 array / to the sign bytes
     int64_t bits_stride;           // bytes between the a1 and the a2 sign bytes of a block's tape
     int32_t stage_out;             // 1: the rows leave their output tiles in LDS (obuf) and the element-wise phase streams them out; 0: no LDS for that, they store them themselves
     int32_t thin_off, thin_floats; // the direction's thin blob: float offset in the packed buffer, size (multiple of 4)

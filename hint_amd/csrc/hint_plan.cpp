@@ -33,8 +33,8 @@ hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock&
                       float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
 hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
                         int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
-                        int64_t act_stride, int64_t param_floats, const float* x, const float* c, const uint8_t* real,
-                        int accumulate, int num_cu, hipStream_t stream);
+                        int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
+                        const float* c, const uint8_t* real, int accumulate, int num_cu, hipStream_t stream);
 hipError_t set_max_lds_apply(int bytes);
 hipError_t set_max_lds_bwd(int bytes);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
@@ -87,6 +87,7 @@ struct hint_plan {
     int WT = 0, ST = 0;
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
     int stage_out = 1;
+    int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
     int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
@@ -461,11 +462,15 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // the thin blobs ride in LDS (staged once per block) when they are small
     P->thin_f_off = 0; P->thin_f_floats = (int)((blob_f + 3) / 4 * 4);
     P->thin_b_off = (int)blob_f_pad; P->thin_b_floats = (int)((blob_b + 3) / 4 * 4);
-    if (P->thin_f_floats * 4 <= THIN_LDS_MAX && P->lds_fwd + P->thin_f_floats * 4 <= LDS_LIMIT) {
+    // (small ones always; larger ones when the block's LDS already rules out two workgroups per CU, or still allows them)
+    auto stage_thin = [&](int lds, int blob) {
+        return lds + blob <= LDS_LIMIT && (blob <= THIN_LDS_MAX || lds > LDS_LIMIT / 2 || lds + blob <= LDS_LIMIT / 2);
+    };
+    if (stage_thin(P->lds_fwd, P->thin_f_floats * 4)) {
         P->thin_lds_f = P->lds_fwd / 4;
         P->lds_fwd += P->thin_f_floats * 4;
     }
-    if (P->thin_b_floats * 4 <= THIN_LDS_MAX && P->lds_bwd + P->thin_b_floats * 4 <= LDS_LIMIT) {
+    if (stage_thin(P->lds_bwd, P->thin_b_floats * 4)) {
         P->thin_lds_b = P->lds_bwd / 4;
         P->lds_bwd += P->thin_b_floats * 4;
     }
@@ -508,6 +513,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
 
     // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
+    // lean: thin layers narrow enough that part B rebuilds a1 and g2 instead of reading them (HINT_LEAN=0: never)
+    P->lean = dc == 0 ? 1 : 0;
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        const hint_node_desc& n = nodes[unit_node[ui]];
+        if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) P->lean = 0;
+    }
+    if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) P->lean = 0;
     std::vector<uint8_t> real((size_t)P->param_floats, 0);
     for (size_t ui = 0; ui < units.size(); ++ui) {
         const Unit& u = units[ui];
@@ -531,10 +543,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                     j.qlevel = qlevel; j.ldo = ldo; j.pmax = pmaxc; j.qmax = qmaxc;
                     j.wofs = wofs + (int64_t)16 * mt * ldo + 16 * nt;
                     j.bofs = (bofs >= 0 && nt == 0) ? bofs + 16 * mt : -1;
+                    j.r_w1 = (int32_t)po[HINT_W1]; j.r_b1 = (int32_t)po[HINT_B1]; j.r_w3 = (int32_t)po[HINT_W3];
+                    j.r_cin = u.cin; j.r_xoff = u.xoff; j.r_r = n.r; j.r_gcol = u.gcol; j.r_h = n.h; j.r_wcol = u.wcol;
                     wjobs.push_back(j);
                 }
         };
-        add_jobs(WSRC_G2, u.wcol, n.h, P->WT - 1, WSRC_A1, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W2], po[HINT_B2]);
+        add_jobs(P->lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, P->lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
+                 P->lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
         add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
         if (u.ku > 0)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
@@ -682,6 +697,7 @@ static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
 // Tape layout (floats): [lane tiles: L x B x d][s: L x B x d][pad to 4][a1: Bp x WT + slack][a2: same]
 //                       [sign bytes of a1: Bp/16 x WT/16 x 64 bytes][of a2: same]
+// (lean plans: no a1 array)
 static inline int64_t tape_act_off(const hint_plan* P, int B) {
     return (2 * (int64_t)P->n_levels * B * P->d + 3) / 4 * 4;
 }
@@ -690,7 +706,7 @@ static inline int64_t bits_stride(const hint_plan* P, int B) { return (int64_t)r
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
-    return tape_act_off(P, B) + 2 * act_stride(P, B) + 2 * bits_stride(P, B) / 4;
+    return tape_act_off(P, B) + (P->lean ? 1 : 2) * act_stride(P, B) + 2 * bits_stride(P, B) / 4;
 }
 
 // batch split of part B: a multiple of 8 splits (one XCD each), enough workgroups to cover the chip,
@@ -708,7 +724,7 @@ static void wgrad_splits(const hint_plan* P, int B, int n_chain, int* splits_out
 }
 
 // Workspace layout (floats): [g1: Bp x WT + slack][g2: same][g_st: Bp x ST + slack, padded to 4][slabs: splits x param_floats]
-static inline int64_t ws_gst_off(const hint_plan* P, int B) { return 2 * act_stride(P, B); }
+static inline int64_t ws_gst_off(const hint_plan* P, int B) { return (P->lean ? 1 : 2) * act_stride(P, B); }      // (lean plans: no g2 array)
 static inline int64_t ws_slab_off(const hint_plan* P, int B) {
     return ws_gst_off(P, B) + ((int64_t)rows_padded(B) * P->ST + WS_SLACK + 3) / 4 * 4;
 }
@@ -745,6 +761,7 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
     a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;
     a.act_stride = act_stride(P, B); a.bits_stride = bits_stride(P, B);
+    a.lean = P->lean; a.a2_off = P->lean ? 0 : a.act_stride; a.bits_off = (P->lean ? 1 : 2) * a.act_stride;
     a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
     return a;
 }
@@ -834,8 +851,9 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
     int splits, rows_per_wg;
     wgrad_splits(P, B, n_chain, &splits, &rows_per_wg);
     HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, splits, one, chain, n_chain, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
-                         rows_padded(B), rows_per_wg, act_stride(P, B), P->param_floats, x, c, P->d_real, accumulate,
-                         P->num_cu, s));
+                         rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
+                         (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
+                         accumulate, P->num_cu, s));
     return 0;
 }
 

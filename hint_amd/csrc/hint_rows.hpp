@@ -179,12 +179,25 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
         f32x4 acc = KIND == K_FWD ? vec(kp) : zero4();
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc += w[k] * vin[k];
-        for (int k = 4; k < K; ++k) acc += vec(k) * input(k);
+        if (STAGED) {
+            for (int k = 4; k < K; ++k) acc += vec(k) * input(k);
+        } else {
+            // (from global memory: TB vectors in flight at a time; the padding terms add w * 0)
+            constexpr int TB = 8;
+            for (int k = 4; k < K; k += TB) {
+                f32x4 wv[TB];
+                float iv[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) { const int kk = k + u < K ? k + u : K - 1; wv[u] = vec(kk); iv[u] = k + u < K ? input(kk) : 0.f; }
+#pragma unroll
+                for (int u = 0; u < TB; ++u) acc += wv[u] * iv[u];
+            }
+        }
         if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         ((LDS_AS f32x4*)c.abuf)[rec.z * 64 + lane] = acc;
         if (KIND == K_FWD && HINT_STORE_ON) {
             c.bits_a1[((c.wcol0 >> 4) + rec.z) * 64 + lane] = (uint8_t)sign_bits(acc);
-            if (c.obuf == nullptr)      // (no LDS staging: the tile goes to the tape from here)
+            if (c.obuf == nullptr && c.out_thin != nullptr)      // (no LDS staging: the tile goes to the tape from here)
                 *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + c.wcol0 + 16 * rec.z) + (m * c.WT + 4 * kq)) = acc;
         }
     }
@@ -214,7 +227,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     bb[1] = zero4();
 
     // one main step: k-block KB, the slot's weight fragments W (backward: W[NTT] = the a2 tile of the k-block), static slot S
-    const bool stg2 = KIND == K_BWD && HINT_STORE_ON && cr.first;      // this row leaves the unit's masked g2 tiles in LDS (streamed out later)
+    const bool stg2 = KIND == K_BWD && HINT_STORE_ON && cr.first && c.out_thin != nullptr;      // this row leaves the unit's masked g2 tiles in LDS (streamed out later)
 #define HINT_MAIN_STEP(KB, W, S)                                                                        \
     {                                                                                                   \
         f32x4 b4 = bb[(S) & 1];                                                                         \

@@ -4,7 +4,11 @@
 //   dW2[m][n] = sum_b g2[b][m] a1[b][n]
 //   dW3[j][f] = sum_b g_st[b][j] a2[b][f]
 //   db1 = colsum g1, db2 = colsum g2, db3 = colsum g_st
-// i.e. GEMMs whose K dimension is the batch.  The OUTPUT is tiled (up to 48x48 per workgroup: 3x3
+// i.e. GEMMs whose K dimension is the batch.  Lean plans (hint_dev.h) keep neither a1 nor g2 in HBM: their dW2 jobs
+// rebuild both operands per 16-row step with ONE extra MFMA per 16-column tile - a1 = relu(v W1^T + b1) and
+// g2 = relu'(a2) (g_st W3), K <= 4 each - whose result layout (lane l: rows 4(l>>4)+i of column l&15) is exactly
+// the A / B operand layout of the products over the row subsets {4 kq + i}; the inputs are one float of v, one of
+// g_st and one word of a2 sign bytes per lane and step.  The OUTPUT is tiled (up to 48x48 per workgroup: 3x3
 // MFMA tiles fed by one 12-byte load per operand and k-step) and the batch is split over `splits`
 // workgroups and the 8 wavefronts of each.  Block ids are mapped so that all tiles of one batch split
 // run on the same XCD (blocks b, b+8, .. share one): the rows of a split are fetched from HBM /
@@ -21,7 +25,7 @@ struct SrcRef { const float* p; int ld; int rows; };
 
 __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bool top, const float* __restrict__ x,
                                        const float* __restrict__ c, int WT, int ST, int d, int dc, int n_levels, int B, int Bp,
-                                       int64_t act_stride) {
+                                       int64_t act_stride, int64_t a2_off) {
     SrcRef r;
     r.rows = Bp;
     switch (src) {
@@ -29,7 +33,7 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
         case WSRC_G2: r.p = (const float*)blk.wsG1 + act_stride; r.ld = WT; break;
         case WSRC_GST: r.p = (const float*)blk.wsGST; r.ld = ST; break;
         case WSRC_A1: r.p = (const float*)blk.actA1; r.ld = WT; break;
-        case WSRC_A2: r.p = (const float*)blk.actA1 + act_stride; r.ld = WT; break;
+        case WSRC_A2: r.p = (const float*)blk.actA1 + a2_off; r.ld = WT; break;
         case WSRC_X: {
             const float* tape = (const float*)blk.tape;
             const size_t lvl = (size_t)B * d;
@@ -45,7 +49,7 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
 __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     const WJob* __restrict__ jobs, int n_jobs, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
     int grid_pb, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
-    int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c) {
+    int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c) {
     __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
     __shared__ float bred[DW_WAVES][3][16];
 
@@ -71,8 +75,6 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     const int wave = rfl(tid >> 6);
     const int nl = lane & 15, kq = lane >> 4;
     const int ntm = job.mw, ntn = job.nw;
-    const SrcRef ps = wsrc(job.psrc, 0, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride);
-    const SrcRef qs = wsrc(job.qsrc, job.qlevel, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride);
     const int b_begin = split * rows_per_wg;
     const int b_end = min(Bp, b_begin + rows_per_wg);
 
@@ -82,6 +84,78 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = zero4();
     float psum[3] = {0.f, 0.f, 0.f};
+    const int step = 16 * DW_WAVES;
+    const bool natural = job.psrc == WSRC_G2R;       // columns in natural order (no 12-byte loads to serve)
+
+    if (natural) {
+        // ---- lean dW2: both operands rebuilt from the thin layers' inputs ----
+        const float* prm = (const float*)blk.params;
+        const SrcRef vs = wsrc(WSRC_X, job.qlevel, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
+        const float* gst = (const float*)blk.wsGST;
+        const uint8_t* bits = (const uint8_t*)blk.actA1 + bits_a2_off;           // a2 sign bytes [row tile][tile][64]
+        const int ntiles = WT >> 4;
+        float w1b[3], b1c[3], w3b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int fq = job.qcol - job.r_wcol + 16 * t + nl, fp = job.pcol - job.r_wcol + 16 * t + nl;
+            w1b[t] = (kq < job.r_cin && fq < job.r_h) ? prm[job.r_w1 + (size_t)fq * job.r_cin + kq] : 0.f;
+            b1c[t] = fq < job.r_h ? prm[job.r_b1 + fq] : 0.f;
+            w3b[t] = (kq < job.r_r && fp < job.r_h) ? prm[job.r_w3 + (size_t)kq * job.r_h + fp] : 0.f;
+        }
+        const int vcol = job.r_xoff + min(kq, job.r_cin - 1), gcol = job.r_gcol + min(kq, job.r_r - 1);
+        const unsigned bofs = 16 * (nl >> 2) + 4 * kq, bsh = nl & 3;
+        struct In { float v, g; unsigned s[3]; };
+        auto load_in = [&](int BB) {
+            In in;
+            in.v = vs.p[(size_t)min(BB + nl, vs.rows - 1) * vs.ld + vcol];
+            in.g = gst[(size_t)(BB + nl) * ST + gcol];
+            const uint8_t* bp = bits + ((size_t)(BB >> 4) * ntiles + (job.pcol >> 4)) * 64 + bofs;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) in.s[t] = t < ntm ? *(const unsigned*)(bp + 64 * t) : 0u;
+            return in;
+        };
+        auto mma = [&](const In& in) {
+            const float va = kq < job.r_cin ? in.v : 0.f, ga = kq < job.r_r ? in.g : 0.f;
+            f32x4 p[3], q[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (t < ntn) {
+                    f32x4 b = {b1c[t], b1c[t], b1c[t], b1c[t]};
+                    q[t] = mfma4(va, w1b[t], b);
+                    q[t].x = fmaxf(q[t].x, 0.f); q[t].y = fmaxf(q[t].y, 0.f); q[t].z = fmaxf(q[t].z, 0.f); q[t].w = fmaxf(q[t].w, 0.f);
+                }
+                if (t < ntm) {
+                    p[t] = mfma4(ga, w3b[t], zero4());
+                    const unsigned sw = in.s[t] >> bsh;
+                    p[t].x = (sw & 1u) ? p[t].x : 0.f; p[t].y = (sw & 0x100u) ? p[t].y : 0.f;
+                    p[t].z = (sw & 0x10000u) ? p[t].z : 0.f; p[t].w = (sw & 0x1000000u) ? p[t].w : 0.f;
+                    psum[t] += (p[t].x + p[t].y) + (p[t].z + p[t].w);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm)
+                    if (tm < ntm)
+#pragma unroll
+                        for (int tn = 0; tn < 3; ++tn)
+                            if (tn < ntn) acc[tm][tn] = mfma4(p[tm][i], q[tn][i], acc[tm][tn]);
+        };
+        int bb = b_begin + wave * 16;
+        if (bb < b_end) {
+            In cur = load_in(bb);
+            while (true) {
+                const int nb = bb + step;
+                const bool last = nb >= b_end;
+                const In nxt = load_in(last ? bb : nb);
+                mma(cur);
+                if (last) break;
+                cur = nxt; bb = nb;
+            }
+        }
+    } else {
+    const SrcRef ps = wsrc(job.psrc, 0, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
+    const SrcRef qs = wsrc(job.qsrc, job.qlevel, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
 
     // lane nl holds columns col0 + w*nl + {0..w-1} of its operand (the permutation of columns inside
     // the up-to-48-wide group is undone at write-out).  Full 48-column groups inside the array: one
@@ -120,7 +194,6 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
 
     // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs of block j
-    const int step = 16 * DW_WAVES;
     int bb = b_begin + wave * 16;
     if (bb < b_end) {
         DW_LOAD(0, bb)
@@ -140,6 +213,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
 #undef DW_LOAD
 #undef DW_MMA
+    }
     // combine the wavefronts (fixed order)
 #pragma unroll
     for (int tm = 0; tm < 3; ++tm)
@@ -163,17 +237,17 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
         f32x4 v = *(f32x4*)&red[0][t][l][0];
 #pragma unroll
         for (int w = 1; w < DW_WAVES; ++w) v += *(f32x4*)&red[w][t][l][0];
-        const int n = ntn * (l & 15) + tn;          // undo the column permutation of the loads
+        const int n = natural ? 16 * tn + (l & 15) : ntn * (l & 15) + tn;          // undo the column permutation of the loads
         if (n >= job.N) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = ntm * (4 * (l >> 4) + i) + tm;
+            const int m = natural ? 16 * tm + 4 * (l >> 4) + i : ntm * (4 * (l >> 4) + i) + tm;
             if (m < job.M) slab[job.wofs + (size_t)m * job.ldo + n] = v[i];
         }
     }
     if (job.bofs >= 0 && tid < 48) {
         const int tm = tid >> 4, l = tid & 15;
-        const int m = ntm * l + tm;
+        const int m = natural ? 16 * tm + l : ntm * l + tm;
         if (tm < ntm && m < job.M) {
             float v = bred[0][tm][l];
 #pragma unroll
@@ -211,14 +285,14 @@ namespace hint {
 
 hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
                         int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
-                        int64_t act_stride, int64_t param_floats, const float* x, const float* c, const uint8_t* real,
-                        int accumulate, int num_cu, hipStream_t stream) {
+                        int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
+                        const float* c, const uint8_t* real, int accumulate, int num_cu, hipStream_t stream) {
     const int used = n_jobs * splits;
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0)
         hipLaunchKernelGGL(hint_wgrad_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs,
                            splits, one, chain, grid_pb, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
-                           param_floats, x, c);
+                           a2_off, bits_a2_off, param_floats, x, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int blocks_pb = (int)((param_floats / 4 + 255) / 256);
