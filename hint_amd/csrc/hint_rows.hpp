@@ -16,10 +16,10 @@
 // the LDS slab the wavefront keeps for the unit.
 //
 // The weight stream runs through a register ring of RING slots x 3 elements: every step consumes one
-// slot and issues its 16-byte-per-lane global loads for the step RING ahead (a row's body is compiled
-// for its tile count; the hand-over to the next row always loads three elements, a narrower row's last
-// tile again: an L1 hit) - weight tiles, bias vectors and the forward activations whose
-// sign masks the backward tiles all travel the same way.  That regularity is what lets hipcc keep the
+// slot and first issues the 16-byte-per-lane global loads of the step RING - 1 ahead into the slot the
+// step before used (no copies of live values; a row's body is compiled for its tile count; the hand-over
+// to the next row always loads three elements, a narrower row's last tile again: an L1 hit) - weight
+// tiles and the sign bytes of the forward activations that mask the backward tiles travel the same way.  That regularity is what lets hipcc keep the
 // loads in flight (counted vmcnt waits): a load under a branch makes its wait-count analysis assume
 // the worst on every path.  A row's stream is [main steps, padded with dummies to a multiple of
 // RING][extra steps: aux, tail, last-layer bias]; position p lives in slot p % RING, so the loops
@@ -35,6 +35,8 @@ enum { K_FWD = 0, K_BWD = 1 };
 #define HINT_RING 2
 #endif
 constexpr int RING = HINT_RING;
+static_assert(RING % 2 == 0, "the B-fragment double buffer alternates with the slot parity");
+constexpr int DIST = RING - 1;      // how many steps ahead of its use a ring element is loaded
 constexpr int NEL = NTT + 1;    // ring elements per slot: the row's weight tiles + (backward) the a2 tile that masks the step's B fragment
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -216,9 +218,6 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     const int n1 = cr.n1;
     const int n1p = (n1 + RING - 1) / RING * RING;
     f32x4 xaux[NTT], xtail[NTT], xb3[NTT];
-    load_extra3<KIND, NA>(xaux, c, cr, 0, lo);
-    load_extra3<KIND, NA>(xtail, c, cr, 1, lo);
-    load_extra3<KIND, 1>(xb3, c, cr, 1 + cr.n2, lo);
     f32x4 acc[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) acc[j] = zero4();
@@ -226,22 +225,28 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     bb[0] = abuf4[cr.tile0 * 64];
     bb[1] = zero4();
 
-    // one main step: k-block KB, the slot's weight fragments W (backward: W[NTT] = the a2 tile of the k-block), static slot S
+    // One main step of static slot S: k-block KB with the slot's weight fragments (backward: element NTT = the sign
+    // byte of the a2 tile of the k-block).  First the loads of the step DIST = RING - 1 ahead - of row NR (this row,
+    // or the next one at the end of the last chunk) - into slot (S + DIST) % RING, whose last use was the step
+    // before: no copy of a live value, nothing at the loop's back edge that waits for a load just issued.
     const bool stg2 = KIND == K_BWD && HINT_STORE_ON && cr.first && c.out_thin != nullptr;      // this row leaves the unit's masked g2 tiles in LDS (streamed out later)
-#define HINT_MAIN_STEP(KB, W, S)                                                                        \
+#define HINT_MAIN_STEP(KB, S, LIVE, NR, NKB, NLOAD)                                                     \
     {                                                                                                   \
+        load_main3<KIND, NLOAD>(ring[((S) + DIST) % RING], c, NR, NKB, lo);                             \
         f32x4 b4 = bb[(S) & 1];                                                                         \
         const int kn = (KB) + 1 < n1 ? (KB) + 1 : (KB);                                                 \
         bb[((S) + 1) & 1] = abuf4[(cr.tile0 + kn) * 64];                                                \
-        if (KIND == K_BWD) {                                                                            \
-            mask_by_bits(b4, __float_as_int((W)[NTT].x));                                               \
-            if (stg2) {                                                                                 \
-                if (c.obuf != nullptr) ((LDS_AS f32x4*)c.abuf)[(cr.tile0 + (KB)) * 64 + lane] = b4;   /* (idempotent for the other readers) */ \
-                else *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + cr.wcol + 16 * (KB)) + (m * c.WT + 4 * kq)) = b4; \
+        if (LIVE) {                                                                                     \
+            if (KIND == K_BWD) {                                                                        \
+                mask_by_bits(b4, __float_as_int(ring[S][NTT].x));                                       \
+                if (stg2) {                                                                             \
+                    if (c.obuf != nullptr) ((LDS_AS f32x4*)c.abuf)[(cr.tile0 + (KB)) * 64 + lane] = b4;   /* (idempotent for the other readers) */ \
+                    else *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + cr.wcol + 16 * (KB)) + (m * c.WT + 4 * kq)) = b4; \
+                }                                                                                       \
             }                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+                _Pragma("unroll") for (int j = 0; j < NA; ++j) acc[j] = mfma4(ring[S][j][i], b4[i], acc[j]); \
         }                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-            _Pragma("unroll") for (int j = 0; j < NA; ++j) acc[j] = mfma4((W)[j][i], b4[i], acc[j]);    \
     }
 
     // ---- main steps: all chunks but the last (no dummies in them) ----
@@ -249,24 +254,24 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     for (; k0 + RING < n1p; k0 += RING) {
 #pragma unroll
         for (int s = 0; s < RING; ++s) {
-            f32x4 w[NEL];
-#pragma unroll
-            for (int j = 0; j < NA; ++j) w[j] = ring[s][j];
-            w[NTT] = ring[s][NTT];
-            load_main3<KIND, NA>(ring[s], c, cr, k0 + s + RING, lo);
-            HINT_MAIN_STEP(k0 + s, w, s)
+            HINT_MAIN_STEP(k0 + s, s, true, cr, k0 + s + DIST, NA)
+            STAMP(384 + ((c.sid >> 4) & 7) * 16 + ((k0 + s) & 15))
         }
     }
     STAMP(c.sid + 10)
-    // ---- last main chunk: its loads fetch the next row's first main steps ----
+    // the row's first extra elements: issued here, behind the loop, so that what waits for them further down can
+    // count the loads in between (a value loaded in front of a loop of unknown trip count is waited for with
+    // vmcnt(0) - i.e. for the hand-over loads below as well)
+    load_extra3<KIND, NA>(xaux, c, cr, 0, lo);
+    load_extra3<KIND, NA>(xtail, c, cr, 1, lo);
+    load_extra3<KIND, 1>(xb3, c, cr, 1 + cr.n2, lo);
+    // ---- last main chunk: its last DIST steps fetch the next row's first DIST main steps (all NTT elements: the
+    //      next row may be wider) ----
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
-        f32x4 w[NEL];
-#pragma unroll
-        for (int j = 0; j < NA; ++j) w[j] = ring[s][j];
-        w[NTT] = ring[s][NTT];
-        load_main3<KIND, NTT>(ring[s], c, nr, s, lo);
-        if (k0 + s < n1) HINT_MAIN_STEP(k0 + s, w, s)
+        const bool live = k0 + s < n1;
+        if (s + DIST < RING) { HINT_MAIN_STEP(k0 + s, s, live, cr, k0 + s + DIST, NA) }
+        else { HINT_MAIN_STEP(k0 + s, s, live, nr, s + DIST - RING, NTT) }
     }
 #undef HINT_MAIN_STEP
 
@@ -327,7 +332,7 @@ __device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
     const RowU cr = decode_rec(load_rec(c.recs, r0));
 #pragma unroll
-    for (int s = 0; s < RING; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
+    for (int s = 0; s < DIST; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
 }
 // rnext: the record whose first main steps the LAST row hands the ring over to - the wavefront's first row of the
 // next group of the block - or -1 (then it re-loads its own: never used)

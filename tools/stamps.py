@@ -62,6 +62,14 @@ def show(title, st, per_block, labels, blocks):
                     continue
                 d = np.where((inner[:, k] != 0) & (inner[:, k + 1] != 0), inner[:, k + 1] - inner[:, k], 0)
                 print(f"   blk {cb} grp {gi} {lab:22s} " + " ".join(f"{int(v):6d}" for v in d))
+            steps = st[:nw, 384 + ((cb * per_block + gi) & 7) * 16: 384 + ((cb * per_block + gi) & 7) * 16 + 16]
+            if per_block <= 2 and (steps != 0).any():
+                t0 = inner[:, 2]
+                for k in range(16):
+                    if (steps[:, k] == 0).all():
+                        break
+                    prev = t0 if k == 0 else steps[:, k - 1]
+                    print(f"   blk {cb} grp {gi}     main step {k:2d}        " + " ".join(f"{int(v):6d}" for v in np.where(steps[:, k] != 0, steps[:, k] - prev, 0)))
         tb = st[:nw, cb * per_block * 16]
         te = st[:nw, (cb + 1) * per_block * 16] if (cb + 1) * per_block * 16 < IDS else None
         if te is not None and (te != 0).all():
