@@ -714,7 +714,6 @@ int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
 static void wgrad_splits(const hint_plan* P, int B, int n_chain, int* splits_out, int* rows_out) {
     const long Bp = rows_padded(B);
     int splits = 8;
-    if (const char* e = std::getenv("HINT_WSPLITS")) splits = std::max(1, std::atoi(e));
     while ((long)splits * P->n_wjobs * n_chain < (long)P->num_cu && Bp / (splits * 2) >= 128) splits *= 2;
     int rows_per_wg = (int)((Bp + splits - 1) / splits);
     rows_per_wg = (rows_per_wg + 15) / 16 * 16;

@@ -19,7 +19,10 @@
 
 using namespace hint;
 
-constexpr int DW_WAVES = 8;
+#ifndef HINT_DW_WAVES
+#define HINT_DW_WAVES 8
+#endif
+constexpr int DW_WAVES = HINT_DW_WAVES;
 
 struct SrcRef { const float* p; int ld; int rows; };
 

@@ -162,7 +162,7 @@ class FlowTrainer:
             for i, e in enumerate(self.engines):
                 a, _ = self.slices[i]
                 _lib.check(self.lib.hint_chain_set_block(
-                    handle, i, e.arena.data_ptr(), (self.engines[0] if os.environ.get('HINT_DEBUG_SAMEW') else e).packed.data_ptr(),
+                    handle, i, e.arena.data_ptr(), e.packed.data_ptr(),
                     perms[i].data_ptr() if perms[i] is not None else None, tapes[i].data_ptr(),
                     ws[i].data_ptr(), ws_bytes, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
             _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
