@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="training iterations per hipGraph replay (FlowTrainer.step_many; one process only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="rows per GPU instead of the workload's (small-batch measurements; the config line says so)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's batch per rank; strong: the workload's batch is the global batch")
     ap.add_argument("--legs", action="store_true",
@@ -170,6 +172,8 @@ def main():
     import hint_amd
     cfg = WORKLOADS[args.workload]
     d, B = cfg["d"], cfg["batch"]
+    if args.batch > 0:
+        B = args.batch
     if args.scaling == "strong":
         if B % world:
             raise SystemExit(f"--scaling strong: the global batch {B} does not divide over {world} ranks")
