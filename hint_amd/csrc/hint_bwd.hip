@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
     float* obuf = abuf + a.abuf_tiles * 256;  // g1 fragment tiles on their way to global memory
     float* slab = obuf + (a.stage_out ? a.abuf_tiles * 256 : 0);  // g_v partials
     float* gj = slab + a.slab_floats;
+    float* xo = gj + ROWS;                    // the lane tile of the level before (first-layer gradients of the group just finished)
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
     const size_t lvl = (size_t)a.B * a.d;     // floats of one [B, d] tape slice
@@ -155,7 +156,45 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     if (soff > 0) qthreads = soff;
                     if (tid >= soff) {
                         if (!a.lean) stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
-                        stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        if (!a.fuse_dw1) {
+                            stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        } else {
+                            // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f] of the finished group's units,
+                            // from the g1 tiles in LDS and the lanes its level saw: into this workgroup's slab (plain stores;
+                            // hint_wreduce_kernel adds the workgroups' slabs in order).  g1 never leaves the chip.
+                            float* tw = (float*)blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
+                            const bool first_tile = tile == (int)blockIdx.x;
+                            // One 16-feature tile per wavefront and turn, on the matrix pipe: out[f][k] = sum over the 16 rows
+                            // as four 16x16x4 MFMAs (A = g1^T from the fragment tile: lane l gives feature l&15 of row 4i + (l>>4);
+                            // B = the lanes, column cin = 1 for the bias gradient).
+                            const int ws = rfl((tid - soff) >> 6), nws = (nthreads - soff) >> 6;
+                            const int nl = lane & 15, kq = lane >> 4;
+                            const CONST_AS i32x4c* wrec = (const CONST_AS i32x4c*)(unsigned long long)((const char*)a.thins +
+                                                          (size_t)2 * a.total_tiles * sizeof(ThinRec)) + gp.tile_begin;
+                            i32x4c nrec = wrec[ws < gp.ntiles ? ws : 0];                      // (records one tile ahead: a scalar load takes as long as the tile)
+                            for (int t = ws; t < gp.ntiles; t += nws) {
+                                const i32x4c rec = nrec;
+                                nrec = wrec[t + nws < gp.ntiles ? t + nws : t];
+                                const int cin = rec.y & 0xff, xoff = (rec.y >> 8) & 0xff, nvalid = rec.y >> 16, kc = cin + 1;
+                                const LDS_AS float* g1p = (const LDS_AS float*)obuf + (rec.z * 64 + kq + 16 * (nl >> 2)) * 4 + (nl & 3);
+                                const LDS_AS float* vp = (const LDS_AS float*)xo + kq * a.xld + xoff + (nl < cin ? nl : 0);
+                                const float one = nl == cin ? 1.f : 0.f;
+                                f32x4 acc = zero4();
+                                float av[4], bv[4];                       // (all eight LDS reads in flight: no read under a lane mask)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * a.xld]; }     // rows 4i + kq
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc = mfma4(av[i], nl < cin ? bv[i] : one, acc);
+                                if (nl < kc) {
+                                    float* dst = tw + rec.x + 4 * kq * kc + nl;              // feature 4 kq + j of the tile, input nl
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (4 * kq + j < nvalid) {
+                                            if (first_tile) dst[j * kc] = acc[j]; else dst[j * kc] += acc[j];
+                                        }
+                                }
+                            }
+                        }
                     }
                 }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
@@ -260,6 +299,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 5)
+                if (a.fuse_dw1)          // the lanes this group's first layers read: kept for their weight gradients (computed across the next boundary)
+                    for (int i = tid; i < ROWS * a.d; i += nthreads) { const int r = fdiv(i, inv_d), j = i - r * a.d; xo[r * a.xld + j] = xs[r * a.xld + j]; }
                 if (lp_pending) level_commit(lp, xs, sb, a.xld, a.d, tid, nthreads);
                 lds_barrier();
                 STAMP(sid + 6)

@@ -195,7 +195,9 @@ struct KArgs {
     int32_t gld;                   // LDS row stride of the coupling-gradient buffer (backward)
     int32_t WT, ST;                // row widths of the activation / coupling-gradient arrays
     int32_t lean;                  // 1: a1 is not kept on the tape and g2 not in the workspace (the a2 / g1 arrays come first)
-    int32_t pad_lean;
+    int32_t fuse_dw1;              // 1: the backward kernel computes dW1, db1 itself (slab per workgroup) and g1 is not stored
+    int32_t tw_floats, pad_tw;     // floats of one such slab
+    int64_t thin_slab_off;         // floats from ChainBlock::wsSlab to the first of them
     int64_t a2_off, bits_off;      // floats from a block's a1 array (ChainBlock::actA1) to its a2 array / to the sign bytes
     int64_t bits_stride;           // bytes between the a1 and the a2 sign bytes of a block's tape
     int32_t stage_out;             // 1: the rows leave their output tiles in LDS (obuf) and the element-wise phase streams them out; 0: no LDS for that, they store them themselves

@@ -34,7 +34,8 @@ hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock&
 hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
                         int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
-                        const float* c, const uint8_t* real, int accumulate, int num_cu, hipStream_t stream);
+                        const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
+                        int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream);
 hipError_t set_max_lds_apply(int bytes);
 hipError_t set_max_lds_bwd(int bytes);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
@@ -88,6 +89,9 @@ struct hint_plan {
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
     int stage_out = 1;
     int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
+    int fuse_dw1 = 0;           // lean plans with LDS-staged outputs: dW1, db1 come from the backward kernel (per-workgroup slabs), g1 stays on chip
+    int tw_floats = 0;          // floats of one such slab
+    int32_t* d_twmap = nullptr; // slab index -> offset in the flat parameter layout (or -1)
     int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
     int lds_fwd = 0, lds_bwd = 0;
     int num_cu = 256;
@@ -401,6 +405,38 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return fail("hint_plan_create: block too large (offsets must fit 31 / 15 bits)");
     }
     for (Unit& u : units) { u.bias1 += (int)packed; u.bias2 += (int)packed; u.bias3 += (int)packed; }   // the bias region follows the weight tiles
+    // lean: thin layers narrow enough that part B rebuilds a1 and g2 instead of reading them (HINT_LEAN=0: never)
+    P->lean = dc == 0 ? 1 : 0;
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        const hint_node_desc& n = nodes[unit_node[ui]];
+        if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) P->lean = 0;
+    }
+    if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) P->lean = 0;
+    // a lean plan's first-layer gradients: [h][cin + 1] per unit (the bias gradient as the last column) in a slab per
+    // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
+    std::vector<int32_t> twmap;
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        Unit& u = units[ui];
+        u.bias1 = -1;
+        if (!P->lean) continue;
+        const hint_node_desc& n = nodes[unit_node[ui]];
+        const int64_t* po = n.p_off + (int)(ui & 1) * 6;
+        u.bias1 = (int)twmap.size();
+        for (int f = 0; f < n.h; ++f)
+            for (int k = 0; k <= u.cin; ++k) twmap.push_back(k < u.cin ? (int32_t)(po[HINT_W1] + (int64_t)f * u.cin + k) : (int32_t)(po[HINT_B1] + f));
+        while (twmap.size() % 4) twmap.push_back(-1);
+    }
+    P->tw_floats = (int)twmap.size();
+    // ... and one record per fragment tile, in the thin records' order, for the backward kernel's first-layer-gradient
+    // pass: {slab offset of the tile's first feature row, cin | xoff << 8 | valid features << 16, tile inside the group}
+    std::vector<ThinRec> thin_w;
+    for (const Group& g : groups)
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+            const Unit& u = units[ui];
+            for (int nt = 0; nt < u.NT; ++nt)
+                thin_w.push_back(ThinRec{u.bias1 < 0 ? 0 : u.bias1 + nt * 16 * (u.cin + 1),
+                                         u.cin | (u.xoff << 8) | (std::min(16, u.h - 16 * nt) << 16), u.tile0 + nt, 0});
+        }
     for (RowRec& r : recs_f) { r.aux += (int)packed; r.bias3 += (int)packed; }
 
     // ---- backward lane tables: per boundary (in front of group gi; slot n_groups: behind group 0) and lane ----
@@ -453,7 +489,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (lops_lds) std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
     // the rows' output tiles wait in LDS for the element-wise phase to stream them out - when there is room for that
     auto lds_f = [&](int nbuf) { return P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + nbuf * P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW); };
-    auto lds_b = [&](int nbuf) { return P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + nbuf * P->abuf_tiles * 256 + P->slab_bwd + ROWS); };
+    auto lds_b = [&](int nbuf) { return P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + nbuf * P->abuf_tiles * 256 + P->slab_bwd + ROWS + ROWS * P->xld); };      // (+ the lanes of the level before: first-layer gradients)
     P->stage_out = (lds_f(2) <= LDS_LIMIT && lds_b(2) <= LDS_LIMIT) ? 1 : 0;
     P->lds_fwd = lds_f(1 + P->stage_out);
     P->lds_bwd = lds_b(1 + P->stage_out);
@@ -513,13 +549,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
 
     // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
-    // lean: thin layers narrow enough that part B rebuilds a1 and g2 instead of reading them (HINT_LEAN=0: never)
-    P->lean = dc == 0 ? 1 : 0;
-    for (size_t ui = 0; ui < units.size(); ++ui) {
-        const hint_node_desc& n = nodes[unit_node[ui]];
-        if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) P->lean = 0;
-    }
-    if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) P->lean = 0;
+    P->fuse_dw1 = (P->lean && P->stage_out && P->tw_floats > 0) ? 1 : 0;
+    if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) P->fuse_dw1 = 0;
     std::vector<uint8_t> real((size_t)P->param_floats, 0);
     for (size_t ui = 0; ui < units.size(); ++ui) {
         const Unit& u = units[ui];
@@ -529,7 +560,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         const int level = max_depth - n.depth;
         const int64_t sizes[6] = {(int64_t)n.h * u.cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
         for (int t = 0; t < 6; ++t)
-            for (int64_t i = 0; i < sizes[t]; ++i) real[(size_t)(po[t] + i)] = 1;
+            for (int64_t i = 0; i < sizes[t]; ++i) real[(size_t)(po[t] + i)] = (P->fuse_dw1 && t < 2) ? 2 : 1;      // 2: summed from the backward kernel's slabs
         auto add_jobs = [&](int psrc, int pcol, int M, int pmaxc, int qsrc, int qcol, int N, int qmaxc, int qlevel, int ldo,
                             int64_t wofs, int64_t bofs) {
             // tiles of up to 48 x 48 outputs; the bias gradient rides with the first column group
@@ -551,7 +582,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         add_jobs(P->lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, P->lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
                  P->lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
         add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
-        if (u.ku > 0)
+        if (u.ku > 0 && !P->fuse_dw1)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
         if (dc > 0)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_C, 0, dc, dc - 1, 0, u.cin, po[HINT_W1] + u.ku, u.ku > 0 ? -1 : po[HINT_B1]);
@@ -584,6 +615,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (e == hipSuccess) {
         std::vector<ThinRec> both(thin_f);
         both.insert(both.end(), thin_b.begin(), thin_b.end());
+        both.insert(both.end(), thin_w.begin(), thin_w.end());
         e = upload((void**)&P->d_thins, both.data(), both.size() * sizeof(ThinRec));
     }
     if (e == hipSuccess) {
@@ -594,6 +626,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (e == hipSuccess) e = upload((void**)&P->d_bmap, bmap.data(), bmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_real, real.data(), real.size());
     if (e == hipSuccess) e = upload((void**)&P->d_wjobs, wjobs.data(), wjobs.size() * sizeof(WJob));
+    if (e == hipSuccess && !twmap.empty()) e = upload((void**)&P->d_twmap, twmap.data(), twmap.size() * sizeof(int32_t));
     if (e == hipSuccess) e = upload((void**)&P->d_segs, segs.data(), segs.size() * sizeof(PackSeg));
     if (e == hipSuccess) e = upload((void**)&P->d_ptiles, ptiles.data(), ptiles.size() * sizeof(int2));
     // the kernels' dynamic-LDS ceiling is a per-kernel attribute: always the hardware limit, so that plans
@@ -684,6 +717,7 @@ void hint_plan_destroy(hint_plan* P) {
     (void)hipFree(P->d_bmap);
     (void)hipFree(P->d_real);
     (void)hipFree(P->d_wjobs);
+    (void)hipFree(P->d_twmap);
     (void)hipFree(P->d_segs);
     (void)hipFree(P->d_ptiles);
     delete P;
@@ -729,11 +763,18 @@ static inline int64_t ws_slab_off(const hint_plan* P, int B) {
     return ws_gst_off(P, B) + ((int64_t)rows_padded(B) * P->ST + WS_SLACK + 3) / 4 * 4;
 }
 
-size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
-    if (!P || B <= 0) return 0;
+static int grid_for(const hint_plan* P, int B);
+// the backward kernel's first-layer gradient slabs (fuse_dw1) follow part B's slabs: [workgroup][tw_floats]
+static inline int64_t ws_thin_off(const hint_plan* P, int B) {        // floats from the part-B slabs' start
     int splits, rows;
     wgrad_splits(P, B, 1, &splits, &rows);        // (a chain never uses more splits than a single block)
-    return (size_t)(ws_slab_off(P, B) + (int64_t)splits * P->param_floats) * sizeof(float);
+    return (int64_t)splits * P->param_floats;
+}
+
+size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
+    if (!P || B <= 0) return 0;
+    const int64_t thin = P->fuse_dw1 ? (int64_t)grid_for(P, B) * P->tw_floats : 0;
+    return (size_t)(ws_slab_off(P, B) + ws_thin_off(P, B) + thin) * sizeof(float);
 }
 
 int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
@@ -761,6 +802,7 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
     a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;
     a.act_stride = act_stride(P, B); a.bits_stride = bits_stride(P, B);
+    a.fuse_dw1 = P->fuse_dw1; a.tw_floats = P->tw_floats; a.thin_slab_off = ws_thin_off(P, B);
     a.lean = P->lean; a.a2_off = P->lean ? 0 : a.act_stride; a.bits_off = (P->lean ? 1 : 2) * a.act_stride;
     a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
     return a;
@@ -853,7 +895,8 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
     HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, splits, one, chain, n_chain, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
                          rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
                          (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
-                         accumulate, P->num_cu, s));
+                         accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),
+                         P->num_cu, s));
     return 0;
 }
 

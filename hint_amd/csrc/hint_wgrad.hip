@@ -264,23 +264,70 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
 // padding between tensors stays untouched when accumulating and is cleared otherwise)
 __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const ChainBlock* __restrict__ chain,
                                                            const uint8_t* __restrict__ real, int64_t param_floats,
-                                                           int splits, int accumulate, int blocks_pb) {
-    const int cbi = (int)blockIdx.x / blocks_pb;
-    const int bid = (int)blockIdx.x - cbi * blocks_pb;
+                                                           int splits, int accumulate, int blocks_pb,
+                                                           const int32_t* __restrict__ twmap, int tw_floats,
+                                                           int64_t thin_slab_off, int thin_slabs, int thin_blocks) {
+    const int per_block = blocks_pb + thin_blocks;
+    const int cbi = (int)blockIdx.x / per_block;
+    const int bid = (int)blockIdx.x - cbi * per_block;
     const GBlock blk = chain_block(chain, one, cbi);
     const float* slab = (const float*)blk.wsSlab;
     float* g = (float*)blk.gparams;
+    if (bid >= blocks_pb) {
+        // first-layer gradients of a lean plan: one slab per workgroup of the backward kernel.  32 slab elements per
+        // block, 8 threads each: thread q adds slabs q, q+8, .. (eight loads in flight), the eight partials are
+        // added in order - a fixed summation order whatever the launch
+        __shared__ float part[8][32];
+        const int tl = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+        const float* tw = slab + thin_slab_off;
+        for (int t0 = (bid - blocks_pb) * 32; t0 < tw_floats; t0 += thin_blocks * 32) {
+            const int t = t0 + tl;
+            float s = 0.f;
+            if (t < tw_floats) {
+                int w = q;
+                for (; w + 56 < thin_slabs; w += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = tw[(size_t)(w + 8 * u) * tw_floats + t];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; w < thin_slabs; w += 8) s += tw[(size_t)w * tw_floats + t];
+            }
+            part[q][tl] = s;
+            __syncthreads();
+            if (q == 0 && t < tw_floats) {
+                const int dst = twmap[t];
+                if (dst >= 0) {
+                    float r = part[0][tl];
+#pragma unroll
+                    for (int u = 1; u < 8; ++u) r += part[u][tl];
+                    g[dst] = accumulate ? g[dst] + r : r;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int64_t n4 = param_floats >> 2;        // param_floats is a multiple of 4 (hint_plan_param_floats)
     for (int64_t i4 = (int64_t)bid * 256 + threadIdx.x; i4 < n4; i4 += (int64_t)blocks_pb * 256) {
-        const uchar4 rl = ((const uchar4*)real)[i4];
+        const uchar4 rl = ((const uchar4*)real)[i4];      // 1: from part B's slabs; 2: from the backward kernel's (above); 0: padding
         f32x4 s = zero4();
         for (int sp = 0; sp < splits; ++sp) s += ((const f32x4*)(slab + (size_t)sp * param_floats))[i4];
         f32x4 o = accumulate ? ((const f32x4*)g)[i4] : zero4();
-        if (rl.x) o.x += s.x;
-        if (rl.y) o.y += s.y;
-        if (rl.z) o.z += s.z;
-        if (rl.w) o.w += s.w;
-        ((f32x4*)g)[i4] = o;
+        if (rl.x == 1) o.x += s.x;
+        if (rl.y == 1) o.y += s.y;
+        if (rl.z == 1) o.z += s.z;
+        if (rl.w == 1) o.w += s.w;
+        if (rl.x != 2 && rl.y != 2 && rl.z != 2 && rl.w != 2) {
+            ((f32x4*)g)[i4] = o;
+        } else {                                        // (elements of the other path are not touched here)
+            float* gp = g + 4 * i4;
+            if (rl.x != 2) gp[0] = o.x;
+            if (rl.y != 2) gp[1] = o.y;
+            if (rl.z != 2) gp[2] = o.z;
+            if (rl.w != 2) gp[3] = o.w;
+        }
     }
 }
 
@@ -289,7 +336,8 @@ namespace hint {
 hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
                         int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
-                        const float* c, const uint8_t* real, int accumulate, int num_cu, hipStream_t stream) {
+                        const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
+                        int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream) {
     const int used = n_jobs * splits;
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0)
@@ -301,8 +349,9 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlo
     int blocks_pb = (int)((param_floats / 4 + 255) / 256);
     const int cap = num_cu * 4 / (n_chain > 0 ? n_chain : 1);
     blocks_pb = blocks_pb < 1 ? 1 : (blocks_pb > cap && cap >= 1 ? cap : blocks_pb);
-    hipLaunchKernelGGL(hint_wreduce_kernel, dim3(blocks_pb * n_chain), dim3(256), 0, stream, one, chain, real,
-                       param_floats, splits, accumulate, blocks_pb);
+    const int thin_blocks = twmap != nullptr ? (tw_floats + 31) / 32 : 0;
+    hipLaunchKernelGGL(hint_wreduce_kernel, dim3((blocks_pb + thin_blocks) * n_chain), dim3(256), 0, stream, one, chain, real,
+                       param_floats, splits, accumulate, blocks_pb, twmap, tw_floats, thin_slab_off, thin_slabs, thin_blocks);
     return hipGetLastError();
 }
 
