@@ -72,6 +72,10 @@ static constexpr int LDS_ATTR = LDS_LIMIT - 33 * 1024;   // the diagnostic build
 #else
 static constexpr int LDS_ATTR = LDS_LIMIT;
 #endif
+#ifndef HINT_THIN_MFMA_MIN
+#define HINT_THIN_MFMA_MIN 24
+#endif
+static constexpr int THIN_MFMA_MIN = HINT_THIN_MFMA_MIN;          // thin layers with more inputs than this use the matrix pipe (fragment tiles of W1 / W3^T)
 static constexpr int THIN_LDS_MAX = 24 * 1024;   // a block's thin-layer vectors are staged in LDS up to this size
 static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
 static constexpr int WS_SLACK = 64;              // floats of slack behind every [Bp][W] array
@@ -139,6 +143,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<int> unit_node;       // node index (into `nodes`) of every unit
     std::vector<RowRec> recs_f, recs_b;   // row records in (group, wavefront, unit) order
     std::vector<ThinRec> thin_f, thin_b;  // thin records in (group, unit, tile) order
+    std::vector<int> unit_f1, unit_b3;    // per unit: first fragment tile of W1 / W3^T for a wide thin layer, or -1
     std::vector<Ent> ents;
     std::vector<int32_t> rng;
     std::vector<PackSeg> segs;
@@ -216,6 +221,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 u.w3v = add_vec(cur_b, blob_f_pad, n.h, n.r, n.h, 1, po[HINT_W3], -1);       // g_st -> g2 (vector ALU)
                 u.b2 = add_seg(n.h, n.h, NT, n.h, 1, po[HINT_W2]);           // g2 -> g1
                 u.b1 = add_seg(cin, n.h, NT, cin, 1, po[HINT_W1]);           // g1 -> g_v
+                // wide thin layers (more than THIN_MFMA_MIN inputs) run on the matrix pipe from fragment tiles instead
+                unit_f1.push_back(cin > THIN_MFMA_MIN ? add_seg(n.h, cin, KB1, cin, 0, po[HINT_W1]) : -1);          // v -> a1
+                unit_b3.push_back(n.r > THIN_MFMA_MIN ? add_seg(n.h, n.r, RT, n.h, 1, po[HINT_W3]) : -1);          // g_st -> g2
                 u.bias1 = (int)bmap.size();                                     // (made absolute below)
                 for (int j = 0; j < 16 * NT; ++j) bmap.push_back(j < n.h ? (int32_t)(po[HINT_B1] + j) : -1);
                 u.bias2 = (int)bmap.size();
@@ -277,8 +285,12 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             const int kpf = std::max(4, u.cin), kpb = std::max(4, u.r);
             for (int nt = 0; nt < u.NT; ++nt) {
-                thin_f.push_back(ThinRec{u.w1v + nt * (kpf + 1) * 16, u.cin | (u.ku << 8) | (u.xoff << 16), u.tile0 + nt, kpf});
-                thin_b.push_back(ThinRec{u.w3v + nt * kpb * 16, u.r | (u.lcol << 16), u.tile0 + nt, kpb});
+                // (kp | (first fragment tile of the tile's k-blocks + 1) << 8: the matrix-pipe variant)
+                const int f1 = unit_f1[ui], b3 = unit_b3[ui];
+                thin_f.push_back(ThinRec{u.w1v + nt * (kpf + 1) * 16, u.cin | (u.ku << 8) | (u.xoff << 16), u.tile0 + nt,
+                                         kpf | ((f1 >= 0 ? f1 + nt * u.KB1 + 1 : 0) << 8)});
+                thin_b.push_back(ThinRec{u.w3v + nt * kpb * 16, u.r | (u.lcol << 16), u.tile0 + nt,
+                                         kpb | ((b3 >= 0 ? b3 + nt * u.RT + 1 : 0) << 8)});
             }
         }
         // ---- deal the rows to the wavefronts: longest first, to the wavefront whose SIMD (wavefronts w and

@@ -164,7 +164,7 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
     for (int t = t0; t < t1; ++t) {
         const i32x4c rec = nrec;
         nrec = trec[t + 1 < t1 ? t + 1 : t];
-        const int K = rec.y & 0xff, kp = rec.w;
+        const int K = rec.y & 0xff, kp = rec.w & 0xff;
         const int vbase = rec.x + 4 * kq;                    // vector k of this lane's features: float offset vbase + 16 k
         auto vec = [&](int k) -> f32x4 {
             if (STAGED) return *(const LDS_AS f32x4*)(c.thin_l + vbase + 16 * k);
@@ -177,11 +177,29 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
             }
             return c.gst[m * c.gld + (rec.y >> 16) + k];
         };
+        f32x4 acc;
+        if ((rec.w >> 8) != 0) {
+            // wide layer: on the matrix pipe, out^T = W * in^T from fragment tiles of W (k-block kb = 1 KiB, lane l: W[16nt + (l&15)]
+            // [16kb + 4(l>>4) + i]); the B operand is gathered from the inputs (row l&15, input 16kb + 4(l>>4) + i; zero beyond K)
+            const GLOBAL_AS f32x4* wp = (const GLOBAL_AS f32x4*)(c.packed + (size_t)((rec.w >> 8) - 1) * 256) + lane;
+            const int KB = (K + 15) >> 4;
+            acc = KIND == K_FWD ? vec(kp) : zero4();
+            f32x4 w = wp[0];
+            for (int kb = 0; kb < KB; ++kb) {
+                const f32x4 wn = wp[(kb + 1 < KB ? kb + 1 : kb) * 64];
+                float b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int k = 16 * kb + 4 * kq + i; b[i] = input(k < K ? k : K - 1); b[i] = k < K ? b[i] : 0.f; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = mfma4(w[i], b[i], acc);
+                w = wn;
+            }
+        } else {
         f32x4 w[4];
         float vin[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { w[k] = vec(k); vin[k] = k < K ? input(k) : 0.f; }
-        f32x4 acc = KIND == K_FWD ? vec(kp) : zero4();
+        acc = KIND == K_FWD ? vec(kp) : zero4();
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc += w[k] * vin[k];
         if (STAGED) {
@@ -197,6 +215,7 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
 #pragma unroll
                 for (int u = 0; u < TB; ++u) acc += wv[u] * iv[u];
             }
+        }
         }
         if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         ((LDS_AS f32x4*)c.abuf)[rec.z * 64 + lane] = acc;

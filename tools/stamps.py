@@ -16,6 +16,7 @@ from bench import WORKLOADS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "power_hint_8"
 cfg = WORKLOADS[name]
+BLK = int(sys.argv[2]) if len(sys.argv) > 2 else 3          # which block of the chain to print (512 stamp ids: block * groups < 32)
 dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.hint_debug_set_stamp_buffer.argtypes = [C.c_void_p]
@@ -93,5 +94,5 @@ descs, _, _, _ = node_descs(nodes)
 lib.hint_plan_check(descs, len(nodes), cfg["d"], 0, 4.0, stats)
 ng = int(stats[0])
 print("groups per block:", ng)
-show("forward", fw, ng, ["P1 thin (VALU)", "barrier", "P2 rows (L2 L3)", "barrier", "P3 coupling", "barrier"], [3])
-show("backward A", bw, ng + 1, ["Q1 couple/scatter", "barrier", "prefetch issue", "Q2 thin + barrier", "Q3 rows (g1 gv)", "commit+barrier"], [3])
+show("forward", fw, ng, ["P1 thin (VALU)", "barrier", "P2 rows (L2 L3)", "barrier", "P3 coupling", "barrier"], [BLK])
+show("backward A", bw, ng + 1, ["Q1 couple/scatter", "barrier", "prefetch issue", "Q2 thin + barrier", "Q3 rows (g1 gv)", "commit+barrier"], [BLK])
