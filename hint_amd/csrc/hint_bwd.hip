@@ -171,11 +171,13 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                             const int nl = lane & 15, kq = lane >> 4;
                             const CONST_AS i32x4c* wrec = (const CONST_AS i32x4c*)(unsigned long long)((const char*)a.thins +
                                                           (size_t)2 * a.total_tiles * sizeof(ThinRec)) + gp.tile_begin;
+                            // (transposed: out^T[k][f], so that a lane ends up with four consecutive inputs of ONE feature - a row of the
+                            //  slab, padded to 4 or 8 floats: one 16-byte store per lane, 256 contiguous bytes per tile)
                             i32x4c nrec = wrec[ws < gp.ntiles ? ws : 0];                      // (records one tile ahead: a scalar load takes as long as the tile)
                             for (int t = ws; t < gp.ntiles; t += nws) {
                                 const i32x4c rec = nrec;
                                 nrec = wrec[t + nws < gp.ntiles ? t + nws : t];
-                                const int cin = rec.y & 0xff, xoff = (rec.y >> 8) & 0xff, nvalid = rec.y >> 16, kc = cin + 1;
+                                const int cin = rec.y & 0xff, xoff = (rec.y >> 8) & 0xff, nvalid = rec.y >> 16, kcp = cin < 4 ? 4 : 8;
                                 const LDS_AS float* g1p = (const LDS_AS float*)obuf + (rec.z * 64 + kq + 16 * (nl >> 2)) * 4 + (nl & 3);
                                 const LDS_AS float* vp = (const LDS_AS float*)xo + kq * a.xld + xoff + (nl < cin ? nl : 0);
                                 const float one = nl == cin ? 1.f : 0.f;
@@ -184,14 +186,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * a.xld]; }     // rows 4i + kq
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) acc = mfma4(av[i], nl < cin ? bv[i] : one, acc);
-                                if (nl < kc) {
-                                    float* dst = tw + rec.x + 4 * kq * kc + nl;              // feature 4 kq + j of the tile, input nl
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        if (4 * kq + j < nvalid) {
-                                            if (first_tile) dst[j * kc] = acc[j]; else dst[j * kc] += acc[j];
-                                        }
+                                for (int i = 0; i < 4; ++i) acc = mfma4(nl < cin ? bv[i] : one, av[i], acc);
+                                if (nl < nvalid && 4 * kq < kcp) {
+                                    f32x4* dst = (f32x4*)(tw + rec.x + nl * kcp + 4 * kq);     // feature nl of the tile, inputs 4 kq .. 4 kq + 3
+                                    if (first_tile) *dst = acc; else *dst = *dst + acc;
                                 }
                             }
                         }

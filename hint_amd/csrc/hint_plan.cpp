@@ -424,7 +424,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) P->lean = 0;
     }
     if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) P->lean = 0;
-    // a lean plan's first-layer gradients: [h][cin + 1] per unit (the bias gradient as the last column) in a slab per
+    // a lean plan's first-layer gradients: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
     // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
     std::vector<int32_t> twmap;
     for (size_t ui = 0; ui < units.size(); ++ui) {
@@ -434,9 +434,10 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         const hint_node_desc& n = nodes[unit_node[ui]];
         const int64_t* po = n.p_off + (int)(ui & 1) * 6;
         u.bias1 = (int)twmap.size();
+        const int kcp = u.cin < 4 ? 4 : 8;          // slab row of a feature: its cin input gradients, the bias gradient, padding
         for (int f = 0; f < n.h; ++f)
-            for (int k = 0; k <= u.cin; ++k) twmap.push_back(k < u.cin ? (int32_t)(po[HINT_W1] + (int64_t)f * u.cin + k) : (int32_t)(po[HINT_B1] + f));
-        while (twmap.size() % 4) twmap.push_back(-1);
+            for (int k = 0; k < kcp; ++k)
+                twmap.push_back(k < u.cin ? (int32_t)(po[HINT_W1] + (int64_t)f * u.cin + k) : k == u.cin ? (int32_t)(po[HINT_B1] + f) : -1);
     }
     P->tw_floats = (int)twmap.size();
     // ... and one record per fragment tile, in the thin records' order, for the backward kernel's first-layer-gradient
@@ -446,7 +447,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
             const Unit& u = units[ui];
             for (int nt = 0; nt < u.NT; ++nt)
-                thin_w.push_back(ThinRec{u.bias1 < 0 ? 0 : u.bias1 + nt * 16 * (u.cin + 1),
+                thin_w.push_back(ThinRec{u.bias1 < 0 ? 0 : u.bias1 + nt * 16 * (u.cin < 4 ? 4 : 8),
                                          u.cin | (u.xoff << 8) | (std::min(16, u.h - 16 * nt) << 16), u.tile0 + nt, 0});
         }
     for (RowRec& r : recs_f) { r.aux += (int)packed; r.bias3 += (int)packed; }
