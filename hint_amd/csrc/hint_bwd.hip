@@ -20,18 +20,20 @@ using namespace hint;
 
 constexpr int LV_REGS = 4;      // floats per thread of a prefetched [16, d] tile: 16*d <= LV_REGS * threads
 
-struct LevelPrefetch { float x[LV_REGS], s[LV_REGS]; };
+struct LevelPrefetch { float x[LV_REGS], s[LV_REGS]; int nvalid; };
+// (the loads only: nothing here may look at the loaded values - a select on them would be a wait for HBM in the
+//  middle of the group; rows beyond the batch are zeroed when the tile is committed)
 __device__ __forceinline__ void level_issue(LevelPrefetch& p, const float* __restrict__ xsrc, const float* __restrict__ ssrc,
                                             int d, int row0, int B, int tid, int nthreads) {
     const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * d;
     const size_t base = (size_t)row0 * d;
+    p.nvalid = nvalid;
 #pragma unroll
     for (int k = 0; k < LV_REGS; ++k) {
         const int i = tid + k * nthreads;
         const int ic = i < nvalid ? i : 0;
-        const float xv = xsrc[base + ic], sv = ssrc[base + ic];
-        p.x[k] = i < nvalid ? xv : 0.f;
-        p.s[k] = i < nvalid ? sv : 0.f;
+        p.x[k] = xsrc[base + ic];
+        p.s[k] = ssrc[base + ic];
     }
 }
 __device__ __forceinline__ void level_commit(const LevelPrefetch& p, float* xs, float* sb, int ld, int d, int tid, int nthreads) {
@@ -41,8 +43,8 @@ __device__ __forceinline__ void level_commit(const LevelPrefetch& p, float* xs, 
         const int i = tid + k * nthreads;
         if (i < ROWS * d) {
             const int r = fdiv(i, inv), j = i - r * d;
-            xs[r * ld + j] = p.x[k];
-            sb[r * ld + j] = p.s[k];
+            xs[r * ld + j] = i < p.nvalid ? p.x[k] : 0.f;
+            sb[r * ld + j] = i < p.nvalid ? p.s[k] : 0.f;
         }
     }
 }

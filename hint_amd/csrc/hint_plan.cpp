@@ -66,12 +66,12 @@ static int fail(const char* fmt, ...) {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int pad4(int v) { return (v + 3) & ~3; }
 
-static constexpr int LDS_LIMIT = 160 * 1024;
 #ifdef HINT_STAMPS
-static constexpr int LDS_ATTR = LDS_LIMIT - 33 * 1024;   // the diagnostic build's static stamp array shares the 160 KiB
+static constexpr int LDS_LIMIT = 160 * 1024 - 33 * 1024;   // the diagnostic build's static stamp array shares the 160 KiB
 #else
-static constexpr int LDS_ATTR = LDS_LIMIT;
+static constexpr int LDS_LIMIT = 160 * 1024;
 #endif
+static constexpr int LDS_ATTR = LDS_LIMIT;
 #ifndef HINT_THIN_MFMA_MIN
 #define HINT_THIN_MFMA_MIN 24
 #endif
