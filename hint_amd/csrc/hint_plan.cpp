@@ -113,6 +113,251 @@ struct hint_plan {
     int2* d_ptiles = nullptr;
 };
 
+// A row of a group's GEMM phase: up to NTT adjacent fragment tiles [tb, tb + ntt) of one unit
+struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
+
+// The rows of a group: per unit at least ceil(NT / NTT) of them; more (narrower ones) while the group has fewer rows
+// than wavefronts.
+static std::vector<Row> split_rows(const std::vector<Unit>& units, const Group& g, int nw) {
+    std::vector<int> nrows(g.unit_end - g.unit_begin);
+    int total = 0;
+    for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, NTT); total += nrows[ui - g.unit_begin]; }
+    while (total < nw) {
+        int best = -1; double bw = 0;
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {       // split where the rows are widest
+            const int nr = nrows[ui - g.unit_begin];
+            if (nr >= units[ui].NT) continue;
+            const double wdt = (double)units[ui].NT / nr * units[ui].NT;
+            if (wdt > bw) { bw = wdt; best = ui; }
+        }
+        if (best < 0) break;
+        ++nrows[best - g.unit_begin]; ++total;
+    }
+    std::vector<Row> rows;
+    for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+        const Unit& u = units[ui];
+        const int nr = nrows[ui - g.unit_begin];
+        int tb = 0;
+        for (int ri = 0; ri < nr; ++ri) {
+            const int ntt = (u.NT - tb + (nr - ri) - 1) / (nr - ri);
+            // matrix-pipe time of the row (main + tail steps) plus what its bookkeeping costs in the same unit
+            const long cost = (long)u.NT * ntt * 4 + std::max(u.RT, u.KB1) * ntt * 4 + 24;
+            rows.push_back(Row{ui, tb, ntt, 0, 0, cost});
+            tb += ntt;
+        }
+    }
+    return rows;
+}
+
+// Deal a group's rows to the wavefronts: longest first, to the wavefront whose SIMD (wavefronts w and w + 4 share one:
+// its matrix pipe and its issue slots) is least loaded; at most unit_waves wavefronts share the rows of one unit (each
+// of them keeps an LDS slab for it).  Returns the row indices of every wavefront in (unit, tile) order.
+static std::vector<std::vector<int>> deal_rows(const std::vector<Row>& rows, int nw, int unit_waves) {
+    std::vector<std::vector<int>> wave_rows(nw);
+    std::vector<int> idx(rows.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return rows[x].cost > rows[y].cost; });
+    std::vector<long> wload(nw, 0), sload(4, 0);
+    auto holds = [&](int w, int unit) {
+        for (int r : wave_rows[w]) if (rows[r].unit == unit) return true;
+        return false;
+    };
+    for (int i : idx) {
+        int best = 0, holders = 0;
+        long best_s = -1, best_w = -1;
+        for (int w = 0; w < nw; ++w) holders += holds(w, rows[i].unit) ? 1 : 0;
+        for (int w = 0; w < nw; ++w) {
+            if (!holds(w, rows[i].unit) && holders >= unit_waves) continue;           // (no further slab for this unit)
+            // (the two wavefronts of a SIMD interleave: what one wavefront runs back to back counts as well)
+            const long sl = sload[w & 3] + wload[w] + 2 * rows[i].cost, wl = wload[w] + rows[i].cost;
+            if (best_s < 0 || sl < best_s || (sl == best_s && wl < best_w)) { best = w; best_s = sl; best_w = wl; }
+        }
+        wave_rows[best].push_back(i);
+        wload[best] += rows[i].cost; sload[best & 3] += rows[i].cost;
+    }
+    for (int w = 0; w < nw; ++w) std::sort(wave_rows[w].begin(), wave_rows[w].end());   // unit order, then tile order
+    return wave_rows;
+}
+
+// LDS slabs for the K-split partials of the tail products: one per (unit, wavefront that has rows of it), a unit's slabs
+// adjacent (forward: 16 rows x pad4(r); backward: 16 rows x pad4(cin)); *off3 / *offv: floats used so far
+static void assign_slabs(std::vector<Unit>& units, const Group& g, std::vector<Row>& rows,
+                         const std::vector<std::vector<int>>& wave_rows, int* off3, int* offv) {
+    for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+        Unit& u = units[ui];
+        u.sl_off = *off3; u.gv_off = *offv; u.sl_n = 0;
+        for (const std::vector<int>& mine : wave_rows) {
+            bool has = false;
+            for (int ri : mine)
+                if (rows[ri].unit == ui) { rows[ri].slab3 = *off3; rows[ri].slabv = *offv; has = true; }
+            if (has) { *off3 += 64 * cdiv(u.r, 4); *offv += 64 * cdiv(u.cin, 4); ++u.sl_n; }
+        }
+    }
+}
+
+// The row records of a group in wavefront order (hint_dev.h: RowRec), both directions, and the wavefronts' ranges in
+// that list (nw + 1 offsets appended to rng).  false: a unit does not fit the records' bit fields.
+static bool emit_row_records(const std::vector<Unit>& units, const std::vector<Row>& rows,
+                             const std::vector<std::vector<int>>& wave_rows, int row_begin, std::vector<RowRec>* recs_f,
+                             std::vector<RowRec>* recs_b, std::vector<int32_t>* rng) {
+    for (const std::vector<int>& mine : wave_rows) {
+        rng->push_back((int)recs_f->size() - row_begin);
+        int last_unit = -1;
+        for (int ri : mine) {
+            const Row& rw = rows[ri];
+            const Unit& u = units[rw.unit];
+            if (u.NT > 255 || u.cin > 255 || u.ku > 255 || u.r > 255 || u.tile0 > 0xffff) return false;
+            const int thin = rw.unit != last_unit ? 1 : 0, first = rw.tb == 0 ? 1 : 0;     // (thin: the wavefront's first row of the unit starts its slab)
+            last_unit = rw.unit;
+            RowRec r{};
+            r.ocol = u.wcol + 16 * rw.tb; r.bias3 = u.bias3; r.wcol = u.wcol; r.tb = rw.tb;
+            r.flags = u.NT | (thin << 8) | (first << 9);
+            // forward: second layer + third layer partials (+ b3 with the unit's first row)
+            r.base1 = u.f2 + rw.tb * u.NT; r.base2 = u.f3 + rw.tb;
+            r.counts = u.NT | (u.RT << 8) | ((first ? u.RT : 0) << 16) | (rw.ntt << 24);
+            r.aux = u.bias2 + 16 * rw.tb; r.tile = u.tile0 | (cdiv(u.r, 4) << 16); r.slab = rw.slab3;
+            r.thin_w = u.w1v; r.thin_b = 0; r.thin_k = u.cin | (u.ku << 8) | (u.xoff << 16);
+            recs_f->push_back(r);
+            // backward: g1 + g_v partials
+            r.base1 = u.b2 + rw.tb * u.NT; r.base2 = u.b1 + rw.tb;
+            r.counts = u.NT | (u.KB1 << 8) | (rw.ntt << 24);
+            r.aux = 0; r.tile = u.tile0 | (cdiv(u.cin, 4) << 16); r.slab = rw.slabv;
+            r.thin_w = u.w3v; r.thin_b = 0; r.thin_k = u.r | (u.lcol << 16);
+            recs_b->push_back(r);
+        }
+    }
+    rng->push_back((int)recs_f->size() - row_begin);
+    return true;
+}
+
+// Coupling entries of a group: one per transformed lane (where its s and t partials wait in the slabs)
+static void emit_coupling_entries(const std::vector<Unit>& units, const Group& g, std::vector<Ent>* ents) {
+    for (int ui = g.unit_begin; ui < g.unit_end; ui += 2) {
+        const Unit& us = units[ui];
+        const Unit& ut = units[ui + 1];
+        for (int j = 0; j < us.r; ++j) {
+            Ent e{};
+            e.xcol = (int16_t)(us.xoff + us.ku + j);
+            e.nquad = (int16_t)cdiv(us.r, 4);
+            e.sl_ns = (int16_t)us.sl_n; e.sl_nt = (int16_t)ut.sl_n;
+            e.s_off = us.sl_off + (j / 4) * 64 + (j % 4);
+            e.t_off = ut.sl_off + (j / 4) * 64 + (j % 4);
+            ents->push_back(e);
+        }
+    }
+}
+
+// Backward lane tables: per boundary (in front of group gi; slot n_groups: behind group 0) and lane, what to add from
+// the group before (the g_v partials of the node whose input this lane is) and where the coupling gradients of the coming
+// group's node that transforms this lane go (hint_dev.h: LaneOp).  Sets every group's lop_begin.
+static std::vector<LaneOp> build_lane_ops(std::vector<Group>& groups, const std::vector<Unit>& units, int d) {
+    const int n_groups = (int)groups.size();
+    std::vector<LaneOp> lops((size_t)(n_groups + 1) * d);
+    for (int b = 0; b <= n_groups; ++b) {
+        const int cur = b < n_groups ? b : -1;                 // the group about to run (none for the last slot)
+        const int prev = b < n_groups ? (b + 1 < n_groups ? b + 1 : -1) : 0;   // the group that ran just before
+        for (int col = 0; col < d; ++col) {
+            LaneOp op{};
+            op.sc_unit = -1; op.sc_k = 0; op.cp_ls = -1; op.cp_lt = 0; op.cp_gs = 0; op.cp_gt = 0;
+            if (prev >= 0)
+                for (int ui = groups[prev].unit_begin; ui < groups[prev].unit_end; ui += 2) {
+                    const Unit& u = units[ui];
+                    if (col >= u.xoff && col < u.xoff + u.ku) { op.sc_unit = (int16_t)ui; op.sc_k = (int16_t)(col - u.xoff); }
+                }
+            if (cur >= 0)
+                for (int ui = groups[cur].unit_begin; ui < groups[cur].unit_end; ui += 2) {
+                    const Unit& us = units[ui];
+                    const Unit& ut = units[ui + 1];
+                    const int j = col - us.xoff - us.ku;
+                    if (j >= 0 && j < us.r) {
+                        op.cp_ls = (int16_t)(us.lcol + j); op.cp_lt = (int16_t)(ut.lcol + j);
+                        op.cp_gs = (int16_t)(us.gcol + j); op.cp_gt = (int16_t)(ut.gcol + j);
+                    }
+                }
+            lops[(size_t)b * d + col] = op;
+        }
+        if (b < n_groups) groups[b].lop_begin = b * d;
+    }
+    return lops;
+}
+
+// Self-check: the record lists of every group cover every fragment tile of every unit exactly once, in both
+// directions, and exactly one row per unit is its first.  Returns what is wrong, or nullptr.
+static const char* check_records(const std::vector<Group>& groups, const std::vector<Unit>& units,
+                                 const std::vector<RowRec>& recs_f, const std::vector<RowRec>& recs_b,
+                                 const std::vector<int32_t>& rng, int nw) {
+    for (const Group& g : groups) {
+        const int32_t* r = rng.data() + g.rng_begin;
+        const int nrows = r[nw];
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<RowRec>& rc = dir ? recs_b : recs_f;
+            std::vector<int> seen(g.ntiles, 0), firsts(g.unit_end - g.unit_begin, 0);
+            for (int w = 0; w < nw; ++w) {
+                if (r[w] > r[w + 1] || r[w + 1] > nrows) return "record ranges";
+                for (int i = r[w]; i < r[w + 1]; ++i) {
+                    const RowRec& q = rc[g.row_begin + i];
+                    const int tile0 = q.tile & 0xffff, ntt = (q.counts >> 24) & 0xff, NT = q.flags & 0xff;
+                    const int tb = (q.ocol - q.wcol) / 16;
+                    int ui = -1;
+                    for (int u = g.unit_begin; u < g.unit_end; ++u) if (units[u].tile0 == tile0) ui = u;
+                    if (ui < 0 || units[ui].NT != NT || ntt < 1 || ntt > NTT || tb < 0 || tb + ntt > NT) return "row record";
+                    if ((q.flags >> 9) & 1) ++firsts[ui - g.unit_begin];
+                    for (int j = 0; j < ntt; ++j) ++seen[tile0 + tb + j];
+                }
+            }
+            for (int c : seen) if (c != 1) return "tiles not covered exactly once";
+            for (int c : firsts) if (c != 1) return "first rows";
+        }
+    }
+    return nullptr;
+}
+
+// The weight-gradient jobs of part B (hint_dev.h: WJob) - per unit dW2, dW3 (+ db2, db3) and, unless the backward kernel
+// computes them itself (fuse_dw1), dW1 (+ db1) - and the map of real parameter elements (1: summed from part B's slabs,
+// 2: from the backward kernel's, 0: padding between tensors)
+static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, const std::vector<Unit>& units,
+                            const std::vector<int>& unit_node, int max_depth, std::vector<WJob>* wjobs,
+                            std::vector<uint8_t>* real) {
+    const int d = P->d, dc = P->dc;
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        const Unit& u = units[ui];
+        const hint_node_desc& n = nodes[unit_node[ui]];
+        const int net = (int)(ui & 1);
+        const int64_t* po = n.p_off + net * 6;
+        const int level = max_depth - n.depth;
+        const int64_t sizes[6] = {(int64_t)n.h * u.cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
+        for (int t = 0; t < 6; ++t)
+            for (int64_t i = 0; i < sizes[t]; ++i) (*real)[(size_t)(po[t] + i)] = (P->fuse_dw1 && t < 2) ? 2 : 1;      // 2: summed from the backward kernel's slabs
+        auto add_jobs = [&](int psrc, int pcol, int M, int pmaxc, int qsrc, int qcol, int N, int qmaxc, int qlevel, int ldo,
+                            int64_t wofs, int64_t bofs) {
+            // tiles of up to 48 x 48 outputs; the bias gradient rides with the first column group
+            const int MT = cdiv(M, 16), NTn = std::max(1, cdiv(N, 16));
+            for (int mt = 0; mt < MT; mt += 3)
+                for (int nt = 0; nt < NTn; nt += 3) {
+                    WJob j{};
+                    j.psrc = psrc; j.pcol = pcol + 16 * mt; j.M = std::min(48, M - 16 * mt); j.mw = std::min(3, MT - mt);
+                    j.qsrc = qsrc; j.qcol = qcol + 16 * nt; j.N = N > 0 ? std::min(48, N - 16 * nt) : 0;
+                    j.nw = N > 0 ? std::min(3, NTn - nt) : 0;
+                    j.qlevel = qlevel; j.ldo = ldo; j.pmax = pmaxc; j.qmax = qmaxc;
+                    j.wofs = wofs + (int64_t)16 * mt * ldo + 16 * nt;
+                    j.bofs = (bofs >= 0 && nt == 0) ? bofs + 16 * mt : -1;
+                    j.r_w1 = (int32_t)po[HINT_W1]; j.r_b1 = (int32_t)po[HINT_B1]; j.r_w3 = (int32_t)po[HINT_W3];
+                    j.r_cin = u.cin; j.r_xoff = u.xoff; j.r_r = n.r; j.r_gcol = u.gcol; j.r_h = n.h; j.r_wcol = u.wcol;
+                    wjobs->push_back(j);
+                }
+        };
+        add_jobs(P->lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, P->lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
+                 P->lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
+        add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
+        if (u.ku > 0 && !P->fuse_dw1)
+            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
+        if (dc > 0)
+            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_C, 0, dc, dc - 1, 0, u.cin, po[HINT_W1] + u.ku, u.ku > 0 ? -1 : po[HINT_B1]);
+        if (u.cin == 0)
+            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_A1, u.wcol, 0, P->WT - 1, 0, 1, po[HINT_W1], po[HINT_B1]);
+    }
+}
+
 // tile_cap: fragment tiles per group (1 KiB of LDS each), unless one node needs more
 // unit_waves: how many wavefronts may share the rows of one unit (each of them keeps a slab for it)
 // returns 0, 1 (error) or 2 (the block does not fit the LDS with these two settings; *retry_smaller: smaller groups exist)
@@ -249,40 +494,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->abuf_tiles = std::max(P->abuf_tiles, tiles);
         P->gld = std::max(P->gld, g.gcols | 1);
 
-        // ---- rows: up to three adjacent tiles of a unit; the rows of a unit that one wavefront runs share a slab
-        //      for the K-split partial of the tail product (the first writes it, the others add) ----
-        struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
-        std::vector<Row> rows;
+        std::vector<Row> rows = split_rows(units, g, nw);
         int off3 = 0, offv = 0;
-        // rows per unit: at least ceil(NT / 3); more (narrower rows) while the group has fewer rows than wavefronts
-        std::vector<int> nrows(g.unit_end - g.unit_begin);
-        {
-            int total = 0;
-            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, NTT); total += nrows[ui - g.unit_begin]; }
-            while (total < nw) {
-                int best = -1; double bw = 0;
-                for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {       // split where the rows are widest
-                    const int nr = nrows[ui - g.unit_begin];
-                    if (nr >= units[ui].NT) continue;
-                    const double wdt = (double)units[ui].NT / nr * units[ui].NT;
-                    if (wdt > bw) { bw = wdt; best = ui; }
-                }
-                if (best < 0) break;
-                ++nrows[best - g.unit_begin]; ++total;
-            }
-        }
         g.tile_begin = (int)thin_f.size();
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
             Unit& u = units[ui];
-            const int nr = nrows[ui - g.unit_begin];
-            int tb = 0;
-            for (int ri = 0; ri < nr; ++ri) {
-                const int ntt = (u.NT - tb + (nr - ri) - 1) / (nr - ri);
-                // matrix-pipe time of the row (main + tail steps) plus what its bookkeeping costs in the same unit
-                const long cost = (long)u.NT * ntt * 4 + std::max(u.RT, u.KB1) * ntt * 4 + 24;
-                rows.push_back(Row{ui, tb, ntt, 0, 0, cost});
-                tb += ntt;
-            }
             const int kpf = std::max(4, u.cin), kpb = std::max(4, u.r);
             for (int nt = 0; nt < u.NT; ++nt) {
                 // (kp | (first fragment tile of the tile's k-blocks + 1) << 8: the matrix-pipe variant)
@@ -293,53 +509,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                                          kpb | ((b3 >= 0 ? b3 + nt * u.RT + 1 : 0) << 8)});
             }
         }
-        // ---- deal the rows to the wavefronts: longest first, to the wavefront whose SIMD (wavefronts w and
-        //      w + 4 share one: its matrix pipe and its issue slots) is least loaded; a wavefront's first row
-        //      of a unit also pays for the unit's thin layer ----
-        std::vector<std::vector<int>> wave_rows(nw);
-        {
-            std::vector<int> idx(rows.size());
-            for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
-            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return rows[x].cost > rows[y].cost; });
-            std::vector<long> wload(nw, 0), sload(4, 0);
-            for (int i : idx) {
-                const long thin = 0;
-                int best = 0;
-                long best_s = -1, best_w = -1;
-                int holders = 0;
-                for (int w = 0; w < nw; ++w) {
-                    bool has = false;
-                    for (int r : wave_rows[w]) has = has || rows[r].unit == rows[i].unit;
-                    holders += has ? 1 : 0;
-                }
-                for (int w = 0; w < nw; ++w) {
-                    bool has = false;
-                    for (int r : wave_rows[w]) has = has || rows[r].unit == rows[i].unit;
-                    if (!has && holders >= unit_waves) continue;           // (no further slab for this unit)
-                    const long add = rows[i].cost + (has ? 0 : thin);
-                    // (the two wavefronts of a SIMD interleave: what one wavefront runs back to back counts as well)
-                    const long sl = sload[w & 3] + wload[w] + 2 * add, wl = wload[w] + add;
-                    if (best_s < 0 || sl < best_s || (sl == best_s && wl < best_w)) { best = w; best_s = sl; best_w = wl; }
-                }
-                bool has = false;
-                for (int r : wave_rows[best]) has = has || rows[r].unit == rows[i].unit;
-                const long add = rows[i].cost + (has ? 0 : thin);
-                wave_rows[best].push_back(i);
-                wload[best] += add; sload[best & 3] += add;
-            }
-            for (int w = 0; w < nw; ++w) std::sort(wave_rows[w].begin(), wave_rows[w].end());   // unit order, then tile order
-        }
-        // slabs: one per (unit, wavefront that has rows of it), a unit's slabs adjacent
-        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
-            Unit& u = units[ui];
-            u.sl_off = off3; u.gv_off = offv; u.sl_n = 0;
-            for (int w = 0; w < nw; ++w) {
-                bool has = false;
-                for (int ri : wave_rows[w])
-                    if (rows[ri].unit == ui) { rows[ri].slab3 = off3; rows[ri].slabv = offv; has = true; }
-                if (has) { off3 += 64 * cdiv(u.r, 4); offv += 64 * cdiv(u.cin, 4); ++u.sl_n; }
-            }
-        }
+        std::vector<std::vector<int>> wave_rows = deal_rows(rows, nw, unit_waves);
+        assign_slabs(units, g, rows, wave_rows, &off3, &offv);
         P->slab_fwd = std::max(P->slab_fwd, off3);
         P->slab_bwd = std::max(P->slab_bwd, offv);
         if (std::getenv("HINT_PLAN_DUMP")) {
@@ -351,56 +522,17 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 std::fprintf(stderr, "\n");
             }
         }
-        // ---- the wavefronts' record lists, forward and backward ----
+        // ---- the wavefronts' record lists, forward and backward; the thin layers' tiles are shared out evenly ----
         g.row_begin = (int)recs_f.size();
         g.rng_begin = (int)rng.size();
-        for (int w = 0; w < nw; ++w) {
-            rng.push_back((int)recs_f.size() - g.row_begin);
-            int last_unit = -1;
-            for (int ri : wave_rows[w]) {
-                const Row& rw = rows[ri];
-                const Unit& u = units[rw.unit];
-                if (u.NT > 255 || u.cin > 255 || u.ku > 255 || u.r > 255 || u.tile0 > 0xffff) {
-                    delete P;
-                    return fail("hint_plan_create: a node is too wide for the row records (h <= 4080, cin <= 255)");
-                }
-                const int thin = rw.unit != last_unit ? 1 : 0, first = rw.tb == 0 ? 1 : 0;
-                last_unit = rw.unit;
-                RowRec r{};
-                r.ocol = u.wcol + 16 * rw.tb; r.bias3 = u.bias3; r.wcol = u.wcol; r.tb = rw.tb;
-                r.flags = u.NT | (thin << 8) | (first << 9);
-                // forward: second layer + third layer partials (+ b3 with the unit's first row)
-                r.base1 = u.f2 + rw.tb * u.NT; r.base2 = u.f3 + rw.tb;
-                r.counts = u.NT | (u.RT << 8) | ((first ? u.RT : 0) << 16) | (rw.ntt << 24);
-                r.aux = u.bias2 + 16 * rw.tb; r.tile = u.tile0 | (cdiv(u.r, 4) << 16); r.slab = rw.slab3;
-                r.thin_w = u.w1v; r.thin_b = 0; r.thin_k = u.cin | (u.ku << 8) | (u.xoff << 16);
-                recs_f.push_back(r);
-                // backward: g1 + g_v partials
-                r.base1 = u.b2 + rw.tb * u.NT; r.base2 = u.b1 + rw.tb;
-                r.counts = u.NT | (u.KB1 << 8) | (rw.ntt << 24);
-                r.aux = 0; r.tile = u.tile0 | (cdiv(u.cin, 4) << 16); r.slab = rw.slabv;
-                r.thin_w = u.w3v; r.thin_b = 0; r.thin_k = u.r | (u.lcol << 16);
-                recs_b.push_back(r);
-            }
+        if (!emit_row_records(units, rows, wave_rows, g.row_begin, &recs_f, &recs_b, &rng)) {
+            delete P;
+            return fail("hint_plan_create: a node is too wide for the row records (h <= 4080, cin <= 255)");
         }
-        rng.push_back((int)recs_f.size() - g.row_begin);
-        for (int w = 0; w <= nw; ++w) rng.push_back((int)((long)tiles * w / nw));      // thin layers: the group's tiles shared out evenly
+        for (int w = 0; w <= nw; ++w) rng.push_back((int)((long)tiles * w / nw));
 
-        // ---- coupling entries: one per transformed lane ----
         g.ent_begin = (int)ents.size();
-        for (int ui = g.unit_begin; ui < g.unit_end; ui += 2) {
-            const Unit& us = units[ui];
-            const Unit& ut = units[ui + 1];
-            for (int j = 0; j < us.r; ++j) {
-                Ent e{};
-                e.xcol = (int16_t)(us.xoff + us.ku + j);
-                e.nquad = (int16_t)cdiv(us.r, 4);
-                e.sl_ns = (int16_t)us.sl_n; e.sl_nt = (int16_t)ut.sl_n;
-                e.s_off = us.sl_off + (j / 4) * 64 + (j % 4);
-                e.t_off = ut.sl_off + (j / 4) * 64 + (j % 4);
-                ents.push_back(e);
-            }
-        }
+        emit_coupling_entries(units, g, &ents);
         g.ent_cnt = (int)ents.size() - g.ent_begin;
         groups.push_back(g);
     }
@@ -452,33 +584,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
     for (RowRec& r : recs_f) { r.aux += (int)packed; r.bias3 += (int)packed; }
 
-    // ---- backward lane tables: per boundary (in front of group gi; slot n_groups: behind group 0) and lane ----
-    std::vector<LaneOp> lops((size_t)(P->n_groups + 1) * d);
-    for (int b = 0; b <= P->n_groups; ++b) {
-        const int cur = b < P->n_groups ? b : -1;                 // the group about to run (none for the last slot)
-        const int prev = b < P->n_groups ? (b + 1 < P->n_groups ? b + 1 : -1) : 0;   // the group that ran just before
-        for (int col = 0; col < d; ++col) {
-            LaneOp op{};
-            op.sc_unit = -1; op.sc_k = 0; op.cp_ls = -1; op.cp_lt = 0; op.cp_gs = 0; op.cp_gt = 0;
-            if (prev >= 0)
-                for (int ui = groups[prev].unit_begin; ui < groups[prev].unit_end; ui += 2) {
-                    const Unit& u = units[ui];
-                    if (col >= u.xoff && col < u.xoff + u.ku) { op.sc_unit = (int16_t)ui; op.sc_k = (int16_t)(col - u.xoff); }
-                }
-            if (cur >= 0)
-                for (int ui = groups[cur].unit_begin; ui < groups[cur].unit_end; ui += 2) {
-                    const Unit& us = units[ui];
-                    const Unit& ut = units[ui + 1];
-                    const int j = col - us.xoff - us.ku;
-                    if (j >= 0 && j < us.r) {
-                        op.cp_ls = (int16_t)(us.lcol + j); op.cp_lt = (int16_t)(ut.lcol + j);
-                        op.cp_gs = (int16_t)(us.gcol + j); op.cp_gt = (int16_t)(ut.gcol + j);
-                    }
-                }
-            lops[(size_t)b * d + col] = op;
-        }
-        if (b < P->n_groups) groups[b].lop_begin = b * d;
-    }
+    std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
 
     // ---- meta blob staged in LDS by the kernels ----
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -532,76 +638,16 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return 2;
     }
 
-    // ---- self-check: the record lists of every group cover every fragment tile of every unit exactly once,
-    //      in both directions, every wavefront runs a unit's thin layer before its first row of the unit,
-    //      and exactly one row per unit stores the thin layer's tiles ----
-    for (const Group& g : groups) {
-        const int32_t* r = rng.data() + g.rng_begin;
-        const int nrows = r[nw];
-        for (int dir = 0; dir < 2; ++dir) {
-            const std::vector<RowRec>& rc = dir ? recs_b : recs_f;
-            std::vector<int> seen(g.ntiles, 0), firsts(g.unit_end - g.unit_begin, 0);
-            for (int w = 0; w < nw; ++w) {
-                if (r[w] > r[w + 1] || r[w + 1] > nrows) { delete P; return fail("hint_plan_create: internal error (record ranges)"); }
-                int have_thin_for = -1;
-                for (int i = r[w]; i < r[w + 1]; ++i) {
-                    const RowRec& q = rc[g.row_begin + i];
-                    const int tile0 = q.tile & 0xffff, ntt = (q.counts >> 24) & 0xff, NT = q.flags & 0xff;
-                    const int tb = (q.ocol - q.wcol) / 16;
-                    int ui = -1;
-                    for (int u = g.unit_begin; u < g.unit_end; ++u) if (units[u].tile0 == tile0) ui = u;
-                    if (ui < 0 || units[ui].NT != NT || ntt < 1 || ntt > 3 || tb < 0 || tb + ntt > NT) { delete P; return fail("hint_plan_create: internal error (row record)"); }
-                    (void)have_thin_for;
-                    if ((q.flags >> 9) & 1) ++firsts[ui - g.unit_begin];
-                    for (int j = 0; j < ntt; ++j) ++seen[tile0 + tb + j];
-                }
-            }
-            for (int c : seen) if (c != 1) { delete P; return fail("hint_plan_create: internal error (tiles not covered exactly once)"); }
-            for (int c : firsts) if (c != 1) { delete P; return fail("hint_plan_create: internal error (first rows)"); }
-        }
+    if (const char* what = check_records(groups, units, recs_f, recs_b, rng, nw)) {
+        delete P;
+        return fail("hint_plan_create: internal error (%s)", what);
     }
 
     // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
     P->fuse_dw1 = (P->lean && P->stage_out && P->tw_floats > 0) ? 1 : 0;
     if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) P->fuse_dw1 = 0;
     std::vector<uint8_t> real((size_t)P->param_floats, 0);
-    for (size_t ui = 0; ui < units.size(); ++ui) {
-        const Unit& u = units[ui];
-        const hint_node_desc& n = nodes[unit_node[ui]];
-        const int net = (int)(ui & 1);
-        const int64_t* po = n.p_off + net * 6;
-        const int level = max_depth - n.depth;
-        const int64_t sizes[6] = {(int64_t)n.h * u.cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
-        for (int t = 0; t < 6; ++t)
-            for (int64_t i = 0; i < sizes[t]; ++i) real[(size_t)(po[t] + i)] = (P->fuse_dw1 && t < 2) ? 2 : 1;      // 2: summed from the backward kernel's slabs
-        auto add_jobs = [&](int psrc, int pcol, int M, int pmaxc, int qsrc, int qcol, int N, int qmaxc, int qlevel, int ldo,
-                            int64_t wofs, int64_t bofs) {
-            // tiles of up to 48 x 48 outputs; the bias gradient rides with the first column group
-            const int MT = cdiv(M, 16), NTn = std::max(1, cdiv(N, 16));
-            for (int mt = 0; mt < MT; mt += 3)
-                for (int nt = 0; nt < NTn; nt += 3) {
-                    WJob j{};
-                    j.psrc = psrc; j.pcol = pcol + 16 * mt; j.M = std::min(48, M - 16 * mt); j.mw = std::min(3, MT - mt);
-                    j.qsrc = qsrc; j.qcol = qcol + 16 * nt; j.N = N > 0 ? std::min(48, N - 16 * nt) : 0;
-                    j.nw = N > 0 ? std::min(3, NTn - nt) : 0;
-                    j.qlevel = qlevel; j.ldo = ldo; j.pmax = pmaxc; j.qmax = qmaxc;
-                    j.wofs = wofs + (int64_t)16 * mt * ldo + 16 * nt;
-                    j.bofs = (bofs >= 0 && nt == 0) ? bofs + 16 * mt : -1;
-                    j.r_w1 = (int32_t)po[HINT_W1]; j.r_b1 = (int32_t)po[HINT_B1]; j.r_w3 = (int32_t)po[HINT_W3];
-                    j.r_cin = u.cin; j.r_xoff = u.xoff; j.r_r = n.r; j.r_gcol = u.gcol; j.r_h = n.h; j.r_wcol = u.wcol;
-                    wjobs.push_back(j);
-                }
-        };
-        add_jobs(P->lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, P->lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
-                 P->lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
-        add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
-        if (u.ku > 0 && !P->fuse_dw1)
-            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
-        if (dc > 0)
-            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_C, 0, dc, dc - 1, 0, u.cin, po[HINT_W1] + u.ku, u.ku > 0 ? -1 : po[HINT_B1]);
-        if (u.cin == 0)
-            add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_A1, u.wcol, 0, P->WT - 1, 0, 1, po[HINT_W1], po[HINT_B1]);
-    }
+    make_wgrad_jobs(P, nodes, units, unit_node, max_depth, &wjobs, &real);
     P->n_wjobs = (int)wjobs.size();
     P->total_rows = (int)recs_f.size();
     P->total_tiles = (int)thin_f.size();

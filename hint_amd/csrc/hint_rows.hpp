@@ -364,7 +364,7 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
         if (rnext >= 0) rows_begin<KIND>(c, ring, rnext, rnext + 1, lane);     // nothing to do here, but the next group has work
         return;
     }
-    const int m = lane & 15, kq = lane >> 4;
+    const int kq = lane >> 4;
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.l = (unsigned)lane;
 
