@@ -78,14 +78,17 @@ int64_t hint_plan_packed_floats(const hint_plan* plan);
 /* floats of the forward "tape" for a batch of B rows, recorded by the training forward and read
  * by the backward pass: per tree level one [B,d] snapshot of the lane tensor as that level saw it
  * (the last slice holds the block's permuted input for the _ex / chain forms) and one [B,d] array
- * of the level's coupling arguments s (indexed by the lane each one scales), then both hidden
- * activations of every subnet, [B rounded up to 16, sum of 2*pad16(h)] each.  The backward pass
- * recomputes nothing (what autograd keeps for hint.py:77, minus the pre-activations), and the
- * weight-gradient kernel takes its a1 / a2 / lane operands from here. */
+ * of the level's coupling arguments s (indexed by the lane each one scales); the hidden activations
+ * a2 of every subnet, [B rounded up to 16, sum of 2*pad16(h)] (and a1, the same size, unless every
+ * subnet of the block has 1..4 inputs, at most 4 outputs and no condition: such "lean" plans rebuild a1
+ * where it is needed); and one sign byte per four activations (what the backward kernel reads instead
+ * of the activations).  The backward pass recomputes nothing else (what autograd keeps for hint.py:77,
+ * minus the pre-activations), and the weight-gradient kernel takes its a2 / lane operands from here. */
 int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
 /* bytes of scratch hint_block_backward needs for a batch of B rows: the per-row gradient factors g1, g2
- * ([B rounded up to 16, sum of 2*pad16(h)] each) and g_s | g_t, and one partial-gradient slab per batch
- * split of the weight-gradient kernel. */
+ * ([B rounded up to 16, sum of 2*pad16(h)] each; neither for lean plans, whose backward kernel computes the
+ * first-layer gradients itself into one small slab per workgroup) and g_s | g_t, and one partial-gradient
+ * slab per batch split of the weight-gradient kernel. */
 size_t hint_plan_workspace_bytes(const hint_plan* plan, int32_t B);
 /* dynamic LDS bytes per workgroup of the forward / backward kernels (informational). */
 int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
