@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
             pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
-            pc.out_thin = a.lean ? nullptr : blk.wsG1 + a.act_stride; pc.out_main = blk.wsG1; pc.wcol0 = 0;      // (lean plans keep no g2)
+            pc.out_thin = nullptr; pc.out_main = blk.wsG1; pc.wcol0 = 0;      // (out_thin: per group - lean groups keep no g2)
             pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
             pc.bits_a1 = (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
             pc.bits_a2 = pc.bits_a1 + a.bits_stride;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
                     if (tid >= soff) {
-                        if (!a.lean) stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
-                        if (!a.fuse_dw1) {
+                        if (!gp.lean) stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        if (!(a.fuse_dw1 && gp.lean)) {
                             stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         } else {
                             // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f] of the finished group's units,
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 lds_barrier();
                 STAMP(sid + 4)
                 // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
+                pc.out_thin = g.lean ? nullptr : (GLOBAL_AS float*)(blk.wsG1 + a.act_stride);
                 {
                     int rnext = -1;         // the last row hands the weight ring to the wavefront's first row of the next group
                     if (slot > 0) {

@@ -100,7 +100,8 @@ struct Group {
     int32_t unit_begin, unit_end, ntiles, row_begin;    // row_begin: the group's first row record (both directions)
     int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[nw+1 | nw+1] = the wavefronts' ranges in the group's row-record list and in its thin-record list
     int32_t level_last, gcol0, gcols, lop_begin;        // first / number of [ST] columns; LaneOp[d] of the boundary in front of the group (backward)
-    int32_t level_first, tile_begin, wcol0, cpad2;      // tile_begin: the group's first thin record (both directions); wcol0: column of its first tile in the [Bp][WT] arrays
+    int32_t level_first, tile_begin, wcol0, lean;       // tile_begin: the group's first thin record (both directions); wcol0: column of its first tile in the [Bp][WT] arrays;
+                                                        // lean: 1 = every unit of the group has 1..4 inputs, <= 4 outputs, no condition: its a1 / g2 tiles are never stored
 };
 static_assert(sizeof(Group) == 64, "Group must be 4 x 16 bytes");
 

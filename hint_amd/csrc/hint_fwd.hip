@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
-            pc.out_thin = a.lean ? nullptr : blk.actA1; pc.out_main = train ? blk.actA1 + a.a2_off : nullptr;      // (lean plans keep no a1)
+            pc.out_thin = nullptr; pc.out_main = train ? blk.actA1 + a.a2_off : nullptr;      // (out_thin: per group - lean groups keep no a1)
             pc.bits_a1 = train ? (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64 : nullptr;
             pc.bits_a2 = train ? pc.bits_a1 + a.bits_stride : nullptr;
             pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 pc.xs = (const LDS_AS float*)(XS);
                 pc.wcol0 = g.wcol0;
+                pc.out_thin = (train && !g.lean) ? (GLOBAL_AS float*)blk.actA1 : nullptr;
                 const int sid = (cb * a.n_groups + gi) * 16;
                 (void)sid;
                 pc.sid = sid;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 if (train && a.stage_out) {
                     const int soff = nthreads > ncpl ? ncpl : 0;   // (a workgroup of one coupling's size does both in turn)
                     if (tid >= soff) {
-                        if (!a.lean) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        if (!g.lean) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         stream_tiles(actA1 + a.a2_off, obuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                     }
                 }

@@ -316,18 +316,19 @@ static const char* check_records(const std::vector<Group>& groups, const std::ve
 // computes them itself (fuse_dw1), dW1 (+ db1) - and the map of real parameter elements (1: summed from part B's slabs,
 // 2: from the backward kernel's, 0: padding between tensors)
 static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, const std::vector<Unit>& units,
-                            const std::vector<int>& unit_node, int max_depth, std::vector<WJob>* wjobs,
-                            std::vector<uint8_t>* real) {
+                            const std::vector<int>& unit_node, const std::vector<char>& unit_lean, int max_depth,
+                            std::vector<WJob>* wjobs, std::vector<uint8_t>* real) {
     const int d = P->d, dc = P->dc;
     for (size_t ui = 0; ui < units.size(); ++ui) {
         const Unit& u = units[ui];
         const hint_node_desc& n = nodes[unit_node[ui]];
+        const bool lean = unit_lean[ui] != 0, fused = lean && P->fuse_dw1;     // (operands rebuilt; dW1 / db1 from the backward kernel)
         const int net = (int)(ui & 1);
         const int64_t* po = n.p_off + net * 6;
         const int level = max_depth - n.depth;
         const int64_t sizes[6] = {(int64_t)n.h * u.cin, n.h, (int64_t)n.h * n.h, n.h, (int64_t)n.r * n.h, n.r};
         for (int t = 0; t < 6; ++t)
-            for (int64_t i = 0; i < sizes[t]; ++i) (*real)[(size_t)(po[t] + i)] = (P->fuse_dw1 && t < 2) ? 2 : 1;      // 2: summed from the backward kernel's slabs
+            for (int64_t i = 0; i < sizes[t]; ++i) (*real)[(size_t)(po[t] + i)] = (fused && t < 2) ? 2 : 1;      // 2: summed from the backward kernel's slabs
         auto add_jobs = [&](int psrc, int pcol, int M, int pmaxc, int qsrc, int qcol, int N, int qmaxc, int qlevel, int ldo,
                             int64_t wofs, int64_t bofs) {
             // tiles of up to 48 x 48 outputs; the bias gradient rides with the first column group
@@ -346,10 +347,10 @@ static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, con
                     wjobs->push_back(j);
                 }
         };
-        add_jobs(P->lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, P->lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
-                 P->lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
+        add_jobs(lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
+                 lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
         add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
-        if (u.ku > 0 && !P->fuse_dw1)
+        if (u.ku > 0 && !fused)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
         if (dc > 0)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_C, 0, dc, dc - 1, 0, u.cin, po[HINT_W1] + u.ku, u.ku > 0 ? -1 : po[HINT_B1]);
@@ -549,20 +550,29 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return fail("hint_plan_create: block too large (offsets must fit 31 / 15 bits)");
     }
     for (Unit& u : units) { u.bias1 += (int)packed; u.bias2 += (int)packed; u.bias3 += (int)packed; }   // the bias region follows the weight tiles
-    // lean: thin layers narrow enough that part B rebuilds a1 and g2 instead of reading them (HINT_LEAN=0: never)
-    P->lean = dc == 0 ? 1 : 0;
-    for (size_t ui = 0; ui < units.size(); ++ui) {
-        const hint_node_desc& n = nodes[unit_node[ui]];
-        if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) P->lean = 0;
+    // lean groups: thin layers narrow enough that part B rebuilds a1 and g2 instead of reading them - every unit of the
+    // group has 1..4 inputs, at most 4 outputs and no condition (HINT_LEAN=0: never).  P->lean: all groups are, and the
+    // a1 / g2 arrays do not exist at all.
+    bool lean_on = dc == 0;
+    if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) lean_on = false;
+    std::vector<char> unit_lean(units.size(), 0);
+    P->lean = 1;
+    for (Group& g : groups) {
+        g.lean = lean_on ? 1 : 0;
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+            const hint_node_desc& n = nodes[unit_node[ui]];
+            if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) g.lean = 0;
+        }
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)g.lean;
+        if (!g.lean) P->lean = 0;
     }
-    if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) P->lean = 0;
-    // a lean plan's first-layer gradients: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
+    // the first-layer gradients of the lean groups' units: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
     // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
     std::vector<int32_t> twmap;
     for (size_t ui = 0; ui < units.size(); ++ui) {
         Unit& u = units[ui];
         u.bias1 = -1;
-        if (!P->lean) continue;
+        if (!unit_lean[ui]) continue;
         const hint_node_desc& n = nodes[unit_node[ui]];
         const int64_t* po = n.p_off + (int)(ui & 1) * 6;
         u.bias1 = (int)twmap.size();
@@ -644,10 +654,10 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
 
     // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
-    P->fuse_dw1 = (P->lean && P->stage_out && P->tw_floats > 0) ? 1 : 0;
+    P->fuse_dw1 = (P->stage_out && P->tw_floats > 0) ? 1 : 0;       // (lean groups' dW1 / db1 in the backward kernel)
     if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) P->fuse_dw1 = 0;
     std::vector<uint8_t> real((size_t)P->param_floats, 0);
-    make_wgrad_jobs(P, nodes, units, unit_node, max_depth, &wjobs, &real);
+    make_wgrad_jobs(P, nodes, units, unit_node, unit_lean, max_depth, &wjobs, &real);
     P->n_wjobs = (int)wjobs.size();
     P->total_rows = (int)recs_f.size();
     P->total_tiles = (int)thin_f.size();

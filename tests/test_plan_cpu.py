@@ -57,17 +57,22 @@ def test_planner_covers_every_tile_exactly_once(d, dc, widths, n_nodes, n_levels
     assert st["WT"] == sum(2 * ((n.s[0].out_features + 15) // 16 * 16) for n, _, _ in nodes)
     assert st["ST"] == sum(2 * ((n.s[4].out_features + 3) // 4 * 4) for n, _, _ in nodes)
     # part B: tiles of up to 48 x 48 outputs of every weight matrix (dW1 in a lane part and a condition part)
-    # lean plans with LDS-staged outputs (1..4 inputs and <= 4 outputs everywhere, no condition): dW1 / db1 come from the
-    # backward kernel, not from part-B jobs
-    fused = dc == 0 and all(1 <= n.split_idx <= 4 and n.s[4].out_features <= 4 for n, _, _ in nodes)
+    # lean groups (every node of a depth has 1..4 inputs and <= 4 outputs, no condition; outputs staged in LDS):
+    # their dW1 / db1 come from the backward kernel, not from part-B jobs
+    node_lean = lambda n: dc == 0 and 1 <= n.split_idx <= 4 and n.s[4].out_features <= 4
+    lean_depth = {}
+    for n, _, depth in nodes:
+        lean_depth[depth] = lean_depth.get(depth, True) and node_lean(n)
     t3 = lambda v: ((v + 15) // 16 + 2) // 3
-    jobs = 0
-    for n, _, _ in nodes:
+    jobs, jobs_unfused = 0, 0
+    for n, _, depth in nodes:
         h, r, k = n.s[0].out_features, n.s[4].out_features, n.split_idx
-        per = t3(h) * t3(h) + t3(r) * t3(h) + (t3(h) * t3(k) if k and not fused else 0) + (t3(h) * t3(dc) if dc else 0)
-        per += t3(h) if (k + dc) == 0 else 0
-        jobs += 2 * per
-    assert st["wjobs"] == jobs
+        base = t3(h) * t3(h) + t3(r) * t3(h) + (t3(h) * t3(dc) if dc else 0) + (t3(h) if (k + dc) == 0 else 0)
+        dw1 = t3(h) * t3(k) if k else 0
+        jobs += 2 * (base + (0 if lean_depth[depth] else dw1))
+        jobs_unfused += 2 * (base + dw1)
+    # (the fusion needs the groups' outputs staged in LDS: blocks too large for that keep their dW1 jobs)
+    assert st["wjobs"] in (jobs, jobs_unfused)
     assert st["abuf_tiles"] >= max(2 * ((n.s[0].out_features + 15) // 16) for n, _, _ in nodes)
 
 
