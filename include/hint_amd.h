@@ -80,8 +80,8 @@ int64_t hint_plan_packed_floats(const hint_plan* plan);
  * (the last slice holds the block's permuted input for the _ex / chain forms) and one [B,d] array
  * of the level's coupling arguments s (indexed by the lane each one scales); the hidden activations
  * a2 of every subnet, [B rounded up to 16, sum of 2*pad16(h)] (and a1, the same size, unless every
- * subnet of the block has 1..4 inputs, at most 4 outputs and no condition: such "lean" plans rebuild a1
- * where it is needed); and one sign byte per four activations (what the backward kernel reads instead
+ * subnet of the block has 1..4 inputs, at most 4 outputs and no condition; tree levels of that kind -
+ * "lean" groups - leave their a1 columns unwritten in any case: a1 is rebuilt where it is needed); and one sign byte per four activations (what the backward kernel reads instead
  * of the activations).  The backward pass recomputes nothing else (what autograd keeps for hint.py:77,
  * minus the pre-activations), and the weight-gradient kernel takes its a2 / lane operands from here. */
 int64_t hint_plan_tape_floats(const hint_plan* plan, int32_t B);
