@@ -159,11 +159,9 @@ typedef int i32x4c __attribute__((ext_vector_type(4)));
 template <int KIND, bool STAGED>
 __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins, int t0, int t1, int lane) {
     const int m = lane & 15, kq = lane >> 4;
-    const CONST_AS i32x4c* trec = (const CONST_AS i32x4c*)(unsigned long long)thins;
-    i32x4c nrec = trec[t0 < t1 ? t0 : 0];            // (records one tile ahead)
     for (int t = t0; t < t1; ++t) {
-        const i32x4c rec = nrec;
-        nrec = trec[t + 1 < t1 ? t + 1 : t];
+        // (no look-ahead: a scalar load in flight would be waited for by every lgkmcnt wait of the tile's LDS reads)
+        const i32x4c rec = ((const CONST_AS i32x4c*)(unsigned long long)thins)[t];
         const int K = rec.y & 0xff, kp = rec.w & 0xff;
         const int vbase = rec.x + 4 * kq;                    // vector k of this lane's features: float offset vbase + 16 k
         auto vec = [&](int k) -> f32x4 {
