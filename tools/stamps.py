@@ -64,7 +64,7 @@ def show(title, st, per_block, labels, blocks):
                 d = np.where((inner[:, k] != 0) & (inner[:, k + 1] != 0), inner[:, k + 1] - inner[:, k], 0)
                 print(f"   blk {cb} grp {gi} {lab:22s} " + " ".join(f"{int(v):6d}" for v in d))
             steps = st[:nw, 384 + ((cb * per_block + gi) & 7) * 16: 384 + ((cb * per_block + gi) & 7) * 16 + 16]
-            if per_block <= 2 and (steps != 0).any():
+            if per_block <= 3 and (steps != 0).any():
                 t0 = inner[:, 2]
                 for k in range(16):
                     if (steps[:, k] == 0).all():
