@@ -66,10 +66,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
     float* cs = sb + ROWS * a.xld;
     float* gcs = cs + ROWS * a.cld;
     float* gst = gcs + ROWS * a.cld;          // [16][gld] coupling gradients of the group
-    float* abuf = gst + ROWS * a.gld;         // g2 fragment tiles
-    float* obuf = abuf + a.abuf_tiles * 256;  // g1 fragment tiles on their way to global memory
-    float* slab = obuf + (a.stage_out ? a.abuf_tiles * 256 : 0);  // g_v partials
-    float* gj = slab + a.slab_floats;
+    float* abuf = gst + ROWS * a.gld;         // per group: [g2 tiles | g1 tiles on their way out (staged groups) | g_v partials (slabs)]
+    float* gj = abuf + a.region_floats;
     float* xo = gj + ROWS;                    // the lane tile of the level before (first-layer gradients of the group just finished)
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
@@ -120,7 +118,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
             pc.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
-            pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
+            pc.abuf = (LDS_AS float*)abuf; pc.obuf = nullptr; pc.slab = nullptr;      // (obuf, slab: per group)
             pc.out_thin = nullptr; pc.out_main = blk.wsG1; pc.wcol0 = 0;      // (out_thin: per group - lean groups keep no g2)
             pc.xs = (const LDS_AS float*)xs; pc.cs = (const LDS_AS float*)cs; pc.gst = (const LDS_AS float*)gst;
             pc.bits_a1 = (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
@@ -152,7 +150,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 // the finished group's g2 (masked) and g1 tiles: out of LDS to the workspace, whole lines per batch row
                 // (by the wavefronts the element-wise work below does not need)
                 int qthreads = nthreads;                            // threads of the element-wise phase
-                if (has_prev && a.stage_out) {
+                // (the finished group's carving of the region: its g1 tiles and its slabs)
+                float* obuf = abuf + gp.ntiles * 256;
+                float* slab = obuf + (gp.staged ? gp.ntiles * 256 : 0);
+                if (has_prev && gp.staged) {
                     const int need = (ROWS * a.d + 63) & ~63;
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
@@ -288,6 +289,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 STAMP(sid + 4)
                 // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
                 pc.out_thin = g.lean ? nullptr : (GLOBAL_AS float*)(blk.wsG1 + a.act_stride);
+                pc.obuf = g.staged ? (LDS_AS float*)(abuf + g.ntiles * 256) : nullptr;
+                pc.slab = (LDS_AS float*)(abuf + g.ntiles * 256 * (1 + g.staged));
                 {
                     int rnext = -1;         // the last row hands the weight ring to the wavefront's first row of the next group
                     if (slot > 0) {

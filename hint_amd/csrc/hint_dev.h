@@ -101,7 +101,8 @@ struct Group {
     int32_t ent_begin, ent_cnt, rng_begin, level;       // rng: int32[nw+1 | nw+1] = the wavefronts' ranges in the group's row-record list and in its thin-record list
     int32_t level_last, gcol0, gcols, lop_begin;        // first / number of [ST] columns; LaneOp[d] of the boundary in front of the group (backward)
     int32_t level_first, tile_begin, wcol0, lean;       // tile_begin: the group's first thin record (both directions); wcol0: column of its first tile in the [Bp][WT] arrays;
-                                                        // lean: 1 = every unit of the group has 1..4 inputs, <= 4 outputs, no condition: its a1 / g2 tiles are never stored
+                                                        // lean: bit 0 = every unit of the group has 1..4 inputs, <= 4 outputs, no condition: its a1 / g2 tiles are never stored;
+                                                        // bit 1 = the group's output tiles (a2 / g1) are staged in LDS and streamed out by the element-wise phase
 };
 static_assert(sizeof(Group) == 64, "Group must be 4 x 16 bytes");
 
@@ -201,6 +202,7 @@ struct KArgs {
     int64_t thin_slab_off;         // floats from ChainBlock::wsSlab to the first of them
     int64_t a2_off, bits_off;      // floats from a block's a1 array (ChainBlock::actA1) to its a2 array / to the sign bytes
     int64_t bits_stride;           // bytes between the a1 and the a2 sign bytes of a block's tape
+    int32_t region_floats;         // LDS floats of the per-group region [group's tiles | staged output tiles | slabs] (this direction)
     int32_t stage_out;             // 1: the rows leave their output tiles in LDS (obuf) and the element-wise phase streams them out; 0: no LDS for that, they store them themselves
     int32_t thin_off, thin_floats; // the direction's thin blob: float offset in the packed buffer, size (multiple of 4)
     int32_t thin_lds;              // float offset in LDS where the kernel stages it per block; 0: read it from global memory

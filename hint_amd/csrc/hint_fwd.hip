@@ -31,10 +31,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
     const Tables T = make_tables(a, lds);
     float* t0 = lds + (a.meta_bytes >> 2);    // two lane tiles: a fused permutation ping-pongs between them
     float* cs = t0 + 2 * ROWS * a.xld;
-    float* abuf = cs + ROWS * a.cld;
-    float* obuf = abuf + a.abuf_tiles * 256;  // a2 fragment tiles on their way to the tape (training)
-    float* slab = obuf + (a.stage_out ? a.abuf_tiles * 256 : 0);
-    float* jac = slab + a.slab_floats;
+    float* abuf = cs + ROWS * a.cld;          // per group: [a1 tiles | a2 tiles on their way to the tape (staged groups) | slabs]
+    float* jac = abuf + a.region_floats;
     float* red = jac + ROWS;                  // MAX_NW floats: loss partials
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
             pc.thin_g = blk.packed + a.thin_off;
-            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = a.stage_out ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
+            pc.recs = a.recs; pc.abuf = (LDS_AS float*)abuf; pc.obuf = nullptr; pc.slab = nullptr;      // (obuf, slab: per group)
             pc.out_thin = nullptr; pc.out_main = train ? blk.actA1 + a.a2_off : nullptr;      // (out_thin: per group - lean groups keep no a1)
             pc.bits_a1 = train ? (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64 : nullptr;
             pc.bits_a2 = train ? pc.bits_a1 + a.bits_stride : nullptr;
@@ -135,6 +133,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 pc.xs = (const LDS_AS float*)(XS);
                 pc.wcol0 = g.wcol0;
+                float* obuf = abuf + g.ntiles * 256;
+                float* slab = obuf + (g.staged ? g.ntiles * 256 : 0);
+                pc.obuf = g.staged ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
                 pc.out_thin = (train && !g.lean) ? (GLOBAL_AS float*)blk.actA1 : nullptr;
                 const int sid = (cb * a.n_groups + gi) * 16;
                 (void)sid;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 //      tape (training), out of LDS, whole lines per batch row ----
                 const int nsub = g.ent_cnt <= 4 ? 4 : 16;
                 const int ncpl = ROWS * nsub;                     // threads of the coupling
-                if (train && a.stage_out) {
+                if (train && g.staged) {
                     const int soff = nthreads > ncpl ? ncpl : 0;   // (a workgroup of one coupling's size does both in turn)
                     if (tid >= soff) {
                         if (!g.lean) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);

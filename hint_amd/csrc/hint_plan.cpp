@@ -91,6 +91,7 @@ struct hint_plan {
     int64_t param_floats = 0, packed_floats = 0;
     int WT = 0, ST = 0;
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
+    int region_fwd = 0, region_bwd = 0;   // LDS floats of the per-group region [tiles | staged output tiles | slabs]
     int stage_out = 1;
     int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
     int fuse_dw1 = 0;           // lean plans with LDS-staged outputs: dW1, db1 come from the backward kernel (per-workgroup slabs), g1 stays on chip
@@ -316,13 +317,14 @@ static const char* check_records(const std::vector<Group>& groups, const std::ve
 // computes them itself (fuse_dw1), dW1 (+ db1) - and the map of real parameter elements (1: summed from part B's slabs,
 // 2: from the backward kernel's, 0: padding between tensors)
 static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, const std::vector<Unit>& units,
-                            const std::vector<int>& unit_node, const std::vector<char>& unit_lean, int max_depth,
-                            std::vector<WJob>* wjobs, std::vector<uint8_t>* real) {
+                            const std::vector<int>& unit_node, const std::vector<char>& unit_lean,
+                            const std::vector<char>& unit_fused, int max_depth, std::vector<WJob>* wjobs,
+                            std::vector<uint8_t>* real) {
     const int d = P->d, dc = P->dc;
     for (size_t ui = 0; ui < units.size(); ++ui) {
         const Unit& u = units[ui];
         const hint_node_desc& n = nodes[unit_node[ui]];
-        const bool lean = unit_lean[ui] != 0, fused = lean && P->fuse_dw1;     // (operands rebuilt; dW1 / db1 from the backward kernel)
+        const bool lean = unit_lean[ui] != 0, fused = unit_fused[ui] != 0;     // (operands rebuilt; dW1 / db1 from the backward kernel)
         const int net = (int)(ui & 1);
         const int64_t* po = n.p_off + net * 6;
         const int level = max_depth - n.depth;
@@ -389,6 +391,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<int> unit_node;       // node index (into `nodes`) of every unit
     std::vector<RowRec> recs_f, recs_b;   // row records in (group, wavefront, unit) order
     std::vector<ThinRec> thin_f, thin_b;  // thin records in (group, unit, tile) order
+    std::vector<int> grp_slab_f, grp_slab_b;  // per group: floats of its slabs (forward / backward)
     std::vector<int> unit_f1, unit_b3;    // per unit: first fragment tile of W1 / W3^T for a wide thin layer, or -1
     std::vector<Ent> ents;
     std::vector<int32_t> rng;
@@ -512,6 +515,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
         std::vector<std::vector<int>> wave_rows = deal_rows(rows, nw, unit_waves);
         assign_slabs(units, g, rows, wave_rows, &off3, &offv);
+        grp_slab_f.push_back(off3); grp_slab_b.push_back(offv);
         P->slab_fwd = std::max(P->slab_fwd, off3);
         P->slab_bwd = std::max(P->slab_bwd, offv);
         if (std::getenv("HINT_PLAN_DUMP")) {
@@ -566,13 +570,44 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)g.lean;
         if (!g.lean) P->lean = 0;
     }
-    // the first-layer gradients of the lean groups' units: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
+    // ---- LDS: the meta blob's size, then per group the region [its tiles | its output tiles, staged for the element-wise
+    //      phase to stream out, when there is room | its slabs]; the launch reserves the largest group's ----
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t groups_bytes = up16(groups.size() * sizeof(Group));
+    const size_t units_bytes = up16(units.size() * sizeof(Unit));
+    const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
+    const size_t rng_bytes = up16(rng.size() * sizeof(int32_t));
+    const size_t lops_count = (size_t)(groups.size() + 1) * d;
+    const bool lops_lds = lops_count * sizeof(LaneOp) <= 16 * 1024;     // larger tables stay in global memory
+    const size_t lops_bytes = lops_lds ? up16(lops_count * sizeof(LaneOp)) : 0;
+    P->units_off = (int)groups_bytes;
+    P->tmap_off = P->units_off + (int)units_bytes;
+    P->ents_off = P->tmap_off;
+    P->rng_off = P->ents_off + (int)ents_bytes;
+    P->lops_off = lops_lds ? P->rng_off + (int)rng_bytes : -1;
+    P->meta_bytes = P->rng_off + (int)rng_bytes + (int)lops_bytes;
+    const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + ROWS + MAX_NW);
+    const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld);   // (+ the lanes of the level before: first-layer gradients)
+    P->stage_out = 0;
+    std::vector<char> unit_fused(units.size(), 0);       // lean and staged: dW1 / db1 come from the backward kernel
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        Group& g = groups[gi];
+        const long tiles = (long)g.ntiles * 256;
+        const bool staged = fixed_f + 4 * (2 * tiles + grp_slab_f[gi]) <= LDS_LIMIT && fixed_b + 4 * (2 * tiles + grp_slab_b[gi]) <= LDS_LIMIT;
+        if (staged) { g.lean |= 2; P->stage_out = 1; }
+        P->region_fwd = std::max(P->region_fwd, (int)(tiles * (staged ? 2 : 1) + grp_slab_f[gi]));
+        P->region_bwd = std::max(P->region_bwd, (int)(tiles * (staged ? 2 : 1) + grp_slab_b[gi]));
+        if (staged && (g.lean & 1))
+            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_fused[ui] = 1;
+    }
+    if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) std::fill(unit_fused.begin(), unit_fused.end(), 0);
+    // the first-layer gradients of the fused units: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
     // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
     std::vector<int32_t> twmap;
     for (size_t ui = 0; ui < units.size(); ++ui) {
         Unit& u = units[ui];
         u.bias1 = -1;
-        if (!unit_lean[ui]) continue;
+        if (!unit_fused[ui]) continue;
         const hint_node_desc& n = nodes[unit_node[ui]];
         const int64_t* po = n.p_off + (int)(ui & 1) * 6;
         u.bias1 = (int)twmap.size();
@@ -597,31 +632,14 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
 
     // ---- meta blob staged in LDS by the kernels ----
-    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t groups_bytes = up16(groups.size() * sizeof(Group));
-    const size_t units_bytes = up16(units.size() * sizeof(Unit));
-    const size_t ents_bytes = up16(ents.size() * sizeof(Ent));
-    const size_t rng_bytes = up16(rng.size() * sizeof(int32_t));
-    const bool lops_lds = lops.size() * sizeof(LaneOp) <= 16 * 1024;     // larger tables stay in global memory
-    const size_t lops_bytes = lops_lds ? up16(lops.size() * sizeof(LaneOp)) : 0;
-    P->units_off = (int)groups_bytes;
-    P->tmap_off = P->units_off + (int)units_bytes;
-    P->ents_off = P->tmap_off;
-    P->rng_off = P->ents_off + (int)ents_bytes;
-    P->lops_off = lops_lds ? P->rng_off + (int)rng_bytes : -1;
-    P->meta_bytes = P->rng_off + (int)rng_bytes + (int)lops_bytes;
     std::vector<char> meta(P->meta_bytes, 0);
     std::memcpy(meta.data(), groups.data(), groups.size() * sizeof(Group));
     std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
     if (lops_lds) std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
-    // the rows' output tiles wait in LDS for the element-wise phase to stream them out - when there is room for that
-    auto lds_f = [&](int nbuf) { return P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + nbuf * P->abuf_tiles * 256 + P->slab_fwd + ROWS + MAX_NW); };
-    auto lds_b = [&](int nbuf) { return P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + nbuf * P->abuf_tiles * 256 + P->slab_bwd + ROWS + ROWS * P->xld); };      // (+ the lanes of the level before: first-layer gradients)
-    P->stage_out = (lds_f(2) <= LDS_LIMIT && lds_b(2) <= LDS_LIMIT) ? 1 : 0;
-    P->lds_fwd = lds_f(1 + P->stage_out);
-    P->lds_bwd = lds_b(1 + P->stage_out);
+    P->lds_fwd = fixed_f + 4 * P->region_fwd;
+    P->lds_bwd = fixed_b + 4 * P->region_bwd;
     P->lds_fwd = (P->lds_fwd + 15) / 16 * 16;
     P->lds_bwd = (P->lds_bwd + 15) / 16 * 16;
     // the thin blobs ride in LDS (staged once per block) when they are small
@@ -654,10 +672,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
 
     // ---- weight-gradient jobs (part B) and the map of real parameter elements ----
-    P->fuse_dw1 = (P->stage_out && P->tw_floats > 0) ? 1 : 0;       // (lean groups' dW1 / db1 in the backward kernel)
-    if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) P->fuse_dw1 = 0;
+    P->fuse_dw1 = P->tw_floats > 0 ? 1 : 0;       // (some lean, staged groups: their dW1 / db1 come from the backward kernel)
     std::vector<uint8_t> real((size_t)P->param_floats, 0);
-    make_wgrad_jobs(P, nodes, units, unit_node, unit_lean, max_depth, &wjobs, &real);
+    make_wgrad_jobs(P, nodes, units, unit_node, unit_lean, unit_fused, max_depth, &wjobs, &real);
     P->n_wjobs = (int)wjobs.size();
     P->total_rows = (int)recs_f.size();
     P->total_tiles = (int)thin_f.size();
@@ -866,6 +883,7 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;
     a.d = P->d; a.dc = P->dc; a.xld = P->xld; a.cld = P->cld;
     a.abuf_tiles = P->abuf_tiles; a.slab_floats = backward ? P->slab_bwd : P->slab_fwd; a.gld = P->gld;
+    a.region_floats = backward ? P->region_bwd : P->region_fwd;
     a.WT = P->WT; a.ST = P->ST; a.perm_lds = 0; a.stage_out = P->stage_out;
     a.thin_off = backward ? P->thin_b_off : P->thin_f_off;
     a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;

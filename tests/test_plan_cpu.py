@@ -71,8 +71,8 @@ def test_planner_covers_every_tile_exactly_once(d, dc, widths, n_nodes, n_levels
         dw1 = t3(h) * t3(k) if k else 0
         jobs += 2 * (base + (0 if lean_depth[depth] else dw1))
         jobs_unfused += 2 * (base + dw1)
-    # (the fusion needs the groups' outputs staged in LDS: blocks too large for that keep their dW1 jobs)
-    assert st["wjobs"] in (jobs, jobs_unfused)
+    # (the fusion needs the group's outputs staged in LDS: groups too large for that keep their dW1 jobs)
+    assert jobs <= st["wjobs"] <= jobs_unfused
     assert st["abuf_tiles"] >= max(2 * ((n.s[0].out_features + 15) // 16) for n, _, _ in nodes)
 
 
