@@ -112,6 +112,9 @@ struct hint_plan {
     WJob* d_wjobs = nullptr;
     PackSeg* d_segs = nullptr;
     int2* d_ptiles = nullptr;
+    // the same block planned for 4 wavefronts per workgroup (two workgroups per CU: one row tile's serial phases overlap
+    // the other's GEMM phases) - used for batches of more row tiles than CUs; owned by this plan; may be absent
+    hint_plan* alt4 = nullptr;
 };
 
 // A row of a group's GEMM phase: up to NTT adjacent fragment tiles [tb, tb + ntt) of one unit
@@ -740,6 +743,19 @@ static int pick_nw(int d) {
     return nw;
 }
 
+// large groups first (fewer phases per block); smaller ones when the block does not fit the LDS, and when the smallest
+// groups do not fit either, fewer wavefronts per unit (fewer slabs)
+static int plan_for(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int nw, hint_plan** out) {
+    for (int unit_waves = nw; unit_waves >= 1; unit_waves /= 2)
+        for (int tile_cap = 72; tile_cap >= 8; tile_cap -= 16) {
+            bool retry = false;
+            const int st = build_plan(nodes, n_nodes, d, dc, clamp, nw, tile_cap, unit_waves, out, &retry);
+            if (st != 2) return st;
+            if (!retry) break;
+        }
+    return 1;          // (the last attempt's message stands)
+}
+
 extern "C" {
 
 int hint_abi_version(void) { return HINT_AMD_ABI_VERSION; }
@@ -766,17 +782,25 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
             if (nodes[i].depth == nodes[j].depth && nodes[i].off < nodes[j].off + nodes[j].D &&
                 nodes[j].off < nodes[i].off + nodes[i].D)
                 return fail("hint_plan_create: nodes %d and %d of depth %d overlap", i, j, nodes[i].depth);
-    // large groups first (fewer phases per block); smaller ones when the block does not fit the LDS
-    // and when the smallest groups do not fit either, fewer wavefronts per unit (fewer slabs)
     const int nw = pick_nw(d);
-    for (int unit_waves = nw; unit_waves >= 1; unit_waves /= 2)
-        for (int tile_cap = 72; tile_cap >= 8; tile_cap -= 16) {
-            bool retry = false;
-            const int st = build_plan(nodes, n_nodes, d, dc, clamp, nw, tile_cap, unit_waves, out, &retry);
-            if (st != 2) return st;
-            if (!retry) break;
+    const int st = plan_for(nodes, n_nodes, d, dc, clamp, nw, out);
+    if (st != 0) return st;
+    // batches of more row tiles than CUs run two 4-wavefront workgroups per CU instead of one 8-wavefront workgroup
+    // after the other (when the block fits twice and the backward kernel's register-held lane tile allows 256 threads)
+    if (nw == 8 && !std::getenv("HINT_NW") && ROWS * d <= LV_REGS * 64 * 4) {
+        const std::string keep = g_err;
+        hint_plan* alt = nullptr;
+        if (plan_for(nodes, n_nodes, d, dc, clamp, 4, &alt) == 0) {
+            const hint_plan* P = *out;
+            const bool same_layout = alt->packed_floats == P->packed_floats && alt->n_bias == P->n_bias && alt->WT == P->WT &&
+                                     alt->ST == P->ST && alt->param_floats == P->param_floats && alt->lean == P->lean;
+            if (same_layout && std::max(alt->lds_fwd, alt->lds_bwd) <= LDS_LIMIT / 2) (*out)->alt4 = alt;
+            else if (g_host_only) delete alt;
+            else hint_plan_destroy(alt);
         }
-    return 1;          // (the last attempt's message stands)
+        g_err = keep;
+    }
+    return 0;
 }
 
 int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int64_t* stats) {
@@ -790,12 +814,14 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
         stats[4] = P->lds_fwd; stats[5] = P->lds_bwd; stats[6] = P->nw; stats[7] = P->n_wjobs;
         stats[8] = P->param_floats; stats[9] = P->packed_floats; stats[10] = P->n_units; stats[11] = P->abuf_tiles;
     }
+    delete P->alt4;
     delete P;                   // (host-only plans own no device memory)
     return 0;
 }
 
 void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
+    hint_plan_destroy(P->alt4);
     (void)hipFree(P->d_meta);
     (void)hipFree(P->d_lops);
     (void)hipFree(P->d_recs);
@@ -807,6 +833,11 @@ void hint_plan_destroy(hint_plan* P) {
     (void)hipFree(P->d_segs);
     (void)hipFree(P->d_ptiles);
     delete P;
+}
+
+// the plan variant a batch of B rows runs on
+static const hint_plan* variant(const hint_plan* P, int B) {
+    return (P && P->alt4 && (B + ROWS - 1) / ROWS > P->num_cu) ? P->alt4 : P;
 }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
@@ -826,6 +857,7 @@ static inline int64_t bits_stride(const hint_plan* P, int B) { return (int64_t)r
 
 int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
     if (!P || B < 0) return -1;
+    P = variant(P, B);
     return tape_act_off(P, B) + (P->lean ? 1 : 2) * act_stride(P, B) + 2 * bits_stride(P, B) / 4;
 }
 
@@ -859,6 +891,7 @@ static inline int64_t ws_thin_off(const hint_plan* P, int B) {        // floats 
 
 size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
     if (!P || B <= 0) return 0;
+    P = variant(P, B);
     const int64_t thin = P->fuse_dw1 ? (int64_t)grid_for(P, B) * P->tw_floats : 0;
     return (size_t)(ws_slab_off(P, B) + ws_thin_off(P, B) + thin) * sizeof(float);
 }
@@ -995,6 +1028,7 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", what, P->dc);
     if (B < 0) return fail("negative batch");
     if (B == 0) return 0;
+    P = variant(P, B);
     ChainBlock one{};
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, rev ? nullptr : tape, &one);
@@ -1050,6 +1084,7 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
         if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
         return 0;
     }
+    P = variant(P, B);
     if (!workspace || workspace_bytes < hint_plan_workspace_bytes(P, B))
         return fail("hint_block_backward: workspace too small (%zu < %zu)", workspace_bytes,
                     hint_plan_workspace_bytes(P, B));
@@ -1085,7 +1120,7 @@ int hint_chain_create(const hint_plan* P, int32_t n_blocks, int32_t B, hint_chai
     if (!P || !out) return fail("hint_chain_create: null argument");
     if (n_blocks < 1 || B < 1) return fail("hint_chain_create: n_blocks and B must be >= 1");
     hint_chain* C = new hint_chain();
-    C->plan = P; C->n = n_blocks; C->B = B;
+    C->plan = variant(P, B); C->n = n_blocks; C->B = B;      // (the variant planned for this many row tiles)
     C->host.assign(n_blocks, ChainBlock{});
     C->set.assign(n_blocks, 0);
     if (hipMalloc((void**)&C->d_table, sizeof(ChainBlock) * (size_t)n_blocks) != hipSuccess) {

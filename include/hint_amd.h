@@ -71,6 +71,9 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
 void hint_plan_destroy(hint_plan* plan);
 
 /* floats the flat parameter (and gradient) buffer must hold: max(p_off + tensor size), rounded up to 4. */
+/* (A plan may hold two launch variants of the block - 8 wavefronts per workgroup for batches of up to one 16-row tile
+ * per CU, 4 for larger ones - and every entry point that takes B picks by B; the sizes below are the picked
+ * variant's, so query them with the B you will run.) */
 int64_t hint_plan_param_floats(const hint_plan* plan);
 /* floats of the packed-weight buffer (both subnets of every node, forward and transposed
  * copies, in MFMA fragment order, zero padded). */

@@ -119,7 +119,9 @@ def test_block_vs_oracle_seeded(d, widths, dc, B):
 @pytest.mark.parametrize("d,widths,B", [(6, [140, 70, 35, 17], 4096), (8, [128, 64, 32, 16], 8192),
                                         (43, [67, 33, 16, 8], 4096), (6, [512, 256, 128], 1000)])
 def test_full_size_properties(d, widths, B):
-    """encode -> decode round trip, J_fwd + J_rev = 0, row independence (batch-size invariance)."""
+    """encode -> decode round trip, J_fwd + J_rev = 0, row independence: a row's result does not depend on where in
+    the batch it sits (bit-identical), nor - up to the summation order of the K-split, which differs between the
+    8-wavefront plan of batches up to 16 rows x CUs and the 4-wavefront plan of larger ones - on the batch size."""
     torch.manual_seed(0)
     blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths).to(DEV)
     x = torch.randn(B, d, device=DEV)
@@ -127,9 +129,15 @@ def test_full_size_properties(d, widths, B):
         (z,) = blk([x]); J = blk.jacobian(None)
         (xr,) = blk([z], rev=True); Jr = blk.jacobian(None)
         (z_small,) = blk([x[37:101]]); J_small = blk.jacobian(None)
+        (z_roll,) = blk([x.roll(48, 0)]); J_roll = blk.jacobian(None)
     assert (xr - x).abs().max().item() < 1e-4
     assert (J + Jr).abs().max().item() < 1e-4
-    assert torch.equal(z[37:101], z_small) and torch.equal(J[37:101], J_small)
+    assert torch.equal(z_roll.roll(-48, 0), z) and torch.equal(J_roll.roll(-48, 0), J)
+    if B <= 4096:
+        assert torch.equal(z[37:101], z_small) and torch.equal(J[37:101], J_small)
+    else:
+        assert (z[37:101] - z_small).abs().max().item() < 2e-6 * max(1.0, z_small.abs().max().item())
+        assert (J[37:101] - J_small).abs().max().item() < 2e-6 * max(1.0, J_small.abs().max().item())
 
 
 def test_parameter_rebinding_and_empty_batch():
