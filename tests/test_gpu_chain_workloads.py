@@ -28,7 +28,12 @@ WORKLOADS = [
     ("cfg4_plus_x_lane_cond", 100, 4, 4, [224, 112, 56], 96, 0.03),
     ("cfg5_miniboone_hint_10", 43, 0, 10, [67, 33, 16, 8], 200, 0.06),
     ("plus_hint_4_big", 100, 0, 2, [512, 256, 128, 64], 48, 0.03),
+    # full BASELINE batch sizes above 16 rows x CUs: the plan variant for more row tiles than CUs
+    # (configs/uci_data/gas_hint_8.py:29-36,55-71 at its batch of 8192; power_hint_8 at the same size)
+    ("cfg3_gas_hint_8_B8192", 8, 0, 8, [128, 64, 32, 16], 8192, 0.06),
+    ("cfg2_power_hint_8_B8192", 6, 0, 8, [140, 70, 35, 17], 8192, 0.06),
 ]
+MAX_KINK_ROWS = 0.15      # at most this share of a batch may be left out as "next to a ReLU kink" (observed: 1-10 %)
 
 
 def make_pair(d, dc, n_blocks, widths, scale, seed=0):
@@ -86,7 +91,9 @@ def test_chain_nll_gradient_and_inverse_match_oracle(name, d, dc, n_blocks, widt
     c64 = torch.randn(B, dc, generator=g, dtype=torch.float64).float().double() if dc else None
     cr = (c64,) if dc else ()
     keep = rows_off_the_kinks(ref, x64, cr)
-    assert int(keep.sum()) >= 0.5 * B, f"{B - int(keep.sum())} of {B} rows next to a ReLU kink"
+    dropped = B - int(keep.sum())
+    print(f"{name}: {dropped} of {B} rows left out (pre-activation within {KINK} of a ReLU kink)")
+    assert dropped <= MAX_KINK_ROWS * B, f"{dropped} of {B} rows next to a ReLU kink"
     x64 = x64[keep]
     if dc:
         c64 = c64[keep]
@@ -113,9 +120,14 @@ def test_chain_nll_gradient_and_inverse_match_oracle(name, d, dc, n_blocks, widt
 
     grads = flat_grads(tr, flow)
     num = den = 0.0
+    gmax = max(float(ref.params[bi][k].grad.abs().max()) for (bi, k) in grads)
     for (bi, k), gg in grads.items():
         r = ref.params[bi][k].grad
         num += float(((gg - r) ** 2).sum()); den += float((r ** 2).sum())
+        # per tensor (a wrong small tensor must not hide in the pooled norm): 1e-4 of the tensor's own norm, with a
+        # floor of 1e-6 of the model's largest gradient entry per element for tensors whose gradient is all but zero
+        tn, tr_ = float(((gg - r) ** 2).sum()) ** 0.5, float((r ** 2).sum()) ** 0.5
+        assert tn <= 1e-4 * tr_ + 1e-6 * gmax * math.sqrt(r.numel()), (name, bi, k, tn, tr_)
     assert math.sqrt(num / den) <= 1e-4, (name, math.sqrt(num / den))
 
     # sampling direction: the whole chain in one launch

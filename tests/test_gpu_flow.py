@@ -52,7 +52,7 @@ def test_trainer_reproduces_reference_adam_steps(use_graph):
     for bi, blk in enumerate(flow.blocks):
         for k, v in blk.state_dict().items():
             assert rel_err(v.cpu().numpy(), g[f"final:{bi}:{k}"]) < 1e-3, (bi, k)
-            np.testing.assert_allclose(v.cpu().numpy(), g[f"final:{bi}:{k}"], rtol=1e-2, atol=3e-5)
+            np.testing.assert_allclose(v.cpu().numpy(), g[f"final:{bi}:{k}"], rtol=2e-3, atol=3e-5)
 
 
 @pytest.mark.parametrize("reshuffle", [False, True])

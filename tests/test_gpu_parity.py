@@ -81,6 +81,12 @@ def test_block_vs_reference_golden(case):
     (6, [512, 256, 128], 0, 200),         # the reference's *_big configs: h > 384, nets planned one at a time
     (8, [472, 400, 64], 2, 333),          # two split levels, condition
     (5, [385], 0, 64),                    # just over the split threshold, max_splits by list length
+    # more row tiles than CUs (B > 16 x 256): the plan variant the launch then picks, every gradient against the oracle
+    (6, [140, 70, 35, 17], 0, 4112),
+    (6, [140, 70, 35, 17], 0, 8192),
+    (8, [128, 64, 32, 16], 0, 8192),
+    (43, [67, 33, 16, 8], 0, 6000),
+    (8, [64, 32, 16], 3, 5000),
 ])
 def test_block_vs_oracle_seeded(d, widths, dc, B):
     dims_c = [(dc,)] if dc else []

@@ -48,6 +48,8 @@ for case in range(n_cases):
               for _ in range(depth)]
     dc = rng.choice([0, 0, 0, 1, 3, 5])
     B = rng.choice([1, 17, 100, 257] if wide else [1, 2, 15, 16, 17, 33, 100, 257, 1000])
+    if not wide and d <= 16 and case % 10 == 7:
+        B = rng.choice([4112, 6000])      # more row tiles than CUs: the launch picks the plan variant for large batches
     max_splits = rng.choice([-1, -1, 0, 1, 2])
     min_split = rng.choice([2, 2, 3])
     clamp = rng.choice([4.0, 4.0, 2.0])
