@@ -163,12 +163,13 @@ struct RowRec {
     int32_t slab;       // float offset of the row's slab inside the slab buffer
     int32_t bias3;      // float offset of the unit's b3 (zero padded to 16) in the packed buffer
     int32_t thin_w;     // float offset of the unit's thin-layer vectors inside the direction's thin blob
-    int32_t thin_b;     // (unused)
+    int32_t thin_b;     // wave-local plans: offset of the OTHER direction's thin vectors of the row's first tile (forward: W3^T, backward: W1 | b1)
     int32_t thin_k;     // forward: cin | ku << 8 | xoff << 16;  backward: r | lcol << 16
     int32_t flags;      // NT | thin << 8 (run the thin layer before this row) | first << 9 (the row holds the unit's tile 0: it stores the thin layer's tiles and adds b3)
+                        // | ulast << 10 (the wavefront's last row of the unit)
     int32_t wcol;       // column of the unit's tile 0 in the [Bp][WT] arrays
     int32_t tb;         // first tile of the row inside its unit
-    int32_t pad1, pad2;
+    int32_t p1, p2;     // wave-local plans, backward: offset of the row's first feature in the workgroup's first-layer gradient slab; cin | xoff << 8 | h << 16
 };
 static_assert(sizeof(RowRec) == 64, "RowRec must be 64 bytes");
 
@@ -211,6 +212,24 @@ struct KArgs {
     float alpha;
     int32_t B;
     unsigned long long* stamps;    // diagnostic builds (-DHINT_STAMPS): where workgroup 0 leaves its phase stamps; else unused
+};
+
+// ---- wave-local plans (hint_wl.hpp) ----
+constexpr int WL_PAR_REGS = 6;      // float4 per thread of the next block's staged parameters in flight
+constexpr int WL_LV = 4;            // floats per lane of a [16, d] tile held in registers: d <= 16
+
+// where the WL kernels keep things in LDS (float offsets) and how the block's small parameters are staged
+struct WlArgs {
+    int32_t par_f4;         // float4 of one staged parameter buffer: [forward thin blob | backward thin blob | biases]
+    int32_t par_bias;       // float offset of the bias region inside it (= size of the two blobs)
+    int32_t bias_src;       // float offset of the bias region inside the packed buffer
+    int32_t off_par;        // two buffers of 4 * par_f4 floats
+    int32_t off_slab;       // two slab sets of slab_floats
+    int32_t slab_floats;
+    int32_t off_perm;       // the chain's d x d matrices (when KArgs::perm_lds != 0)
+    int32_t off_priv;       // per wavefront: priv_stride floats
+    int32_t priv_stride;
+    int32_t off_misc;       // 32 floats shared: loss partials / g_J of the tile
 };
 
 }  // namespace hint

@@ -38,6 +38,15 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlo
                         int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream);
 hipError_t set_max_lds_apply(int bytes);
 hipError_t set_max_lds_bwd(int bytes);
+hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
+                           const ChainBlock* chain, int n_chain, const float* x, float* z, float* J, const float* J_in,
+                           float* loss_acc, float noise, const unsigned long long* rng_state, float* x_noisy,
+                           hipStream_t stream);
+hipError_t launch_wl_bwd(const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
+                         const ChainBlock* chain, int n_chain, const float* x, const float* g_z, const float* g_J,
+                         float* g_x, float gz_scale, float gJ_const, hipStream_t stream);
+hipError_t set_max_lds_wl_apply(int bytes);
+hipError_t set_max_lds_wl_bwd(int bytes);
 hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
                        float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads,
                        int num_cu, const float* dev_state, hipStream_t stream);
@@ -99,6 +108,9 @@ struct hint_plan {
     int32_t* d_twmap = nullptr; // slab index -> offset in the flat parameter layout (or -1)
     int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
     int lds_fwd = 0, lds_bwd = 0;
+    // wave-local plans (hint_wl.hpp): narrow trees run on hint_wl_apply_kernel / hint_wl_bwd_kernel
+    int wl = 0;
+    WlArgs wl_f{}, wl_b{};
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
@@ -116,6 +128,11 @@ struct hint_plan {
     // the other's GEMM phases) - used for batches of more row tiles than CUs; owned by this plan; may be absent
     hint_plan* alt4 = nullptr;
 };
+
+static inline int plan_lds(const hint_plan* P, bool backward) {
+    if (P->wl) return 4 * (backward ? P->wl_b.off_perm : P->wl_f.off_perm);
+    return backward ? P->lds_bwd : P->lds_fwd;
+}
 
 // A row of a group's GEMM phase: up to NTT adjacent fragment tiles [tb, tb + ntt) of one unit
 struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
@@ -203,19 +220,22 @@ static void assign_slabs(std::vector<Unit>& units, const Group& g, std::vector<R
 // that list (nw + 1 offsets appended to rng).  false: a unit does not fit the records' bit fields.
 static bool emit_row_records(const std::vector<Unit>& units, const std::vector<Row>& rows,
                              const std::vector<std::vector<int>>& wave_rows, int row_begin, std::vector<RowRec>* recs_f,
-                             std::vector<RowRec>* recs_b, std::vector<int32_t>* rng) {
+                             std::vector<RowRec>* recs_b, std::vector<int32_t>* rng, std::vector<int>* rec_unit) {
     for (const std::vector<int>& mine : wave_rows) {
         rng->push_back((int)recs_f->size() - row_begin);
         int last_unit = -1;
-        for (int ri : mine) {
+        for (size_t mi = 0; mi < mine.size(); ++mi) {
+            const int ri = mine[mi];
             const Row& rw = rows[ri];
+            const int ulast = (mi + 1 == mine.size() || rows[mine[mi + 1]].unit != rw.unit) ? 1 : 0;     // the wavefront's last row of the unit
+            rec_unit->push_back(rw.unit);
             const Unit& u = units[rw.unit];
             if (u.NT > 255 || u.cin > 255 || u.ku > 255 || u.r > 255 || u.tile0 > 0xffff) return false;
             const int thin = rw.unit != last_unit ? 1 : 0, first = rw.tb == 0 ? 1 : 0;     // (thin: the wavefront's first row of the unit starts its slab)
             last_unit = rw.unit;
             RowRec r{};
             r.ocol = u.wcol + 16 * rw.tb; r.bias3 = u.bias3; r.wcol = u.wcol; r.tb = rw.tb;
-            r.flags = u.NT | (thin << 8) | (first << 9);
+            r.flags = u.NT | (thin << 8) | (first << 9) | (ulast << 10);
             // forward: second layer + third layer partials (+ b3 with the unit's first row)
             r.base1 = u.f2 + rw.tb * u.NT; r.base2 = u.f3 + rw.tb;
             r.counts = u.NT | (u.RT << 8) | ((first ? u.RT : 0) << 16) | (rw.ntt << 24);
@@ -393,6 +413,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<Unit> units;
     std::vector<int> unit_node;       // node index (into `nodes`) of every unit
     std::vector<RowRec> recs_f, recs_b;   // row records in (group, wavefront, unit) order
+    std::vector<int> rec_unit;            // ... and the unit of each
     std::vector<ThinRec> thin_f, thin_b;  // thin records in (group, unit, tile) order
     std::vector<int> grp_slab_f, grp_slab_b;  // per group: floats of its slabs (forward / backward)
     std::vector<int> unit_f1, unit_b3;    // per unit: first fragment tile of W1 / W3^T for a wide thin layer, or -1
@@ -533,7 +554,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         // ---- the wavefronts' record lists, forward and backward; the thin layers' tiles are shared out evenly ----
         g.row_begin = (int)recs_f.size();
         g.rng_begin = (int)rng.size();
-        if (!emit_row_records(units, rows, wave_rows, g.row_begin, &recs_f, &recs_b, &rng)) {
+        if (!emit_row_records(units, rows, wave_rows, g.row_begin, &recs_f, &recs_b, &rng, &rec_unit)) {
             delete P;
             return fail("hint_plan_create: a node is too wide for the row records (h <= 4080, cin <= 255)");
         }
@@ -573,6 +594,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)g.lean;
         if (!g.lean) P->lean = 0;
     }
+    // ---- wave-local plans (hint_wl.hpp): every group lean, narrow lane tile, the block's thin vectors and biases small
+    //      enough to ride in LDS twice (HINT_WL=0: never) ----
+    const int par_bias = (int)(blob_f_pad + blob_b_pad);
+    const int par_f4 = (par_bias + (int)bmap.size() + 3) / 4;
+    bool wl = P->lean && dc == 0 && d <= 4 * WL_LV && par_f4 <= WL_PAR_REGS * 64 * nw;
+    for (const Unit& u : units) if (u.xoff > 255 || u.h > 32767) wl = false;
+    if (const char* e = std::getenv("HINT_WL")) if (std::atoi(e) == 0) wl = false;
     // ---- LDS: the meta blob's size, then per group the region [its tiles | its output tiles, staged for the element-wise
     //      phase to stream out, when there is room | its slabs]; the launch reserves the largest group's ----
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -604,6 +632,28 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_fused[ui] = 1;
     }
     if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) std::fill(unit_fused.begin(), unit_fused.end(), 0);
+    if (wl) {
+        // LDS of the wave-local kernels (float offsets): [meta | 2 x staged parameters | 2 x slab set | per wavefront: its own
+        // tiles | 32 floats shared] (+ the chain's permutation matrices behind, when the launch finds room)
+        auto r4 = [](int v) { return (v + 3) & ~3; };
+        WlArgs wf{}, wb{};
+        wf.par_f4 = wb.par_f4 = par_f4; wf.par_bias = wb.par_bias = par_bias;
+        wf.off_par = wb.off_par = P->meta_bytes / 4;
+        wf.off_slab = wb.off_slab = wf.off_par + 2 * 4 * par_f4;
+        wf.slab_floats = r4(P->slab_fwd); wb.slab_floats = r4(P->slab_bwd);
+        wf.off_priv = wf.off_slab + 2 * wf.slab_floats; wb.off_priv = wb.off_slab + 2 * wb.slab_floats;
+        wf.priv_stride = r4(2 * ROWS * P->xld);
+        wb.priv_stride = r4(4 * ROWS * P->xld + r4(ROWS * P->gld) + 256);
+        wf.off_misc = wf.off_priv + nw * wf.priv_stride; wb.off_misc = wb.off_priv + nw * wb.priv_stride;
+        wf.off_perm = wf.off_misc + 32; wb.off_perm = wb.off_misc + 32;
+        if (4 * wf.off_perm > LDS_LIMIT || 4 * wb.off_perm > LDS_LIMIT) wl = false;
+        else { P->wl_f = wf; P->wl_b = wb; }
+    }
+    P->wl = wl ? 1 : 0;
+    if (std::getenv("HINT_PLAN_DUMP"))
+        std::fprintf(stderr, "[hint plan] nw %d: wave-local %d (lean %d, par_f4 %d of %d, LDS fwd %d bwd %d bytes)\n", nw, P->wl, P->lean,
+                     par_f4, WL_PAR_REGS * 64 * nw, 4 * P->wl_f.off_perm, 4 * P->wl_b.off_perm);
+    if (wl) std::fill(unit_fused.begin(), unit_fused.end(), 1);      // dW1 / db1 always come from the backward kernel
     // the first-layer gradients of the fused units: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
     // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
     std::vector<int32_t> twmap;
@@ -631,6 +681,22 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                                          u.cin | (u.xoff << 8) | (std::min(16, u.h - 16 * nt) << 16), u.tile0 + nt, 0});
         }
     for (RowRec& r : recs_f) { r.aux += (int)packed; r.bias3 += (int)packed; }
+    if (wl) {
+        // the wave-local kernels read thin vectors and biases from the staged parameter buffer [forward blob | backward
+        // blob | biases]: offsets relative to it
+        P->wl_f.bias_src = P->wl_b.bias_src = (int)packed;
+        for (size_t i = 0; i < recs_f.size(); ++i) {
+            const Unit& u = units[rec_unit[i]];
+            RowRec& f = recs_f[i];
+            RowRec& b = recs_b[i];
+            f.aux = par_bias + (f.aux - (int)packed); f.bias3 = par_bias + (f.bias3 - (int)packed);
+            f.thin_b = (int)blob_f_pad + u.w3v + f.tb * 64;                 // W3^T vectors of the row's first tile
+            b.thin_w = (int)blob_f_pad + u.w3v;
+            b.thin_b = u.w1v + b.tb * 80;                                    // W1 | b1 vectors of the row's first tile
+            b.p1 = u.bias1 + b.tb * 16 * (u.cin < 4 ? 4 : 8);
+            b.p2 = u.cin | (u.xoff << 8) | (u.h << 16);
+        }
+    }
 
     std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
 
@@ -722,6 +788,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // of different sizes created in any order (or on several devices) cannot lower it for each other
     if (e == hipSuccess) e = set_max_lds_apply(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_bwd(LDS_ATTR);
+    if (e == hipSuccess) e = set_max_lds_wl_apply(LDS_ATTR);
+    if (e == hipSuccess) e = set_max_lds_wl_bwd(LDS_ATTR);
     if (e != hipSuccess) {
         hint_plan_destroy(P);
         return fail("hint_plan_create: device setup failed: %s", hipGetErrorString(e));
@@ -794,7 +862,9 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
             const hint_plan* P = *out;
             const bool same_layout = alt->packed_floats == P->packed_floats && alt->n_bias == P->n_bias && alt->WT == P->WT &&
                                      alt->ST == P->ST && alt->param_floats == P->param_floats && alt->lean == P->lean;
-            if (same_layout && std::max(alt->lds_fwd, alt->lds_bwd) <= LDS_LIMIT / 2) (*out)->alt4 = alt;
+            // (a few KiB of margin for the chain's permutation matrices behind a wave-local plan's LDS)
+            const int alt_lds = std::max(plan_lds(alt, false), plan_lds(alt, true)) + (alt->wl ? 4096 : 0);
+            if (same_layout && alt->wl == P->wl && alt_lds <= LDS_LIMIT / 2) (*out)->alt4 = alt;
             else if (g_host_only) delete alt;
             else hint_plan_destroy(alt);
         }
@@ -897,7 +967,7 @@ size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
 }
 
 int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
-    return P ? (backward ? P->lds_bwd : P->lds_fwd) : -1;
+    return P ? plan_lds(P, backward != 0) : -1;
 }
 
 // LDS bytes of the launch: the plan's, plus the chain's permutation matrices when they fit behind it
@@ -1001,10 +1071,18 @@ static int grid_for(const hint_plan* P, int B) {
 
 // part A (row-parallel, bit 0 of `parts`) and part B (weight gradients, bit 1) of the backward pass of
 // one block or a chain
-static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, int n_chain,
+static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, const ChainBlock* chain_host, int n_chain,
                         const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
                         float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s) {
-    if (parts & 1) {
+    if ((parts & 1) && P->wl) {
+        KArgs a = make_args(P, B, true);
+        WlArgs w = P->wl_b;
+        bool any_perm = one.perm != nullptr;
+        if (chain_host) for (int i = 0; i < n_chain; ++i) any_perm = any_perm || chain_host[i].perm != nullptr;
+        const int lds = lds_with_perms(P, plan_lds(P, true), n_chain, any_perm, &a);
+        w.off_perm = a.perm_lds;
+        HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
+    } else if (parts & 1) {
         // (the permutation matrices stay in global memory here: one d x d product per block)
         HIP_TRY(launch_bwd(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c, g_z, g_J, g_x,
                            g_c, gz_scale, gJ_const, s));
@@ -1033,7 +1111,14 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, rev ? nullptr : tape, &one);
     KArgs a = make_args(P, B, false);
-    const int lds = lds_with_perms(P, P->lds_fwd, 1, perm != nullptr, &a);
+    const int lds = lds_with_perms(P, plan_lds(P, false), 1, perm != nullptr, &a);
+    if (P->wl) {
+        WlArgs w = P->wl_f;
+        w.off_perm = a.perm_lds;
+        HIP_TRY(launch_wl_apply(rev, a, w, lds, grid_for(P, B), one, nullptr, 1, x, z, J, J_in, loss_acc, 0.f, nullptr, nullptr,
+                                (hipStream_t)stream));
+        return 0;
+    }
     HIP_TRY(launch_apply(rev, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
@@ -1095,7 +1180,7 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
     bind_tape(P, B, const_cast<float*>(tape), &one);
     one.gparams = g_params;
     split_workspace(P, B, workspace, &one);
-    return run_backward(P, one, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, 3, s);
+    return run_backward(P, one, nullptr, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, 3, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1178,7 +1263,14 @@ int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
     KArgs a = make_args(P, C->B, false);
-    const int lds = lds_with_perms(P, P->lds_fwd, C->n, chain_any_perm(C), &a);
+    const int lds = lds_with_perms(P, plan_lds(P, false), C->n, chain_any_perm(C), &a);
+    if (P->wl) {
+        WlArgs w = P->wl_f;
+        w.off_perm = a.perm_lds;
+        HIP_TRY(launch_wl_apply(false, a, w, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, z, J, J_in, loss_acc, noise,
+                                (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
+        return 0;
+    }
     HIP_TRY(launch_apply(false, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, c, z, J,
                          J_in, loss_acc, noise, (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
     return 0;
@@ -1191,7 +1283,14 @@ int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, floa
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_inverse: plan has dc=%d but c is NULL", P->dc);
     KArgs a = make_args(P, C->B, false);
-    const int lds = lds_with_perms(P, P->lds_fwd, C->n, chain_any_perm(C), &a);
+    const int lds = lds_with_perms(P, plan_lds(P, false), C->n, chain_any_perm(C), &a);
+    if (P->wl) {
+        WlArgs w = P->wl_f;
+        w.off_perm = a.perm_lds;
+        HIP_TRY(launch_wl_apply(true, a, w, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, x, J, J_in, nullptr, 0.f,
+                                nullptr, nullptr, (hipStream_t)stream));
+        return 0;
+    }
     HIP_TRY(launch_apply(true, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, c, x, J, J_in, nullptr, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
@@ -1209,7 +1308,7 @@ int hint_chain_backward_parts(const hint_chain* C, const float* x, const float* 
         if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
             return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
     if ((parts & 3) == 0) return fail("hint_chain_backward_parts: parts must select part A (1), part B (2) or both (3)");
-    return run_backward(P, C->host[0], C->d_table, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
+    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
                         accumulate ? 1 : 0, parts & 3, (hipStream_t)stream);
 }
 

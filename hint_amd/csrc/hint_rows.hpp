@@ -48,6 +48,7 @@ __device__ __forceinline__ i32x16 load_rec(const void* recs, int idx) {
 struct RowU {           // decoded record (all wave-uniform)
     int base1, base2, n1, n2, n3, ntt, aux, ocol, tile0, nquad, slab, bias3;
     int thin_w, thin_b, thin_k, NT, thin, first, wcol, tb;
+    int ulast, p1, p2;      // (wave-local kernels, hint_wl.hpp)
 };
 __device__ __forceinline__ RowU decode_rec(const i32x16 r) {
     RowU u;
@@ -59,6 +60,7 @@ __device__ __forceinline__ RowU decode_rec(const i32x16 r) {
     u.thin_w = r[8]; u.thin_b = r[9]; u.thin_k = r[10];
     u.NT = r[11] & 0xff; u.thin = (r[11] >> 8) & 1; u.first = (r[11] >> 9) & 1;
     u.wcol = r[12]; u.tb = r[13];
+    u.ulast = (r[11] >> 10) & 1; u.p1 = r[14]; u.p2 = r[15];
     return u;
 }
 

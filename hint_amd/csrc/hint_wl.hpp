@@ -1,0 +1,288 @@
+// Wave-local ("WL") block kernels for narrow trees: every unit of the block has 1..4 inputs, at most 4 outputs and no
+// condition (all of POWER d = 6 and GAS d = 8, i.e. BASELINE configs 1-3).  Same rows, same packed weights, same tape
+// and workspace as the general kernels (hint_fwd.hip / hint_bwd.hip), but everything that is not the h x h product
+// has moved INTO the wavefronts, so that a tree level costs ONE workgroup barrier instead of three:
+//
+//   * the thin layers are never a phase of their own: the B operand of k-block kb - a1 = relu(W1 v + b1) forward,
+//     g2 = relu'(a2) (W3^T g_st) backward, four features per lane - is computed by the wavefront that needs it, on the
+//     vector ALU, right in front of the k-block's MFMAs (<= 4 inputs: 16 FMAs), from the block's thin vectors that the
+//     workgroup keeps in LDS (double buffered: the next block's are fetched while this one runs);
+//   * the thin product BEHIND the h x h layer (W3 a2 forward, W1^T g1 backward: <= 4 outputs) is 16 FMAs per finished
+//     tile and lane plus one xor-butterfly over the four lane groups per (unit, wavefront); its K-split partial goes to
+//     the (unit, wavefront) slab in LDS - the only thing that crosses wavefronts, hence the one barrier;
+//   * the element-wise coupling, the log-det sum, the fixed permutation between blocks and (backward) the scatter of
+//     the g_v partials are done by EVERY wavefront for itself on a private copy of the 16 x d lane tile in LDS (the
+//     transformed lanes shared out over the four lane groups of the wavefront): no second and third barrier, no
+//     wavefront waiting for another one's atanf;
+//   * the matrix pipe sees the h x h products only (and, backward, the 4 MFMAs per tile of the first-layer weight
+//     gradient, whose operand - the g1 tile - exists nowhere else).
+// The weight stream (fragment tiles from L2, register ring of hint_rows.hpp) is handed from a wavefront's last row of
+// a group to its first row of the next group and of the next block.
+#pragma once
+#include "hint_rows.hpp"
+
+namespace hint {
+
+__device__ __forceinline__ f32x4 fma4(const f32x4 w, float s, const f32x4 a) {
+    return f32x4{fmaf(w.x, s, a.x), fmaf(w.y, s, a.y), fmaf(w.z, s, a.z), fmaf(w.w, s, a.w)};
+}
+__device__ __forceinline__ float dot4(const f32x4 w, const f32x4 v, float a) {
+    return fmaf(w.w, v.w, fmaf(w.z, v.z, fmaf(w.y, v.y, fmaf(w.x, v.x, a))));
+}
+__device__ __forceinline__ f32x4 relu4(const f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
+// sum over the four lane groups (lanes l, l^16, l^32, l^48): every lane ends with the same bits
+__device__ __forceinline__ float kq_sum(float v) {
+    // v_permlane32_swap: upper half of the first <-> lower half of the second; v_permlane16_swap: odd rows of the first <->
+    // even rows of the second (gfx950): two vector-ALU steps instead of two trips through the LDS crossbar
+    const unsigned u = (unsigned)__float_as_int(v);
+    const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a = __int_as_float((int)h[0]) + __int_as_float((int)h[1]);
+    const unsigned ua = (unsigned)__float_as_int(a);
+    const auto q = __builtin_amdgcn_permlane16_swap(ua, ua, false, false);
+    return __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
+}
+
+// The first-layer pre-activation of features 4 kq .. +3 of a tile (vector layout: five float4 per tile and lane group,
+// inputs 0..3 then the bias; inputs beyond cin are zero vectors): bias first, then the inputs in order - the order of
+// the MFMA chain with which part B rebuilds a1 (hint_wgrad.hip), and the same expression forward and backward, so
+// that the ReLU decisions agree bit for bit.
+__device__ __forceinline__ f32x4 wl_layer1(const LDS_AS f32x4* q, const float (&vin)[4]) {
+    const f32x4 qb = q[16], q0 = q[0], q1 = q[4], q2 = q[8], q3 = q[12];
+    return fma4(q3, vin[3], fma4(q2, vin[2], fma4(q1, vin[1], fma4(q0, vin[0], qb))));
+}
+
+struct WlCtx {
+    const GLOBAL_AS float* pk;           // packed weights of the block
+    const GLOBAL_AS float* pk_next;      // ... of the block worked on next (the last row of a block hands the ring over)
+    const GLOBAL_AS uint8_t* bits;       // backward: a2 sign bytes of this row tile (block, next block)
+    const GLOBAL_AS uint8_t* bits_next;
+    const void* recs;                    // this direction's row records
+    const LDS_AS float* par;             // the block's staged thin vectors and biases
+    LDS_AS float* slab;                  // the group's slab set
+    const LDS_AS float* xs;              // private lane tile: the inputs of the level's first layers
+    const LDS_AS float* gst;             // backward: private coupling gradients [16][gld]
+    LDS_AS float* scratch;               // backward: private fragment tile (first-layer weight gradient)
+    GLOBAL_AS float* a2;                 // training forward: this row tile's rows of the [Bp][WT] array
+    GLOBAL_AS uint8_t* bits_out;         // training forward: its a2 sign bytes
+    GLOBAL_AS float* tw;                 // backward: this workgroup's first-layer gradient slab
+    int xld, gld, WT;
+    int sid, sid0;                       // diagnostic builds: stamp id base of the wavefront's current row / of the group
+    bool train, first_tile;
+};
+
+template <int KIND, int N>
+__device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float* pk, const GLOBAL_AS uint8_t* bits,
+                                        const RowU& r, int kb, const LaneOff& lo) {
+    const GLOBAL_AS char* p = (const GLOBAL_AS char*)pk + lo.w;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int jj = j < r.ntt ? j : r.ntt - 1;
+#ifdef HINT_WL_ABL_W        // diagnostic: every k-block reads the row's first tiles again (L1 hits): what the weight stream's latency costs
+        dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj + (kb & 0)) * 1024);
+#else
+        dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj * r.n1 + kb) * 1024);
+#endif
+    }
+    if (KIND == K_BWD) {
+        const int kc = kb < r.n1 ? kb : r.n1 - 1;
+        dst[NTT].x = __int_as_float((int)bits[((r.wcol >> 4) + kc) * 64 + lo.l]);
+    }
+}
+
+// One row: ntt (1..3) adjacent 16-feature tiles of one unit.  Ring slot 0 holds k-block 0 on entry; on exit k-block 0 of
+// row `nr` (fetched from pkn / bitsn: the next block's when the row is the wavefront's last of this block).  `part`: the
+// wavefront's running partial of the unit's thin product behind the layer (forward: s | t of the node, backward: g_v).
+// ONE code path for every tile count: the ring always carries three tiles (a narrower row's last tile again: L1 hits) and
+// only the MFMA groups and the per-tile epilogues sit under (wave-uniform) branches - a path per tile count would define the
+// ring in three places, and the merge costs sixteen register copies behind a vmcnt(0) at the end of every row.
+template <int KIND>
+__device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const RowU& nr, const GLOBAL_AS float* pkn,
+                                       const GLOBAL_AS uint8_t* bitsn, f32x4 (&ring)[RING][NEL], f32x4& part,
+                                       const LaneOff& lo, int lane) {
+    static_assert(RING == 2 && NTT == 3, "the WL rows alternate two ring slots of three tiles");
+    const int m = lane & 15, kq = lane >> 4;
+    const int n1 = cr.n1, ntt = cr.ntt;
+    STAMP(c.sid + 0)
+    // the unit's thin-layer inputs of this lane's batch row: forward the lanes feeding the subnet, backward g_s | g_t
+    float vin[4];
+    {
+        const int K = cr.thin_k & 0xff;
+        const LDS_AS float* src = KIND == K_FWD ? c.xs + m * c.xld + (cr.thin_k >> 16) : c.gst + m * c.gld + (cr.thin_k >> 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float v = src[k < K ? k : 0]; vin[k] = k < K ? v : 0.f; }
+    }
+    // forward: W1 vectors of k-block kb at tq[20 kb + 4 k] (bias: k = 4); backward: W3^T vectors at tq[16 kb + 4 j]
+    const LDS_AS f32x4* tq = (const LDS_AS f32x4*)(c.par + cr.thin_w) + kq;
+    f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4();
+
+    // The B operand of k-block kb, before the backward's mask: computed one step ahead, between the MFMAs of the step
+    // before (the matrix pipe runs a step's MFMAs for 128 ntt cycles; the wavefront issues these ~25 vector / LDS
+    // instructions meanwhile).
+    auto bfrag = [&](int kb) -> f32x4 {
+#ifdef HINT_WL_ABL_THIN     // diagnostic: no thin-layer arithmetic in the k-loop
+        return f32x4{vin[0], vin[1], vin[2], vin[3]};
+#endif
+        if (KIND == K_FWD) return relu4(wl_layer1(tq + 20 * kb, vin));
+        const LDS_AS f32x4* q = tq + 16 * kb;
+        const f32x4 q0 = q[0], q1 = q[4], q2 = q[8], q3 = q[12];
+        return fma4(q3, vin[3], fma4(q2, vin[2], fma4(q1, vin[1], fma4(q0, vin[0], zero4()))));
+    };
+    f32x4 b4n = bfrag(0);
+    STAMP(c.sid + 1)
+    // Program order of a step is pinned with empty asm statements that "use" the accumulators and clobber memory: the
+    // prefetch of the next step's tiles goes out behind the MFMAs of the step before (its ring slot is dead then: no
+    // register copies) and in front of this step's MFMAs (a full step of flight time).  Left to itself the compiler
+    // either hoists the loads over the previous step (copies + vmcnt(0) at the back edge) or sinks them to their use.
+#define WL_PIN() asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2) : : "memory");
+#define WL_STEP(KB, S, LIVE, PK, BITS, NR, NKB)                                                         \
+    {                                                                                                   \
+        wl_load<KIND, NTT>(ring[((S) + 1) & 1], PK, BITS, NR, NKB, lo);                                 \
+        WL_PIN()                                                                                        \
+        if (LIVE) {                                                                                     \
+            f32x4 b4 = b4n;                                                                             \
+            if (KIND == K_BWD) mask_by_bits(b4, __float_as_int(ring[S][NTT].x));                        \
+            b4n = bfrag((KB) + 1);              /* (behind the row's last k-block: never used) */        \
+            if (ntt >= 3) {                                                                             \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+                    acc0 = mfma4(ring[S][0][i], b4[i], acc0); acc1 = mfma4(ring[S][1][i], b4[i], acc1); \
+                    acc2 = mfma4(ring[S][2][i], b4[i], acc2);                                           \
+                }                                                                                       \
+            } else if (ntt == 2) {                                                                      \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+                    acc0 = mfma4(ring[S][0][i], b4[i], acc0); acc1 = mfma4(ring[S][1][i], b4[i], acc1); \
+                }                                                                                       \
+            } else {                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc0 = mfma4(ring[S][0][i], b4[i], acc0); \
+            }                                                                                           \
+        }                                                                                               \
+        WL_PIN()                                                                                        \
+        STAMP(c.sid + 8 + ((KB) & 15))                                                                  \
+    }
+    const int n1p = (n1 + 1) & ~1;
+    int k0 = 0;
+    for (; k0 + 2 < n1p; k0 += 2) {
+        WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1)
+        WL_STEP(k0 + 1, 1, true, c.pk, c.bits, cr, k0 + 2)
+    }
+    WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1)              // (an odd row's step n1: a dummy load of the tile behind)
+    WL_STEP(k0 + 1, 1, k0 + 1 < n1, pkn, bitsn, nr, 0)          // hands the ring to the next row
+#undef WL_STEP
+#undef WL_PIN
+
+    STAMP(c.sid + 2)
+    // ---- the tiles are finished: activation, tape, the thin product behind the layer ----
+    if (KIND == K_FWD) {
+        const LDS_AS f32x4* w3 = (const LDS_AS f32x4*)(c.par + cr.thin_b) + kq;     // W3^T vector o of the row's tile t: w3[16 t + 4 o]
+        const LDS_AS f32x4* b2 = (const LDS_AS f32x4*)(c.par + cr.aux) + kq;
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) {
+            if (j < ntt) {
+                // (the bias last, as the reference's addmm adds it: fewer rows land on the other side of a ReLU kink)
+                const f32x4 v = relu4((j == 0 ? acc0 : j == 1 ? acc1 : acc2) + b2[4 * j]);
+                if (c.train) {
+                    c.bits_out[((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
+                    *(GLOBAL_AS f32x4*)(c.a2 + (m * c.WT + cr.ocol + 16 * j + 4 * kq)) = v;
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[o] = dot4(w3[16 * j + 4 * o], v, part[o]);
+            }
+        }
+    } else {
+        // g1 = acc .* relu'(a1), a1 recomputed from the level's lanes; g_v partial = W1^T g1; dW1 | db1 of the tile
+        float xin[4];
+        const int cin = cr.p2 & 0xff, xoff = (cr.p2 >> 8) & 0xff, kcp = cin < 4 ? 4 : 8, h = cr.p2 >> 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float v = c.xs[m * c.xld + xoff + (k < cin ? k : 0)]; xin[k] = k < cin ? v : 0.f; }
+        const LDS_AS f32x4* w1 = (const LDS_AS f32x4*)(c.par + cr.thin_b) + kq;     // W1 vector k of the row's tile t: w1[20 t + 4 k]
+        const int nl = m;
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) {
+            if (j < ntt) {
+                const f32x4 pre = wl_layer1(w1 + 20 * j, xin);
+                f32x4 g = j == 0 ? acc0 : j == 1 ? acc1 : acc2;
+                g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f; g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[o] = dot4(w1[20 * j + 4 * o], g, part[o]);
+                // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f]: the tile transposed through the
+                // private scratch tile, then four 16x16x4 MFMAs over the 16 rows (out^T[k][f]: a lane ends with four inputs of
+                // one feature)
+                ((LDS_AS f32x4*)c.scratch)[lane] = g;
+                const LDS_AS float* g1p = (const LDS_AS float*)c.scratch + (kq + 16 * (nl >> 2)) * 4 + (nl & 3);
+                const LDS_AS float* vp = c.xs + kq * c.xld + xoff + (nl < cin ? nl : 0);
+                const float one = nl == cin ? 1.f : 0.f;
+                float av[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * c.xld]; }      // rows 4 i + kq
+                f32x4 dw = zero4();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dw = mfma4(nl < cin ? bv[i] : one, av[i], dw);
+                const int nvalid = h - 16 * (cr.tb + j);
+                if (nl < nvalid && 4 * kq < kcp) {
+                    GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(c.tw + cr.p1 + (16 * j + nl) * kcp + 4 * kq);
+                    if (c.first_tile) *dst = dw; else *dst = *dst + dw;
+                }
+            }
+        }
+    }
+    STAMP(c.sid + 3)
+    // (forward: b3 rides with the row that holds the unit's tile 0 - in one lane group, the fold below sums the four)
+    if (KIND == K_FWD && cr.first && kq == 0) part += *(const LDS_AS f32x4*)(c.par + cr.bias3);
+    if (cr.ulast) {
+        // the wavefront's last row of the unit: fold the four lane groups -> slab
+        f32x4 s;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) s[o] = kq_sum(part[o]);
+        if (kq == 0) ((LDS_AS f32x4*)(c.slab + cr.slab))[m] = s;
+        part = zero4();
+    }
+    STAMP(c.sid + 4)
+}
+
+// The wavefront's rows [r0, r1) of a group.  `primed`: the record whose k-block 0 sits in ring slot 0 (or -1);
+// rnext: the record the last row hands the ring to (the wavefront's first row of the next group, of the next block when
+// other_block) or -1.
+template <int KIND>
+__device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL], int& primed, int r0, int r1, int rnext,
+                                        bool other_block, int lane) {
+    if (r0 >= r1) return;
+    LaneOff lo;
+    lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
+    RowU cr = decode_rec(load_rec(c.recs, r0));
+    if (primed != r0) wl_load<KIND, NTT>(ring[0], c.pk, c.bits, cr, 0, lo);
+    const int rlast = rnext >= 0 ? rnext : r1 - 1;
+    i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);
+    f32x4 part = zero4();
+    for (int t = r0; t < r1; ++t) {
+        const RowU nr = decode_rec(nrec);
+        nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
+        const bool hand = t + 1 == r1 && other_block;
+#ifdef HINT_STAMPS
+        const_cast<WlCtx&>(c).sid = 256 + ((c.sid0 >> 3) & 3) * 64 + (t - r0 < 2 ? t - r0 : 1) * 32;
+#endif
+        const GLOBAL_AS float* pkn = hand ? c.pk_next : c.pk;
+        const GLOBAL_AS uint8_t* bitsn = hand ? c.bits_next : c.bits;
+        wl_row<KIND>(c, cr, nr, pkn, bitsn, ring, part, lo, lane);
+        cr = nr;
+    }
+    primed = rnext;
+}
+
+// The block's small parameters: 4 * par_f4 floats = [thin blobs: the start of the packed buffer | biases: at bias_src]
+__device__ __forceinline__ void wl_par_issue(f32x4 (&pf)[WL_PAR_REGS], const GLOBAL_AS float* packed, const WlArgs& w, int tid, int nthreads) {
+#pragma unroll
+    for (int q = 0; q < WL_PAR_REGS; ++q) {
+        int i = tid + q * nthreads;
+        i = i < w.par_f4 ? i : w.par_f4 - 1;
+        const int f = 4 * i;
+        pf[q] = *(const GLOBAL_AS f32x4*)(packed + (f < w.par_bias ? f : f - w.par_bias + w.bias_src));
+    }
+}
+__device__ __forceinline__ void wl_par_commit(const f32x4 (&pf)[WL_PAR_REGS], float* dst, const WlArgs& w, int tid, int nthreads) {
+#pragma unroll
+    for (int q = 0; q < WL_PAR_REGS; ++q) {
+        const int i = tid + q * nthreads;
+        if (i < w.par_f4) ((f32x4*)dst)[i] = pf[q];
+    }
+}
+
+}  // namespace hint

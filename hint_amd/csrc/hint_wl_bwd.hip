@@ -1,0 +1,267 @@
+// Backward kernel, part A, of the wave-local plans (hint_wl.hpp; gfx950 / CDNA4 only): gradients with respect to
+// the lanes, the coupling gradients g_st that part B (hint_wgrad.hip) reduces into dW2 / dW3 / db2 / db3, and the
+// first-layer weight gradients dW1 / db1 themselves (per-workgroup slabs, added up by hint_wreduce_kernel).
+//
+// What autograd derives from /root/reference/hint.py:62-101 when the training loop calls loss.backward()
+// (train_unconditional.py:137), per node, root first:
+//   g_t = g_l' ; g_a = g_l'*exp(a)*l + g_J ; g_l = g_l'*exp(a) ; g_s = g_a*alpha/(1+s^2)
+//   g2 = (W3^T g_st) .* relu'(a2) ; g1 = (W2^T g2) .* relu'(a1) ; g_u += W1^T g1
+// From the forward's tape come s, the lane tiles of every level and the a2 sign bytes; relu'(a1) is recomputed from the
+// level's lanes with the forward's own expression (bit-identical decisions).  One workgroup carries the gradient tile
+// of 16 batch rows through all blocks of the chain, last to first.  Per tree level, root first: every wavefront adds
+// the g_v partials of the level before and runs the coupling backward on its own copy of the tiles, runs its rows
+// (g2 on the fly, W2^T on the matrix pipe, g_v partial to its slab), then ONE workgroup barrier.
+#include "hint_wl.hpp"
+
+using namespace hint;
+
+struct WlLevel { float x[WL_LV], s[WL_LV]; };
+// (loads only: a select on the loaded values would be a wait for HBM in the middle of the level)
+__device__ __forceinline__ void wl_level_issue(WlLevel& p, const float* __restrict__ xsrc, const float* __restrict__ ssrc,
+                                               int d, int row0, int nvalid, int lane) {
+    const size_t base = (size_t)row0 * d;
+#pragma unroll
+    for (int k = 0; k < WL_LV; ++k) {
+        const int i = lane + 64 * k;
+        const int ic = i < nvalid ? i : 0;
+        p.x[k] = xsrc[base + ic];
+        p.s[k] = ssrc[base + ic];
+    }
+}
+__device__ __forceinline__ void wl_level_commit(const WlLevel& p, float* xs, float* sb, int ld, int d, int nvalid, int lane) {
+    const float inv = frcp(d);
+#pragma unroll
+    for (int k = 0; k < WL_LV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < ROWS * d) {
+            const int r = fdiv(i, inv), j = i - r * d;
+            xs[r * ld + j] = i < nvalid ? p.x[k] : 0.f;
+            sb[r * ld + j] = i < nvalid ? p.s[k] : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_wl_bwd_kernel(
+    KArgs a, WlArgs w, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
+    const float* __restrict__ x, const float* __restrict__ g_z, const float* __restrict__ g_J,
+    float* __restrict__ g_x, float gz_scale, float gJ_const) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const float inv_d = frcp(a.d);
+    const Tables T = make_tables(a, lds);
+    float* par = lds + w.off_par;
+    float* slabs = lds + w.off_slab;
+    float* ptab = lds + w.off_perm;
+    float* gj = lds + w.off_misc;               // g_J of the tile's rows
+    // this wavefront's own tiles: lanes of the level (as the forward saw them), s of the level, two gradient tiles (a fused
+    // permutation ping-pongs), coupling gradients, one fragment tile of scratch
+    float* priv = lds + w.off_priv + wave * w.priv_stride;
+    const int tl = ROWS * a.xld;
+    float* xs = priv;
+    float* sb = priv + tl;
+    float* g0 = priv + 2 * tl;
+    float* gst = priv + 4 * tl;
+    float* scratch = gst + ((ROWS * a.gld + 3) & ~3);
+    const int par_floats = 4 * w.par_f4;
+    const int ntiles = (a.B + ROWS - 1) / ROWS;
+    const int pdd = a.d * a.d;
+    const size_t lvl = (size_t)a.B * a.d;
+    STAMP_DECL()
+    copy_meta(a, lds, tid, nthreads);
+    if (a.perm_lds > 0) {
+        for (int i = tid; i < n_chain * pdd; i += nthreads) {
+            const int cbi = fdiv(i, frcp(pdd));
+            const float* pp = (chain != nullptr) ? chain[cbi].perm : one.perm;
+            ptab[i] = pp != nullptr ? ((const GLOBAL_AS float*)pp)[i - cbi * pdd] : 0.f;
+        }
+    }
+#define HINT_CB(I) chain_block(chain, one, I)
+#define LEVEL_SRC(TAPE, TOP, LV) ((LV) == 0 ? ((TOP) ? (TAPE) + (size_t)(a.n_levels - 1) * lvl : x) : (TAPE) + (size_t)((LV) - 1) * lvl)
+#define BITS_A2(BLK) ((const GLOBAL_AS uint8_t*)((BLK).actA1 + a.bits_off) + a.bits_stride + (size_t)(row0 >> 4) * (a.WT >> 4) * 64)
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
+        int gcur = 0;
+#define GS (g0 + gcur)
+#define GO (g0 + (tl - gcur))
+        for (int i = lane; i < ROWS * a.d; i += 64) {
+            const int r = fdiv(i, inv_d);
+            GS[r * a.xld + (i - r * a.d)] = i < nvalid ? g_z[(size_t)row0 * a.d + i] * gz_scale : 0.f;      // (gz_scale: the loss gradient g_z = z / B fused)
+        }
+        if (tid < ROWS) gj[tid] = (row0 + tid < a.B) ? (g_J != nullptr ? g_J[row0 + tid] : gJ_const) : 0.f;
+        {
+            const GBlock lb = HINT_CB(n_chain - 1);
+            const float* tape = (const float*)lb.tape;
+            const bool top = lb.perm != nullptr || n_chain > 1;
+            WlLevel lp;
+            wl_level_issue(lp, LEVEL_SRC(tape, top, a.n_levels - 1), tape + (size_t)(2 * a.n_levels - 1) * lvl, a.d, row0, nvalid, lane);
+            f32x4 pf[WL_PAR_REGS];
+            wl_par_issue(pf, lb.packed, w, tid, nthreads);
+            wl_level_commit(lp, xs, sb, a.xld, a.d, nvalid, lane);
+            wl_par_commit(pf, par, w, tid, nthreads);
+        }
+        __syncthreads();
+        int phase = 0, primed = -1;
+        f32x4 ring[RING][NEL];
+
+        for (int cb = n_chain - 1; cb >= 0; --cb) {
+            const int wi = n_chain - 1 - cb;                           // position in the walk
+            const bool has_next = cb > 0;
+            const GBlock blk = HINT_CB(cb);
+            const GBlock nblk = HINT_CB(has_next ? cb - 1 : cb);       // the block worked on after this one
+            const float* perm = (const float*)blk.perm;
+            const float* tape = (const float*)blk.tape;
+            const bool top = perm != nullptr || cb > 0;
+            float* wsGST = (float*)blk.wsGST;
+            const int tsel = wi & (a.nw - 1);                          // the wavefront that writes this block's g_st rows
+            f32x4 pf[WL_PAR_REGS];
+            wl_par_issue(pf, nblk.packed, w, tid, nthreads);
+
+            WlCtx c;
+            c.pk = blk.packed; c.pk_next = nblk.packed;
+            c.bits = BITS_A2(blk); c.bits_next = BITS_A2(nblk);
+            c.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
+            c.par = (const LDS_AS float*)(par + (wi & 1) * par_floats);
+            c.xs = (const LDS_AS float*)xs; c.gst = (const LDS_AS float*)gst; c.scratch = (LDS_AS float*)scratch;
+            c.a2 = nullptr; c.bits_out = nullptr;
+            c.tw = blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
+            c.xld = a.xld; c.gld = a.gld; c.WT = a.WT; c.train = true; c.first_tile = tile == (int)blockIdx.x;
+
+            for (int gi = a.n_groups; gi >= 0; --gi) {
+                // gi == n_groups .. 1: the boundary in front of group gi - 1 (root first), then its rows; gi == 0: the
+                // boundary BEHIND group 0 (scatter only)
+                const int slot = gi > 0 ? gi - 1 : a.n_groups;
+                const bool tail_only = gi == 0;
+                const GroupU g = load_group(T.groups + (tail_only ? 0 : slot));
+                const int lop0 = tail_only ? a.n_groups * a.d : g.lop_begin;
+                const float* slab_prev = slabs + ((phase + 1) & 1) * w.slab_floats;     // the g_v partials of the group just finished
+                const int sid = (wi * (a.n_groups + 1) + (a.n_groups - gi)) * 8;
+                (void)sid;
+                STAMP(sid + 0)
+                // ---- scatter of the previous group's g_v + coupling backward of this one, on the wavefront's own tiles ----
+                for (int idx = lane; idx < ROWS * a.d; idx += 64) {
+                    const int row = fdiv(idx, inv_d), col = idx - row * a.d;
+                    unsigned w0, w1, w2;
+                    if (a.lops_off >= 0) {
+                        const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
+                        w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
+                    } else {
+                        const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + col];
+                        w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
+                    }
+                    const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
+                    const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
+                    const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);
+                    float gval = GS[row * a.xld + col];
+                    if (sc_unit >= 0) {
+#pragma unroll
+                        for (int net = 0; net < 2; ++net) {
+                            const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + sc_unit + net);
+                            const int sl_n = up[21], gv_off = up[22];
+                            const float* sp = slab_prev + gv_off + row * 4 + sc_k;
+                            for (int sl = 0; sl < sl_n; ++sl) gval += sp[sl * 64];
+                        }
+                    }
+                    if (!tail_only && cp_ls >= 0) {
+                        const float s = sb[row * a.xld + col];
+                        const float aa = a.alpha * atanf(s);
+                        const float ea = expf(aa);
+                        const float l = xs[row * a.xld + col];              // lower input of the node
+                        const float ga = gval * ea * l + gj[row];           // g_a (a feeds both l' and J)
+                        const float gsv = ga * a.alpha / (1.f + s * s);     // g_s
+                        gst[row * a.gld + cp_ls] = gsv;
+                        gst[row * a.gld + cp_lt] = gval;                    // g_t = g_l'
+                        if (wave == tsel) {
+                            float* go = wsGST + (size_t)(row0 + row) * a.ST;
+                            go[cp_gs] = gsv;
+                            go[cp_gt] = gval;
+                        }
+                        gval *= ea;                                         // g_l
+                    }
+                    GS[row * a.xld + col] = gval;
+                }
+                c.sid0 = sid; c.sid = 256;
+                STAMP(sid + 1)
+                // the next block's parameters -> the other buffer, behind the first group's rows, barrier and this scatter (loaded
+                // long ago: nothing waits here); visible behind the next barrier (a one-group block: its own)
+                if (gi == a.n_groups - 1) {
+                    wl_par_commit(pf, par + ((wi + 1) & 1) * par_floats, w, tid, nthreads);
+                    if (a.n_groups == 1) lds_barrier();
+                }
+                if (tail_only) break;
+
+                // ---- lane tile and s of the level the NEXT boundary needs: global -> registers now, -> LDS behind the rows ----
+                WlLevel lp;
+                bool lp_pending = false;
+                {
+                    const bool block_switch = slot == 0;                     // next: root level of the block before
+                    int nlevel = a.n_levels - 1;
+                    if (!block_switch) nlevel = lds_i32((const LDS_AS int32_t*)(T.groups + slot - 1) + 7);
+                    if (block_switch ? cb > 0 : nlevel != g.level) {
+                        const float* ntape = block_switch ? (const float*)nblk.tape : tape;
+                        const bool ntop = block_switch ? (nblk.perm != nullptr || cb > 1) : top;
+                        wl_level_issue(lp, LEVEL_SRC(ntape, ntop, nlevel), ntape + (size_t)(a.n_levels + nlevel) * lvl, a.d, row0, nvalid, lane);
+                        lp_pending = true;
+                    }
+                }
+                const LDS_AS int32_t* rng = T.rng + g.rng_begin;
+                c.slab = (LDS_AS float*)(slabs + (phase & 1) * w.slab_floats);
+                ++phase;
+                {
+                    int rnext = -1;         // the wavefront's first row of the next group - of the next block's root behind group 0
+                    const bool wrap = slot == 0;
+                    if (!wrap || has_next) {
+                        const int gn = wrap ? a.n_groups - 1 : slot - 1;
+                        const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + gn);
+                        const int row_begin = lds_i32(gp + 3), rngb = lds_i32(gp + 6);
+                        const int n0 = lds_i32(T.rng + rngb + wave), n1 = lds_i32(T.rng + rngb + wave + 1);
+                        if (n0 < n1) rnext = row_begin + n0;
+                    }
+                    wl_rows<K_BWD>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
+                                   wrap, lane);
+                }
+                STAMP(sid + 2)
+                if (lp_pending) wl_level_commit(lp, xs, sb, a.xld, a.d, nvalid, lane);
+                STAMP(sid + 3)
+                lds_barrier();
+                STAMP(sid + 4)
+            }
+            if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
+                const float* wm = a.perm_lds > 0 ? ptab + cb * pdd : perm;
+                for (int i = lane; i < ROWS * a.d; i += 64) {
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
+                    GO[r * a.xld + j] = perm_dot(GS + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
+                }
+                gcur = tl - gcur;
+            }
+        }
+        if (wave == 0)
+            for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); g_x[(size_t)row0 * a.d + i] = GS[r * a.xld + (i - r * a.d)]; }
+        __syncthreads();
+#undef GS
+#undef GO
+    }
+    STAMP_FLUSH(a.stamps)
+#undef HINT_CB
+#undef LEVEL_SRC
+#undef BITS_A2
+}
+
+namespace hint {
+
+hipError_t launch_wl_bwd(const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
+                         const ChainBlock* chain, int n_chain, const float* x, const float* g_z, const float* g_J,
+                         float* g_x, float gz_scale, float gJ_const, hipStream_t stream) {
+    hipLaunchKernelGGL(hint_wl_bwd_kernel, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x,
+                       g_z, g_J, g_x, gz_scale, gJ_const);
+    return hipGetLastError();
+}
+
+hipError_t set_max_lds_wl_bwd(int bytes) {
+    return hipFuncSetAttribute((const void*)hint_wl_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace hint

@@ -1,0 +1,243 @@
+// Forward / inverse kernel of the wave-local plans (hint_wl.hpp; gfx950 / CDNA4 only): HINT's recursive
+// affine-coupling block for trees whose every subnet has 1..4 inputs and at most 4 outputs.
+//
+// Arithmetic reproduced (reference, read-only): /root/reference/hint.py:62-101
+//   per node:  s = mlp_s(u), t = mlp_t(u)                           (hint.py:76-77, :10-13)
+//              a = alpha*atan(s), alpha = clamp*0.636               (hint.py:56-60)
+//   forward    l' = exp(a)*l + t ;  J += sum a   (children first)   (hint.py:70-80,97-99)
+//   inverse    l  = (l' - t)/exp(a); J -= sum a  (root first)       (hint.py:82-88)
+//
+// One workgroup carries 16 batch rows through all tree levels of all blocks of a flow.  Per level: every
+// wavefront runs its rows (first layer on the fly, h x h layer on the matrix pipe, third layer's K-split partial
+// to its slab), ONE workgroup barrier, then every wavefront sums the slabs and applies the coupling to its own
+// copy of the lane tile.  Tape and packed-weight layouts are those of hint_fwd.hip (hint_plan.cpp).
+#include "hint_wl.hpp"
+
+using namespace hint;
+
+template <bool REV>
+__global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_wl_apply_kernel(
+    KArgs a, WlArgs w, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
+    const float* __restrict__ x, float* __restrict__ z, float* __restrict__ J, const float* __restrict__ J_in,
+    float* __restrict__ loss_acc, float noise, const unsigned long long* __restrict__ rng_state,
+    float* __restrict__ x_noisy) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, m = lane & 15, kq = lane >> 4;
+    const int wave = rfl(tid >> 6);
+    const float inv_d = frcp(a.d);
+    const Tables T = make_tables(a, lds);
+    float* par = lds + w.off_par;               // [2][4 * par_f4]
+    float* slabs = lds + w.off_slab;            // [2][slab_floats]
+    float* ptab = lds + w.off_perm;
+    float* priv = lds + w.off_priv + wave * w.priv_stride;      // this wavefront's two lane tiles (a fused permutation ping-pongs)
+    const int par_floats = 4 * w.par_f4;
+    const int ntiles = (a.B + ROWS - 1) / ROWS;
+    const int pdd = a.d * a.d;
+    const size_t lvl = (size_t)a.B * a.d;
+    STAMP_DECL()
+    copy_meta(a, lds, tid, nthreads);
+    if (a.perm_lds > 0) {
+        for (int i = tid; i < n_chain * pdd; i += nthreads) {
+            const int cbi = fdiv(i, frcp(pdd));
+            const float* pp = (chain != nullptr) ? chain[cbi].perm : one.perm;
+            ptab[i] = pp != nullptr ? ((const GLOBAL_AS float*)pp)[i - cbi * pdd] : 0.f;
+        }
+    }
+#define HINT_CB(I) chain_block(chain, one, I)
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
+        int xcur = 0;
+        const int xflip = ROWS * a.xld;
+#define XS (priv + xcur)
+#define XO (priv + (xflip - xcur))
+        // every wavefront its own copy of the lane tile
+        for (int i = lane; i < ROWS * a.d; i += 64) {
+            const int r = fdiv(i, inv_d);
+            XS[r * a.xld + (i - r * a.d)] = i < nvalid ? x[(size_t)row0 * a.d + i] : 0.f;
+        }
+        if (!REV && rng_state != nullptr) {
+            // x += noise * N(0,1), four values per Philox call, keyed by (seed, step, element group): the same numbers in
+            // every wavefront (and as hint_fwd.hip draws them)
+            const unsigned long long seed = rng_state[0], step = rng_state[1];
+            for (int q = lane; 4 * q < nvalid; q += 64) {
+                float nz[4];
+                philox_normal4(seed, step, (unsigned)(((size_t)row0 * a.d) / 4 + (size_t)q), nz);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    if (i < nvalid) { const int r = fdiv(i, inv_d); XS[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
+                }
+            }
+            if (x_noisy != nullptr && wave == 0)
+                for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); x_noisy[(size_t)row0 * a.d + i] = XS[r * a.xld + (i - r * a.d)]; }
+        }
+        {   // the first block's thin vectors and biases
+            const GBlock b0 = HINT_CB(REV ? n_chain - 1 : 0);
+            f32x4 pf[WL_PAR_REGS];
+            wl_par_issue(pf, b0.packed, w, tid, nthreads);
+            wl_par_commit(pf, par, w, tid, nthreads);
+        }
+        __syncthreads();                          // meta, permutations, parameters visible
+        float jpart = 0.f;                        // this lane's share of the log-det of batch row m
+        int phase = 0;                            // slab set: alternates per group, across blocks
+        int primed = -1;
+        f32x4 ring[RING][NEL];
+
+        for (int cb = 0; cb < n_chain; ++cb) {
+            const int bi = REV ? n_chain - 1 - cb : cb;
+            const bool has_next = cb + 1 < n_chain;
+            const GBlock blk = HINT_CB(bi);
+            const GBlock nblk = HINT_CB(has_next ? (REV ? bi - 1 : bi + 1) : bi);
+            const float* perm = (const float*)blk.perm;
+            float* tape = (float*)blk.tape;
+            const bool train = !REV && blk.actA1 != nullptr;
+            const int tsel = cb & (a.nw - 1);          // the wavefront that writes this block's small tape entries
+            if (!REV && perm != nullptr) {
+                // fused fixed permutation in front of the block (power_hint_8.py:59-62): x' = x W
+                const float* wm = a.perm_lds > 0 ? ptab + bi * pdd : perm;
+                for (int i = lane; i < ROWS * a.d; i += 64) {
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
+                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, wm + j, a.d, a.d);
+                }
+                xcur = xflip - xcur;
+            }
+            if (!REV && tape != nullptr && (perm != nullptr || cb > 0) && wave == tsel) {
+                // the block's input exists nowhere else: the top tape slice is what the backward pass starts from
+                float* dst = tape + (size_t)(a.n_levels - 1) * lvl + (size_t)row0 * a.d;
+                for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS[r * a.xld + (i - r * a.d)]; }
+            }
+            // the next block's thin vectors and biases: in flight across this block's first group
+            f32x4 pf[WL_PAR_REGS];
+            wl_par_issue(pf, nblk.packed, w, tid, nthreads);
+
+            WlCtx c;
+            c.pk = blk.packed; c.pk_next = nblk.packed; c.bits = nullptr; c.bits_next = nullptr;
+            c.recs = a.recs;
+            c.par = (const LDS_AS float*)(par + (cb & 1) * par_floats);
+            c.gst = nullptr; c.scratch = nullptr; c.tw = nullptr;
+            c.a2 = train ? blk.actA1 + a.a2_off + (size_t)row0 * a.WT : nullptr;
+            c.bits_out = train ? (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + a.bits_stride + (size_t)(row0 >> 4) * (a.WT >> 4) * 64 : nullptr;
+            c.xld = a.xld; c.gld = 0; c.WT = a.WT; c.train = train; c.first_tile = false;
+
+            for (int gi = 0; gi < a.n_groups; ++gi) {
+                const int gidx = REV ? a.n_groups - 1 - gi : gi;
+                const GroupU g = load_group(T.groups + gidx);
+                const LDS_AS int32_t* rng = T.rng + g.rng_begin;
+                float* slab = slabs + (phase & 1) * w.slab_floats;
+                ++phase;
+                c.xs = (const LDS_AS float*)XS;
+                c.slab = (LDS_AS float*)slab;
+                const int sid = (cb * a.n_groups + gi) * 8;
+                (void)sid;
+                c.sid0 = sid; c.sid = 256;
+                STAMP(sid + 0)
+                {
+                    // the wavefront's first row of the next group - of the next block behind the block's last group
+                    int rnext = -1;
+                    const bool wrap = gi + 1 == a.n_groups;
+                    if (!wrap || has_next) {
+                        const int gn = wrap ? (REV ? a.n_groups - 1 : 0) : (REV ? gidx - 1 : gidx + 1);
+                        const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + gn);
+                        const int row_begin = lds_i32(gp + 3), rngb = lds_i32(gp + 6);
+                        const int n0 = lds_i32(T.rng + rngb + wave), n1 = lds_i32(T.rng + rngb + wave + 1);
+                        if (n0 < n1) rnext = row_begin + n0;
+                    }
+                    wl_rows<K_FWD>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
+                                   wrap, lane);
+                }
+                STAMP(sid + 1)
+                STAMP(sid + 2)
+                lds_barrier();
+                STAMP(sid + 3)
+                // ---- coupling (hint.py:79-83) on this wavefront's copy of the lane tile: lane group kq takes the
+                //      transformed lanes kq, kq + 4, ..; batch row m ----
+                for (int e = kq; e < g.ent_cnt; e += 4) {
+                    const i32x4 ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + e);
+                    const int xcol = ent.x & 0xffff, sl_ns = ent.y & 0xffff, sl_nt = (int)((unsigned)ent.y >> 16);
+                    const float* sp = slab + ent.z + m * 4;
+                    const float* tp = slab + ent.w + m * 4;
+                    float s = 0.f, t = 0.f;
+                    for (int sl = 0; sl < sl_ns; ++sl) s += sp[sl * 64];
+                    for (int sl = 0; sl < sl_nt; ++sl) t += tp[sl * 64];
+                    const float aa = a.alpha * atanf(s);
+                    float* px = XS + m * a.xld + xcol;
+                    // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
+                    if (train && tape != nullptr && wave == tsel && row0 + m < a.B)
+                        tape[(size_t)(a.n_levels + g.level) * lvl + (size_t)(row0 + m) * a.d + xcol] = s;
+                    if (!REV) { *px = expf(aa) * (*px) + t; jpart += aa; }
+                    else      { *px = ((*px) - t) / expf(aa); jpart -= aa; }
+                }
+                STAMP(sid + 4)
+                // the next block's parameters -> the other buffer (loaded long ago: behind the rows, the barrier and the coupling
+                // nothing waits here); visible behind the next group's barrier (a one-group block: its own)
+                if (gi == 0) {
+                    wl_par_commit(pf, par + ((cb + 1) & 1) * par_floats, w, tid, nthreads);
+                    if (a.n_groups == 1) lds_barrier();
+                }
+                // training: the lane tile as it stands after each level except the root's (tape[level][B][d])
+                if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1 && wave == tsel) {
+                    float* dst = tape + (size_t)g.level * lvl + (size_t)row0 * a.d;
+                    for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS[r * a.xld + (i - r * a.d)]; }
+                }
+                STAMP(sid + 5)
+            }
+            if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
+                const float* wm = a.perm_lds > 0 ? ptab + bi * pdd : perm;
+                for (int i = lane; i < ROWS * a.d; i += 64) {
+                    const int r = fdiv(i, inv_d), j = i - r * a.d;
+                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
+                }
+                xcur = xflip - xcur;
+            }
+        }
+        // ---- results: every wavefront holds them; the first one writes ----
+        const float jrow = kq_sum(jpart) + ((J_in != nullptr && row0 + m < a.B) ? J_in[row0 + m] : 0.f);
+        if (wave == 0) {
+            for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); z[(size_t)row0 * a.d + i] = XS[r * a.xld + (i - r * a.d)]; }
+            if (kq == 0 && row0 + m < a.B) J[row0 + m] = jrow;
+            if (loss_acc != nullptr) {
+                // partial sums of the two loss terms (train_unconditional.py:128-129): slot[0] += sum 0.5*|z|^2, slot[1] += sum J
+                float zz = 0.f;
+                for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); const float v = XS[r * a.xld + (i - r * a.d)]; zz += v * v; }
+                float js = (kq == 0 && row0 + m < a.B) ? jrow : 0.f;
+                for (int o = 32; o > 0; o >>= 1) { zz += __shfl_xor(zz, o, 64); js += __shfl_xor(js, o, 64); }
+                if (lane == 0) {
+                    float* slot = loss_acc + 2 * (blockIdx.x & 63);      // 64 slots spread the atomics of the workgroups
+                    atomicAdd(slot, 0.5f * zz);
+                    atomicAdd(slot + 1, js);
+                }
+            }
+        }
+        __syncthreads();          // (the parameter buffers and slabs are re-used by the next row tile)
+#undef XS
+#undef XO
+    }
+    STAMP_FLUSH(a.stamps)
+#undef HINT_CB
+}
+
+namespace hint {
+
+hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
+                           const ChainBlock* chain, int n_chain, const float* x, float* z, float* J, const float* J_in,
+                           float* loss_acc, float noise, const unsigned long long* rng_state, float* x_noisy,
+                           hipStream_t stream) {
+    if (rev)
+        hipLaunchKernelGGL(hint_wl_apply_kernel<true>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain,
+                           n_chain, x, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr, (float*)nullptr);
+    else
+        hipLaunchKernelGGL(hint_wl_apply_kernel<false>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain,
+                           n_chain, x, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
+    return hipGetLastError();
+}
+
+hipError_t set_max_lds_wl_apply(int bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)hint_wl_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)hint_wl_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace hint

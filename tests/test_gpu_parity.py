@@ -30,6 +30,24 @@ def make_block(c, params=None, perms=None):
     return blk.to(DEV)
 
 
+def kink_distance(nodes, P, x, cond, clamp=4.0):
+    """per row: the hidden pre-activation of the float32 oracle closest to zero, relative to the row's largest one"""
+    pre = []
+    relu = torch.relu
+
+    def spy(t):
+        pre.append(t.detach().abs())
+        return relu(t)
+    torch.relu = spy
+    try:
+        with torch.no_grad():
+            orc.block_apply(nodes, P, x, cond, rev=False, clamp=clamp)
+    finally:
+        torch.relu = relu
+    allp = torch.cat([p.reshape(p.shape[0], -1) for p in pre if p.numel() > 0], dim=1)
+    return allp.min(dim=1).values / allp.max(dim=1).values.clamp(min=1.0)
+
+
 def close(a, b, rtol=1e-5, atol=1e-5):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     scale = max(1.0, float(np.abs(b).max())) if np.size(b) else 1.0
@@ -98,22 +116,40 @@ def test_block_vs_oracle_seeded(d, widths, dc, B):
     c = dict(d=d, dims_c=dims_c, c_internal=widths, clamp=4.0, max_splits=-1, min_split_size=2)
     blk = make_block(c, {k: v.numpy() for k, v in P.items()})
 
-    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    xo = x.clone().requires_grad_(True)
-    co = [t.clone().requires_grad_(True) for t in cond]
-    zo, Jo = orc.block_apply(nodes, Po, xo, co, rev=False)
-    Lo = (0.5 * torch.sum(zo ** 2, dim=1) - Jo).mean()
-    Lo.backward()
+    def run(x, cond):
+        Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        xo = x.clone().requires_grad_(True)
+        co = [t.clone().requires_grad_(True) for t in cond]
+        zo, Jo = orc.block_apply(nodes, Po, xo, co, rev=False)
+        Lo = (0.5 * torch.sum(zo ** 2, dim=1) - Jo).mean()
+        Lo.backward()
+        blk.zero_grad()
+        xg = x.to(DEV).requires_grad_(True)
+        cg = [t.to(DEV).requires_grad_(True) for t in cond]
+        (z,) = blk([xg], c=cg)
+        J = blk.jacobian(None)
+        L = (0.5 * torch.sum(z ** 2, dim=1) - J).mean()
+        L.backward()
+        close(z, zo.detach().numpy())
+        close(J, Jo.detach().numpy())
+        assert abs(L.item() - Lo.item()) <= 1e-4 * abs(Lo.item())
+        return xg, cg, xo, co, Po
 
-    xg = x.to(DEV).requires_grad_(True)
-    cg = [t.to(DEV).requires_grad_(True) for t in cond]
-    (z,) = blk([xg], c=cg)
-    J = blk.jacobian(None)
-    L = (0.5 * torch.sum(z ** 2, dim=1) - J).mean()
-    L.backward()
-    close(z, zo.detach().numpy())
-    close(J, Jo.detach().numpy())
-    assert abs(L.item() - Lo.item()) <= 1e-4 * abs(Lo.item())
+    xg, cg, xo, co, Po = run(x, cond)
+    row_err = (xg.grad.cpu() - xo.grad).abs().max(dim=1).values / (xo.grad.abs().max() + 1e-30)
+    if row_err.max().item() >= 1e-4:
+        # A row one of whose hidden pre-activations rounds to the other side of zero than in the float32 oracle gets the
+        # other ReLU subgradient (either is correct).  Accept at most KINK_ROWS such rows, each verified to sit within
+        # KINK_EPS of a kink in the oracle, and compare everything again without them.
+        KINK_ROWS, KINK_EPS = 3, 1e-5
+        bad = torch.nonzero(row_err > 3e-5).flatten()
+        dist = kink_distance(nodes, P, x, cond)
+        print(f"rows off in g_x: {[(int(i), float(row_err[i]), float(dist[i])) for i in bad]}")
+        assert 0 < len(bad) <= KINK_ROWS and all(dist[i].item() <= KINK_EPS for i in bad), \
+            [(int(i), float(row_err[i]), float(dist[i])) for i in bad[:10]]
+        keep = torch.ones(B, dtype=torch.bool)
+        keep[bad] = False
+        xg, cg, xo, co, Po = run(x[keep], [t[keep] for t in cond])
     assert rel_err(xg.grad.cpu().numpy(), xo.grad.numpy()) < 1e-4
     for a, b in zip(cg, co):
         assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 1e-4
