@@ -115,19 +115,29 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     const LDS_AS f32x4* tq = (const LDS_AS f32x4*)(c.par + cr.thin_w) + kq;
     f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4();
 
-    // The B operand of k-block kb, before the backward's mask: computed one step ahead, between the MFMAs of the step
-    // before (the matrix pipe runs a step's MFMAs for 128 ntt cycles; the wavefront issues these ~25 vector / LDS
-    // instructions meanwhile).
-    auto bfrag = [&](int kb) -> f32x4 {
+    // The B operand of k-block kb, before the backward's mask, is software-pipelined two steps deep so that no step waits
+    // for the LDS: step kb issues the reads of the thin vectors of k-block kb + 2 (five / four float4 per lane), turns the
+    // vectors of kb + 1 (read a step ago) into the operand of the next step - 16 FMAs (+ ReLU) issued between this step's
+    // MFMAs - and multiplies with the operand computed a step ago.
+    constexpr int NQ = KIND == K_FWD ? 5 : 4;
+    f32x4 qv[NQ];
+    auto q_load = [&](int kb) {
+        const LDS_AS f32x4* q = tq + (KIND == K_FWD ? 20 : 16) * kb;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qv[k] = q[4 * k];
+    };
+    auto q_frag = [&]() -> f32x4 {
 #ifdef HINT_WL_ABL_THIN     // diagnostic: no thin-layer arithmetic in the k-loop
         return f32x4{vin[0], vin[1], vin[2], vin[3]};
 #endif
-        if (KIND == K_FWD) return relu4(wl_layer1(tq + 20 * kb, vin));
-        const LDS_AS f32x4* q = tq + 16 * kb;
-        const f32x4 q0 = q[0], q1 = q[4], q2 = q[8], q3 = q[12];
-        return fma4(q3, vin[3], fma4(q2, vin[2], fma4(q1, vin[1], fma4(q0, vin[0], zero4()))));
+        // (forward: bias first, then the inputs in order - wl_layer1's expression; backward: from zero)
+        const f32x4 a0 = KIND == K_FWD ? qv[4] : zero4();
+        const f32x4 r = fma4(qv[3], vin[3], fma4(qv[2], vin[2], fma4(qv[1], vin[1], fma4(qv[0], vin[0], a0))));
+        return KIND == K_FWD ? relu4(r) : r;
     };
-    f32x4 b4n = bfrag(0);
+    q_load(0);
+    f32x4 b4n = q_frag();
+    q_load(1);
     STAMP(c.sid + 1)
     // Program order of a step is pinned with empty asm statements that "use" the accumulators and clobber memory: the
     // prefetch of the next step's tiles goes out behind the MFMAs of the step before (its ring slot is dead then: no
@@ -141,7 +151,8 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
         if (LIVE) {                                                                                     \
             f32x4 b4 = b4n;                                                                             \
             if (KIND == K_BWD) mask_by_bits(b4, __float_as_int(ring[S][NTT].x));                        \
-            b4n = bfrag((KB) + 1);              /* (behind the row's last k-block: never used) */        \
+            b4n = q_frag();                     /* k-block KB + 1 (behind the row's last one: never used) */ \
+            q_load((KB) + 2);                                                                           \
             if (ntt >= 3) {                                                                             \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
                     acc0 = mfma4(ring[S][0][i], b4[i], acc0); acc1 = mfma4(ring[S][1][i], b4[i], acc1); \
