@@ -149,13 +149,16 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                                    wrap, lane);
                 }
                 STAMP(sid + 1)
+                // ---- coupling (hint.py:79-83) on this wavefront's copy of the lane tile: lane group kq takes the
+                //      transformed lanes kq, kq + 4, ..; batch row m.  What does not depend on the other wavefronts - the
+                //      entry's record and the lane's old value - is fetched in front of the barrier. ----
+                const bool has_ent = kq < g.ent_cnt;
+                i32x4 ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + (has_ent ? kq : 0));
+                float xold = XS[m * a.xld + (ent.x & 0xffff)];
                 STAMP(sid + 2)
                 lds_barrier();
                 STAMP(sid + 3)
-                // ---- coupling (hint.py:79-83) on this wavefront's copy of the lane tile: lane group kq takes the
-                //      transformed lanes kq, kq + 4, ..; batch row m ----
                 for (int e = kq; e < g.ent_cnt; e += 4) {
-                    const i32x4 ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + e);
                     const int xcol = ent.x & 0xffff, sl_ns = ent.y & 0xffff, sl_nt = (int)((unsigned)ent.y >> 16);
                     const float* sp = slab + ent.z + m * 4;
                     const float* tp = slab + ent.w + m * 4;
@@ -163,12 +166,17 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     for (int sl = 0; sl < sl_ns; ++sl) s += sp[sl * 64];
                     for (int sl = 0; sl < sl_nt; ++sl) t += tp[sl * 64];
                     const float aa = a.alpha * atanf(s);
-                    float* px = XS + m * a.xld + xcol;
                     // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
                     if (train && tape != nullptr && wave == tsel && row0 + m < a.B)
                         tape[(size_t)(a.n_levels + g.level) * lvl + (size_t)(row0 + m) * a.d + xcol] = s;
-                    if (!REV) { *px = expf(aa) * (*px) + t; jpart += aa; }
-                    else      { *px = ((*px) - t) / expf(aa); jpart -= aa; }
+                    float xn;
+                    if (!REV) { xn = expf(aa) * xold + t; jpart += aa; }
+                    else      { xn = (xold - t) / expf(aa); jpart -= aa; }
+                    XS[m * a.xld + xcol] = xn;
+                    if (e + 4 < g.ent_cnt) {        // (more than four transformed lanes in the group: the next entry)
+                        ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + e + 4);
+                        xold = XS[m * a.xld + (ent.x & 0xffff)];
+                    }
                 }
                 STAMP(sid + 4)
                 // the next block's parameters -> the other buffer (loaded long ago: behind the rows, the barrier and the coupling

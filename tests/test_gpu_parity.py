@@ -62,8 +62,16 @@ def test_block_vs_reference_golden(case):
     conds = [torch.from_numpy(a).to(DEV).requires_grad_(True) for a in conds_np]
     (z,) = blk([x], c=conds)
     J = blk.jacobian(None)
-    close(z, g["z"])
-    close(J, g["J"])
+    # how far the float32 reference itself is from the exact result (float64 oracle on the same inputs): for an
+    # ill-conditioned block (big_s: scales e^+-4 on |z| ~ 5e3) that is 2e-4 in J, and another float32 evaluation order
+    # may deviate from the reference by as much; everywhere else this term is below the 1e-5 floor
+    P64 = to_torch(params, torch.float64)
+    z64, J64 = orc.block_apply(nodes, P64, torch.from_numpy(x_np).double(), [torch.from_numpy(a).double() for a in conds_np],
+                               rev=False, clamp=c["clamp"], perms=({k: torch.from_numpy(v).double() for k, v in case_perms(g).items()} or None))
+    ref_z = float(np.abs(z64.numpy() - g["z"]).max()) / max(1.0, float(np.abs(g["z"]).max()))
+    ref_J = float(np.abs(J64.numpy() - g["J"]).max()) / max(1.0, float(np.abs(g["J"]).max()))
+    close(z, g["z"], atol=max(1e-5, 4 * ref_z))
+    close(J, g["J"], atol=max(1e-5, 4 * ref_J))
     L = (0.5 * torch.sum(z ** 2, dim=1) - J).mean()
     assert abs(L.item() - float(g["L"])) <= 1e-4 * abs(float(g["L"]))     # north_star tolerance
     L.backward()
