@@ -224,12 +224,13 @@ struct WlArgs {
     int32_t par_bias;       // float offset of the bias region inside it (= size of the two blobs)
     int32_t bias_src;       // float offset of the bias region inside the packed buffer
     int32_t off_par;        // two buffers of 4 * par_f4 floats
-    int32_t off_slab;       // two slab sets of slab_floats
+    int32_t off_slab;       // two (alternating per group) x nr slab sets of slab_floats
     int32_t slab_floats;
     int32_t off_perm;       // the chain's d x d matrices (when KArgs::perm_lds != 0)
-    int32_t off_priv;       // per wavefront: priv_stride floats
-    int32_t priv_stride;
-    int32_t off_misc;       // 32 floats shared: loss partials / g_J of the tile
+    int32_t off_priv;       // per wavefront: priv_stride floats = nr x priv_tile (+ backward: one scratch tile)
+    int32_t priv_stride, priv_tile;
+    int32_t off_misc;       // 32 floats shared: g_J of the tiles' rows
+    int32_t nr;             // 16-row tiles per workgroup: 1, or 2 (a row pair on one weight stream)
 };
 
 }  // namespace hint

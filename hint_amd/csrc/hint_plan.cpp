@@ -109,8 +109,8 @@ struct hint_plan {
     int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
     int lds_fwd = 0, lds_bwd = 0;
     // wave-local plans (hint_wl.hpp): narrow trees run on hint_wl_apply_kernel / hint_wl_bwd_kernel
-    int wl = 0;
-    WlArgs wl_f{}, wl_b{};
+    int wl = 0, wl_nr2 = 0;     // wl_nr2: two 16-row tiles per workgroup on one weight stream fit the LDS as well
+    WlArgs wl_f[2]{}, wl_b[2]{};  // [nr - 1]
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
@@ -129,8 +129,8 @@ struct hint_plan {
     hint_plan* alt4 = nullptr;
 };
 
-static inline int plan_lds(const hint_plan* P, bool backward) {
-    if (P->wl) return 4 * (backward ? P->wl_b.off_perm : P->wl_f.off_perm);
+static inline int plan_lds(const hint_plan* P, bool backward, int nr = 1) {
+    if (P->wl) return 4 * (backward ? P->wl_b[nr - 1].off_perm : P->wl_f[nr - 1].off_perm);
     return backward ? P->lds_bwd : P->lds_fwd;
 }
 
@@ -633,26 +633,31 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
     if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) std::fill(unit_fused.begin(), unit_fused.end(), 0);
     if (wl) {
-        // LDS of the wave-local kernels (float offsets): [meta | 2 x staged parameters | 2 x slab set | per wavefront: its own
-        // tiles | 32 floats shared] (+ the chain's permutation matrices behind, when the launch finds room)
+        // LDS of the wave-local kernels (float offsets): [meta | 2 x staged parameters | 2 x nr slab sets | per wavefront: its own
+        // tiles of nr row tiles | 32 floats shared] (+ the chain's permutation matrices behind, when the launch finds room)
         auto r4 = [](int v) { return (v + 3) & ~3; };
-        WlArgs wf{}, wb{};
-        wf.par_f4 = wb.par_f4 = par_f4; wf.par_bias = wb.par_bias = par_bias;
-        wf.off_par = wb.off_par = P->meta_bytes / 4;
-        wf.off_slab = wb.off_slab = wf.off_par + 2 * 4 * par_f4;
-        wf.slab_floats = r4(P->slab_fwd); wb.slab_floats = r4(P->slab_bwd);
-        wf.off_priv = wf.off_slab + 2 * wf.slab_floats; wb.off_priv = wb.off_slab + 2 * wb.slab_floats;
-        wf.priv_stride = r4(2 * ROWS * P->xld);
-        wb.priv_stride = r4(4 * ROWS * P->xld + r4(ROWS * P->gld) + 256);
-        wf.off_misc = wf.off_priv + nw * wf.priv_stride; wb.off_misc = wb.off_priv + nw * wb.priv_stride;
-        wf.off_perm = wf.off_misc + 32; wb.off_perm = wb.off_misc + 32;
-        if (4 * wf.off_perm > LDS_LIMIT || 4 * wb.off_perm > LDS_LIMIT) wl = false;
-        else { P->wl_f = wf; P->wl_b = wb; }
+        for (int nr = 1; nr <= 2; ++nr) {
+            WlArgs wf{}, wb{};
+            wf.nr = wb.nr = nr;
+            wf.par_f4 = wb.par_f4 = par_f4; wf.par_bias = wb.par_bias = par_bias;
+            wf.off_par = wb.off_par = P->meta_bytes / 4;
+            wf.off_slab = wb.off_slab = wf.off_par + 2 * 4 * par_f4;
+            wf.slab_floats = r4(P->slab_fwd); wb.slab_floats = r4(P->slab_bwd);
+            wf.off_priv = wf.off_slab + 2 * nr * wf.slab_floats; wb.off_priv = wb.off_slab + 2 * nr * wb.slab_floats;
+            wf.priv_tile = r4(2 * ROWS * P->xld); wf.priv_stride = nr * wf.priv_tile;
+            wb.priv_tile = r4(4 * ROWS * P->xld + r4(ROWS * P->gld)); wb.priv_stride = nr * wb.priv_tile + 256;
+            wf.off_misc = wf.off_priv + nw * wf.priv_stride; wb.off_misc = wb.off_priv + nw * wb.priv_stride;
+            wf.off_perm = wf.off_misc + 32; wb.off_perm = wb.off_misc + 32;
+            const bool fits = 4 * wf.off_perm <= LDS_LIMIT && 4 * wb.off_perm <= LDS_LIMIT;
+            if (nr == 1 && !fits) { wl = false; break; }
+            if (fits) { P->wl_f[nr - 1] = wf; P->wl_b[nr - 1] = wb; if (nr == 2) P->wl_nr2 = 1; }
+        }
     }
     P->wl = wl ? 1 : 0;
     if (std::getenv("HINT_PLAN_DUMP"))
-        std::fprintf(stderr, "[hint plan] nw %d: wave-local %d (lean %d, par_f4 %d of %d, LDS fwd %d bwd %d bytes)\n", nw, P->wl, P->lean,
-                     par_f4, WL_PAR_REGS * 64 * nw, 4 * P->wl_f.off_perm, 4 * P->wl_b.off_perm);
+        std::fprintf(stderr, "[hint plan] nw %d: wave-local %d (lean %d, par_f4 %d of %d, LDS fwd %d bwd %d bytes; row pairs %d: %d / %d)\n", nw, P->wl,
+                     P->lean, par_f4, WL_PAR_REGS * 64 * nw, 4 * P->wl_f[0].off_perm, 4 * P->wl_b[0].off_perm, P->wl_nr2,
+                     4 * P->wl_f[1].off_perm, 4 * P->wl_b[1].off_perm);
     if (wl) std::fill(unit_fused.begin(), unit_fused.end(), 1);      // dW1 / db1 always come from the backward kernel
     // the first-layer gradients of the fused units: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
     // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
@@ -684,7 +689,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (wl) {
         // the wave-local kernels read thin vectors and biases from the staged parameter buffer [forward blob | backward
         // blob | biases]: offsets relative to it
-        P->wl_f.bias_src = P->wl_b.bias_src = (int)packed;
+        for (int q = 0; q < 2; ++q) P->wl_f[q].bias_src = P->wl_b[q].bias_src = (int)packed;
         for (size_t i = 0; i < recs_f.size(); ++i) {
             const Unit& u = units[rec_unit[i]];
             RowRec& f = recs_f[i];
@@ -905,9 +910,30 @@ void hint_plan_destroy(hint_plan* P) {
     delete P;
 }
 
-// the plan variant a batch of B rows runs on
+// the plan variant a batch of B rows runs on, and (wave-local plans) how many 16-row tiles a workgroup takes:
+//   up to one row tile per CU                  the 8-wavefront plan, one tile per workgroup
+//   more                                       wave-local plans: ROW PAIRS - two tiles on one weight stream (hint_wl.hpp) - on the
+//                                              8-wavefront plan; beyond two pairs per CU on the 4-wavefront plan (two workgroups
+//                                              per CU) when that fits the LDS twice
+//                                              other plans: the 4-wavefront plan, one tile per workgroup
+static int env_int(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; }
 static const hint_plan* variant(const hint_plan* P, int B) {
-    return (P && P->alt4 && (B + ROWS - 1) / ROWS > P->num_cu) ? P->alt4 : P;
+    if (!P || !P->alt4) return P;
+    const int ntiles = (B + ROWS - 1) / ROWS;
+    if (ntiles <= P->num_cu) return P;
+    static const int nr_forced = env_int("HINT_WL_NR");
+    if (P->wl && P->wl_nr2 && nr_forced != 1) {
+        const hint_plan* A = P->alt4;
+        const bool alt_twice = A->wl && A->wl_nr2 && std::max(plan_lds(A, false, 2), plan_lds(A, true, 2)) + 4096 <= LDS_LIMIT / 2;
+        return (alt_twice && ntiles > 4 * P->num_cu) ? A : P;
+    }
+    return P->alt4;
+}
+static int wl_nr_for(const hint_plan* Pv, int B) {       // Pv: the variant already picked
+    if (!Pv->wl || !Pv->wl_nr2) return 1;
+    static const int nr_forced = env_int("HINT_WL_NR");
+    if (nr_forced == 1 || nr_forced == 2) return nr_forced;
+    return (B + ROWS - 1) / ROWS > Pv->num_cu ? 2 : 1;
 }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
@@ -1065,8 +1091,8 @@ static void bind_tape(const hint_plan* P, int B, float* tape, ChainBlock* b) {
 }
 
 static int grid_for(const hint_plan* P, int B) {
-    const int ntiles = (B + ROWS - 1) / ROWS;
-    return std::min(ntiles, P->num_cu * 8);
+    const int ntiles = (B + ROWS - 1) / ROWS, nr = wl_nr_for(P, B);
+    return std::min((ntiles + nr - 1) / nr, P->num_cu * 8);
 }
 
 // part A (row-parallel, bit 0 of `parts`) and part B (weight gradients, bit 1) of the backward pass of
@@ -1076,10 +1102,11 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
                         float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s) {
     if ((parts & 1) && P->wl) {
         KArgs a = make_args(P, B, true);
-        WlArgs w = P->wl_b;
+        const int nr = wl_nr_for(P, B);
+        WlArgs w = P->wl_b[nr - 1];
         bool any_perm = one.perm != nullptr;
         if (chain_host) for (int i = 0; i < n_chain; ++i) any_perm = any_perm || chain_host[i].perm != nullptr;
-        const int lds = lds_with_perms(P, plan_lds(P, true), n_chain, any_perm, &a);
+        const int lds = lds_with_perms(P, plan_lds(P, true, nr), n_chain, any_perm, &a);
         w.off_perm = a.perm_lds;
         HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
     } else if (parts & 1) {
@@ -1111,9 +1138,10 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, rev ? nullptr : tape, &one);
     KArgs a = make_args(P, B, false);
-    const int lds = lds_with_perms(P, plan_lds(P, false), 1, perm != nullptr, &a);
+    const int nr = wl_nr_for(P, B);
+    const int lds = lds_with_perms(P, plan_lds(P, false, nr), 1, perm != nullptr, &a);
     if (P->wl) {
-        WlArgs w = P->wl_f;
+        WlArgs w = P->wl_f[nr - 1];
         w.off_perm = a.perm_lds;
         HIP_TRY(launch_wl_apply(rev, a, w, lds, grid_for(P, B), one, nullptr, 1, x, z, J, J_in, loss_acc, 0.f, nullptr, nullptr,
                                 (hipStream_t)stream));
@@ -1263,9 +1291,10 @@ int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
     KArgs a = make_args(P, C->B, false);
-    const int lds = lds_with_perms(P, plan_lds(P, false), C->n, chain_any_perm(C), &a);
+    const int nr = wl_nr_for(P, C->B);
+    const int lds = lds_with_perms(P, plan_lds(P, false, nr), C->n, chain_any_perm(C), &a);
     if (P->wl) {
-        WlArgs w = P->wl_f;
+        WlArgs w = P->wl_f[nr - 1];
         w.off_perm = a.perm_lds;
         HIP_TRY(launch_wl_apply(false, a, w, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, z, J, J_in, loss_acc, noise,
                                 (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
@@ -1283,9 +1312,10 @@ int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, floa
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_inverse: plan has dc=%d but c is NULL", P->dc);
     KArgs a = make_args(P, C->B, false);
-    const int lds = lds_with_perms(P, plan_lds(P, false), C->n, chain_any_perm(C), &a);
+    const int nr = wl_nr_for(P, C->B);
+    const int lds = lds_with_perms(P, plan_lds(P, false, nr), C->n, chain_any_perm(C), &a);
     if (P->wl) {
-        WlArgs w = P->wl_f;
+        WlArgs w = P->wl_f[nr - 1];
         w.off_perm = a.perm_lds;
         HIP_TRY(launch_wl_apply(true, a, w, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, x, J, J_in, nullptr, 0.f,
                                 nullptr, nullptr, (hipStream_t)stream));

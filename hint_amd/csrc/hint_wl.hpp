@@ -51,31 +51,35 @@ __device__ __forceinline__ f32x4 wl_layer1(const LDS_AS f32x4* q, const float (&
     return fma4(q3, vin[3], fma4(q2, vin[2], fma4(q1, vin[1], fma4(q0, vin[0], qb))));
 }
 
+// NR = 1 or 2 adjacent 16-row tiles per workgroup ("row pair"): both ride the SAME weight stream - every fragment tile
+// fetched feeds two MFMAs instead of one (the stream from L2 / L1, not the matrix pipe, is what bounds the k-loop of a
+// single tile), and the latency chains of the two tiles' element-wise phases interleave in every wavefront.  Used when
+// the batch has more row tiles than the chip has CUs.
 struct WlCtx {
     const GLOBAL_AS float* pk;           // packed weights of the block
     const GLOBAL_AS float* pk_next;      // ... of the block worked on next (the last row of a block hands the ring over)
-    const GLOBAL_AS uint8_t* bits;       // backward: a2 sign bytes of this row tile (block, next block)
-    const GLOBAL_AS uint8_t* bits_next;
+    const GLOBAL_AS uint8_t* bits[2];    // backward: a2 sign bytes of the row tiles (this block, the next one)
+    const GLOBAL_AS uint8_t* bits_next[2];
     const void* recs;                    // this direction's row records
     const LDS_AS float* par;             // the block's staged thin vectors and biases
-    LDS_AS float* slab;                  // the group's slab set
-    const LDS_AS float* xs;              // private lane tile: the inputs of the level's first layers
-    const LDS_AS float* gst;             // backward: private coupling gradients [16][gld]
+    LDS_AS float* slab;                  // the group's slab set of row tile 0 (tile 1: + slab_h)
+    const LDS_AS float* xs[2];           // private lane tiles: the inputs of the level's first layers
+    const LDS_AS float* gst[2];          // backward: private coupling gradients [16][gld]
     LDS_AS float* scratch;               // backward: private fragment tile (first-layer weight gradient)
-    GLOBAL_AS float* a2;                 // training forward: this row tile's rows of the [Bp][WT] array
-    GLOBAL_AS uint8_t* bits_out;         // training forward: its a2 sign bytes
+    GLOBAL_AS float* a2[2];              // training forward: the row tiles' rows of the [Bp][WT] array
+    GLOBAL_AS uint8_t* bits_out[2];      // training forward: their a2 sign bytes
     GLOBAL_AS float* tw;                 // backward: this workgroup's first-layer gradient slab
-    int xld, gld, WT;
+    int xld, gld, WT, slab_h;
     int sid, sid0;                       // diagnostic builds: stamp id base of the wavefront's current row / of the group
     bool train, first_tile;
 };
 
-template <int KIND, int N>
-__device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float* pk, const GLOBAL_AS uint8_t* bits,
+template <int KIND, int NR>
+__device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float* pk, const GLOBAL_AS uint8_t* const (&bits)[2],
                                         const RowU& r, int kb, const LaneOff& lo) {
     const GLOBAL_AS char* p = (const GLOBAL_AS char*)pk + lo.w;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < NTT; ++j) {
         const int jj = j < r.ntt ? j : r.ntt - 1;
 #ifdef HINT_WL_ABL_W        // diagnostic: every k-block reads the row's first tiles again (L1 hits): what the weight stream's latency costs
         dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj + (kb & 0)) * 1024);
@@ -85,40 +89,48 @@ __device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float
     }
     if (KIND == K_BWD) {
         const int kc = kb < r.n1 ? kb : r.n1 - 1;
-        dst[NTT].x = __int_as_float((int)bits[((r.wcol >> 4) + kc) * 64 + lo.l]);
+        const int o = ((r.wcol >> 4) + kc) * 64 + lo.l;
+        dst[NTT].x = __int_as_float((int)bits[0][o]);
+        if (NR == 2) dst[NTT].y = __int_as_float((int)bits[1][o]);
     }
 }
 
-// One row: ntt (1..3) adjacent 16-feature tiles of one unit.  Ring slot 0 holds k-block 0 on entry; on exit k-block 0 of
-// row `nr` (fetched from pkn / bitsn: the next block's when the row is the wavefront's last of this block).  `part`: the
-// wavefront's running partial of the unit's thin product behind the layer (forward: s | t of the node, backward: g_v).
+// One row: ntt (1..3) adjacent 16-feature tiles of one unit, for NR row tiles.  Ring slot 0 holds k-block 0 on entry; on
+// exit k-block 0 of row `nr` (fetched from pkn / bitsn: the next block's when the row is the wavefront's last of this
+// block).  `part`: the wavefront's running partial of the unit's thin product behind the layer (forward: s | t of the
+// node, backward: g_v), per row tile.
 // ONE code path for every tile count: the ring always carries three tiles (a narrower row's last tile again: L1 hits) and
 // only the MFMA groups and the per-tile epilogues sit under (wave-uniform) branches - a path per tile count would define the
 // ring in three places, and the merge costs sixteen register copies behind a vmcnt(0) at the end of every row.
-template <int KIND>
+template <int KIND, int NR>
 __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const RowU& nr, const GLOBAL_AS float* pkn,
-                                       const GLOBAL_AS uint8_t* bitsn, f32x4 (&ring)[RING][NEL], f32x4& part,
+                                       const GLOBAL_AS uint8_t* const (&bitsn)[2], f32x4 (&ring)[RING][NEL], f32x4 (&part)[NR],
                                        const LaneOff& lo, int lane) {
     static_assert(RING == 2 && NTT == 3, "the WL rows alternate two ring slots of three tiles");
     const int m = lane & 15, kq = lane >> 4;
     const int n1 = cr.n1, ntt = cr.ntt;
     STAMP(c.sid + 0)
     // the unit's thin-layer inputs of this lane's batch row: forward the lanes feeding the subnet, backward g_s | g_t
-    float vin[4];
-    {
-        const int K = cr.thin_k & 0xff;
-        const LDS_AS float* src = KIND == K_FWD ? c.xs + m * c.xld + (cr.thin_k >> 16) : c.gst + m * c.gld + (cr.thin_k >> 16);
+    float vin[NR][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const float v = src[k < K ? k : 0]; vin[k] = k < K ? v : 0.f; }
+    for (int h = 0; h < NR; ++h) {
+        const int K = cr.thin_k & 0xff;
+        const LDS_AS float* src = KIND == K_FWD ? c.xs[h] + m * c.xld + (cr.thin_k >> 16) : c.gst[h] + m * c.gld + (cr.thin_k >> 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float v = src[k < K ? k : 0]; vin[h][k] = k < K ? v : 0.f; }
     }
     // forward: W1 vectors of k-block kb at tq[20 kb + 4 k] (bias: k = 4); backward: W3^T vectors at tq[16 kb + 4 j]
     const LDS_AS f32x4* tq = (const LDS_AS f32x4*)(c.par + cr.thin_w) + kq;
-    f32x4 acc0 = zero4(), acc1 = zero4(), acc2 = zero4();
+    f32x4 acc[NR][NTT];
+#pragma unroll
+    for (int h = 0; h < NR; ++h)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) acc[h][j] = zero4();
 
     // The B operand of k-block kb, before the backward's mask, is software-pipelined two steps deep so that no step waits
     // for the LDS: step kb issues the reads of the thin vectors of k-block kb + 2 (five / four float4 per lane), turns the
-    // vectors of kb + 1 (read a step ago) into the operand of the next step - 16 FMAs (+ ReLU) issued between this step's
-    // MFMAs - and multiplies with the operand computed a step ago.
+    // vectors of kb + 1 (read a step ago) into the operand of the next step - 16 FMAs (+ ReLU) per row tile, issued between
+    // this step's MFMAs - and multiplies with the operand computed a step ago.
     constexpr int NQ = KIND == K_FWD ? 5 : 4;
     f32x4 qv[NQ];
     auto q_load = [&](int kb) {
@@ -126,44 +138,51 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
 #pragma unroll
         for (int k = 0; k < NQ; ++k) qv[k] = q[4 * k];
     };
-    auto q_frag = [&]() -> f32x4 {
+    auto q_frag = [&](int h) -> f32x4 {
 #ifdef HINT_WL_ABL_THIN     // diagnostic: no thin-layer arithmetic in the k-loop
-        return f32x4{vin[0], vin[1], vin[2], vin[3]};
+        return f32x4{vin[h][0], vin[h][1], vin[h][2], vin[h][3]};
 #endif
         // (forward: bias first, then the inputs in order - wl_layer1's expression; backward: from zero)
         const f32x4 a0 = KIND == K_FWD ? qv[4] : zero4();
-        const f32x4 r = fma4(qv[3], vin[3], fma4(qv[2], vin[2], fma4(qv[1], vin[1], fma4(qv[0], vin[0], a0))));
+        const f32x4 r = fma4(qv[3], vin[h][3], fma4(qv[2], vin[h][2], fma4(qv[1], vin[h][1], fma4(qv[0], vin[h][0], a0))));
         return KIND == K_FWD ? relu4(r) : r;
     };
     q_load(0);
-    f32x4 b4n = q_frag();
+    f32x4 b4n[NR];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) b4n[h] = q_frag(h);
     q_load(1);
     STAMP(c.sid + 1)
     // Program order of a step is pinned with empty asm statements that "use" the accumulators and clobber memory: the
     // prefetch of the next step's tiles goes out behind the MFMAs of the step before (its ring slot is dead then: no
     // register copies) and in front of this step's MFMAs (a full step of flight time).  Left to itself the compiler
     // either hoists the loads over the previous step (copies + vmcnt(0) at the back edge) or sinks them to their use.
-#define WL_PIN() asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2) : : "memory");
-#define WL_STEP(KB, S, LIVE, PK, BITS, NR, NKB)                                                         \
+#define WL_PIN()                                                                                        \
     {                                                                                                   \
-        wl_load<KIND, NTT>(ring[((S) + 1) & 1], PK, BITS, NR, NKB, lo);                                 \
+        if constexpr (NR == 1) asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]) : : "memory"); \
+        else asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[NR - 1][0]), "+v"(acc[NR - 1][1]), "+v"(acc[NR - 1][2]) : : "memory"); \
+    }
+#define WL_MFMA(J)                                                                                      \
+    _Pragma("unroll") for (int h_ = 0; h_ < NR; ++h_) acc[h_][J] = mfma4(ring[S_][J][i_], b4[h_][i_], acc[h_][J]);
+#define WL_STEP(KB, S, LIVE, PK, BITS, NR_, NKB)                                                        \
+    {                                                                                                   \
+        constexpr int S_ = (S);                                                                         \
+        wl_load<KIND, NR>(ring[(S_ + 1) & 1], PK, BITS, NR_, NKB, lo);                                  \
         WL_PIN()                                                                                        \
         if (LIVE) {                                                                                     \
-            f32x4 b4 = b4n;                                                                             \
-            if (KIND == K_BWD) mask_by_bits(b4, __float_as_int(ring[S][NTT].x));                        \
-            b4n = q_frag();                     /* k-block KB + 1 (behind the row's last one: never used) */ \
+            f32x4 b4[NR];                                                                               \
+            _Pragma("unroll") for (int h = 0; h < NR; ++h) {                                            \
+                b4[h] = b4n[h];                                                                         \
+                if (KIND == K_BWD) mask_by_bits(b4[h], __float_as_int(h == 0 ? ring[S_][NTT].x : ring[S_][NTT].y)); \
+                b4n[h] = q_frag(h);                 /* k-block KB + 1 (behind the row's last one: never used) */ \
+            }                                                                                           \
             q_load((KB) + 2);                                                                           \
             if (ntt >= 3) {                                                                             \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
-                    acc0 = mfma4(ring[S][0][i], b4[i], acc0); acc1 = mfma4(ring[S][1][i], b4[i], acc1); \
-                    acc2 = mfma4(ring[S][2][i], b4[i], acc2);                                           \
-                }                                                                                       \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { WL_MFMA(0) WL_MFMA(1) WL_MFMA(2) }    \
             } else if (ntt == 2) {                                                                      \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
-                    acc0 = mfma4(ring[S][0][i], b4[i], acc0); acc1 = mfma4(ring[S][1][i], b4[i], acc1); \
-                }                                                                                       \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { WL_MFMA(0) WL_MFMA(1) }               \
             } else {                                                                                    \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) acc0 = mfma4(ring[S][0][i], b4[i], acc0); \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { WL_MFMA(0) }                          \
             }                                                                                           \
         }                                                                                               \
         WL_PIN()                                                                                        \
@@ -178,6 +197,7 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1)              // (an odd row's step n1: a dummy load of the tile behind)
     WL_STEP(k0 + 1, 1, k0 + 1 < n1, pkn, bitsn, nr, 0)          // hands the ring to the next row
 #undef WL_STEP
+#undef WL_MFMA
 #undef WL_PIN
 
     STAMP(c.sid + 2)
@@ -188,46 +208,58 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
 #pragma unroll
         for (int j = 0; j < NTT; ++j) {
             if (j < ntt) {
-                // (the bias last, as the reference's addmm adds it: fewer rows land on the other side of a ReLU kink)
-                const f32x4 v = relu4((j == 0 ? acc0 : j == 1 ? acc1 : acc2) + b2[4 * j]);
-                if (c.train) {
-                    c.bits_out[((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
-                    *(GLOBAL_AS f32x4*)(c.a2 + (m * c.WT + cr.ocol + 16 * j + 4 * kq)) = v;
-                }
+                const f32x4 bias = b2[4 * j];
+                f32x4 wv[4];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) part[o] = dot4(w3[16 * j + 4 * o], v, part[o]);
+                for (int o = 0; o < 4; ++o) wv[o] = w3[16 * j + 4 * o];
+#pragma unroll
+                for (int h = 0; h < NR; ++h) {
+                    // (the bias last, as the reference's addmm adds it: fewer rows land on the other side of a ReLU kink)
+                    const f32x4 v = relu4(acc[h][j] + bias);
+                    if (c.a2[h] != nullptr) {          // (training, and the row tile exists)
+                        c.bits_out[h][((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
+                        *(GLOBAL_AS f32x4*)(c.a2[h] + (m * c.WT + cr.ocol + 16 * j + 4 * kq)) = v;
+                    }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) part[h][o] = dot4(wv[o], v, part[h][o]);
+                }
             }
         }
     } else {
         // g1 = acc .* relu'(a1), a1 recomputed from the level's lanes; g_v partial = W1^T g1; dW1 | db1 of the tile
-        float xin[4];
-        const int cin = cr.p2 & 0xff, xoff = (cr.p2 >> 8) & 0xff, kcp = cin < 4 ? 4 : 8, h = cr.p2 >> 16;
+        float xin[NR][4];
+        const int cin = cr.p2 & 0xff, xoff = (cr.p2 >> 8) & 0xff, kcp = cin < 4 ? 4 : 8, hw = cr.p2 >> 16;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const float v = c.xs[m * c.xld + xoff + (k < cin ? k : 0)]; xin[k] = k < cin ? v : 0.f; }
+        for (int h = 0; h < NR; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float v = c.xs[h][m * c.xld + xoff + (k < cin ? k : 0)]; xin[h][k] = k < cin ? v : 0.f; }
         const LDS_AS f32x4* w1 = (const LDS_AS f32x4*)(c.par + cr.thin_b) + kq;     // W1 vector k of the row's tile t: w1[20 t + 4 k]
         const int nl = m;
 #pragma unroll
         for (int j = 0; j < NTT; ++j) {
             if (j < ntt) {
-                const f32x4 pre = wl_layer1(w1 + 20 * j, xin);
-                f32x4 g = j == 0 ? acc0 : j == 1 ? acc1 : acc2;
-                g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f; g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) part[o] = dot4(w1[20 * j + 4 * o], g, part[o]);
-                // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f]: the tile transposed through the
-                // private scratch tile, then four 16x16x4 MFMAs over the 16 rows (out^T[k][f]: a lane ends with four inputs of
-                // one feature)
-                ((LDS_AS f32x4*)c.scratch)[lane] = g;
-                const LDS_AS float* g1p = (const LDS_AS float*)c.scratch + (kq + 16 * (nl >> 2)) * 4 + (nl & 3);
-                const LDS_AS float* vp = c.xs + kq * c.xld + xoff + (nl < cin ? nl : 0);
-                const float one = nl == cin ? 1.f : 0.f;
-                float av[4], bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * c.xld]; }      // rows 4 i + kq
                 f32x4 dw = zero4();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dw = mfma4(nl < cin ? bv[i] : one, av[i], dw);
-                const int nvalid = h - 16 * (cr.tb + j);
+                for (int h = 0; h < NR; ++h) {
+                    const f32x4 pre = wl_layer1(w1 + 20 * j, xin[h]);
+                    f32x4 g = acc[h][j];
+                    g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f; g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) part[h][o] = dot4(w1[20 * j + 4 * o], g, part[h][o]);
+                    // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f]: the tile transposed through the
+                    // private scratch tile, then four 16x16x4 MFMAs over the 16 rows (out^T[k][f]: a lane ends with four inputs
+                    // of one feature); the second row tile adds into the same accumulator
+                    ((LDS_AS f32x4*)c.scratch)[lane] = g;
+                    const LDS_AS float* g1p = (const LDS_AS float*)c.scratch + (kq + 16 * (nl >> 2)) * 4 + (nl & 3);
+                    const LDS_AS float* vp = c.xs[h] + kq * c.xld + xoff + (nl < cin ? nl : 0);
+                    const float one = nl == cin ? 1.f : 0.f;
+                    float av[4], bv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * c.xld]; }      // rows 4 i + kq
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dw = mfma4(nl < cin ? bv[i] : one, av[i], dw);
+                }
+                const int nvalid = hw - 16 * (cr.tb + j);
                 if (nl < nvalid && 4 * kq < kcp) {
                     GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(c.tw + cr.p1 + (16 * j + nl) * kcp + 4 * kq);
                     if (c.first_tile) *dst = dw; else *dst = *dst + dw;
@@ -237,14 +269,21 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     }
     STAMP(c.sid + 3)
     // (forward: b3 rides with the row that holds the unit's tile 0 - in one lane group, the fold below sums the four)
-    if (KIND == K_FWD && cr.first && kq == 0) part += *(const LDS_AS f32x4*)(c.par + cr.bias3);
+    if (KIND == K_FWD && cr.first && kq == 0) {
+        const f32x4 b3 = *(const LDS_AS f32x4*)(c.par + cr.bias3);
+#pragma unroll
+        for (int h = 0; h < NR; ++h) part[h] += b3;
+    }
     if (cr.ulast) {
         // the wavefront's last row of the unit: fold the four lane groups -> slab
-        f32x4 s;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) s[o] = kq_sum(part[o]);
-        if (kq == 0) ((LDS_AS f32x4*)(c.slab + cr.slab))[m] = s;
-        part = zero4();
+        for (int h = 0; h < NR; ++h) {
+            f32x4 s;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) s[o] = kq_sum(part[h][o]);
+            if (kq == 0) ((LDS_AS f32x4*)(c.slab + h * c.slab_h + cr.slab))[m] = s;
+            part[h] = zero4();
+        }
     }
     STAMP(c.sid + 4)
 }
@@ -252,17 +291,19 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
 // The wavefront's rows [r0, r1) of a group.  `primed`: the record whose k-block 0 sits in ring slot 0 (or -1);
 // rnext: the record the last row hands the ring to (the wavefront's first row of the next group, of the next block when
 // other_block) or -1.
-template <int KIND>
+template <int KIND, int NR>
 __device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL], int& primed, int r0, int r1, int rnext,
                                         bool other_block, int lane) {
     if (r0 >= r1) return;
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
     RowU cr = decode_rec(load_rec(c.recs, r0));
-    if (primed != r0) wl_load<KIND, NTT>(ring[0], c.pk, c.bits, cr, 0, lo);
+    if (primed != r0) wl_load<KIND, NR>(ring[0], c.pk, c.bits, cr, 0, lo);
     const int rlast = rnext >= 0 ? rnext : r1 - 1;
     i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);
-    f32x4 part = zero4();
+    f32x4 part[NR];
+#pragma unroll
+    for (int h = 0; h < NR; ++h) part[h] = zero4();
     for (int t = r0; t < r1; ++t) {
         const RowU nr = decode_rec(nrec);
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
@@ -271,8 +312,8 @@ __device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL]
         const_cast<WlCtx&>(c).sid = 256 + ((c.sid0 >> 3) & 3) * 64 + (t - r0 < 2 ? t - r0 : 1) * 32;
 #endif
         const GLOBAL_AS float* pkn = hand ? c.pk_next : c.pk;
-        const GLOBAL_AS uint8_t* bitsn = hand ? c.bits_next : c.bits;
-        wl_row<KIND>(c, cr, nr, pkn, bitsn, ring, part, lo, lane);
+        const GLOBAL_AS uint8_t* const bitsn[2] = {hand ? c.bits_next[0] : c.bits[0], hand ? c.bits_next[1] : c.bits[1]};
+        wl_row<KIND, NR>(c, cr, nr, pkn, bitsn, ring, part, lo, lane);
         cr = nr;
     }
     primed = rnext;

@@ -41,6 +41,7 @@ __device__ __forceinline__ void wl_level_commit(const WlLevel& p, float* xs, flo
     }
 }
 
+template <int NR>
 __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_wl_bwd_kernel(
     KArgs a, WlArgs w, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, const float* __restrict__ g_z, const float* __restrict__ g_J,
@@ -52,20 +53,21 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     const float inv_d = frcp(a.d);
     const Tables T = make_tables(a, lds);
     float* par = lds + w.off_par;
-    float* slabs = lds + w.off_slab;
+    float* slabs = lds + w.off_slab;            // [2][NR][slab_floats]
     float* ptab = lds + w.off_perm;
-    float* gj = lds + w.off_misc;               // g_J of the tile's rows
-    // this wavefront's own tiles: lanes of the level (as the forward saw them), s of the level, two gradient tiles (a fused
-    // permutation ping-pongs), coupling gradients, one fragment tile of scratch
+    float* gj = lds + w.off_misc;               // g_J of the tiles' rows [NR][16]
+    // this wavefront's own tiles, per row tile: lanes of the level (as the forward saw them), s of the level, two gradient
+    // tiles (a fused permutation ping-pongs), coupling gradients; behind them one fragment tile of scratch
     float* priv = lds + w.off_priv + wave * w.priv_stride;
     const int tl = ROWS * a.xld;
-    float* xs = priv;
-    float* sb = priv + tl;
-    float* g0 = priv + 2 * tl;
-    float* gst = priv + 4 * tl;
-    float* scratch = gst + ((ROWS * a.gld + 3) & ~3);
+#define XSP(H) (priv + (H) * w.priv_tile)
+#define SBP(H) (priv + (H) * w.priv_tile + tl)
+#define G0P(H) (priv + (H) * w.priv_tile + 2 * tl)
+#define GSTP(H) (priv + (H) * w.priv_tile + 4 * tl)
+    float* scratch = priv + NR * w.priv_tile;
     const int par_floats = 4 * w.par_f4;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
+    const int ngroups = (ntiles + NR - 1) / NR;
     const int pdd = a.d * a.d;
     const size_t lvl = (size_t)a.B * a.d;
     STAMP_DECL()
@@ -79,28 +81,42 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     }
 #define HINT_CB(I) chain_block(chain, one, I)
 #define LEVEL_SRC(TAPE, TOP, LV) ((LV) == 0 ? ((TOP) ? (TAPE) + (size_t)(a.n_levels - 1) * lvl : x) : (TAPE) + (size_t)((LV) - 1) * lvl)
-#define BITS_A2(BLK) ((const GLOBAL_AS uint8_t*)((BLK).actA1 + a.bits_off) + a.bits_stride + (size_t)(row0 >> 4) * (a.WT >> 4) * 64)
+#define BITS_A2(BLK, R0) ((const GLOBAL_AS uint8_t*)((BLK).actA1 + a.bits_off) + a.bits_stride + (size_t)((R0) >> 4) * (a.WT >> 4) * 64)
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row0 = tile * ROWS;
-        const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
-        int gcur = 0;
-#define GS (g0 + gcur)
-#define GO (g0 + (tl - gcur))
-        for (int i = lane; i < ROWS * a.d; i += 64) {
-            const int r = fdiv(i, inv_d);
-            GS[r * a.xld + (i - r * a.d)] = i < nvalid ? g_z[(size_t)row0 * a.d + i] * gz_scale : 0.f;      // (gz_scale: the loss gradient g_z = z / B fused)
+    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        int row0[NR], nvalid[NR], rowt[NR];
+#pragma unroll
+        for (int h = 0; h < NR; ++h) {
+            row0[h] = (tg * NR + h) * ROWS;
+            const int rows = a.B - row0[h];
+            nvalid[h] = (rows < 0 ? 0 : rows < ROWS ? rows : ROWS) * a.d;
+            rowt[h] = row0[h] < ntiles * ROWS ? row0[h] : row0[0];    // (a pair's second tile behind the batch reads the first one's tape: all its gradients are zero)
         }
-        if (tid < ROWS) gj[tid] = (row0 + tid < a.B) ? (g_J != nullptr ? g_J[row0 + tid] : gJ_const) : 0.f;
+        int gcur = 0;
+#define GS(H) (G0P(H) + gcur)
+#define GO(H) (G0P(H) + (tl - gcur))
+#pragma unroll
+        for (int h = 0; h < NR; ++h)
+            for (int i = lane; i < ROWS * a.d; i += 64) {
+                const int r = fdiv(i, inv_d);
+                GS(h)[r * a.xld + (i - r * a.d)] = i < nvalid[h] ? g_z[(size_t)row0[h] * a.d + i] * gz_scale : 0.f;      // (gz_scale: the loss gradient g_z = z / B fused)
+            }
+        if (tid < ROWS * NR) {
+            const int h = tid >> 4, r = tid & 15;
+            gj[tid] = ((tg * NR + h) * ROWS + r < a.B) ? (g_J != nullptr ? g_J[(tg * NR + h) * ROWS + r] : gJ_const) : 0.f;
+        }
         {
             const GBlock lb = HINT_CB(n_chain - 1);
             const float* tape = (const float*)lb.tape;
             const bool top = lb.perm != nullptr || n_chain > 1;
-            WlLevel lp;
-            wl_level_issue(lp, LEVEL_SRC(tape, top, a.n_levels - 1), tape + (size_t)(2 * a.n_levels - 1) * lvl, a.d, row0, nvalid, lane);
+            WlLevel lp[NR];
+#pragma unroll
+            for (int h = 0; h < NR; ++h)
+                wl_level_issue(lp[h], LEVEL_SRC(tape, top, a.n_levels - 1), tape + (size_t)(2 * a.n_levels - 1) * lvl, a.d, rowt[h], nvalid[h], lane);
             f32x4 pf[WL_PAR_REGS];
             wl_par_issue(pf, lb.packed, w, tid, nthreads);
-            wl_level_commit(lp, xs, sb, a.xld, a.d, nvalid, lane);
+#pragma unroll
+            for (int h = 0; h < NR; ++h) wl_level_commit(lp[h], XSP(h), SBP(h), a.xld, a.d, nvalid[h], lane);
             wl_par_commit(pf, par, w, tid, nthreads);
         }
         __syncthreads();
@@ -122,13 +138,18 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 
             WlCtx c;
             c.pk = blk.packed; c.pk_next = nblk.packed;
-            c.bits = BITS_A2(blk); c.bits_next = BITS_A2(nblk);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int hh = h < NR ? h : 0;
+                c.bits[h] = BITS_A2(blk, rowt[hh]); c.bits_next[h] = BITS_A2(nblk, rowt[hh]);
+                c.xs[h] = (const LDS_AS float*)XSP(hh); c.gst[h] = (const LDS_AS float*)GSTP(hh);
+                c.a2[h] = nullptr; c.bits_out[h] = nullptr;
+            }
             c.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
             c.par = (const LDS_AS float*)(par + (wi & 1) * par_floats);
-            c.xs = (const LDS_AS float*)xs; c.gst = (const LDS_AS float*)gst; c.scratch = (LDS_AS float*)scratch;
-            c.a2 = nullptr; c.bits_out = nullptr;
+            c.scratch = (LDS_AS float*)scratch;
             c.tw = blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
-            c.xld = a.xld; c.gld = a.gld; c.WT = a.WT; c.train = true; c.first_tile = tile == (int)blockIdx.x;
+            c.xld = a.xld; c.gld = a.gld; c.WT = a.WT; c.slab_h = w.slab_floats; c.train = true; c.first_tile = tg == (int)blockIdx.x;
 
             for (int gi = a.n_groups; gi >= 0; --gi) {
                 // gi == n_groups .. 1: the boundary in front of group gi - 1 (root first), then its rows; gi == 0: the
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 const bool tail_only = gi == 0;
                 const GroupU g = load_group(T.groups + (tail_only ? 0 : slot));
                 const int lop0 = tail_only ? a.n_groups * a.d : g.lop_begin;
-                const float* slab_prev = slabs + ((phase + 1) & 1) * w.slab_floats;     // the g_v partials of the group just finished
+                const float* slab_prev = slabs + ((phase + 1) & 1) * NR * w.slab_floats;     // the g_v partials of the group just finished
                 const int sid = (wi * (a.n_groups + 1) + (a.n_groups - gi)) * 8;
                 (void)sid;
                 STAMP(sid + 0)
@@ -155,33 +176,42 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
                     const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);
-                    float gval = GS[row * a.xld + col];
+                    float gval[NR];
+#pragma unroll
+                    for (int h = 0; h < NR; ++h) gval[h] = GS(h)[row * a.xld + col];
                     if (sc_unit >= 0) {
 #pragma unroll
                         for (int net = 0; net < 2; ++net) {
                             const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + sc_unit + net);
                             const int sl_n = up[21], gv_off = up[22];
-                            const float* sp = slab_prev + gv_off + row * 4 + sc_k;
-                            for (int sl = 0; sl < sl_n; ++sl) gval += sp[sl * 64];
+#pragma unroll
+                            for (int h = 0; h < NR; ++h) {
+                                const float* sp = slab_prev + h * w.slab_floats + gv_off + row * 4 + sc_k;
+                                for (int sl = 0; sl < sl_n; ++sl) gval[h] += sp[sl * 64];
+                            }
                         }
                     }
                     if (!tail_only && cp_ls >= 0) {
-                        const float s = sb[row * a.xld + col];
-                        const float aa = a.alpha * atanf(s);
-                        const float ea = expf(aa);
-                        const float l = xs[row * a.xld + col];              // lower input of the node
-                        const float ga = gval * ea * l + gj[row];           // g_a (a feeds both l' and J)
-                        const float gsv = ga * a.alpha / (1.f + s * s);     // g_s
-                        gst[row * a.gld + cp_ls] = gsv;
-                        gst[row * a.gld + cp_lt] = gval;                    // g_t = g_l'
-                        if (wave == tsel) {
-                            float* go = wsGST + (size_t)(row0 + row) * a.ST;
-                            go[cp_gs] = gsv;
-                            go[cp_gt] = gval;
+#pragma unroll
+                        for (int h = 0; h < NR; ++h) {
+                            const float s = SBP(h)[row * a.xld + col];
+                            const float aa = a.alpha * atanf(s);
+                            const float ea = expf(aa);
+                            const float l = XSP(h)[row * a.xld + col];          // lower input of the node
+                            const float ga = gval[h] * ea * l + gj[h * ROWS + row];   // g_a (a feeds both l' and J)
+                            const float gsv = ga * a.alpha / (1.f + s * s);     // g_s
+                            GSTP(h)[row * a.gld + cp_ls] = gsv;
+                            GSTP(h)[row * a.gld + cp_lt] = gval[h];             // g_t = g_l'
+                            if (wave == tsel && row0[h] < ntiles * ROWS) {
+                                float* go = wsGST + (size_t)(row0[h] + row) * a.ST;
+                                go[cp_gs] = gsv;
+                                go[cp_gt] = gval[h];
+                            }
+                            gval[h] *= ea;                                      // g_l
                         }
-                        gval *= ea;                                         // g_l
                     }
-                    GS[row * a.xld + col] = gval;
+#pragma unroll
+                    for (int h = 0; h < NR; ++h) GS(h)[row * a.xld + col] = gval[h];
                 }
                 c.sid0 = sid; c.sid = 256;
                 STAMP(sid + 1)
@@ -194,7 +224,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 if (tail_only) break;
 
                 // ---- lane tile and s of the level the NEXT boundary needs: global -> registers now, -> LDS behind the rows ----
-                WlLevel lp;
+                WlLevel lp[NR];
                 bool lp_pending = false;
                 {
                     const bool block_switch = slot == 0;                     // next: root level of the block before
@@ -203,12 +233,14 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     if (block_switch ? cb > 0 : nlevel != g.level) {
                         const float* ntape = block_switch ? (const float*)nblk.tape : tape;
                         const bool ntop = block_switch ? (nblk.perm != nullptr || cb > 1) : top;
-                        wl_level_issue(lp, LEVEL_SRC(ntape, ntop, nlevel), ntape + (size_t)(a.n_levels + nlevel) * lvl, a.d, row0, nvalid, lane);
+#pragma unroll
+                        for (int h = 0; h < NR; ++h)
+                            wl_level_issue(lp[h], LEVEL_SRC(ntape, ntop, nlevel), ntape + (size_t)(a.n_levels + nlevel) * lvl, a.d, rowt[h], nvalid[h], lane);
                         lp_pending = true;
                     }
                 }
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
-                c.slab = (LDS_AS float*)(slabs + (phase & 1) * w.slab_floats);
+                c.slab = (LDS_AS float*)(slabs + (phase & 1) * NR * w.slab_floats);
                 ++phase;
                 {
                     int rnext = -1;         // the wavefront's first row of the next group - of the next block's root behind group 0
@@ -220,26 +252,34 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                         const int n0 = lds_i32(T.rng + rngb + wave), n1 = lds_i32(T.rng + rngb + wave + 1);
                         if (n0 < n1) rnext = row_begin + n0;
                     }
-                    wl_rows<K_BWD>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
-                                   wrap, lane);
+                    wl_rows<K_BWD, NR>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
+                                       wrap, lane);
                 }
                 STAMP(sid + 2)
-                if (lp_pending) wl_level_commit(lp, xs, sb, a.xld, a.d, nvalid, lane);
+                if (lp_pending) {
+#pragma unroll
+                    for (int h = 0; h < NR; ++h) wl_level_commit(lp[h], XSP(h), SBP(h), a.xld, a.d, nvalid[h], lane);
+                }
                 STAMP(sid + 3)
                 lds_barrier();
                 STAMP(sid + 4)
             }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
                 const float* wm = a.perm_lds > 0 ? ptab + cb * pdd : perm;
-                for (int i = lane; i < ROWS * a.d; i += 64) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    GO[r * a.xld + j] = perm_dot(GS + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
-                }
+#pragma unroll
+                for (int h = 0; h < NR; ++h)
+                    for (int i = lane; i < ROWS * a.d; i += 64) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        GO(h)[r * a.xld + j] = perm_dot(GS(h) + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
+                    }
                 gcur = tl - gcur;
             }
         }
-        if (wave == 0)
-            for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); g_x[(size_t)row0 * a.d + i] = GS[r * a.xld + (i - r * a.d)]; }
+        if (wave == 0) {
+#pragma unroll
+            for (int h = 0; h < NR; ++h)
+                for (int i = lane; i < nvalid[h]; i += 64) { const int r = fdiv(i, inv_d); g_x[(size_t)row0[h] * a.d + i] = GS(h)[r * a.xld + (i - r * a.d)]; }
+        }
         __syncthreads();
 #undef GS
 #undef GO
@@ -248,6 +288,10 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #undef HINT_CB
 #undef LEVEL_SRC
 #undef BITS_A2
+#undef XSP
+#undef SBP
+#undef G0P
+#undef GSTP
 }
 
 namespace hint {
@@ -255,13 +299,19 @@ namespace hint {
 hipError_t launch_wl_bwd(const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
                          const ChainBlock* chain, int n_chain, const float* x, const float* g_z, const float* g_J,
                          float* g_x, float gz_scale, float gJ_const, hipStream_t stream) {
-    hipLaunchKernelGGL(hint_wl_bwd_kernel, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x,
-                       g_z, g_J, g_x, gz_scale, gJ_const);
+    if (w.nr == 2)
+        hipLaunchKernelGGL(hint_wl_bwd_kernel<2>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x,
+                           g_z, g_J, g_x, gz_scale, gJ_const);
+    else
+        hipLaunchKernelGGL(hint_wl_bwd_kernel<1>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x,
+                           g_z, g_J, g_x, gz_scale, gJ_const);
     return hipGetLastError();
 }
 
 hipError_t set_max_lds_wl_bwd(int bytes) {
-    return hipFuncSetAttribute((const void*)hint_wl_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)hint_wl_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)hint_wl_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace hint

@@ -15,7 +15,7 @@
 
 using namespace hint;
 
-template <bool REV>
+template <bool REV, int NR>
 __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_wl_apply_kernel(
     KArgs a, WlArgs w, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, float* __restrict__ z, float* __restrict__ J, const float* __restrict__ J_in,
@@ -28,11 +28,12 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     const float inv_d = frcp(a.d);
     const Tables T = make_tables(a, lds);
     float* par = lds + w.off_par;               // [2][4 * par_f4]
-    float* slabs = lds + w.off_slab;            // [2][slab_floats]
+    float* slabs = lds + w.off_slab;            // [2][NR][slab_floats]
     float* ptab = lds + w.off_perm;
-    float* priv = lds + w.off_priv + wave * w.priv_stride;      // this wavefront's two lane tiles (a fused permutation ping-pongs)
+    float* priv = lds + w.off_priv + wave * w.priv_stride;      // this wavefront's lane tiles: per row tile two (a fused permutation ping-pongs)
     const int par_floats = 4 * w.par_f4;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
+    const int ngroups = (ntiles + NR - 1) / NR;                  // workgroup-sized pieces of the batch: NR adjacent row tiles
     const int pdd = a.d * a.d;
     const size_t lvl = (size_t)a.B * a.d;
     STAMP_DECL()
@@ -46,33 +47,43 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     }
 #define HINT_CB(I) chain_block(chain, one, I)
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row0 = tile * ROWS;
-        const int nvalid = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
+    for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
+        int row0[NR], nvalid[NR];
+#pragma unroll
+        for (int h = 0; h < NR; ++h) {
+            row0[h] = (tg * NR + h) * ROWS;             // (a pair's second tile may lie behind the batch: no valid rows)
+            const int rows = a.B - row0[h];
+            nvalid[h] = (rows < 0 ? 0 : rows < ROWS ? rows : ROWS) * a.d;
+        }
         int xcur = 0;
         const int xflip = ROWS * a.xld;
-#define XS (priv + xcur)
-#define XO (priv + (xflip - xcur))
-        // every wavefront its own copy of the lane tile
-        for (int i = lane; i < ROWS * a.d; i += 64) {
-            const int r = fdiv(i, inv_d);
-            XS[r * a.xld + (i - r * a.d)] = i < nvalid ? x[(size_t)row0 * a.d + i] : 0.f;
-        }
+#define XS(H) (priv + (H) * w.priv_tile + xcur)
+#define XO(H) (priv + (H) * w.priv_tile + (xflip - xcur))
+        // every wavefront its own copy of the lane tiles
+#pragma unroll
+        for (int h = 0; h < NR; ++h)
+            for (int i = lane; i < ROWS * a.d; i += 64) {
+                const int r = fdiv(i, inv_d);
+                XS(h)[r * a.xld + (i - r * a.d)] = i < nvalid[h] ? x[(size_t)row0[h] * a.d + i] : 0.f;
+            }
         if (!REV && rng_state != nullptr) {
             // x += noise * N(0,1), four values per Philox call, keyed by (seed, step, element group): the same numbers in
             // every wavefront (and as hint_fwd.hip draws them)
             const unsigned long long seed = rng_state[0], step = rng_state[1];
-            for (int q = lane; 4 * q < nvalid; q += 64) {
-                float nz[4];
-                philox_normal4(seed, step, (unsigned)(((size_t)row0 * a.d) / 4 + (size_t)q), nz);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * q + e;
-                    if (i < nvalid) { const int r = fdiv(i, inv_d); XS[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
+            for (int h = 0; h < NR; ++h) {
+                for (int q = lane; 4 * q < nvalid[h]; q += 64) {
+                    float nz[4];
+                    philox_normal4(seed, step, (unsigned)(((size_t)row0[h] * a.d) / 4 + (size_t)q), nz);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q + e;
+                        if (i < nvalid[h]) { const int r = fdiv(i, inv_d); XS(h)[r * a.xld + (i - r * a.d)] += noise * nz[e]; }
+                    }
                 }
+                if (x_noisy != nullptr && wave == 0)
+                    for (int i = lane; i < nvalid[h]; i += 64) { const int r = fdiv(i, inv_d); x_noisy[(size_t)row0[h] * a.d + i] = XS(h)[r * a.xld + (i - r * a.d)]; }
             }
-            if (x_noisy != nullptr && wave == 0)
-                for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); x_noisy[(size_t)row0 * a.d + i] = XS[r * a.xld + (i - r * a.d)]; }
         }
         {   // the first block's thin vectors and biases
             const GBlock b0 = HINT_CB(REV ? n_chain - 1 : 0);
@@ -81,7 +92,9 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             wl_par_commit(pf, par, w, tid, nthreads);
         }
         __syncthreads();                          // meta, permutations, parameters visible
-        float jpart = 0.f;                        // this lane's share of the log-det of batch row m
+        float jpart[NR];                          // this lane's share of the log-det of batch row m
+#pragma unroll
+        for (int h = 0; h < NR; ++h) jpart[h] = 0.f;
         int phase = 0;                            // slab set: alternates per group, across blocks
         int primed = -1;
         f32x4 ring[RING][NEL];
@@ -98,37 +111,50 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             if (!REV && perm != nullptr) {
                 // fused fixed permutation in front of the block (power_hint_8.py:59-62): x' = x W
                 const float* wm = a.perm_lds > 0 ? ptab + bi * pdd : perm;
-                for (int i = lane; i < ROWS * a.d; i += 64) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, wm + j, a.d, a.d);
-                }
+#pragma unroll
+                for (int h = 0; h < NR; ++h)
+                    for (int i = lane; i < ROWS * a.d; i += 64) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        XO(h)[r * a.xld + j] = perm_dot(XS(h) + r * a.xld, wm + j, a.d, a.d);
+                    }
                 xcur = xflip - xcur;
             }
             if (!REV && tape != nullptr && (perm != nullptr || cb > 0) && wave == tsel) {
                 // the block's input exists nowhere else: the top tape slice is what the backward pass starts from
-                float* dst = tape + (size_t)(a.n_levels - 1) * lvl + (size_t)row0 * a.d;
-                for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS[r * a.xld + (i - r * a.d)]; }
+#pragma unroll
+                for (int h = 0; h < NR; ++h) {
+                    float* dst = tape + (size_t)(a.n_levels - 1) * lvl + (size_t)row0[h] * a.d;
+                    for (int i = lane; i < nvalid[h]; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS(h)[r * a.xld + (i - r * a.d)]; }
+                }
             }
             // the next block's thin vectors and biases: in flight across this block's first group
             f32x4 pf[WL_PAR_REGS];
             wl_par_issue(pf, nblk.packed, w, tid, nthreads);
 
             WlCtx c;
-            c.pk = blk.packed; c.pk_next = nblk.packed; c.bits = nullptr; c.bits_next = nullptr;
+            c.pk = blk.packed; c.pk_next = nblk.packed;
             c.recs = a.recs;
             c.par = (const LDS_AS float*)(par + (cb & 1) * par_floats);
-            c.gst = nullptr; c.scratch = nullptr; c.tw = nullptr;
-            c.a2 = train ? blk.actA1 + a.a2_off + (size_t)row0 * a.WT : nullptr;
-            c.bits_out = train ? (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + a.bits_stride + (size_t)(row0 >> 4) * (a.WT >> 4) * 64 : nullptr;
-            c.xld = a.xld; c.gld = 0; c.WT = a.WT; c.train = train; c.first_tile = false;
+            c.scratch = nullptr; c.tw = nullptr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int hh = h < NR ? h : 0;
+                c.bits[h] = nullptr; c.bits_next[h] = nullptr; c.gst[h] = nullptr;
+                // (a pair's second tile may lie behind the batch: its rows of the padded arrays do not exist - nothing of it is kept)
+                const bool tile_ok = train && h < NR && row0[hh] < ntiles * ROWS;
+                c.a2[h] = tile_ok ? blk.actA1 + a.a2_off + (size_t)row0[hh] * a.WT : nullptr;
+                c.bits_out[h] = tile_ok ? (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + a.bits_stride + (size_t)(row0[hh] >> 4) * (a.WT >> 4) * 64 : nullptr;
+            }
+            c.xld = a.xld; c.gld = 0; c.WT = a.WT; c.slab_h = w.slab_floats; c.train = train; c.first_tile = false;
 
             for (int gi = 0; gi < a.n_groups; ++gi) {
                 const int gidx = REV ? a.n_groups - 1 - gi : gi;
                 const GroupU g = load_group(T.groups + gidx);
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
-                float* slab = slabs + (phase & 1) * w.slab_floats;
+                float* slab = slabs + (phase & 1) * NR * w.slab_floats;
                 ++phase;
-                c.xs = (const LDS_AS float*)XS;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) c.xs[h] = (const LDS_AS float*)XS(h < NR ? h : 0);
                 c.slab = (LDS_AS float*)slab;
                 const int sid = (cb * a.n_groups + gi) * 8;
                 (void)sid;
@@ -145,37 +171,43 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                         const int n0 = lds_i32(T.rng + rngb + wave), n1 = lds_i32(T.rng + rngb + wave + 1);
                         if (n0 < n1) rnext = row_begin + n0;
                     }
-                    wl_rows<K_FWD>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
-                                   wrap, lane);
+                    wl_rows<K_FWD, NR>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
+                                       wrap, lane);
                 }
                 STAMP(sid + 1)
-                // ---- coupling (hint.py:79-83) on this wavefront's copy of the lane tile: lane group kq takes the
+                // ---- coupling (hint.py:79-83) on this wavefront's copy of the lane tiles: lane group kq takes the
                 //      transformed lanes kq, kq + 4, ..; batch row m.  What does not depend on the other wavefronts - the
-                //      entry's record and the lane's old value - is fetched in front of the barrier. ----
+                //      entry's record and the lanes' old values - is fetched in front of the barrier. ----
                 const bool has_ent = kq < g.ent_cnt;
                 i32x4 ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + (has_ent ? kq : 0));
-                float xold = XS[m * a.xld + (ent.x & 0xffff)];
+                float xold[NR];
+#pragma unroll
+                for (int h = 0; h < NR; ++h) xold[h] = XS(h)[m * a.xld + (ent.x & 0xffff)];
                 STAMP(sid + 2)
                 lds_barrier();
                 STAMP(sid + 3)
                 for (int e = kq; e < g.ent_cnt; e += 4) {
                     const int xcol = ent.x & 0xffff, sl_ns = ent.y & 0xffff, sl_nt = (int)((unsigned)ent.y >> 16);
-                    const float* sp = slab + ent.z + m * 4;
-                    const float* tp = slab + ent.w + m * 4;
-                    float s = 0.f, t = 0.f;
-                    for (int sl = 0; sl < sl_ns; ++sl) s += sp[sl * 64];
-                    for (int sl = 0; sl < sl_nt; ++sl) t += tp[sl * 64];
-                    const float aa = a.alpha * atanf(s);
-                    // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
-                    if (train && tape != nullptr && wave == tsel && row0 + m < a.B)
-                        tape[(size_t)(a.n_levels + g.level) * lvl + (size_t)(row0 + m) * a.d + xcol] = s;
-                    float xn;
-                    if (!REV) { xn = expf(aa) * xold + t; jpart += aa; }
-                    else      { xn = (xold - t) / expf(aa); jpart -= aa; }
-                    XS[m * a.xld + xcol] = xn;
+#pragma unroll
+                    for (int h = 0; h < NR; ++h) {
+                        const float* sp = slab + h * w.slab_floats + ent.z + m * 4;
+                        const float* tp = slab + h * w.slab_floats + ent.w + m * 4;
+                        float s = 0.f, t = 0.f;
+                        for (int sl = 0; sl < sl_ns; ++sl) s += sp[sl * 64];
+                        for (int sl = 0; sl < sl_nt; ++sl) t += tp[sl * 64];
+                        const float aa = a.alpha * atanf(s);
+                        // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
+                        if (train && tape != nullptr && wave == tsel && row0[h] + m < a.B)
+                            tape[(size_t)(a.n_levels + g.level) * lvl + (size_t)(row0[h] + m) * a.d + xcol] = s;
+                        float xn;
+                        if (!REV) { xn = expf(aa) * xold[h] + t; jpart[h] += aa; }
+                        else      { xn = (xold[h] - t) / expf(aa); jpart[h] -= aa; }
+                        XS(h)[m * a.xld + xcol] = xn;
+                    }
                     if (e + 4 < g.ent_cnt) {        // (more than four transformed lanes in the group: the next entry)
                         ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + e + 4);
-                        xold = XS[m * a.xld + (ent.x & 0xffff)];
+#pragma unroll
+                        for (int h = 0; h < NR; ++h) xold[h] = XS(h)[m * a.xld + (ent.x & 0xffff)];
                     }
                 }
                 STAMP(sid + 4)
@@ -187,39 +219,51 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 }
                 // training: the lane tile as it stands after each level except the root's (tape[level][B][d])
                 if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1 && wave == tsel) {
-                    float* dst = tape + (size_t)g.level * lvl + (size_t)row0 * a.d;
-                    for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS[r * a.xld + (i - r * a.d)]; }
+#pragma unroll
+                    for (int h = 0; h < NR; ++h) {
+                        float* dst = tape + (size_t)g.level * lvl + (size_t)row0[h] * a.d;
+                        for (int i = lane; i < nvalid[h]; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS(h)[r * a.xld + (i - r * a.d)]; }
+                    }
                 }
                 STAMP(sid + 5)
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
                 const float* wm = a.perm_lds > 0 ? ptab + bi * pdd : perm;
-                for (int i = lane; i < ROWS * a.d; i += 64) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
-                }
+#pragma unroll
+                for (int h = 0; h < NR; ++h)
+                    for (int i = lane; i < ROWS * a.d; i += 64) {
+                        const int r = fdiv(i, inv_d), j = i - r * a.d;
+                        XO(h)[r * a.xld + j] = perm_dot(XS(h) + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
+                    }
                 xcur = xflip - xcur;
             }
         }
         // ---- results: every wavefront holds them; the first one writes ----
-        const float jrow = kq_sum(jpart) + ((J_in != nullptr && row0 + m < a.B) ? J_in[row0 + m] : 0.f);
-        if (wave == 0) {
-            for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); z[(size_t)row0 * a.d + i] = XS[r * a.xld + (i - r * a.d)]; }
-            if (kq == 0 && row0 + m < a.B) J[row0 + m] = jrow;
-            if (loss_acc != nullptr) {
-                // partial sums of the two loss terms (train_unconditional.py:128-129): slot[0] += sum 0.5*|z|^2, slot[1] += sum J
-                float zz = 0.f;
-                for (int i = lane; i < nvalid; i += 64) { const int r = fdiv(i, inv_d); const float v = XS[r * a.xld + (i - r * a.d)]; zz += v * v; }
-                float js = (kq == 0 && row0 + m < a.B) ? jrow : 0.f;
-                for (int o = 32; o > 0; o >>= 1) { zz += __shfl_xor(zz, o, 64); js += __shfl_xor(js, o, 64); }
-                if (lane == 0) {
-                    float* slot = loss_acc + 2 * (blockIdx.x & 63);      // 64 slots spread the atomics of the workgroups
-                    atomicAdd(slot, 0.5f * zz);
-                    atomicAdd(slot + 1, js);
+        float zz = 0.f, js = 0.f;
+#pragma unroll
+        for (int h = 0; h < NR; ++h) {
+            const bool rok = row0[h] + m < a.B;
+            const float jrow = kq_sum(jpart[h]) + ((J_in != nullptr && rok) ? J_in[row0[h] + m] : 0.f);
+            if (wave == 0) {
+                for (int i = lane; i < nvalid[h]; i += 64) {
+                    const int r = fdiv(i, inv_d);
+                    const float v = XS(h)[r * a.xld + (i - r * a.d)];
+                    z[(size_t)row0[h] * a.d + i] = v;
+                    zz += v * v;
                 }
+                if (kq == 0 && rok) { J[row0[h] + m] = jrow; js += jrow; }
             }
         }
-        __syncthreads();          // (the parameter buffers and slabs are re-used by the next row tile)
+        if (wave == 0 && loss_acc != nullptr) {
+            // partial sums of the two loss terms (train_unconditional.py:128-129): slot[0] += sum 0.5*|z|^2, slot[1] += sum J
+            for (int o = 32; o > 0; o >>= 1) { zz += __shfl_xor(zz, o, 64); js += __shfl_xor(js, o, 64); }
+            if (lane == 0) {
+                float* slot = loss_acc + 2 * (blockIdx.x & 63);      // 64 slots spread the atomics of the workgroups
+                atomicAdd(slot, 0.5f * zz);
+                atomicAdd(slot + 1, js);
+            }
+        }
+        __syncthreads();          // (the parameter buffers and slabs are re-used by the next row tiles)
 #undef XS
 #undef XO
     }
@@ -233,19 +277,25 @@ hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_by
                            const ChainBlock* chain, int n_chain, const float* x, float* z, float* J, const float* J_in,
                            float* loss_acc, float noise, const unsigned long long* rng_state, float* x_noisy,
                            hipStream_t stream) {
-    if (rev)
-        hipLaunchKernelGGL(hint_wl_apply_kernel<true>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain,
-                           n_chain, x, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr, (float*)nullptr);
-    else
-        hipLaunchKernelGGL(hint_wl_apply_kernel<false>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain,
-                           n_chain, x, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
+    const unsigned long long* no_rng = nullptr;
+    float* no_f = nullptr;
+#define HINT_LAUNCH(REV, NRV, LOSS, NOISE, RNG, XN)                                                                  \
+    hipLaunchKernelGGL((hint_wl_apply_kernel<REV, NRV>), dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, \
+                       n_chain, x, z, J, J_in, LOSS, NOISE, RNG, XN)
+    if (rev) { if (w.nr == 2) HINT_LAUNCH(true, 2, no_f, 0.f, no_rng, no_f); else HINT_LAUNCH(true, 1, no_f, 0.f, no_rng, no_f); }
+    else { if (w.nr == 2) HINT_LAUNCH(false, 2, loss_acc, noise, rng_state, x_noisy); else HINT_LAUNCH(false, 1, loss_acc, noise, rng_state, x_noisy); }
+#undef HINT_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t set_max_lds_wl_apply(int bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)hint_wl_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)hint_wl_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const void* fns[4] = {(const void*)hint_wl_apply_kernel<false, 1>, (const void*)hint_wl_apply_kernel<true, 1>,
+                          (const void*)hint_wl_apply_kernel<false, 2>, (const void*)hint_wl_apply_kernel<true, 2>};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace hint
