@@ -18,7 +18,6 @@
 
 using namespace hint;
 
-constexpr int LV_REGS = 4;      // floats per thread of a prefetched [16, d] tile: 16*d <= LV_REGS * threads
 
 struct LevelPrefetch { float x[LV_REGS], s[LV_REGS]; int nvalid; };
 // (the loads only: nothing here may look at the loaded values - a select on them would be a wait for HBM in the

@@ -31,6 +31,7 @@ constexpr int MAX_NW = HINT_MAX_NW;   // wavefronts per workgroup (plan-time cho
 constexpr int NTT = HINT_NTT;         // fragment tiles per row (hint_rows.hpp)
 constexpr int MAX_RT = 4;       // 16-wide tiles of a unit's output (r <= 64) and of its input (cin <= 64 + dc)
 constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (cin <= 192)
+constexpr int LV_REGS = 4;      // hint_bwd.hip holds a prefetched [16, d] tile in LV_REGS floats per thread: 16 * d <= LV_REGS * threads (the planner picks the wavefront count for it)
 
 // ---------------------------------------------------------------------------------------
 // Packed weights.  The GEMMs read their weight operand from a buffer in MFMA fragment order, zero

@@ -88,7 +88,6 @@ static constexpr int THIN_MFMA_MIN = HINT_THIN_MFMA_MIN;          // thin layers
 static constexpr int THIN_LDS_MAX = 24 * 1024;   // a block's thin-layer vectors are staged in LDS up to this size
 static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
 static constexpr int WS_SLACK = 64;              // floats of slack behind every [Bp][W] array
-static constexpr int LV_REGS = 4;                // hint_bwd.hip: a [16, d] tile in <= 4 registers per thread
 static constexpr int MAX_TAIL = 8;               // hint_rows.hpp: tail accumulators
 static unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only (hint_debug_set_stamp_buffer)
 static thread_local bool g_host_only = false;    // hint_plan_check: build and verify the plan, touch no device
@@ -760,9 +759,15 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return 0;
     }
     // ---- upload ----
-    HIP_TRY(hipGetDevice(&P->device));
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, P->device));
+    {
+        hipError_t e0 = hipGetDevice(&P->device);
+        if (e0 == hipSuccess) e0 = hipGetDeviceProperties(&prop, P->device);
+        if (e0 != hipSuccess) {
+            delete P;
+            return fail("hint_plan_create: no device: %s", hipGetErrorString(e0));
+        }
+    }
     P->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     auto upload = [](void** dst, const void* srcp, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));

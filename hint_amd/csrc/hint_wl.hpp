@@ -164,10 +164,10 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     }
 #define WL_MFMA(J)                                                                                      \
     _Pragma("unroll") for (int h_ = 0; h_ < NR; ++h_) acc[h_][J] = mfma4(ring[S_][J][i_], b4[h_][i_], acc[h_][J]);
-#define WL_STEP(KB, S, LIVE, PK, BITS, NR_, NKB)                                                        \
+#define WL_STEP(KB, S, LIVE, PK, BITS, NR_, NKB, PREFETCH)                                              \
     {                                                                                                   \
         constexpr int S_ = (S);                                                                         \
-        wl_load<KIND, NR>(ring[(S_ + 1) & 1], PK, BITS, NR_, NKB, lo);                                  \
+        if (PREFETCH) wl_load<KIND, NR>(ring[(S_ + 1) & 1], PK, BITS, NR_, NKB, lo);                    \
         WL_PIN()                                                                                        \
         if (LIVE) {                                                                                     \
             f32x4 b4[NR];                                                                               \
@@ -188,14 +188,18 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
         WL_PIN()                                                                                        \
         STAMP(c.sid + 8 + ((KB) & 15))                                                                  \
     }
+    // Steps in pairs (slots 0, 1).  The second step of a pair prefetches k-block k0 + 2 into slot 0 - behind the row's last
+    // k-block that is k-block 0 of the next row (the hand-over).  An odd row ends with a single step on slot 0, which can
+    // only be re-loaded behind its MFMAs: the hand-over then flies across the epilogue and whatever follows the row.
+    // (an odd row pays one dummy step; a single last step that re-loads its own slot behind its MFMAs measured slower)
     const int n1p = (n1 + 1) & ~1;
     int k0 = 0;
     for (; k0 + 2 < n1p; k0 += 2) {
-        WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1)
-        WL_STEP(k0 + 1, 1, true, c.pk, c.bits, cr, k0 + 2)
+        WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1, true)
+        WL_STEP(k0 + 1, 1, true, c.pk, c.bits, cr, k0 + 2, true)
     }
-    WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1)              // (an odd row's step n1: a dummy load of the tile behind)
-    WL_STEP(k0 + 1, 1, k0 + 1 < n1, pkn, bitsn, nr, 0)          // hands the ring to the next row
+    WL_STEP(k0, 0, true, c.pk, c.bits, cr, k0 + 1, true)              // (an odd row's step n1: a dummy load of the tile behind)
+    WL_STEP(k0 + 1, 1, k0 + 1 < n1, pkn, bitsn, nr, 0, true)          // hands the ring to the next row
 #undef WL_STEP
 #undef WL_MFMA
 #undef WL_PIN
@@ -288,17 +292,19 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     STAMP(c.sid + 4)
 }
 
-// The wavefront's rows [r0, r1) of a group.  `primed`: the record whose k-block 0 sits in ring slot 0 (or -1);
-// rnext: the record the last row hands the ring to (the wavefront's first row of the next group, of the next block when
+// The wavefront's rows [r0, r1) of a group.  rnext: the record the last row hands the ring to (the wavefront's first row of the next group, of the next block when
 // other_block) or -1.
+struct WlCarry { int primed; };      // the record whose k-block 0 sits in ring slot 0 (index, or -1)
 template <int KIND, int NR>
-__device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL], int& primed, int r0, int r1, int rnext,
+__device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL], WlCarry& cy, int r0, int r1, int rnext,
                                         bool other_block, int lane) {
     if (r0 >= r1) return;
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
+    // (carrying the handed-over row's record across the element-wise phases instead of fetching it again measured slower:
+    //  sixteen more live scalars)
     RowU cr = decode_rec(load_rec(c.recs, r0));
-    if (primed != r0) wl_load<KIND, NR>(ring[0], c.pk, c.bits, cr, 0, lo);
+    if (cy.primed != r0) wl_load<KIND, NR>(ring[0], c.pk, c.bits, cr, 0, lo);
     const int rlast = rnext >= 0 ? rnext : r1 - 1;
     i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);
     f32x4 part[NR];
@@ -316,7 +322,7 @@ __device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL]
         wl_row<KIND, NR>(c, cr, nr, pkn, bitsn, ring, part, lo, lane);
         cr = nr;
     }
-    primed = rnext;
+    cy.primed = rnext;
 }
 
 // The block's small parameters: 4 * par_f4 floats = [thin blobs: the start of the packed buffer | biases: at bias_src]
@@ -335,6 +341,7 @@ __device__ __forceinline__ void wl_par_commit(const f32x4 (&pf)[WL_PAR_REGS], fl
         const int i = tid + q * nthreads;
         if (i < w.par_f4) ((f32x4*)dst)[i] = pf[q];
     }
+
 }
 
 }  // namespace hint

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             wl_par_commit(pf, par, w, tid, nthreads);
         }
         __syncthreads();
-        int phase = 0, primed = -1;
+        int phase = 0;
+        WlCarry primed; primed.primed = -1;
         f32x4 ring[RING][NEL];
 
         for (int cb = n_chain - 1; cb >= 0; --cb) {
@@ -187,7 +188,13 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
                             for (int h = 0; h < NR; ++h) {
                                 const float* sp = slab_prev + h * w.slab_floats + gv_off + row * 4 + sc_k;
-                                for (int sl = 0; sl < sl_n; ++sl) gval[h] += sp[sl * 64];
+                                for (int sl = 0; sl < sl_n; sl += 4) {       // (four reads in flight, added in slab order)
+                                    float v[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) v[u] = sp[(sl + u < sl_n ? sl + u : sl_n - 1) * 64];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) gval[h] += sl + u < sl_n ? v[u] : 0.f;
+                                }
                             }
                         }
                     }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int h = 0; h < NR; ++h) jpart[h] = 0.f;
         int phase = 0;                            // slab set: alternates per group, across blocks
-        int primed = -1;
+        WlCarry primed; primed.primed = -1;
         f32x4 ring[RING][NEL];
 
         for (int cb = 0; cb < n_chain; ++cb) {
@@ -192,9 +192,22 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     for (int h = 0; h < NR; ++h) {
                         const float* sp = slab + h * w.slab_floats + ent.z + m * 4;
                         const float* tp = slab + h * w.slab_floats + ent.w + m * 4;
+                        // (the slabs of the wavefronts that share the unit, four reads in flight, added in slab order)
                         float s = 0.f, t = 0.f;
-                        for (int sl = 0; sl < sl_ns; ++sl) s += sp[sl * 64];
-                        for (int sl = 0; sl < sl_nt; ++sl) t += tp[sl * 64];
+                        for (int sl = 0; sl < sl_ns; sl += 4) {
+                            float v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = sp[(sl + u < sl_ns ? sl + u : sl_ns - 1) * 64];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) s += sl + u < sl_ns ? v[u] : 0.f;
+                        }
+                        for (int sl = 0; sl < sl_nt; sl += 4) {
+                            float v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = tp[(sl + u < sl_nt ? sl + u : sl_nt - 1) * 64];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) t += sl + u < sl_nt ? v[u] : 0.f;
+                        }
                         const float aa = a.alpha * atanf(s);
                         // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
                         if (train && tape != nullptr && wave == tsel && row0[h] + m < a.B)

@@ -69,7 +69,14 @@ class FlowTrainer:
             # p.data = init_scale*randn_like(p) draws per-process values): rank 0's win; M and V are zero
             src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
             torch.distributed.broadcast(self.P, src=src, group=group)
+            # ... and from the same buffers: the fixed permutations between the blocks and the node permutations of
+            # reshuffle=True trees are drawn per process as well (hint.py:36-39 / power_hint_8.py:59-62), and the
+            # kernels read them - replicas with different matrices would sum gradients of different functions
+            for buf in flow.buffers():
+                if buf.is_cuda and buf.numel() > 0:
+                    torch.distributed.broadcast(buf, src=src, group=group)
             for e in self.engines:
+                e._perm_key = None         # (composed permutations are rebuilt from the received matrices)
                 e.pack()
         self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)   # per-slot partial loss sums
         self._loss_single = self.loss_acc      # (step_many points loss_acc at its last iteration's sums)
@@ -85,6 +92,7 @@ class FlowTrainer:
         # one chain (handle, tapes, workspaces) per batch size: a captured graph keeps raw pointers into
         # its chain's buffers, so a chain is never destroyed while a graph that used it is alive
         self._chains = {}
+        self._ichains = {}          # inference chains (sample()): no tape, no workspace - a few hundred bytes each
         # state of the in-kernel noise generator (hint_chain_forward_noisy): {seed, step}; every rank
         # of a data-parallel job draws its own stream
         if seed is None:
@@ -115,6 +123,9 @@ class FlowTrainer:
             for handle, _, _ in getattr(self, "_chains", {}).values():
                 self.lib.hint_chain_destroy(handle)
             self._chains = {}
+            for handle, _, _ in getattr(self, "_ichains", {}).values():
+                self.lib.hint_chain_destroy(handle)
+            self._ichains = {}
             if getattr(self, "_pack_group", None):
                 self.lib.hint_pack_group_destroy(self._pack_group)
                 self._pack_group = None
@@ -167,6 +178,37 @@ class FlowTrainer:
                     ws[i].data_ptr(), ws_bytes, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
             _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
         self._chains[B] = (handle, key, (tapes, ws, perms))
+        return handle
+
+    def _chain_infer(self, B: int):
+        """the chain handle of the sampling / evaluation direction for batch size B: blocks set WITHOUT tape and
+        workspace (hint_chain_inverse and an inference forward touch neither) - a 100 k-row evaluation batch costs
+        no memory beyond its own rows, and asking for a new batch size never evicts a training chain"""
+        import ctypes as C
+        flow = self.flow
+        front = [flow.perms[i].W if flow.has_perm(i) else None for i in range(flow.n_blocks)]
+        perms = [e.compose_perm(f) for e, f in zip(self.engines, front)]
+        key = (B,) + tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) \
+            + tuple(p.data_ptr() if p is not None else 0 for p in perms)
+        have = self._ichains.get(B)
+        if have is not None and have[1] == key:
+            return have[0]
+        if have is not None:
+            self.lib.hint_chain_destroy(have[0])
+            del self._ichains[B]
+        elif len(self._ichains) >= 32:
+            for b in list(self._ichains):
+                self.lib.hint_chain_destroy(self._ichains[b][0])
+                del self._ichains[b]
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.hint_chain_create(self.engines[0].plan, len(self.engines), B, C.byref(handle)), "hint_chain_create")
+            for i, e in enumerate(self.engines):
+                _lib.check(self.lib.hint_chain_set_block(
+                    handle, i, e.arena.data_ptr(), e.packed.data_ptr(),
+                    perms[i].data_ptr() if perms[i] is not None else None, None, None, 0, None), "hint_chain_set_block")
+            _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
+        self._ichains[B] = (handle, key, perms)
         return handle
 
     # ---- the un-captured step body ----------------------------------------------------
@@ -515,7 +557,7 @@ class FlowTrainer:
             return x, J
         self._check_arenas()
         self._pack_all()
-        chain = self._chain_for(B)
+        chain = self._chain_infer(B)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.hint_chain_inverse(chain, z.data_ptr(), c.data_ptr() if c is not None else None, x.data_ptr(),
                                                    J.data_ptr(), None, torch.cuda.current_stream(self.device).cuda_stream),

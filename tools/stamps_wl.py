@@ -16,7 +16,9 @@ from hint_amd import _lib
 from bench import WORKLOADS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "power_hint_8"
-cfg = WORKLOADS[name]
+cfg = dict(WORKLOADS[name])
+if os.environ.get("WIDTHS"):
+    cfg["c_internal"] = [int(v) for v in os.environ["WIDTHS"].split(",")]
 BLK = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda:0")
 lib = _lib.load()
