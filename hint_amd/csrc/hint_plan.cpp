@@ -32,7 +32,7 @@ hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock&
                       int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                       float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
 hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
-                        int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
+                        int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
                         int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream);
@@ -1103,7 +1103,7 @@ static int grid_for(const hint_plan* P, int B) {
 // part A (row-parallel, bit 0 of `parts`) and part B (weight gradients, bit 1) of the backward pass of
 // one block or a chain
 static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, const ChainBlock* chain_host, int n_chain,
-                        const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
+                        int cb0, const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
                         float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s) {
     if ((parts & 1) && P->wl) {
         KArgs a = make_args(P, B, true);
@@ -1122,7 +1122,7 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
     if (!(parts & 2)) return 0;
     int splits, rows_per_wg;
     wgrad_splits(P, B, n_chain, &splits, &rows_per_wg);
-    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, splits, one, chain, n_chain, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
+    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, splits, one, chain, n_chain, cb0, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
                          rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
                          (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
                          accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),
@@ -1213,7 +1213,7 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
     bind_tape(P, B, const_cast<float*>(tape), &one);
     one.gparams = g_params;
     split_workspace(P, B, workspace, &one);
-    return run_backward(P, one, nullptr, nullptr, 1, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, 3, s);
+    return run_backward(P, one, nullptr, nullptr, 1, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, 3, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1343,8 +1343,24 @@ int hint_chain_backward_parts(const hint_chain* C, const float* x, const float* 
         if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
             return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
     if ((parts & 3) == 0) return fail("hint_chain_backward_parts: parts must select part A (1), part B (2) or both (3)");
-    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
+    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
                         accumulate ? 1 : 0, parts & 3, (hipStream_t)stream);
+}
+
+int hint_chain_wgrad_range(const hint_chain* C, const float* x, const float* c, int32_t accumulate, int32_t block_begin,
+                           int32_t block_end, void* stream) {
+    if (!C) return fail("hint_chain_wgrad_range: null argument");
+    if (!C->committed) return fail("hint_chain_wgrad_range: hint_chain_commit() has not been called");
+    if (block_begin < 0 || block_end > C->n || block_begin >= block_end)
+        return fail("hint_chain_wgrad_range: blocks [%d, %d) out of range (chain has %d)", block_begin, block_end, C->n);
+    const hint_plan* P = C->plan;
+    if (P->dc > 0 && !c) return fail("hint_chain_wgrad_range: plan has dc=%d but c is NULL", P->dc);
+    if (!x && !C->host[0].perm) return fail("hint_chain_wgrad_range: x is NULL but the first block has no fused permutation");
+    for (int i = block_begin; i < block_end; ++i)
+        if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
+            return fail("hint_chain_wgrad_range: block %d was set without workspace / g_params", i);
+    return run_backward(P, C->host[block_begin], C->d_table + block_begin, C->host.data() + block_begin, block_end - block_begin,
+                        block_begin, x, c, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, C->B, accumulate ? 1 : 0, 2, (hipStream_t)stream);
 }
 
 int hint_chain_backward(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,

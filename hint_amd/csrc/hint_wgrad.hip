@@ -51,7 +51,7 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
 
 __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     const WJob* __restrict__ jobs, int n_jobs, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
-    int grid_pb, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
+    int grid_pb, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
     int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c) {
     __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
     __shared__ float bred[DW_WAVES][3][16];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     const int bid = (int)blockIdx.x - cbi * grid_pb;
     if (bid >= n_jobs * splits) return;
     const GBlock blk = chain_block(chain, one, cbi);
-    const bool top = blk.perm != nullptr || cbi > 0;
+    const bool top = blk.perm != nullptr || cbi + cb0 > 0;        // (cb0: position of the launch's first block in its chain)
 
     int jidx, split;
     if ((splits & 7) == 0) {          // XCD-aware: split s lives on XCD s % 8
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const
 namespace hint {
 
 hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
-                        int n_chain, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
+                        int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
                         int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream) {
@@ -342,7 +342,7 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlo
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0)
         hipLaunchKernelGGL(hint_wgrad_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs,
-                           splits, one, chain, grid_pb, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
+                           splits, one, chain, grid_pb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
                            a2_off, bits_a2_off, param_floats, x, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

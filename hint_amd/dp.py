@@ -40,6 +40,17 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> float:
     return 1.0 / world
 
 
+def allreduce_buckets_(flat: torch.Tensor, cuts, group=None) -> float:
+    """the same sum in several collectives: flat[cuts[i]:cuts[i+1]] each (last bucket first - the order in which the
+    backward pass finishes them); element for element the single-bucket result"""
+    edges = [0] + list(cuts) + [flat.numel()]
+    scale = 1.0
+    for a, b in reversed(list(zip(edges[:-1], edges[1:]))):
+        if b > a:
+            scale = allreduce_sum_(flat[a:b], group)
+    return scale
+
+
 def dp_step(local_grads: Callable[[], torch.Tensor], optimizer_step: Callable[[torch.Tensor, float], None],
             group=None) -> None:
     """The step protocol, independent of where the compute runs: local backward into the flat

@@ -107,6 +107,12 @@ class FlowTrainer:
                                       device=dev)
         self._adam_in_graph = False
         self._allreduce_in_graph = False
+        # data-parallel jobs all-reduce the gradient arena in TWO buckets: the second half of the blocks (whose part B runs
+        # first) while the weight gradients of the first half are still being computed ("launch it on a side
+        # stream as soon as backward finishes"); HINT_DP_BUCKETS=1: one bucket behind the whole backward pass
+        nb = len(self.engines)
+        self._split = nb // 2 if (self._chainable and nb >= 2 and os.environ.get("HINT_DP_BUCKETS", "2") != "1") else 0
+        self._side = None
 
     @property
     def lr(self) -> float:
@@ -211,6 +217,12 @@ class FlowTrainer:
         self._ichains[B] = (handle, key, perms)
         return handle
 
+    def _dp_overlap(self) -> bool:
+        """the bucket all-reduces are issued from inside the backward pass (side stream) when the backend is RCCL
+        (stream-ordered, capturable); with gloo (CPU tests, two ranks on one GPU) they follow the backward pass"""
+        return torch.distributed.is_available() and torch.distributed.is_initialized() and self.P.is_cuda and \
+            torch.distributed.get_backend(self.group) == "nccl" and os.environ.get("HINT_DP_OVERLAP", "1") != "0"
+
     # ---- the un-captured step body ----------------------------------------------------
     def _adam_dev(self, scale: float = 1.0):
         """the fused clamp+Adam launch with its step factors read from opt_state (capturable: nothing in
@@ -227,6 +239,7 @@ class FlowTrainer:
         permutations, the running log-det, the two loss sums and the loss gradient are folded
         into the block kernels (hint_block_*_ex)."""
         flow, B = self.flow, x.shape[0]
+        self._reduced = False
         # weights of the previous optimizer step -> MFMA order; the same launch clears the loss sums
         # and advances the noise counter
         self._pack_all(step_prologue=True)
@@ -245,11 +258,36 @@ class FlowTrainer:
                     float(self.noise), self.rng_state.data_ptr() if noisy else None, xn.data_ptr() if noisy else None,
                     stream), "hint_chain_forward_noisy")
                 # dL/dz = z / B and dL/dJ = -1/B: applied inside the kernel
-                _lib.check(self.lib.hint_chain_backward(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
-                                                        None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")
+                dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+                if dist_on and self._split > 0:
+                    # part A, then part B in two launches: blocks [h, n) first - their slice of G is final behind it and its
+                    # all-reduce starts on a side stream (overlap: RCCL only; gloo blocks the host) - then blocks [0, h)
+                    h, n = self._split, len(self.engines)
+                    cut = self.slices[h][0]
+                    _lib.check(self.lib.hint_chain_backward_parts(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
+                                                                  None, 1.0 / B, -1.0 / B, 1, 1, stream), "hint_chain_backward_parts")
+                    _lib.check(self.lib.hint_chain_wgrad_range(chain, xn.data_ptr(), cp, 1, h, n, stream), "hint_chain_wgrad_range")
+                    # (inside a graph capture only when the collectives are captured as well)
+                    overlap = self._dp_overlap() and (self._allreduce_in_graph or not torch.cuda.is_current_stream_capturing())
+                    if overlap:
+                        if self._side is None:
+                            self._side = torch.cuda.Stream(device=self.device)
+                        cur = torch.cuda.current_stream(self.device)
+                        self._side.wait_stream(cur)
+                        with torch.cuda.stream(self._side):
+                            torch.distributed.all_reduce(self.G[cut:], op=torch.distributed.ReduceOp.SUM, group=self.group)
+                    _lib.check(self.lib.hint_chain_wgrad_range(chain, xn.data_ptr(), cp, 1, 0, h, stream), "hint_chain_wgrad_range")
+                    if overlap:
+                        torch.distributed.all_reduce(self.G[:cut], op=torch.distributed.ReduceOp.SUM, group=self.group)
+                        torch.cuda.current_stream(self.device).wait_stream(self._side)
+                        self._reduced = True      # step() must not reduce again
+                else:
+                    _lib.check(self.lib.hint_chain_backward(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
+                                                            None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")
             if with_adam:
-                if self._allreduce_in_graph:      # data-parallel job: the RCCL all-reduce is captured as well
-                    torch.distributed.all_reduce(self.G, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                if self._allreduce_in_graph:      # data-parallel job: the RCCL all-reduces are captured as well
+                    if not getattr(self, "_reduced", False):
+                        torch.distributed.all_reduce(self.G, op=torch.distributed.ReduceOp.SUM, group=self.group)
                     self._adam_dev(1.0 / dp.world_info(self.group)[1])
                 else:
                     self._adam_dev()
@@ -347,7 +385,14 @@ class FlowTrainer:
         if self.use_graph and self._adam_in_graph:
             self.step_count += 1               # the optimizer ran inside the graph
         else:
-            scale = dp.allreduce_sum_(self.G, self.group)
+            if getattr(self, "_reduced", False) and not self.use_graph:
+                scale = 1.0 / dp.world_info(self.group)[1]     # (the eager backward pass issued the bucket all-reduces itself)
+            elif self._split > 0 and torch.distributed.is_available() and torch.distributed.is_initialized():
+                cut = self.slices[self._split][0]              # the same two buckets, one after the other
+                dp.allreduce_sum_(self.G[cut:], self.group)
+                scale = dp.allreduce_sum_(self.G[:cut], self.group)
+            else:
+                scale = dp.allreduce_sum_(self.G, self.group)
             self._optimizer(scale)
         return _LossPair(self)
 

@@ -209,6 +209,12 @@ int hint_chain_backward(const hint_chain* chain, const float* x, const float* c,
 int hint_chain_backward_parts(const hint_chain* chain, const float* x, const float* c, const float* g_z,
                               const float* g_J, float* g_x, float* g_c, float gz_scale, float gJ_const,
                               int32_t accumulate, int32_t parts, void* stream);
+/* Part B (the weight-gradient kernels) for the blocks [block_begin, block_end) of the chain only: a data-parallel
+ * step finishes the gradient of the last blocks first and starts their all-reduce while the rest of part B runs
+ * (one bucket per call; the blocks' gradients are whatever g_params slices hint_chain_set_block was given).  Part A
+ * (hint_chain_backward_parts, parts = 1) must have run. */
+int hint_chain_wgrad_range(const hint_chain* chain, const float* x, const float* c, int32_t accumulate,
+                           int32_t block_begin, int32_t block_end, void* stream);
 /* Sampling direction (train_unconditional.py:152-153, rev=True through the whole graph): the blocks
  * of the chain last to first in ONE launch, x = chain^-1(z), J = J_in - sum of the blocks' log-dets
  * (the reference's rev=True sign, hint.py:83).  x may alias z. */

@@ -55,7 +55,7 @@ def _adam_like_kernel(flow, state, flat_grad, scale, step, lr=3e-3, b1=0.9, b2=0
             off += p.numel()
 
 
-def _run(rank, world, port, xs, out_q):
+def _run(rank, world, port, xs, out_q, buckets=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
@@ -67,8 +67,12 @@ def _run(rank, world, port, xs, out_q):
     for step, x in enumerate(xs, 1):
         lo, hi = dp.shard_rows(x.shape[0], *dp.world_info())
         # 50x gradient so that the +-5 clamp is active and its order w.r.t. the averaging matters
-        dp.dp_step(lambda: 50.0 * _local_flat_grad(flow, x[lo:hi]),
-                   lambda g, scale: _adam_like_kernel(flow, state, g, scale, step))
+        if buckets == 1:
+            dp.dp_step(lambda: 50.0 * _local_flat_grad(flow, x[lo:hi]),
+                       lambda g, scale: _adam_like_kernel(flow, state, g, scale, step))
+        else:       # the trainer's two buckets (second half of the blocks first): the same sums
+            g = 50.0 * _local_flat_grad(flow, x[lo:hi])
+            _adam_like_kernel(flow, state, g, dp.allreduce_buckets_(g, [n // 2]), step)
     out_q.put((rank, _flat([p.detach() for p in flow.parameters()]).numpy()))
     if world > 1:
         dist.destroy_process_group()
@@ -100,6 +104,15 @@ def test_two_rank_step_equals_single_process_global_batch():
         assert p.exitcode == 0
     np.testing.assert_array_equal(results[0], results[1])          # replicas stay identical
     np.testing.assert_allclose(results[0], ref, rtol=2e-5, atol=2e-7)   # == global-batch step
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, xs, q, 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(two[0], results[0])              # two buckets == one bucket, bit for bit
 
 
 def test_shard_rows_and_scale():

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 D, WIDTHS, NBLOCKS, GLOBAL_B, STEPS = 6, [32, 16], 3, 512, 4
 
 
-def _run(rank, world, port, xs, use_graph, out_q):
+def _run(rank, world, port, xs, use_graph, out_q, buckets="2"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["HINT_DP_BUCKETS"] = buckets
     import hint_amd
     from hint_amd import dp
     if world > 1:
@@ -78,6 +79,21 @@ def test_two_rank_gpu_step_equals_single_process_global_batch(use_graph):
     np.testing.assert_allclose(res[0][0], ref, rtol=2e-4, atol=2e-6)       # == global-batch step
     # the mean of the two shards' loss terms is the global batch's
     np.testing.assert_allclose(0.5 * (res[0][1] + res[1][1]), ref_losses, rtol=1e-4, atol=1e-5)
+    # the step above all-reduced the gradient arena in two buckets (part B of the last blocks, bucket, part B of the first
+    # blocks, bucket): bit for bit the single-bucket step
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, xs, use_graph, q, "1")) for r in range(2)]
+    for p in procs:
+        p.start()
+    one = {}
+    for _ in range(2):
+        r, flat, losses = q.get(timeout=240)
+        one[r] = (flat, losses)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(one[0][0], res[0][0])
+    np.testing.assert_array_equal(one[0][1], res[0][1])
 
 
 def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
@@ -133,6 +149,7 @@ def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
     try:
         tr1, got1 = run(copy.deepcopy(flow0))
         assert tr1._allreduce_in_graph and tr1._adam_in_graph
+        assert tr1._split == 1 and tr1._side is not None      # two buckets, the first one's all-reduce on the side stream, captured
         tr2, got2 = run(copy.deepcopy(flow0), break_capture=True)
         assert not tr2._allreduce_in_graph and not tr2._adam_in_graph
         ctr, cgot = run_cond()                               # the conditional two-lane trainer: same capture
