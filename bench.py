@@ -35,6 +35,9 @@ WORKLOADS = {
     # configs/plus_shape/unconditional_hint_4_3_big.py (h = 512: the s and t nets of the wide nodes run one at a time)
     "plus_hint_4_big": dict(d=100, n_blocks=4, c_internal=[512, 256, 128, 64], batch=4096),
 }
+# BASELINE.json configs[3]: configs/plus_shape/conditional_hint_4_full.py:58-94 - the two-lane conditional model (x lane: recursive
+# block d = 100 + ExternalAffineCoupling given y; y lane: AffineCoupling d = 4), 4 blocks, internal width 224, 4096 rows per GPU
+CONDITIONAL = {"conditional_hint_4_full": dict(nx=100, ny=4, n_blocks=4, hidden=224, batch=4096)}
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
 PEAK_HBM_GBS = 8000.0
 
@@ -45,6 +48,133 @@ def flops_per_sample_block(d, widths, dc=0):
     from oracle import hint_oracle as orc   # only for the node list (bench-side bookkeeping)
     nodes = orc.build_nodes(d, [(dc,)] if dc else [], widths)
     return sum(2 * 2 * (n.cin * n.h + n.h * n.h + n.h * n.r) for n in nodes)
+
+
+def tree_nodes(tree, dc):
+    """oracle node list of a hint_amd tree module (any split rule): what the CPU restatement runs on"""
+    from oracle import hint_oracle as orc
+    out = []
+
+    def rec(node, path, off, depth):
+        D, k = node.data_shape[0], node.split_idx
+        out.append(orc.ONode(path, off, D, k, D - k, node.s[0].out_features, k + dc, depth, node.leaf))
+        if not node.leaf:
+            rec(node.upper, path + ".upper", off, depth + 1)
+            rec(node.lower, path + ".lower", off + k, depth + 1)
+
+    rec(tree, "tree", 0, 0)
+    return out
+
+
+def conditional_main(args, name, rank, world, dev, use_dist, dist):
+    """the conditional two-lane model (BASELINE.json configs[3]) on hint_amd.ConditionalFlowTrainer: one step = noise, both
+    lanes forward and backward (train_conditional.py:120-150), one all-reduce of the flat gradient arena, fused clamp + Adam"""
+    import hint_amd
+    from oracle import hint_oracle as orc
+    cfg = CONDITIONAL[name]
+    B = args.batch if args.batch > 0 else cfg["batch"]
+    if args.scaling == "strong":
+        B //= world
+    torch.manual_seed(0)
+    model = hint_amd.ConditionalHintFlow(cfg["nx"], cfg["ny"], cfg["n_blocks"], cfg["hidden"]).to(dev)
+    with torch.no_grad():
+        gw = torch.Generator().manual_seed(0)
+        for p in model.parameters():
+            p.data = (0.005 * torch.randn(p.shape, generator=gw)).to(dev)
+    tr = hint_amd.ConditionalFlowTrainer(model, use_graph=not args.no_graph)
+    gx = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, cfg["nx"], generator=gx).to(dev)
+    y = torch.randn(B, cfg["ny"], generator=gx).to(dev)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l0, l1 = tr.step(x, y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    # algorithmic FLOPs of a step: forward MACs of every subnet (SURVEY §8d's F, summed over the three modules of a
+    # block) x 3 (forward, dX, dW)
+    F = 0
+    mods = []
+    for i in range(cfg["n_blocks"]):
+        mods += [(model.hac_x[i], 0), (model.ac_y_to_x[i], cfg["ny"]), (model.ac_y[i], 0)]
+    for m, dc in mods:
+        F += sum(2 * 2 * (n.cin * n.h + n.h * n.h + n.h * n.r) for n in tree_nodes(m.tree, dc))
+    ms = elapsed / args.steps * 1e3
+    ach = 3.0 * F * B / (ms * 1e-3) / 1e12
+    res = {
+        "metric": "train_samples_per_sec", "value": B * world * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}: two-lane conditional HINT, x d={cfg['nx']}, y d={cfg['ny']}, {cfg['n_blocks']} blocks, "
+                               f"internal width {cfg['hidden']}, batch {B} per GPU (configs/plus_shape/conditional_hint_4_full.py:58-94)",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+        "last_step_loss": float(l0) + float(l1),
+        "roofline": {"bound": "mfma", "kernel": "whole step (the x lane's hint_apply / hint_bwd / hint_wgrad launches dominate)",
+                     "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "algorithmic_flops_per_step": 3.0 * F * B,
+                     "timing": "wall clock of the timed steps (graph replays), all launches of a step"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # the same step on the host cores: oracle blocks (plain torch CPU ops + autograd) composed as the two-lane graph, a
+        # bounded sample of 256 rows
+        Bc = min(B, 256)
+        P = [{k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()} for m, _ in mods]
+        nodes = [tree_nodes(m.tree, dc) for m, dc in mods]
+        Wy = [model.perm_y[i].W.cpu() if i > 0 else None for i in range(cfg["n_blocks"])]
+        Wx = [model.perm_x[i].W.cpu() if i > 0 else None for i in range(cfg["n_blocks"])]
+        opt = torch.optim.Adam([p for d_ in P for p in d_.values()], lr=0.01 * 3e-2, betas=(0.9, 0.95), eps=1e-4, weight_decay=1.86e-5)
+        xc, yc = x[:Bc].cpu(), y[:Bc].cpu()
+
+        def cpu_step():
+            opt.zero_grad()
+            xo, yo = xc + 0.01 * torch.randn_like(xc), yc
+            J = 0
+            for i in range(cfg["n_blocks"]):
+                if i > 0:
+                    yo = yo @ Wy[i]; xo = xo @ Wx[i]
+                xo, j = orc.block_apply(nodes[3 * i], P[3 * i], xo, [], clamp=4.0); J = J + j
+                xo, j = orc.block_apply(nodes[3 * i + 1], P[3 * i + 1], xo, [yo], clamp=5.0); J = J + j
+                yo, j = orc.block_apply(nodes[3 * i + 2], P[3 * i + 2], yo, [], clamp=5.0); J = J + j
+            loss = 0.5 * (torch.cat([xo, yo], -1) ** 2).sum(1).mean() - J.mean()
+            loss.backward()
+            for d_ in P:
+                for p in d_.values():
+                    p.grad.clamp_(-5.0, 5.0)
+            opt.step()
+
+        ncores = os.cpu_count() or 1
+        best_nt, best_t = None, float("inf")
+        for nt in sorted({min(ncores, v) for v in (8, 16, 32)}):
+            torch.set_num_threads(nt)
+            cpu_step()
+            t1 = time.perf_counter(); cpu_step(); t = time.perf_counter() - t1
+            if t < best_t:
+                best_nt, best_t = nt, t
+        torch.set_num_threads(best_nt)
+        n = int(max(2, min(50, 12.0 / best_t)))
+        t1 = time.perf_counter()
+        for _ in range(n):
+            cpu_step()
+        dt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=Bc * n / dt, unit="samples/s", cores=best_nt, kind="port",
+                                   sample=f"{n} training steps of {Bc} rows ({dt:.1f} s): oracle blocks composed as the two-lane graph "
+                                          f"(torch CPU ops + autograd + clamp + Adam), best of 8/16/32 threads = {best_nt}; host has {ncores} cores")
+        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(cfg, budget_s=12.0, max_steps=200):
@@ -140,7 +270,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="power_hint_8", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="power_hint_8", choices=sorted(WORKLOADS) + sorted(CONDITIONAL))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="training iterations per hipGraph replay (FlowTrainer.step_many; one process only)")
@@ -170,6 +300,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import hint_amd
+    if args.workload in CONDITIONAL:
+        conditional_main(args, args.workload, rank, world, dev, use_dist, dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     cfg = WORKLOADS[args.workload]
     d, B = cfg["d"], cfg["batch"]
     if args.batch > 0:

@@ -133,6 +133,8 @@ static inline int plan_lds(const hint_plan* P, bool backward, int nr = 1) {
     return backward ? P->lds_bwd : P->lds_fwd;
 }
 
+static int env_int(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; }
+
 // A row of a group's GEMM phase: up to NTT adjacent fragment tiles [tb, tb + ntt) of one unit
 struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
 
@@ -921,7 +923,6 @@ void hint_plan_destroy(hint_plan* P) {
 //                                              8-wavefront plan; beyond two pairs per CU on the 4-wavefront plan (two workgroups
 //                                              per CU) when that fits the LDS twice
 //                                              other plans: the 4-wavefront plan, one tile per workgroup
-static int env_int(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; }
 static const hint_plan* variant(const hint_plan* P, int B) {
     if (!P || !P->alt4) return P;
     const int ntiles = (B + ROWS - 1) / ROWS;
@@ -968,6 +969,8 @@ static void wgrad_splits(const hint_plan* P, int B, int n_chain, int* splits_out
     const long Bp = rows_padded(B);
     int splits = 8;
     while ((long)splits * P->n_wjobs * n_chain < (long)P->num_cu && Bp / (splits * 2) >= 128) splits *= 2;
+    static const int forced = env_int("HINT_DW_SPLITS");          // (experiments)
+    if (forced > 0 && Bp / forced >= 16) splits = forced;
     int rows_per_wg = (int)((Bp + splits - 1) / splits);
     rows_per_wg = (rows_per_wg + 15) / 16 * 16;
     if ((long)rows_per_wg * (splits - 1) >= Bp)   // tiny batches: fewer, non-empty splits
