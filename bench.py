@@ -377,7 +377,7 @@ def main():
     if trainer._chainable:
         from hint_amd import _lib
         lib = _lib.load()
-        chain = trainer._chain_for(B)
+        chain = trainer._chain_infer(B)
         zi = torch.randn(B, d, device=dev)
         xi, Ji = torch.empty_like(zi), torch.empty(B, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
@@ -413,34 +413,42 @@ def main():
                        "input": "batch resident in the captured step's input buffer (no per-step copy)"},
             "mean_nll_nats": nll, "last_step_loss": loss_last,
         }
+        # HBM traffic per launch comes from rocprofv3 PMC passes run separately (tools/refresh_profiles.sh); it is NOT measured in
+        # this process - the line says where it was read from
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        pmc_file = "profiles/r03_pmc_summary.json"
+        pmc_path = os.path.join(ROOT, pmc_file)
         if os.path.exists(pmc_path) and args.workload == "power_hint_8" and B == 4096:
             try:
                 pmc = json.load(open(pmc_path))
             except Exception:
                 pmc = {}
 
-        def hbm_traffic(kernel):           # PMC bytes per launch (profiles/README.md), the 8-block launches of this workload
-            return next((v.get("hbm_bytes_per_launch") for k, v in pmc.items() if k.startswith(kernel)), None)
+        def pmc_entry(kernel):             # rocprof's kernel names carry the template arguments: match on the prefix
+            return next((v for k, v in pmc.items() if k.replace(" ", "").startswith(kernel.replace(" ", ""))), None)
 
         def mfma_roofline(kernel, us, flops):
             ach = flops / (us * 1e-6) / 1e12
+            e = pmc_entry(kernel) or {}
+            issued = e.get("sq", {}).get("SQ_INSTS_MFMA")
             return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": hbm_traffic(kernel), "avg_launch_us": us,
-                    "algorithmic_flops_per_launch": flops, "blocks_per_launch": nb}
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": e.get("hbm_bytes_per_launch"),
+                    "traffic_source": f"{pmc_file} (rocprofv3 --pmc passes of tools/steps.py, builder-run; not measured in this run)" if e else None,
+                    "avg_launch_us": us, "timing": "HIP events around the launch inside 20 un-captured training steps (FlowTrainer.timed_step); "
+                                                   "`value` is timed on graph replays",
+                    "algorithmic_flops_per_launch": flops, "blocks_per_launch": nb,
+                    "mfma_issued_over_algorithmic": (issued * 2048.0 / flops) if issued else None}
 
         if in_step:
+            fwd_name, bwd_name = trainer.kernel_names(B)
             # dominant kernel = the row-parallel backward kernel, one launch for all blocks: dX through the three
-            # layers of every subnet = the forward's MAC count F per sample and block (the hidden activations come
-            # from the forward's tape, nothing is recomputed; the weight gradients are the wgrad kernel's)
-            res["roofline"] = mfma_roofline("hint_bwd_kernel", in_step["hint_bwd_kernel"], F * B * nb)
+            # layers of every subnet = the forward's MAC count F per sample and block (the hidden activations' signs come
+            # from the forward's tape; the weight gradients are the wgrad kernel's, the first-layer ones - not counted - its own)
+            res["roofline"] = mfma_roofline(bwd_name, in_step[bwd_name], F * B * nb)
             res["kernels_in_step_us"] = in_step       # inside real (un-captured) steps, HIP events between the launches
-            fwd_us = in_step["hint_apply_kernel<fwd>"]
+            fwd_us = in_step[fwd_name]
             wg_us = in_step.get("hint_wgrad_kernel+hint_wreduce_kernel")
-            res["roofline_other_kernels"] = {
-                "hint_apply_kernel<fwd>": mfma_roofline("hint_apply_kernel<false>", fwd_us, F * B * nb),
-            }
+            res["roofline_other_kernels"] = {fwd_name: mfma_roofline(fwd_name, fwd_us, F * B * nb)}
             if wg_us:
                 # weight gradients: every weight matrix once, 2*B MACs per element -> F per sample and block as well
                 res["roofline_other_kernels"]["hint_wgrad_kernel+hint_wreduce_kernel"] = mfma_roofline("hint_wgrad_kernel", wg_us, F * B * nb)
@@ -451,9 +459,13 @@ def main():
             res["hbm_view_fwd_kernel"] = {"achieved": hb, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hb / PEAK_HBM_GBS,
                                           "bytes_per_launch": hbytes}
         if inv_us is not None:
+            inv_name = trainer.kernel_names(B)[0].replace("<false", "<true")
             res["inverse_samples_per_sec"] = B * world / (inv_us * 1e-6)
-            res["inverse"] = {"what": f"x = f^-1(z), {nb} blocks in one launch of hint_apply_kernel<true>, {B} rows per GPU, no tape",
-                              "avg_launch_us": inv_us, "roofline": mfma_roofline("hint_apply_kernel<true>", inv_us, F * B * nb)}
+            res["inverse"] = {"what": f"x = f^-1(z), {nb} blocks in one launch of {inv_name}, {B} rows per GPU, no tape",
+                              "avg_launch_us": inv_us, "roofline": mfma_roofline(inv_name, inv_us, F * B * nb)}
+        if world > 1:
+            res["config"]["rows_per_gpu"] = B
+            res["config"]["gradient_allreduce"] = "two buckets (second half of the blocks first, beside the rest of part B), RCCL, captured in the step graph"
         if legs:
             res["kernels_hot_loop_us"] = legs         # back-to-back loops of one kernel (caches hot)
         if world == 1 and not args.no_cpu_baseline:

@@ -39,6 +39,7 @@ _PROTOS = {
     "hint_plan_tape_floats": (C.c_int64, [C.c_void_p, C.c_int32]),
     "hint_plan_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "hint_plan_lds_bytes": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "hint_plan_describe": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "hint_block_pack": (C.c_int, [C.c_void_p] * 4),
     "hint_pack_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.c_int32, C.POINTER(C.c_void_p)]),

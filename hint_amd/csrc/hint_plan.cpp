@@ -649,7 +649,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             wb.priv_tile = r4(4 * ROWS * P->xld + r4(ROWS * P->gld)); wb.priv_stride = nr * wb.priv_tile + 256;
             wf.off_misc = wf.off_priv + nw * wf.priv_stride; wb.off_misc = wb.off_priv + nw * wb.priv_stride;
             wf.off_perm = wf.off_misc + 32; wb.off_perm = wb.off_misc + 32;
-            const bool fits = 4 * wf.off_perm <= LDS_LIMIT && 4 * wb.off_perm <= LDS_LIMIT;
+            const bool fits = 4 * wf.off_perm <= LDS_LIMIT && 4 * wb.off_perm <= LDS_LIMIT && (nr == 1 || par_f4 <= WL_PAR_REGS2 * 64 * nw);
             if (nr == 1 && !fits) { wl = false; break; }
             if (fits) { P->wl_f[nr - 1] = wf; P->wl_b[nr - 1] = wb; if (nr == 2) P->wl_nr2 = 1; }
         }
@@ -1002,6 +1002,13 @@ size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
 
 int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
     return P ? plan_lds(P, backward != 0) : -1;
+}
+
+int hint_plan_describe(const hint_plan* P, int32_t B, int32_t* out) {
+    if (!P || !out || B < 0) return fail("hint_plan_describe: bad arguments");
+    P = variant(P, B);
+    out[0] = P->wl; out[1] = wl_nr_for(P, B); out[2] = P->nw; out[3] = P->lean;
+    return 0;
 }
 
 // LDS bytes of the launch: the plan's, plus the chain's permutation matrices when they fit behind it

@@ -326,18 +326,20 @@ __device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL]
 }
 
 // The block's small parameters: 4 * par_f4 floats = [thin blobs: the start of the packed buffer | biases: at bias_src]
-__device__ __forceinline__ void wl_par_issue(f32x4 (&pf)[WL_PAR_REGS], const GLOBAL_AS float* packed, const WlArgs& w, int tid, int nthreads) {
+template <int PR>
+__device__ __forceinline__ void wl_par_issue(f32x4 (&pf)[PR], const GLOBAL_AS float* packed, const WlArgs& w, int tid, int nthreads) {
 #pragma unroll
-    for (int q = 0; q < WL_PAR_REGS; ++q) {
+    for (int q = 0; q < PR; ++q) {
         int i = tid + q * nthreads;
         i = i < w.par_f4 ? i : w.par_f4 - 1;
         const int f = 4 * i;
         pf[q] = *(const GLOBAL_AS f32x4*)(packed + (f < w.par_bias ? f : f - w.par_bias + w.bias_src));
     }
 }
-__device__ __forceinline__ void wl_par_commit(const f32x4 (&pf)[WL_PAR_REGS], float* dst, const WlArgs& w, int tid, int nthreads) {
+template <int PR>
+__device__ __forceinline__ void wl_par_commit(const f32x4 (&pf)[PR], float* dst, const WlArgs& w, int tid, int nthreads) {
 #pragma unroll
-    for (int q = 0; q < WL_PAR_REGS; ++q) {
+    for (int q = 0; q < PR; ++q) {
         const int i = tid + q * nthreads;
         if (i < w.par_f4) ((f32x4*)dst)[i] = pf[q];
     }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
             for (int h = 0; h < NR; ++h)
                 wl_level_issue(lp[h], LEVEL_SRC(tape, top, a.n_levels - 1), tape + (size_t)(2 * a.n_levels - 1) * lvl, a.d, rowt[h], nvalid[h], lane);
-            f32x4 pf[WL_PAR_REGS];
+            f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
             wl_par_issue(pf, lb.packed, w, tid, nthreads);
 #pragma unroll
             for (int h = 0; h < NR; ++h) wl_level_commit(lp[h], XSP(h), SBP(h), a.xld, a.d, nvalid[h], lane);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             const bool top = perm != nullptr || cb > 0;
             float* wsGST = (float*)blk.wsGST;
             const int tsel = wi & (a.nw - 1);                          // the wavefront that writes this block's g_st rows
-            f32x4 pf[WL_PAR_REGS];
+            f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
             wl_par_issue(pf, nblk.packed, w, tid, nthreads);
 
             WlCtx c;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
         }
         {   // the first block's thin vectors and biases
             const GBlock b0 = HINT_CB(REV ? n_chain - 1 : 0);
-            f32x4 pf[WL_PAR_REGS];
+            f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
             wl_par_issue(pf, b0.packed, w, tid, nthreads);
             wl_par_commit(pf, par, w, tid, nthreads);
         }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 }
             }
             // the next block's thin vectors and biases: in flight across this block's first group
-            f32x4 pf[WL_PAR_REGS];
+            f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
             wl_par_issue(pf, nblk.packed, w, tid, nthreads);
 
             WlCtx c;

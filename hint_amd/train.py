@@ -524,9 +524,19 @@ class FlowTrainer:
             self._optimizer(scale)
             ev[5].record()
         torch.cuda.synchronize(self.device)
-        names = ["hint_pack_many_kernel", "hint_apply_kernel<fwd>", "hint_bwd_kernel", "hint_wgrad_kernel+hint_wreduce_kernel",
-                 "allreduce+hint_adam_kernel"]
+        fwd, bwd = self.kernel_names(B)
+        names = ["hint_pack_many_kernel", fwd, bwd, "hint_wgrad_kernel+hint_wreduce_kernel", "allreduce+hint_adam_kernel"]
         return {n: ev[i].elapsed_time(ev[i + 1]) * 1e3 for i, n in enumerate(names)}
+
+    def kernel_names(self, B: int):
+        """(forward, backward part A) kernel of a batch of B rows as rocprof prints them: the wave-local kernels for narrow
+        trees (template arguments: direction / row tiles per workgroup), the general ones otherwise"""
+        import ctypes as C
+        info = (C.c_int32 * 4)()
+        _lib.check(self.lib.hint_plan_describe(self.engines[0].plan, B, info), "hint_plan_describe")
+        if info[0]:
+            return f"hint_wl_apply_kernel<false, {info[1]}>", f"hint_wl_bwd_kernel<{info[1]}>"
+        return "hint_apply_kernel<false>", "hint_bwd_kernel"
 
     def _capture(self, x, c):
         self._check_arenas()
