@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/refresh_profiles.sh left under gpurun_out/<round>/ into profiles/ (tracked).
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 O=gpurun_out/$R
 tail -1 $O/bench.json | python -m json.tool > profiles/${R}_bench.json

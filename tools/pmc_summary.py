@@ -17,7 +17,7 @@ res = {}
 for k, v in agg.items():
     if "hint_" not in k:
         continue
-    e = {"launches": max(len(x) for x in v.values()), "blocks_per_launch": nblk if any(t in k for t in ("hint_apply", "hint_bwd", "hint_wgrad", "hint_wreduce")) else None}
+    e = {"launches": max(len(x) for x in v.values()), "blocks_per_launch": nblk if any(t in k for t in ("hint_apply", "hint_bwd", "hint_wl_", "hint_wgrad", "hint_wreduce")) else None}
     sq = {}
     for c, x in sorted(v.items()):
         m = sum(x) / len(x)
