@@ -1015,7 +1015,9 @@ int hint_plan_describe(const hint_plan* P, int32_t B, int32_t* out) {
 static int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a) {
     const long extra = (long)n_blocks * P->d * P->d * (long)sizeof(float);
     a->perm_lds = 0;
-    if (!any_perm || extra > PERM_LDS_MAX || lds_plan + extra > LDS_LIMIT) return lds_plan;
+    const int cap = env_int("HINT_PERM_LDS_MAX") > 0 ? env_int("HINT_PERM_LDS_MAX") : PERM_LDS_MAX;
+    if (env_int("HINT_PLAN_DUMP")) fprintf(stderr, "[hint plan] lds %d + perms %ld (cap %d)\n", lds_plan, extra, cap);
+    if (!any_perm || extra > cap || lds_plan + extra > LDS_LIMIT) return lds_plan;
     a->perm_lds = lds_plan / (int)sizeof(float);
     return lds_plan + (int)extra;
 }

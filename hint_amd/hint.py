@@ -280,9 +280,10 @@ class _Engine:
 
 
 class _CouplingFn(torch.autograd.Function):
-    """autograd node of one block forward.  Saves the input and the tape the forward kernel wrote (the lanes
-    at every level, s, and the hidden activations a1, a2 of every subnet); the backward kernels read the
-    activations from it, nothing is recomputed."""
+    """autograd node of one block forward.  Saves the input and the tape the forward kernel wrote: the lanes at
+    every level, the coupling arguments s, the hidden activations a2 of every subnet and one sign byte per four
+    activations (a1 as well, except for the subnets with at most four inputs and outputs: theirs is rebuilt from the
+    level's lanes where it is needed - DESIGN.md section 3).  The backward kernels never re-run the h x h layers."""
 
     @staticmethod
     def forward(ctx, engine, x, c, *params):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HINT_AMD_ABI_VERSION 2
+#define HINT_AMD_ABI_VERSION 3
 
 /* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
  * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],

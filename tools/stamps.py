@@ -15,13 +15,15 @@ from hint_amd import _lib
 from bench import WORKLOADS
 
 name = sys.argv[1] if len(sys.argv) > 1 else "power_hint_8"
-cfg = WORKLOADS[name]
+cfg = dict(WORKLOADS[name])
+if os.environ.get("WIDTHS"):
+    cfg["c_internal"] = [int(v) for v in os.environ["WIDTHS"].split(",")]     # (what-if runs: same tree, other hidden widths)
 BLK = int(sys.argv[2]) if len(sys.argv) > 2 else 3          # which block of the chain to print (512 stamp ids: block * groups < 32)
 dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.hint_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 torch.manual_seed(0)
-flow = hint_amd.HintFlow(cfg["d"], cfg["n_blocks"], cfg["c_internal"]).to(dev)
+flow = hint_amd.HintFlow(cfg["d"], cfg["n_blocks"], cfg["c_internal"], max_splits=int(os.environ.get("MAX_SPLITS", "-1"))).to(dev)
 with torch.no_grad():
     for p in flow.parameters():
         p.data = 0.005 * torch.randn_like(p)
@@ -75,6 +77,9 @@ def show(title, st, per_block, labels, blocks):
         te = st[:nw, (cb + 1) * per_block * 16] if (cb + 1) * per_block * 16 < IDS else None
         if te is not None and (te != 0).all():
             print(f"   blk {cb} total {int((te - tb).max())} cycles")
+            tl = st[:nw, ((cb + 1) * per_block - 1) * 16 + 6]
+            if (tl != 0).all():
+                print(f"   blk {cb} -> {cb + 1} between the blocks (permutation, tape, thin vectors) " + " ".join(f"{int(v):6d}" for v in te - tl))
 
 
 lib.hint_debug_set_stamp_buffer(buf.data_ptr())

@@ -14,7 +14,7 @@ if os.environ.get("WIDTHS"):
 B = int(sys.argv[3]) if len(sys.argv) > 3 else cfg["batch"]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-flow = hint_amd.HintFlow(cfg["d"], cfg["n_blocks"], cfg["c_internal"]).to(dev)
+flow = hint_amd.HintFlow(cfg["d"], cfg["n_blocks"], cfg["c_internal"], max_splits=int(os.environ.get("MAX_SPLITS", "-1"))).to(dev)     # (what-if runs: a shallower tree)
 with torch.no_grad():
     for p in flow.parameters():
         p.data = (0.005 * torch.randn(p.shape)).to(dev)
