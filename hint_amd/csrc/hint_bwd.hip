@@ -309,25 +309,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 STAMP(sid + 6)
             }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
-                // 16*d <= LV_REGS*threads (plan check): the products are held in registers across the
-                // barrier so that they can go back into gs
-                float pacc[LV_REGS];
-#pragma unroll
-                for (int q = 0; q < LV_REGS; ++q) {
-                    const int i = tid + q * nthreads;
-                    float acc = 0.f;
-                    if (i < ROWS * a.d) {
-                        const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        acc = perm_dot(gs + r * a.xld, perm + (size_t)j * a.d, 1, a.d);
-                    }
-                    pacc[q] = acc;
-                }
+                // (in place: the products wait in registers for the barrier)
+                f32x4 pacc[PERM_TQ];
+                perm_mfma<true>(pacc, gs, a.xld, perm, a.d, wave, a.nw, lane);
                 __syncthreads();
-#pragma unroll
-                for (int q = 0; q < LV_REGS; ++q) {
-                    const int i = tid + q * nthreads;
-                    if (i < ROWS * a.d) { const int r = fdiv(i, inv_d); gs[r * a.xld + (i - r * a.d)] = pacc[q]; }
-                }
+                perm_store(pacc, gs, a.xld, a.d, wave, a.nw, lane);
                 __syncthreads();
             }
         }

@@ -123,6 +123,55 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
     }
 }
 
+// The fixed d x d matrix between two blocks on the matrix pipe: out[r][j] = sum_k in[r][k] * M(k, j) for the 16 rows of a
+// lane tile, M(k, j) = w[k*d + j] (x' = x W) or, TRANS, w[j*d + k] (x = x' W^T; g_x = g_x' W^T).  Transposed like every
+// product here: out^T[16 columns x 16 rows] = M^T * in^T, k in steps of four; wavefront `wave` of nw takes the 16-column
+// tiles wave, wave + nw (d <= 128 on >= 4 wavefronts: at most PERM_TQ of them).  Eight steps' operands are fetched at a
+// time.  (As scalar code - 16 d outputs of d FMAs with two loads each, perm_dot below - the product cost a d = 43 block 7 k
+// cycles per kernel; k ascends in both, so the sums agree.)
+constexpr int PERM_TQ = 2;
+template <bool TRANS>
+__device__ __forceinline__ void perm_mfma(f32x4 (&acc)[PERM_TQ], const float* in, int ld, const float* __restrict__ w, int d,
+                                          int wave, int nw, int lane) {
+    const int m = lane & 15, kq = lane >> 4;
+    const int nt = (d + 15) >> 4, ns = (d + 3) >> 2;
+#pragma unroll
+    for (int q = 0; q < PERM_TQ; ++q) {
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int t = wave + q * nw;
+        if (t >= nt) continue;
+        const int j = 16 * t + m;
+        const bool jok = j < d;
+        const int jc = jok ? j : d - 1;
+        constexpr int U = 8;
+        for (int s0 = 0; s0 < ns; s0 += U) {
+            float av[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = 4 * (s0 + u) + kq;
+                const int kc = k < d ? k : d - 1;
+                av[u] = TRANS ? w[(size_t)jc * d + kc] : w[(size_t)kc * d + jc];
+                bv[u] = in[m * ld + kc];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = 4 * (s0 + u) + kq < d;
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32((ok && jok) ? av[u] : 0.f, ok ? bv[u] : 0.f, acc[q], 0, 0, 0);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void perm_store(const f32x4 (&acc)[PERM_TQ], float* out, int ld, int d, int wave, int nw, int lane) {
+    const int m = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < PERM_TQ; ++q) {
+        const int j0 = 16 * (wave + q * nw) + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (j0 + i < d) out[m * ld + j0 + i] = acc[q][i];
+    }
+}
+
 // sum_k row[k] * w[k * stride]: a row of the lane tile times a column (or row) of a fixed d x d matrix
 __device__ __forceinline__ float perm_dot(const float* row, const float* __restrict__ w, int stride, int d) {
     float acc = 0.f;

@@ -89,10 +89,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
                 const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
-                for (int i = tid; i < ROWS * a.d; i += nthreads) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, w + j, a.d, a.d);
-                }
+                f32x4 pacc[PERM_TQ];
+                perm_mfma<false>(pacc, XS, a.xld, w, a.d, wave, a.nw, lane);
+                perm_store(pacc, XO, a.xld, a.d, wave, a.nw, lane);
                 xcur = xflip - xcur;
                 __syncthreads();
                 if (tape != nullptr)      // the permuted input is what the backward pass starts from
@@ -215,10 +214,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
                 const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
-                for (int i = tid; i < ROWS * a.d; i += nthreads) {
-                    const int r = fdiv(i, inv_d), j = i - r * a.d;
-                    XO[r * a.xld + j] = perm_dot(XS + r * a.xld, w + (size_t)j * a.d, 1, a.d);
-                }
+                f32x4 pacc[PERM_TQ];
+                perm_mfma<true>(pacc, XS, a.xld, w, a.d, wave, a.nw, lane);
+                perm_store(pacc, XO, a.xld, a.d, wave, a.nw, lane);
                 xcur = xflip - xcur;
                 __syncthreads();
             }

@@ -203,7 +203,16 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc += w[k] * vin[k];
         if (STAGED) {
-            for (int k = 4; k < K; ++k) acc += vec(k) * input(k);
+            // (eight inputs' reads in flight at a time: one at a time is a dependent LDS round trip per input)
+            constexpr int TL = 8;
+            for (int k = 4; k < K; k += TL) {
+                f32x4 wv[TL];
+                float iv[TL];
+#pragma unroll
+                for (int u = 0; u < TL; ++u) { const int kk = k + u < K ? k + u : K - 1; wv[u] = vec(kk); iv[u] = input(kk); }
+#pragma unroll
+                for (int u = 0; u < TL; ++u) acc += wv[u] * (k + u < K ? iv[u] : 0.f);
+            }
         } else {
             // (from global memory: TB vectors in flight at a time; the padding terms add w * 0)
             constexpr int TB = 8;
