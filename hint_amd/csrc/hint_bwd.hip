@@ -14,7 +14,7 @@
 //       the accumulator the K-split partial of g_v into the row's slab            (run_rows<K_BWD>)
 // All weight gradients are batch reductions of (g1, g2, g_st) against (v, a1, a2): part B
 // (hint_wgrad.hip) computes them from the arrays written here.
-#include "hint_rows.hpp"
+#include "hint_sub.hpp"
 
 using namespace hint;
 
@@ -107,11 +107,12 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             const float* tape = (const float*)blk.tape;
             const bool top = perm != nullptr || cb > 0;
             float* wsGST = (float*)blk.wsGST;
+            if (a.n_sub > 0) sub_par_stage(a, blk.packed, lds, tid, nthreads);     // (the subtree groups' thin vectors and biases)
             if (a.thin_lds > 0) {
                 const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
                 for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
-                __syncthreads();
             }
+            if (a.thin_lds > 0 || a.n_sub > 0) __syncthreads();
             PhaseCtx pc;
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
@@ -258,6 +259,22 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 lds_barrier();
                 STAMP(sid + 2)
                 if (tail_only) break;
+                if (slot < a.n_sub) {
+                    // ---- the subtree groups: from here down every wavefront runs its own subtrees, wave-local synchronisation
+                    //      only (hint_sub.hpp); the root level of the block before is fetched meanwhile ----
+                    LevelPrefetch lq;
+                    if (cb > 0) {
+                        const float* ntape = (const float*)nblk.tape;
+                        const bool ntop = nblk.perm != nullptr || cb > 1;
+                        level_issue(lq, LEVEL_SRC(ntape, ntop, a.n_levels - 1), ntape + (size_t)(2 * a.n_levels - 1) * lvl, a.d, row0, a.B, tid, nthreads);
+                    }
+                    sub_bwd(a, T, lds, blk, x, top, xs, sb, gs, gst, gj, row0, tile == (int)blockIdx.x, wave, lane, sid);
+                    STAMP(sid + 3)
+                    lds_barrier();
+                    STAMP(sid + 4)
+                    if (cb > 0) { level_commit(lq, xs, sb, a.xld, a.d, tid, nthreads); lds_barrier(); }
+                    break;
+                }
 
                 // ---- lane tile and s of the level the NEXT boundary needs: global -> registers now,
                 //      registers -> LDS at the end of Q3 (xs / sb are not read by the GEMM phases) ----
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 pc.slab = (LDS_AS float*)(abuf + g.ntiles * 256 * (1 + g.staged));
                 {
                     int rnext = -1;         // the last row hands the weight ring to the wavefront's first row of the next group
-                    if (slot > 0) {
+                    if (slot > a.n_sub) {
                         const GroupU gn = load_group(T.groups + (slot - 1));
                         const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);

@@ -103,7 +103,8 @@ struct Group {
     int32_t level_last, gcol0, gcols, lop_begin;        // first / number of [ST] columns; LaneOp[d] of the boundary in front of the group (backward)
     int32_t level_first, tile_begin, wcol0, lean;       // tile_begin: the group's first thin record (both directions); wcol0: column of its first tile in the [Bp][WT] arrays;
                                                         // lean: bit 0 = every unit of the group has 1..4 inputs, <= 4 outputs, no condition: its a1 / g2 tiles are never stored;
-                                                        // bit 1 = the group's output tiles (a2 / g1) are staged in LDS and streamed out by the element-wise phase
+                                                        // bit 1 = the group's output tiles (a2 / g1) are staged in LDS and streamed out by the element-wise phase;
+                                                        // bit 2 = subtree group (hint_sub.hpp): rng's second half holds the wavefronts' ranges in the group's entry list
 };
 static_assert(sizeof(Group) == 64, "Group must be 4 x 16 bytes");
 
@@ -213,6 +214,15 @@ struct KArgs {
     float alpha;
     int32_t B;
     unsigned long long* stamps;    // diagnostic builds (-DHINT_STAMPS): where workgroup 0 leaves its phase stamps; else unused
+    // subtree groups (hint_sub.hpp): the block's deepest n_sub groups (Group::lean bit 2) run one subtree per wavefront,
+    // wave-local synchronisation only
+    int32_t n_sub;                 // 0: none
+    int32_t sub_par, sub_par_f4;   // LDS float offset of their staged parameters [forward vectors | backward vectors | biases]; float4 of it
+    int32_t sub_pf, sub_pb;        // floats of the first two segments
+    int32_t sub_bsrc, sub_bias_src;    // float offsets of the backward vectors / the biases in the packed buffer (the forward vectors start it)
+    int32_t sub_slab;              // LDS float offset of their slabs (this direction)
+    int32_t sub_misc;              // LDS float offset: forward nw x 16 log-det partials; backward one 256-float scratch tile per wavefront
+    int32_t sub_cols;              // index in the ranges table of the wavefronts' lane bounds: four per wavefront (hint_plan.cpp)
 };
 
 // ---- wave-local plans (hint_wl.hpp) ----

@@ -13,7 +13,7 @@
 //       fragment tiles in LDS), the second layer on the matrix pipe and, straight from its
 //       accumulator, the third layer's K-split partial (+ bias) into the row's slab   (run_rows<K_FWD>)
 //   P3  coupling: s, t = sum of the slabs; l' = exp(a) l + t; log-det
-#include "hint_rows.hpp"
+#include "hint_sub.hpp"
 
 using namespace hint;
 
@@ -100,13 +100,14 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 // inner block of a chain without a permutation: its input exists nowhere else
                 store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
             }
+            if (a.n_sub > 0) sub_par_stage(a, blk.packed, lds, tid, nthreads);     // (the subtree groups' thin vectors and biases)
             if (a.thin_lds > 0) {
                 // this block's thin-layer weights (vector layout, a few KiB) into LDS: every wavefront re-reads them
                 // for its units, and all workgroups asking L2 for the same few lines at once is what made them slow
                 const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
                 for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
-                __syncthreads();
             }
+            if (a.thin_lds > 0 || a.n_sub > 0) __syncthreads();
             PhaseCtx pc;
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
@@ -122,13 +123,23 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             // the weight stream of a group's first row starts one phase early: before the block's first group
             // here, for the later ones right behind the rows of the group before (i.e. across its coupling phase)
             f32x4 ring[RING][NEL];
+            const int ngen = a.n_groups - a.n_sub;        // the general groups: [n_sub, n_groups)
+            if (!REV && a.n_sub > 0) {
+                // the deepest levels: one subtree per wavefront, no workgroup barrier until they rejoin (hint_sub.hpp)
+                STAMP((cb * a.n_groups + ngen) * 16 + 0)
+                sub_apply<false>(a, T, lds, blk, XS, train, row0, wave, lane, (cb * a.n_groups + ngen) * 16);
+                STAMP((cb * a.n_groups + ngen) * 16 + 1)
+                lds_barrier();
+                STAMP((cb * a.n_groups + ngen) * 16 + 2)
+                if (tid < ROWS) { float t = 0.f; for (int w = 0; w < a.nw; ++w) t += (lds + a.sub_misc)[w * ROWS + tid]; jac[tid] += t; }
+            }
             {
-                const GroupU g0 = load_group(T.groups + (REV ? a.n_groups - 1 : 0));
+                const GroupU g0 = load_group(T.groups + (REV ? a.n_groups - 1 : a.n_sub));
                 const LDS_AS int32_t* rng0 = T.rng + g0.rng_begin;
                 rows_begin<K_FWD>(pc, ring, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
             }
-            for (int gi = 0; gi < a.n_groups; ++gi) {
-                const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : gi));
+            for (int gi = 0; gi < ngen; ++gi) {
+                const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : a.n_sub + gi));
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 pc.xs = (const LDS_AS float*)(XS);
                 pc.wcol0 = g.wcol0;
@@ -153,8 +164,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 //      first row of the next group (its loads fly across the coupling and thin phases) ----
                 {
                     int rnext = -1;
-                    if (gi + 1 < a.n_groups) {
-                        const GroupU gn = load_group(T.groups + (REV ? a.n_groups - 2 - gi : gi + 1));
+                    if (gi + 1 < ngen) {
+                        const GroupU gn = load_group(T.groups + (REV ? a.n_groups - 2 - gi : a.n_sub + gi + 1));
                         const LDS_AS int32_t* rngn = T.rng + gn.rng_begin;
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
                         if (n0 < n1) rnext = gn.row_begin + n0;
@@ -211,6 +222,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 // the backward pass sees bit-identical subnet inputs (tape[level][B][d])
                 if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1)
                     store_tile(tape + (size_t)g.level * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
+            }
+            if (REV && a.n_sub > 0) {
+                sub_apply<true>(a, T, lds, blk, XS, false, row0, wave, lane, (cb * a.n_groups + ngen) * 16);
+                lds_barrier();
+                if (tid < ROWS) { float t = 0.f; for (int w = 0; w < a.nw; ++w) t += (lds + a.sub_misc)[w * ROWS + tid]; jac[tid] += t; }
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
                 const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;

@@ -110,6 +110,10 @@ struct hint_plan {
     // wave-local plans (hint_wl.hpp): narrow trees run on hint_wl_apply_kernel / hint_wl_bwd_kernel
     int wl = 0, wl_nr2 = 0;     // wl_nr2: two 16-row tiles per workgroup on one weight stream fit the LDS as well
     WlArgs wl_f[2]{}, wl_b[2]{};  // [nr - 1]
+    // subtree groups (hint_sub.hpp): the deepest n_sub groups run one subtree per wavefront
+    int n_sub = 0, sub_pf = 0, sub_pb = 0, sub_pbias = 0, sub_bsrc = 0, sub_cols = 0;
+    int sub_slab_f = 0, sub_slab_b = 0;                 // floats of their slabs
+    int sub_lds_f[3] = {0, 0, 0}, sub_lds_b[3] = {0, 0, 0};   // LDS float offsets: slabs, staged parameters, misc
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
@@ -410,6 +414,68 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int i = 0; i < n_nodes; ++i)
             if (nodes[i].depth == dep) order.push_back(i);
 
+    // ---- subtree groups (hint_sub.hpp): from depth sub_depth down every subnet is lean (1..4 inputs, at most 4 outputs, no
+    //      condition) and at most two tiles wide, every level is one group, and the level sub_depth has enough nodes to
+    //      occupy half the wavefronts: those levels run one subtree per wavefront without workgroup barriers.  Not for
+    //      trees the wave-local kernels take whole.  node_wave: the wavefront of a node of these levels.  (HINT_SUB=0: never) ----
+    int sub_depth = max_depth + 1;
+    std::vector<int> node_wave(n_nodes, -1);
+    std::vector<int32_t> sub_cols_v;
+    {
+        bool all_lean = dc == 0;
+        for (int i = 0; i < n_nodes; ++i)
+            if (nodes[i].k < 1 || nodes[i].k > 4 || nodes[i].r < 1 || nodes[i].r > 4) all_lean = false;
+        bool on = dc == 0 && !(all_lean && d <= 4 * WL_LV);
+        if (const char* e = std::getenv("HINT_SUB")) on = on && std::atoi(e) != 0;
+        if (const char* e = std::getenv("HINT_LEAN")) on = on && std::atoi(e) != 0;
+        if (const char* e = std::getenv("HINT_FUSE_DW1")) on = on && std::atoi(e) != 0;
+        for (int dep = max_depth; on && dep >= 1; --dep) {
+            int cnt = 0, tiles = 0, last_off = -1;
+            bool ok = true;
+            for (int i = 0; i < n_nodes; ++i) {
+                if (nodes[i].depth != dep) continue;
+                const hint_node_desc& n = nodes[i];
+                if (n.k < 1 || n.k > 4 || n.r < 1 || n.r > 4 || n.h > 16 || n.off <= last_off || n.off > 255) ok = false;
+                last_off = n.off; ++cnt; tiles += 2 * cdiv(n.h, 16);
+            }
+            if (!ok || tiles > tile_cap || 2 * cnt < nw) break;
+            sub_depth = dep;
+        }
+        if (sub_depth <= max_depth) {
+            std::vector<int> roots;
+            for (int i = 0; i < n_nodes; ++i) if (nodes[i].depth == sub_depth) roots.push_back(i);
+            const int nsub = (int)roots.size();
+            for (int i = 0; i < n_nodes; ++i) {
+                if (nodes[i].depth < sub_depth) continue;
+                for (int j = 0; j < nsub; ++j) {
+                    const hint_node_desc& rt = nodes[roots[j]];
+                    if (nodes[i].off >= rt.off && nodes[i].off < rt.off + rt.D) node_wave[i] = nsub >= nw ? (int)((long)j * nw / nsub) : j;
+                }
+                if (node_wave[i] < 0) { sub_depth = max_depth + 1; break; }
+            }
+            // per wavefront four lane bounds: [0], [1] = the lanes of its subtrees (what it reads of a level's tape slices: at most
+            // 16 lanes, hint_sub.hpp SUB_LV); [2], [3] = the lanes it stores to the tape after a level - the subtrees' lanes and
+            // the lanes up to the next wavefront's (a partition of all d lanes: a tape slice is the whole lane tile)
+            std::vector<int> lo(nw, d), hi(nw, 0);
+            for (int j = 0; j < nsub; ++j) {
+                const int w = node_wave[roots[j]];
+                lo[w] = std::min(lo[w], nodes[roots[j]].off); hi[w] = std::max(hi[w], nodes[roots[j]].off + nodes[roots[j]].D);
+            }
+            int prev = 0;
+            for (int w = 0; w < nw && sub_depth <= max_depth; ++w) {
+                const bool has = lo[w] < hi[w];
+                if (has && hi[w] - lo[w] > 16) { sub_depth = max_depth + 1; break; }
+                int next = d;                  // where the next wavefront with subtrees starts
+                for (int v = w + 1; v < nw; ++v) if (lo[v] < hi[v]) { next = lo[v]; break; }
+                sub_cols_v.push_back(has ? lo[w] : 0); sub_cols_v.push_back(has ? hi[w] : 0);
+                sub_cols_v.push_back(has ? prev : 0); sub_cols_v.push_back(has ? next : 0);
+                if (has) prev = next;
+            }
+        }
+    }
+    int sub_off3 = 0, sub_offv = 0;       // the subtree groups' slabs: one area for all of them (the wavefronts are at different levels at any time)
+    bool sub_closed = false;             // the first group above the subtree levels has been seen
+
     std::vector<Group> groups;
     std::vector<Unit> units;
     std::vector<int> unit_node;       // node index (into `nodes`) of every unit
@@ -472,6 +538,13 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         g.gcol0 = gcol;
         g.wcol0 = wcol;
         const int depth = nodes[order[pos]].depth;
+        const bool sub = depth >= sub_depth;
+        if (!sub && !sub_closed) {
+            // what the subtree groups read from LDS: the vectors and biases of their units open the two blobs and the bias region
+            sub_closed = true;
+            P->n_sub = (int)groups.size();
+            P->sub_pf = (int)cur_f; P->sub_pb = (int)(cur_b - blob_f_pad); P->sub_pbias = (int)bmap.size(); P->sub_bsrc = (int)blob_f_pad;
+        }
         int tiles = 0;
         const size_t first_pos = pos;
         while (pos < order.size() && nodes[order[pos]].depth == depth) {
@@ -507,7 +580,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 u.wcol = wcol; u.tile0 = tiles; u.gcol = gcol;
                 u.NT = NT; u.KB1 = KB1; u.RT = RT; u.cin = cin;
                 u.ku = n.k; u.r = n.r; u.xoff = n.off; u.h = n.h;
-                u.lcol = gcol - g.gcol0;
+                u.lcol = sub ? gcol : gcol - g.gcol0;       // (subtree groups: one coupling-gradient buffer for all of them)
                 units.push_back(u);
                 unit_node.push_back(order[pos]);
                 wcol += 16 * NT; gcol += pad4(n.r); tiles += NT;
@@ -521,7 +594,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         g.level_first = (first_pos == 0 || nodes[order[first_pos - 1]].depth != depth) ? 1 : 0;
         g.level_last = (pos >= order.size() || nodes[order[pos]].depth != depth) ? 1 : 0;
         P->abuf_tiles = std::max(P->abuf_tiles, tiles);
-        P->gld = std::max(P->gld, g.gcols | 1);
+        P->gld = std::max(P->gld, (sub ? gcol : g.gcols) | 1);      // (subtree groups: the columns of all of them side by side)
 
         std::vector<Row> rows = split_rows(units, g, nw);
         int off3 = 0, offv = 0;
@@ -538,11 +611,23 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                                          kpb | ((b3 >= 0 ? b3 + nt * u.RT + 1 : 0) << 8)});
             }
         }
-        std::vector<std::vector<int>> wave_rows = deal_rows(rows, nw, unit_waves);
-        assign_slabs(units, g, rows, wave_rows, &off3, &offv);
-        grp_slab_f.push_back(off3); grp_slab_b.push_back(offv);
-        P->slab_fwd = std::max(P->slab_fwd, off3);
-        P->slab_bwd = std::max(P->slab_bwd, offv);
+        std::vector<std::vector<int>> wave_rows;
+        if (sub) {
+            // every row of a node goes to the wavefront that owns the node's subtree
+            wave_rows.assign(nw, std::vector<int>());
+            for (size_t ri = 0; ri < rows.size(); ++ri) wave_rows[node_wave[unit_node[rows[ri].unit]]].push_back((int)ri);
+            off3 = sub_off3; offv = sub_offv;
+            assign_slabs(units, g, rows, wave_rows, &off3, &offv);
+            sub_off3 = off3; sub_offv = offv;
+            grp_slab_f.push_back(0); grp_slab_b.push_back(0);
+            g.lean |= 4;                   // (bits 0, 1 are set further down)
+        } else {
+            wave_rows = deal_rows(rows, nw, unit_waves);
+            assign_slabs(units, g, rows, wave_rows, &off3, &offv);
+            grp_slab_f.push_back(off3); grp_slab_b.push_back(offv);
+            P->slab_fwd = std::max(P->slab_fwd, off3);
+            P->slab_bwd = std::max(P->slab_bwd, offv);
+        }
         if (std::getenv("HINT_PLAN_DUMP")) {
             std::fprintf(stderr, "[hint plan] group %d level %d: %d units, %d tiles, %d rows\n", (int)groups.size(), g.level,
                          g.unit_end - g.unit_begin, tiles, (int)rows.size());
@@ -559,12 +644,28 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             delete P;
             return fail("hint_plan_create: a node is too wide for the row records (h <= 4080, cin <= 255)");
         }
-        for (int w = 0; w <= nw; ++w) rng.push_back((int)((long)tiles * w / nw));
+        if (sub) {
+            // the wavefronts' ranges in the group's entry list (entries are emitted in unit order = wavefront order)
+            int acc = 0;
+            for (int w = 0; w < nw; ++w) {
+                rng.push_back(acc);
+                for (int ui = g.unit_begin; ui < g.unit_end; ui += 2)
+                    if (node_wave[unit_node[ui]] == w) acc += units[ui].r;
+            }
+            rng.push_back(acc);
+        } else {
+            for (int w = 0; w <= nw; ++w) rng.push_back((int)((long)tiles * w / nw));
+        }
 
         g.ent_begin = (int)ents.size();
         emit_coupling_entries(units, g, &ents);
         g.ent_cnt = (int)ents.size() - g.ent_begin;
         groups.push_back(g);
+    }
+    if (P->n_sub > 0) {
+        P->sub_cols = (int)rng.size();
+        rng.insert(rng.end(), sub_cols_v.begin(), sub_cols_v.end());
+        P->sub_slab_f = sub_off3; P->sub_slab_b = sub_offv;
     }
     P->n_groups = (int)groups.size();
     P->n_units = (int)units.size();
@@ -587,6 +688,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<char> unit_lean(units.size(), 0);
     P->lean = 1;
     for (Group& g : groups) {
+        const int sub_bit = g.lean & 4;
         g.lean = lean_on ? 1 : 0;
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
             const hint_node_desc& n = nodes[unit_node[ui]];
@@ -594,6 +696,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)g.lean;
         if (!g.lean) P->lean = 0;
+        g.lean |= sub_bit;
     }
     // ---- wave-local plans (hint_wl.hpp): every group lean, narrow lane tile, the block's thin vectors and biases small
     //      enough to ride in LDS twice (HINT_WL=0: never) ----
@@ -618,13 +721,21 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->rng_off = P->ents_off + (int)ents_bytes;
     P->lops_off = lops_lds ? P->rng_off + (int)rng_bytes : -1;
     P->meta_bytes = P->rng_off + (int)rng_bytes + (int)lops_bytes;
-    const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + ROWS + MAX_NW);
-    const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld);   // (+ the lanes of the level before: first-layer gradients)
+    // (subtree groups: their slabs, their staged parameters, nw x 16 log-det partials / nw scratch tiles)
+    const int sub_par_floats = P->sub_pf + P->sub_pb + P->sub_pbias;
+    const int sub_f_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_f) + sub_par_floats + nw * 16) : 0;
+    const int sub_b_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_b) + sub_par_floats + nw * 256) : 0;
+    const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + ROWS + MAX_NW) + sub_f_bytes;
+    const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld) + sub_b_bytes;   // (+ the lanes of the level before: first-layer gradients)
     P->stage_out = 0;
     std::vector<char> unit_fused(units.size(), 0);       // lean and staged: dW1 / db1 come from the backward kernel
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         Group& g = groups[gi];
         const long tiles = (long)g.ntiles * 256;
+        if (g.lean & 4) {          // subtree group: no fragment tiles in LDS at all; dW1 / db1 come from the backward kernel
+            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_fused[ui] = 1;
+            continue;
+        }
         const bool staged = fixed_f + 4 * (2 * tiles + grp_slab_f[gi]) <= LDS_LIMIT && fixed_b + 4 * (2 * tiles + grp_slab_b[gi]) <= LDS_LIMIT;
         if (staged) { g.lean |= 2; P->stage_out = 1; }
         P->region_fwd = std::max(P->region_fwd, (int)(tiles * (staged ? 2 : 1) + grp_slab_f[gi]));
@@ -659,6 +770,9 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         std::fprintf(stderr, "[hint plan] nw %d: wave-local %d (lean %d, par_f4 %d of %d, LDS fwd %d bwd %d bytes; row pairs %d: %d / %d)\n", nw, P->wl,
                      P->lean, par_f4, WL_PAR_REGS * 64 * nw, 4 * P->wl_f[0].off_perm, 4 * P->wl_b[0].off_perm, P->wl_nr2,
                      4 * P->wl_f[1].off_perm, 4 * P->wl_b[1].off_perm);
+    if (std::getenv("HINT_PLAN_DUMP") && P->n_sub > 0)
+        std::fprintf(stderr, "[hint plan] nw %d: %d subtree groups (depth >= %d): parameters %d + %d + %d floats, slabs %d / %d floats\n", nw,
+                     P->n_sub, sub_depth, P->sub_pf, P->sub_pb, P->sub_pbias, P->sub_slab_f, P->sub_slab_b);
     if (wl) std::fill(unit_fused.begin(), unit_fused.end(), 1);      // dW1 / db1 always come from the backward kernel
     // the first-layer gradients of the fused units: [h][4 or 8] per unit (cin input gradients, then the bias gradient) in a slab per
     // workgroup of the backward kernel; Unit::bias1 (not needed by the kernels otherwise) = the unit's offset in it
@@ -704,6 +818,23 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
     }
 
+    if (P->n_sub > 0 && !wl) {
+        // the subtree groups' rows run on the wave-local row engine: thin vectors and biases relative to the staged
+        // parameters [forward vectors | backward vectors | biases] of their units
+        const int nrec = groups[P->n_sub].row_begin;
+        for (int i = 0; i < nrec; ++i) {
+            const Unit& u = units[rec_unit[i]];
+            RowRec& f = recs_f[i];
+            RowRec& b = recs_b[i];
+            f.aux = P->sub_pf + P->sub_pb + (f.aux - (int)packed); f.bias3 = P->sub_pf + P->sub_pb + (f.bias3 - (int)packed);
+            f.thin_b = P->sub_pf + u.w3v + f.tb * 64;
+            b.thin_w = P->sub_pf + u.w3v;
+            b.thin_b = u.w1v + b.tb * 80;
+            b.p1 = u.bias1 + b.tb * 16 * (u.cin < 4 ? 4 : 8);
+            b.p2 = u.cin | (u.xoff << 8) | (u.h << 16);
+        }
+    }
+
     std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
 
     // ---- meta blob staged in LDS by the kernels ----
@@ -713,15 +844,19 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
     if (lops_lds) std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
-    P->lds_fwd = fixed_f + 4 * P->region_fwd;
-    P->lds_bwd = fixed_b + 4 * P->region_bwd;
-    P->lds_fwd = (P->lds_fwd + 15) / 16 * 16;
-    P->lds_bwd = (P->lds_bwd + 15) / 16 * 16;
+    P->lds_fwd = (fixed_f - sub_f_bytes + 4 * P->region_fwd + 15) / 16 * 16;
+    P->lds_bwd = (fixed_b - sub_b_bytes + 4 * P->region_bwd + 15) / 16 * 16;
+    if (P->n_sub > 0) {
+        P->sub_lds_f[0] = P->lds_fwd / 4; P->sub_lds_f[1] = P->sub_lds_f[0] + pad4(P->sub_slab_f); P->sub_lds_f[2] = P->sub_lds_f[1] + sub_par_floats;
+        P->sub_lds_b[0] = P->lds_bwd / 4; P->sub_lds_b[1] = P->sub_lds_b[0] + pad4(P->sub_slab_b); P->sub_lds_b[2] = P->sub_lds_b[1] + sub_par_floats;
+        P->lds_fwd += sub_f_bytes; P->lds_bwd += sub_b_bytes;
+    }
     // the thin blobs ride in LDS (staged once per block) when they are small
     P->thin_f_off = 0; P->thin_f_floats = (int)((blob_f + 3) / 4 * 4);
     P->thin_b_off = (int)blob_f_pad; P->thin_b_floats = (int)((blob_b + 3) / 4 * 4);
     // (small ones always; larger ones when the block's LDS already rules out two workgroups per CU, or still allows them)
     auto stage_thin = [&](int lds, int blob) {
+        if (const char* e = std::getenv("HINT_THIN_LDS")) if (std::atoi(e) == 0) return false;     // (diagnostic: read the thin vectors from L2)
         return lds + blob <= LDS_LIMIT && (blob <= THIN_LDS_MAX || lds > LDS_LIMIT / 2 || lds + blob <= LDS_LIMIT / 2);
     };
     if (stage_thin(P->lds_fwd, P->thin_f_floats * 4)) {
@@ -1038,6 +1173,13 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.fuse_dw1 = P->fuse_dw1; a.tw_floats = P->tw_floats; a.thin_slab_off = ws_thin_off(P, B);
     a.lean = P->lean; a.a2_off = P->lean ? 0 : a.act_stride; a.bits_off = (P->lean ? 1 : 2) * a.act_stride;
     a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
+    a.n_sub = P->n_sub;
+    if (P->n_sub > 0) {
+        const int* o = backward ? P->sub_lds_b : P->sub_lds_f;
+        a.sub_slab = o[0]; a.sub_par = o[1]; a.sub_misc = o[2];
+        a.sub_pf = P->sub_pf; a.sub_pb = P->sub_pb; a.sub_par_f4 = (P->sub_pf + P->sub_pb + P->sub_pbias) / 4;
+        a.sub_bsrc = P->sub_bsrc; a.sub_bias_src = (int)P->packed_floats; a.sub_cols = P->sub_cols;
+    }
     return a;
 }
 

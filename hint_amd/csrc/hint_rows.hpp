@@ -210,6 +210,7 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
                 float iv[TL];
 #pragma unroll
                 for (int u = 0; u < TL; ++u) { const int kk = k + u < K ? k + u : K - 1; wv[u] = vec(kk); iv[u] = input(kk); }
+                __builtin_amdgcn_sched_barrier(0);      // (all sixteen reads first: hipcc otherwise waits for them pair by pair)
 #pragma unroll
                 for (int u = 0; u < TL; ++u) acc += wv[u] * (k + u < K ? iv[u] : 0.f);
             }

@@ -1,0 +1,343 @@
+// Subtree groups of the general block kernels (hint_fwd.hip / hint_bwd.hip): the deepest levels of a wide tree, where
+// every subnet has 1..4 inputs, at most 4 outputs and at most two 16-feature tiles (MINIBOONE d = 43: the 24 nodes of
+// depth 3 and 4, hidden width 8), cost a general group's three phases and barriers per level although a level is a few
+// hundred FMAs - and below some depth the subtrees never exchange anything (hint.py:70-73,85-88: the children of a node
+// are independent).  So from that depth down (Group::lean bit 2, hint_plan.cpp) every wavefront takes whole subtrees and
+// runs their levels back to back on the wave-local row engine (hint_wl.hpp: first layer on the fly, h x h on the matrix
+// pipe, thin product behind it by FMAs + lane-group fold) with WAVE-local synchronisation only: its rows, then the
+// coupling of its own nodes on its own columns of the workgroup's lane tile, then the next level; one workgroup barrier
+// where the subtrees rejoin the general groups.  Tape, workspace and packed weights are unchanged (part B does not know).
+#pragma once
+#include "hint_wl.hpp"
+
+namespace hint {
+
+// LDS traffic of one wavefront is processed in order: what it wrote it can read back; the compiler must not reorder
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// the subtree units' thin vectors and biases -> LDS: [forward vectors | backward vectors | biases] (what the rows' records index)
+__device__ __forceinline__ void sub_par_stage(const KArgs& a, const GLOBAL_AS float* packed, float* lds, int tid, int nthreads) {
+    f32x4* dst = (f32x4*)(lds + a.sub_par);
+    for (int i = tid; i < a.sub_par_f4; i += nthreads) {
+        const int f = 4 * i;
+        const int src = f < a.sub_pf ? f : f < a.sub_pf + a.sub_pb ? f - a.sub_pf + a.sub_bsrc : f - a.sub_pf - a.sub_pb + a.sub_bias_src;
+        dst[i] = *(const GLOBAL_AS f32x4*)(packed + src);
+    }
+}
+
+// a global load the compiler's wait-count bookkeeping does not see, and the wait that belongs to it
+__device__ __forceinline__ void sub_load(f32x4& dst, const GLOBAL_AS f32x4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sub_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+// One subnet of a subtree node, forward: one 16-feature tile, one k-block (h <= 16).  w: the W2 fragment tile (in registers
+// since the node before); returns the lane's four hidden activations a2 (features 4 kq .. +3 of batch row m) and leaves the
+// third layer's outputs of row m in out (every lane of the row holds all four).  The expressions are hint_wl.hpp's
+// (wl_layer1, bias last, dot4 + fold): the backward pass recomputes relu'(a1) from them.
+__device__ __forceinline__ f32x4 sub_unit_fwd(const LDS_AS f32x4* par4, const KArgs& a, const UnitU& u, const f32x4 w, const float (&vin)[4],
+                                              int kq, f32x4& out) {
+    const f32x4 a1 = relu4(wl_layer1(par4 + (u.w1v >> 2) + kq, vin));
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma4(w[i], a1[i], acc);
+    const int pb = (a.sub_pf + a.sub_pb - a.sub_bias_src) >> 2;          // (float4 index of packed-buffer bias offset 0 inside the staged parameters)
+    const f32x4 v = relu4(acc + par4[pb + (u.bias2 >> 2) + kq]);
+    const LDS_AS f32x4* w3 = par4 + ((a.sub_pf + u.w3v) >> 2) + kq;
+    f32x4 p;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) p[o] = dot4(w3[4 * o], v, 0.f);
+    if (kq == 0) p += par4[pb + (u.bias3 >> 2)];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) out[o] = kq_sum(p[o]);
+    return v;
+}
+
+// Forward (children first) / inverse (parents first) through the subtree groups; xs: the workgroup's lane tile.  Per node:
+// both subnets (their W2 tiles were fetched while the node before ran), then the coupling (hint.py:79-83) of the node's r
+// lanes by the lane groups kq < r - everything between the lane tile and the lane tile stays in registers.  Leaves the
+// wavefront's share of the log-det of batch row l & 15 in LDS (a.sub_misc + 16 wave + row); the caller adds them up behind
+// its barrier.
+template <bool REV>
+__device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float* lds, const GBlock& blk, float* xs, bool train,
+                                          int row0, int wave, int lane, int sid) {
+    (void)sid;
+    const int m = lane & 15, kq = lane >> 4;
+    const LDS_AS f32x4* par4 = (const LDS_AS f32x4*)(lds + a.sub_par);
+    float* tape = (float*)blk.tape;
+    const size_t lvl = (size_t)a.B * a.d;
+    GLOBAL_AS float* a2 = train ? blk.actA1 + a.a2_off + (size_t)row0 * a.WT : nullptr;
+    GLOBAL_AS uint8_t* bits = train ? (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + a.bits_stride + (size_t)(row0 >> 4) * (a.WT >> 4) * 64 : nullptr;
+    const GLOBAL_AS f32x4* wt = (const GLOBAL_AS f32x4*)blk.packed + lane;        // fragment tile t: wt[64 t]
+    const int c0 = lds_i32(T.rng + a.sub_cols + 4 * wave + 2), c1 = lds_i32(T.rng + a.sub_cols + 4 * wave + 3);     // the lanes it stores to the tape
+    const int wc = c1 - c0;
+    const float inv_wc = frcp(wc > 0 ? wc : 1);
+    float jpart = 0.f;
+    // the wavefront's units of subtree group gidx: [ub, ue) (one row per unit: the row ranges are unit ranges)
+    auto range = [&](int gidx, int& ub, int& ue, int& level) {
+        const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + gidx);
+        const int unit_begin = lds_i32(gp + 0), rngb = lds_i32(gp + 6);
+        level = lds_i32(gp + 7);
+        ub = unit_begin + lds_i32(T.rng + rngb + wave); ue = unit_begin + lds_i32(T.rng + rngb + wave + 1);
+    };
+    auto tile_of = [&](int u) -> int { return lds_i32((const LDS_AS int32_t*)(T.units + u) + 1); };     // Unit::f2
+    int ub, ue, level;
+    range(REV ? a.n_sub - 1 : 0, ub, ue, level);
+    // The W2 tiles of a node are fetched while the node before runs - with loads the compiler does not track (sub_load): a
+    // tracked load that is carried around the loop is waited for with vmcnt(0), i.e. for the tape stores of the node in
+    // between as well (2-3 k cycles per node); the waits are placed by hand (sub_wait: at least four stores follow a
+    // training node's loads, none an inference node's).
+    f32x4 ws = zero4(), wtt = zero4();
+    int have = -1;                      // the node whose tiles are in ws / wtt
+    for (int q = 0; q < a.n_sub; ++q) {
+        int nb = 0, ne = 0, nlevel = 0;
+        if (q + 1 < a.n_sub) range(REV ? a.n_sub - 2 - q : q + 1, nb, ne, nlevel);
+        for (int u = ub; u < ue; u += 2) {
+            if (have != u) {            // (the wavefront's first node, or the first one behind a level without nodes of its own)
+                sub_load(ws, wt + (size_t)tile_of(u) * 64); sub_load(wtt, wt + (size_t)tile_of(u + 1) * 64);
+                sub_wait<0>();
+            }
+            // the next node (of the next level behind this level's last node)
+            const bool has_next = u + 2 < ue || nb < ne;
+            const int nu = u + 2 < ue ? u + 2 : nb;
+            f32x4 nws = ws, nwt = wtt;
+            if (has_next) { sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64); }
+            STAMP(sid + 3)
+            const UnitU us = load_unit(T.units + u), ut = load_unit(T.units + u + 1);
+            STAMP(sid + 4)
+            float vin[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float v = xs[m * a.xld + us.xoff + (k < us.cin ? k : 0)]; vin[k] = k < us.cin ? v : 0.f; }
+            const int xcol = us.xoff + us.ku + (kq < us.r ? kq : 0);
+            const float xold = xs[m * a.xld + xcol];
+            f32x4 so, to;
+            const f32x4 vs = sub_unit_fwd(par4, a, us, ws, vin, kq, so);
+            const f32x4 vt = sub_unit_fwd(par4, a, ut, wtt, vin, kq, to);
+            STAMP(sid + 5)
+            if (train) {
+                bits[(us.wcol >> 4) * 64 + lane] = (uint8_t)sign_bits(vs);
+                bits[(ut.wcol >> 4) * 64 + lane] = (uint8_t)sign_bits(vt);
+                *(GLOBAL_AS f32x4*)(a2 + (m * a.WT + us.wcol + 4 * kq)) = vs;
+                *(GLOBAL_AS f32x4*)(a2 + (m * a.WT + ut.wcol + 4 * kq)) = vt;
+            }
+            STAMP(sid + 6)
+            const float sv = kq == 0 ? so.x : kq == 1 ? so.y : kq == 2 ? so.z : so.w;
+            const float tv = kq == 0 ? to.x : kq == 1 ? to.y : kq == 2 ? to.z : to.w;
+            if (kq < us.r) {
+                const float aa = a.alpha * atanf(sv);
+                // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
+                if (!REV && tape != nullptr && row0 + m < a.B) tape[(size_t)(a.n_levels + level) * lvl + (size_t)(row0 + m) * a.d + xcol] = sv;
+                float xn;
+                if (!REV) { xn = expf(aa) * xold + tv; jpart += aa; }
+                else      { xn = (xold - tv) / expf(aa); jpart -= aa; }
+                xs[m * a.xld + xcol] = xn;
+            }
+            STAMP(sid + 7)
+            if (has_next) {
+                if (train) sub_wait<4>(); else sub_wait<0>();
+                ws = nws; wtt = nwt; have = nu;
+            }
+        }
+        wave_sync();
+        // training: the wavefront's lanes as they stand after the level (tape[level][B][d])
+        if (!REV && tape != nullptr && level < a.n_levels - 1) {
+            float* dst = tape + (size_t)level * lvl + (size_t)row0 * a.d + c0;
+            for (int i = lane; i < ROWS * wc; i += 64) {
+                const int r = fdiv(i, inv_wc), j = i - r * wc;
+                if (row0 + r < a.B) dst[(size_t)r * a.d + j] = xs[r * a.xld + c0 + j];
+            }
+        }
+        STAMP(sid + 8)
+        ub = nb; ue = ne; level = nlevel;
+    }
+    const float js = kq_sum(jpart);
+    if (kq == 0) (lds + a.sub_misc)[wave * ROWS + m] = js;
+}
+
+constexpr int SUB_LV = 4;       // floats per lane of a wavefront's columns of a level tile: 16 x (its lanes) <= 64 SUB_LV (hint_plan.cpp checks)
+constexpr int SUB_MAXG = 3;     // subtree groups (levels) at most
+
+__device__ __forceinline__ void sub_load_byte(int& dst, const GLOBAL_AS uint8_t* p) {
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+
+// One subnet of a subtree node, backward (hint_wl.hpp's expressions): vin = the coupling gradients of its r outputs, w = the
+// W2^T fragment tile, bits = the sign byte of its a2 tile, xin = the lanes its first layer saw.  Returns the lane's g1
+// (features 4 kq .. +3 of batch row m); gv: g_v = W1^T g1 of row m (every lane of the row holds all four).
+__device__ __forceinline__ f32x4 sub_unit_bwd(const LDS_AS f32x4* par4, const KArgs& a, const UnitU& u, const f32x4 w, int bits,
+                                              const float (&vin)[4], const float (&xin)[4], int kq, f32x4& gv) {
+    const LDS_AS f32x4* w3 = par4 + ((a.sub_pf + u.w3v) >> 2) + kq;
+    f32x4 g2 = fma4(w3[12], vin[3], fma4(w3[8], vin[2], fma4(w3[4], vin[1], fma4(w3[0], vin[0], zero4()))));
+    mask_by_bits(g2, bits);
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma4(w[i], g2[i], acc);
+    const LDS_AS f32x4* w1 = par4 + (u.w1v >> 2) + kq;
+    const f32x4 pre = wl_layer1(w1, xin);
+    f32x4 g = acc;
+    g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f; g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) gv[o] = kq_sum(dot4(w1[4 * o], g, 0.f));
+    return g;
+}
+
+// dW1 | db1 of one subnet's tile from its g1 (hint_wl.hpp: transposed through the wavefront's scratch tile, four MFMAs over the
+// 16 rows) into the workgroup's first-layer gradient slab
+__device__ __forceinline__ void sub_dw1(const f32x4 g, float* scratch, const float* xs, int xld, const UnitU& u, GLOBAL_AS float* tw,
+                                        bool first_tile, int lane) {
+    const int nl = lane & 15, kq = lane >> 4;
+    ((f32x4*)scratch)[lane] = g;
+    asm volatile("" ::: "memory");          // (the wavefront's own LDS traffic is in order)
+    const float* g1p = scratch + (kq + 16 * (nl >> 2)) * 4 + (nl & 3);
+    const float* vp = xs + kq * xld + u.xoff + (nl < u.cin ? nl : 0);
+    const float one = nl == u.cin ? 1.f : 0.f;
+    float av[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * xld]; }      // rows 4 i + kq
+    f32x4 dw = zero4();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dw = mfma4(nl < u.cin ? bv[i] : one, av[i], dw);
+    const int kcp = u.cin < 4 ? 4 : 8;
+    if (nl < u.h && 4 * kq < kcp) {
+        GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(tw + u.bias1 + nl * kcp + 4 * kq);
+        if (first_tile) *dst = dw; else *dst = *dst + dw;
+    }
+}
+
+// Backward through the subtree groups, parents first.  On entry the boundary in front of the top subtree level has been
+// worked off by the workgroup (hint_bwd.hip: the g_v partials of the general group above scattered, the level's coupling
+// backward done: its coupling gradients wait in gst, xs / sb hold its level).  Per node: coupling backward (below the top
+// level), both subnets (g2 on the fly, W2^T on the matrix pipe, relu'(a1) recomputed), their dW1 | db1, and the g_v of the
+// node's inputs added to the wavefront's columns of the gradient tile gs.
+__device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* lds, const GBlock& blk, const float* x, bool top,
+                                        float* xs, float* sb, float* gs, float* gst, const float* gj, int row0, bool first_tile,
+                                        int wave, int lane, int sid) {
+    (void)sid;
+    const int m = lane & 15, kq = lane >> 4;
+    const LDS_AS f32x4* par4 = (const LDS_AS f32x4*)(lds + a.sub_par);
+    float* scratch = lds + a.sub_misc + wave * 256;
+    const float* tape = (const float*)blk.tape;
+    float* wsGST = (float*)blk.wsGST;
+    const size_t lvl = (size_t)a.B * a.d;
+    GLOBAL_AS float* tw = blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
+    const GLOBAL_AS uint8_t* bits = (const GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + a.bits_stride + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
+    const GLOBAL_AS f32x4* wt = (const GLOBAL_AS f32x4*)blk.packed + lane;
+    const int c0 = lds_i32(T.rng + a.sub_cols + 4 * wave), c1 = lds_i32(T.rng + a.sub_cols + 4 * wave + 1);     // the lanes of its subtrees
+    const int wc = c1 - c0;
+    const float inv_wc = frcp(wc > 0 ? wc : 1);
+    auto range = [&](int gidx, int& ub, int& ue, int& level) {
+        const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + gidx);
+        const int unit_begin = lds_i32(gp + 0), rngb = lds_i32(gp + 6);
+        level = lds_i32(gp + 7);
+        ub = unit_begin + lds_i32(T.rng + rngb + wave); ue = unit_begin + lds_i32(T.rng + rngb + wave + 1);
+    };
+    auto tile_of = [&](int u) -> int { return lds_i32((const LDS_AS int32_t*)(T.units + u) + 4); };     // Unit::b2 (W2^T)
+    auto byte_of = [&](int u) -> const GLOBAL_AS uint8_t* { return bits + (lds_i32((const LDS_AS int32_t*)(T.units + u) + 9) >> 4) * 64 + lane; };   // Unit::wcol
+    // ---- the wavefront's columns of the levels below the top one (lanes as the forward saw them, s): tape -> registers now,
+    //      -> xs / sb when the level starts ----
+    float lx[SUB_MAXG - 1][SUB_LV], ls[SUB_MAXG - 1][SUB_LV];
+#pragma unroll
+    for (int t = 0; t < SUB_MAXG - 1; ++t) {
+        if (t < a.n_sub - 1) {
+            const int level = lds_i32((const LDS_AS int32_t*)(T.groups + (a.n_sub - 2 - t)) + 7);
+            const float* xsrc = level == 0 ? (top ? tape + (size_t)(a.n_levels - 1) * lvl : x) : tape + (size_t)(level - 1) * lvl;
+            const float* ssrc = tape + (size_t)(a.n_levels + level) * lvl;
+#pragma unroll
+            for (int k = 0; k < SUB_LV; ++k) {
+                const int i = lane + 64 * k;
+                const int r = fdiv(i < ROWS * wc ? i : 0, inv_wc), j = (i < ROWS * wc ? i : 0) - r * wc;
+                const size_t o = (size_t)(row0 + r < a.B ? row0 + r : row0) * a.d + c0 + j;
+                lx[t][k] = xsrc[o]; ls[t][k] = ssrc[o];
+            }
+        }
+    }
+    int ub, ue, level;
+    range(a.n_sub - 1, ub, ue, level);
+    f32x4 ws = zero4(), wtt = zero4();
+    int bs = 0, bt = 0;
+    int have = -1;                      // the node whose tiles and sign bytes are in ws / wtt / bs / bt
+    for (int q = a.n_sub - 1; q >= 0; --q) {
+        const bool is_top = q == a.n_sub - 1;
+        int nb = 0, ne = 0, nlevel = 0;
+        if (q > 0) range(q - 1, nb, ne, nlevel);
+        if (!is_top) {
+            // this level's lanes and s into the wavefront's columns of the tiles
+#pragma unroll
+            for (int t = 0; t < SUB_MAXG - 1; ++t) {
+                if (t == a.n_sub - 2 - q) {
+#pragma unroll
+                    for (int k = 0; k < SUB_LV; ++k) {
+                        const int i = lane + 64 * k;
+                        if (i < ROWS * wc) {
+                            const int r = fdiv(i, inv_wc), j = i - r * wc;
+                            const bool ok = row0 + r < a.B;
+                            xs[r * a.xld + c0 + j] = ok ? lx[t][k] : 0.f;
+                            sb[r * a.xld + c0 + j] = ok ? ls[t][k] : 0.f;
+                        }
+                    }
+                }
+            }
+            wave_sync();
+        }
+        for (int u = ub; u < ue; u += 2) {
+            if (have != u) {
+                sub_load(ws, wt + (size_t)tile_of(u) * 64); sub_load(wtt, wt + (size_t)tile_of(u + 1) * 64);
+                sub_load_byte(bs, byte_of(u)); sub_load_byte(bt, byte_of(u + 1));
+                sub_wait<0>();
+            }
+            const bool has_next = u + 2 < ue || nb < ne;
+            const int nu = u + 2 < ue ? u + 2 : nb;
+            f32x4 nws = ws, nwt = wtt;
+            int nbs = bs, nbt = bt;
+            if (has_next) {
+                sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64);
+                sub_load_byte(nbs, byte_of(nu)); sub_load_byte(nbt, byte_of(nu + 1));
+            }
+            const UnitU us = load_unit(T.units + u), ut = load_unit(T.units + u + 1);
+            if (!is_top) {
+                // coupling backward of the node: lane group kq < r takes the transformed lane xoff + ku + kq of batch row m
+                if (kq < us.r) {
+                    const int xcol = us.xoff + us.ku + kq;
+                    const float gval = gs[m * a.xld + xcol];
+                    const float sv = sb[m * a.xld + xcol];
+                    const float aa = a.alpha * atanf(sv);
+                    const float ea = expf(aa);
+                    const float l = xs[m * a.xld + xcol];                 // lower input of the node
+                    const float ga = gval * ea * l + gj[m];               // g_a (a feeds both l' and J)
+                    const float gsv = ga * a.alpha / (1.f + sv * sv);     // g_s
+                    gst[m * a.gld + us.lcol + kq] = gsv;
+                    gst[m * a.gld + ut.lcol + kq] = gval;                 // g_t = g_l'
+                    float* go = wsGST + (size_t)(row0 + m) * a.ST;
+                    go[us.gcol + kq] = gsv;
+                    go[ut.gcol + kq] = gval;
+                    gs[m * a.xld + xcol] = gval * ea;                     // g_l
+                }
+                wave_sync();
+            }
+            float vs[4], vt[4], xin[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jr = k < us.r ? k : 0, kc = k < us.cin ? k : 0;
+                const float a0 = gst[m * a.gld + us.lcol + jr], a1 = gst[m * a.gld + ut.lcol + jr], a2 = xs[m * a.xld + us.xoff + kc];
+                vs[k] = k < us.r ? a0 : 0.f; vt[k] = k < us.r ? a1 : 0.f; xin[k] = k < us.cin ? a2 : 0.f;
+            }
+            f32x4 gvs, gvt;
+            const f32x4 g1s = sub_unit_bwd(par4, a, us, ws, bs, vs, xin, kq, gvs);
+            const f32x4 g1t = sub_unit_bwd(par4, a, ut, wtt, bt, vt, xin, kq, gvt);
+            sub_dw1(g1s, scratch, xs, a.xld, us, tw, first_tile, lane);
+            sub_dw1(g1t, scratch, xs, a.xld, ut, tw, first_tile, lane);
+            // g_v of the node's inputs: lane group kq < cin adds input kq of batch row m
+            const float gsum = kq == 0 ? gvs.x + gvt.x : kq == 1 ? gvs.y + gvt.y : kq == 2 ? gvs.z + gvt.z : gvs.w + gvt.w;
+            if (kq < us.cin) gs[m * a.xld + us.xoff + kq] += gsum;
+            if (has_next) {
+                sub_wait<0>();
+                ws = nws; wtt = nwt; bs = nbs; bt = nbt; have = nu;
+            }
+        }
+        wave_sync();
+        ub = nb; ue = ne; level = nlevel;
+    }
+}
+
+}  // namespace hint

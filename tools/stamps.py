@@ -51,6 +51,10 @@ def show(title, st, per_block, labels, blocks):
         for gi in range(per_block):
             base = (cb * per_block + gi) * 16
             row = st[:nw, base:base + 7]
+            if title == "forward" and (st[:nw, base + 3] != 0).all() and (st[:nw, base + 8] != 0).all() and (st[:nw, base + 7] > st[:nw, base + 3]).all():
+                # subtree phase (hint_sub.hpp): the stamps of the wavefront's last node
+                for k, lab in enumerate(["  unit records", "  two subnets", "  tape stores", "  coupling", "  (to the level's end)"]):
+                    print(f"   blk {cb} grp {gi} {lab:22s} " + " ".join(f"{int(v):6d}" for v in st[:nw, base + 4 + k] - st[:nw, base + 3 + k]))
             if (row == 0).all():
                 continue
             for k, lab in enumerate(labels):
@@ -99,5 +103,11 @@ descs, _, _, _ = node_descs(nodes)
 lib.hint_plan_check(descs, len(nodes), cfg["d"], 0, 4.0, stats)
 ng = int(stats[0])
 print("groups per block:", ng)
+if True:
+    st = fw.reshape(NW, IDS)
+    print("   (with subtree groups the general groups come first in the list below; the first slot behind them is the subtree phase and its barrier)")
+    for rb in (256, 288):
+        for k, lab in enumerate(["inputs, first operand", "k-loop", "epilogue", "fold + slab"]):
+            print(f"   row {(rb - 256) // 32} {lab:24s}", " ".join(f"{int(v):6d}" for v in st[:, rb + k + 1] - st[:, rb + k]))
 show("forward", fw, ng, ["P1 thin (VALU)", "barrier", "P2 rows (L2 L3)", "barrier", "P3 coupling", "barrier"], [BLK])
 show("backward A", bw, ng + 1, ["Q1 couple/scatter", "barrier", "prefetch issue", "Q2 thin + barrier", "Q3 rows (g1 gv)", "commit+barrier"], [BLK])
