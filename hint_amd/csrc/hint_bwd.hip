@@ -262,14 +262,14 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 if (slot < a.n_sub) {
                     // ---- the subtree groups: from here down every wavefront runs its own subtrees, wave-local synchronisation
                     //      only (hint_sub.hpp); the root level of the block before is fetched meanwhile ----
-                    LevelPrefetch lq;
+                    sub_bwd(a, T, lds, blk, x, top, xs, sb, gs, gst, gj, row0, tile == (int)blockIdx.x, wave, lane, sid);
+                    STAMP(sid + 3)
+                    LevelPrefetch lq;           // (issued behind the subtree phase: nine registers less in it; the barrier's wait hides most of it)
                     if (cb > 0) {
                         const float* ntape = (const float*)nblk.tape;
                         const bool ntop = nblk.perm != nullptr || cb > 1;
                         level_issue(lq, LEVEL_SRC(ntape, ntop, a.n_levels - 1), ntape + (size_t)(2 * a.n_levels - 1) * lvl, a.d, row0, a.B, tid, nthreads);
                     }
-                    sub_bwd(a, T, lds, blk, x, top, xs, sb, gs, gst, gj, row0, tile == (int)blockIdx.x, wave, lane, sid);
-                    STAMP(sid + 3)
                     lds_barrier();
                     STAMP(sid + 4)
                     if (cb > 0) { level_commit(lq, xs, sb, a.xld, a.d, tid, nthreads); lds_barrier(); }

@@ -221,7 +221,7 @@ struct KArgs {
     int32_t sub_pf, sub_pb;        // floats of the first two segments
     int32_t sub_bsrc, sub_bias_src;    // float offsets of the backward vectors / the biases in the packed buffer (the forward vectors start it)
     int32_t sub_slab;              // LDS float offset of their slabs (this direction)
-    int32_t sub_misc;              // LDS float offset: forward nw x 16 log-det partials; backward one 256-float scratch tile per wavefront
+    int32_t sub_misc;              // LDS float offset: forward nw x 16 log-det partials; backward two 256-float scratch tiles per wavefront
     int32_t sub_cols;              // index in the ranges table of the wavefronts' lane bounds: four per wavefront (hint_plan.cpp)
 };
 

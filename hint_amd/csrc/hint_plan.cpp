@@ -31,7 +31,7 @@ hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const
 hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
                       int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                       float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
-hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
+hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, const ChainBlock& one, const ChainBlock* chain,
                         int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
@@ -82,7 +82,7 @@ static constexpr int LDS_LIMIT = 160 * 1024;
 #endif
 static constexpr int LDS_ATTR = LDS_LIMIT;
 #ifndef HINT_THIN_MFMA_MIN
-#define HINT_THIN_MFMA_MIN 24
+#define HINT_THIN_MFMA_MIN 8
 #endif
 static constexpr int THIN_MFMA_MIN = HINT_THIN_MFMA_MIN;          // thin layers with more inputs than this use the matrix pipe (fragment tiles of W1 / W3^T)
 static constexpr int THIN_LDS_MAX = 24 * 1024;   // a block's thin-layer vectors are staged in LDS up to this size
@@ -94,7 +94,7 @@ static thread_local bool g_host_only = false;    // hint_plan_check: build and v
 
 struct hint_plan {
     int device = -1;
-    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_units = 0, n_wjobs = 0, n_ptiles = 0, nw = 8;
+    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_units = 0, n_wjobs = 0, n_wsmall = 0, n_ptiles = 0, nw = 8;   // n_wsmall: single-tile jobs at the end of the job list (hint_wgrad.hip)
     float alpha = 0.f;
     int64_t param_floats = 0, packed_floats = 0;
     int WT = 0, ST = 0;
@@ -724,7 +724,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // (subtree groups: their slabs, their staged parameters, nw x 16 log-det partials / nw scratch tiles)
     const int sub_par_floats = P->sub_pf + P->sub_pb + P->sub_pbias;
     const int sub_f_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_f) + sub_par_floats + nw * 16) : 0;
-    const int sub_b_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_b) + sub_par_floats + nw * 256) : 0;
+    const int sub_b_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_b) + sub_par_floats + nw * 512) : 0;
     const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + ROWS + MAX_NW) + sub_f_bytes;
     const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld) + sub_b_bytes;   // (+ the lanes of the level before: first-layer gradients)
     P->stage_out = 0;
@@ -885,6 +885,15 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->fuse_dw1 = P->tw_floats > 0 ? 1 : 0;       // (some lean, staged groups: their dW1 / db1 come from the backward kernel)
     std::vector<uint8_t> real((size_t)P->param_floats, 0);
     make_wgrad_jobs(P, nodes, units, unit_node, unit_lean, unit_fused, max_depth, &wjobs, &real);
+    {   // single-tile jobs last: eight of them share a workgroup (hint_wgrad.hip) - for the trees with subtree groups, whose part B
+        // is hundreds of 8 x 8 jobs (MINIBOONE: 272 -> 239 us); the d = 100 trees' single-tile jobs are column remainders of wide
+        // arrays, and one wavefront walking 512 rows of a 9600-column array alone is slower (+6 %).  HINT_DW_SMALL=0 / 1 overrides.
+        bool small_on = P->n_sub > 0;
+        if (const char* e = std::getenv("HINT_DW_SMALL")) small_on = std::atoi(e) != 0;
+        auto is_small = [&](const WJob& j) { return small_on && j.mw <= 1 && j.nw <= 1; };
+        std::stable_partition(wjobs.begin(), wjobs.end(), [&](const WJob& j) { return !is_small(j); });
+        P->n_wsmall = (int)std::count_if(wjobs.begin(), wjobs.end(), is_small);
+    }
     P->n_wjobs = (int)wjobs.size();
     P->total_rows = (int)recs_f.size();
     P->total_tiles = (int)thin_f.size();
@@ -1276,7 +1285,7 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
     if (!(parts & 2)) return 0;
     int splits, rows_per_wg;
     wgrad_splits(P, B, n_chain, &splits, &rows_per_wg);
-    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, splits, one, chain, n_chain, cb0, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
+    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, P->n_wsmall, splits, one, chain, n_chain, cb0, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
                          rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
                          (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
                          accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),

@@ -32,26 +32,49 @@ __device__ __forceinline__ void sub_load(f32x4& dst, const GLOBAL_AS f32x4* p) {
 template <int N>
 __device__ __forceinline__ void sub_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-// One subnet of a subtree node, forward: one 16-feature tile, one k-block (h <= 16).  w: the W2 fragment tile (in registers
-// since the node before); returns the lane's four hidden activations a2 (features 4 kq .. +3 of batch row m) and leaves the
-// third layer's outputs of row m in out (every lane of the row holds all four).  The expressions are hint_wl.hpp's
+// Both subnets (s, t) of a subtree node, forward, in lockstep - every stage of the two independent chains is issued back to
+// back, so that their LDS and MFMA latencies overlap: one 16-feature tile, one k-block each (h <= 16).  w: the W2 fragment
+// tiles (in registers since the node before); v: the lane's four hidden activations a2 (features 4 kq .. +3 of batch row m);
+// out: the third layer's outputs of row m (every lane of the row holds all four).  The expressions are hint_wl.hpp's
 // (wl_layer1, bias last, dot4 + fold): the backward pass recomputes relu'(a1) from them.
-__device__ __forceinline__ f32x4 sub_unit_fwd(const LDS_AS f32x4* par4, const KArgs& a, const UnitU& u, const f32x4 w, const float (&vin)[4],
-                                              int kq, f32x4& out) {
-    const f32x4 a1 = relu4(wl_layer1(par4 + (u.w1v >> 2) + kq, vin));
-    f32x4 acc = zero4();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = mfma4(w[i], a1[i], acc);
+__device__ __forceinline__ void sub_node_fwd(const LDS_AS f32x4* par4, const KArgs& a, const UnitU (&u)[2], const f32x4 (&w)[2],
+                                             const float (&vin)[4], int kq, f32x4 (&v)[2], f32x4 (&out)[2]) {
     const int pb = (a.sub_pf + a.sub_pb - a.sub_bias_src) >> 2;          // (float4 index of packed-buffer bias offset 0 inside the staged parameters)
-    const f32x4 v = relu4(acc + par4[pb + (u.bias2 >> 2) + kq]);
-    const LDS_AS f32x4* w3 = par4 + ((a.sub_pf + u.w3v) >> 2) + kq;
-    f32x4 p;
+    // everything the node reads from the staged parameters, up front: none of it depends on what is computed
+    f32x4 q1[2][5], b2[2], w3[2][4], b3[2];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) p[o] = dot4(w3[4 * o], v, 0.f);
-    if (kq == 0) p += par4[pb + (u.bias3 >> 2)];
+    for (int n = 0; n < 2; ++n) {
+        const LDS_AS f32x4* q = par4 + (u[n].w1v >> 2) + kq;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) out[o] = kq_sum(p[o]);
-    return v;
+        for (int k = 0; k < 5; ++k) q1[n][k] = q[4 * k];
+        b2[n] = par4[pb + (u[n].bias2 >> 2) + kq];
+        const LDS_AS f32x4* w3p = par4 + ((a.sub_pf + u[n].w3v) >> 2) + kq;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w3[n][o] = w3p[4 * o];
+        b3[n] = par4[pb + (u[n].bias3 >> 2)];
+    }
+    f32x4 a1[2], acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {      // (wl_layer1's expression: bias first, then the inputs in order)
+        a1[n] = relu4(fma4(q1[n][3], vin[3], fma4(q1[n][2], vin[2], fma4(q1[n][1], vin[1], fma4(q1[n][0], vin[0], q1[n][4])))));
+        acc[n] = zero4();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[n] = mfma4(w[n][i], a1[n][i], acc[n]);
+    f32x4 p[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        v[n] = relu4(acc[n] + b2[n]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) p[n][o] = dot4(w3[n][o], v[n], 0.f);
+        if (kq == 0) p[n] += b3[n];
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) out[n][o] = kq_sum(p[n][o]);
 }
 
 // Forward (children first) / inverse (parents first) through the subtree groups; xs: the workgroup's lane tile.  Per node:
@@ -111,9 +134,11 @@ __device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float
             for (int k = 0; k < 4; ++k) { const float v = xs[m * a.xld + us.xoff + (k < us.cin ? k : 0)]; vin[k] = k < us.cin ? v : 0.f; }
             const int xcol = us.xoff + us.ku + (kq < us.r ? kq : 0);
             const float xold = xs[m * a.xld + xcol];
-            f32x4 so, to;
-            const f32x4 vs = sub_unit_fwd(par4, a, us, ws, vin, kq, so);
-            const f32x4 vt = sub_unit_fwd(par4, a, ut, wtt, vin, kq, to);
+            const UnitU uu[2] = {us, ut};
+            const f32x4 ww[2] = {ws, wtt};
+            f32x4 vv[2], oo[2];
+            sub_node_fwd(par4, a, uu, ww, vin, kq, vv, oo);
+            const f32x4 vs = vv[0], vt = vv[1], so = oo[0], to = oo[1];
             STAMP(sid + 5)
             if (train) {
                 bits[(us.wcol >> 4) * 64 + lane] = (uint8_t)sign_bits(vs);
@@ -156,52 +181,89 @@ __device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float
 }
 
 constexpr int SUB_LV = 4;       // floats per lane of a wavefront's columns of a level tile: 16 x (its lanes) <= 64 SUB_LV (hint_plan.cpp checks)
-constexpr int SUB_MAXG = 3;     // subtree groups (levels) at most
 
 __device__ __forceinline__ void sub_load_byte(int& dst, const GLOBAL_AS uint8_t* p) {
     asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 
-// One subnet of a subtree node, backward (hint_wl.hpp's expressions): vin = the coupling gradients of its r outputs, w = the
-// W2^T fragment tile, bits = the sign byte of its a2 tile, xin = the lanes its first layer saw.  Returns the lane's g1
-// (features 4 kq .. +3 of batch row m); gv: g_v = W1^T g1 of row m (every lane of the row holds all four).
-__device__ __forceinline__ f32x4 sub_unit_bwd(const LDS_AS f32x4* par4, const KArgs& a, const UnitU& u, const f32x4 w, int bits,
-                                              const float (&vin)[4], const float (&xin)[4], int kq, f32x4& gv) {
-    const LDS_AS f32x4* w3 = par4 + ((a.sub_pf + u.w3v) >> 2) + kq;
-    f32x4 g2 = fma4(w3[12], vin[3], fma4(w3[8], vin[2], fma4(w3[4], vin[1], fma4(w3[0], vin[0], zero4()))));
-    mask_by_bits(g2, bits);
-    f32x4 acc = zero4();
+// Both subnets of a subtree node, backward, in lockstep (hint_wl.hpp's expressions): vin = the coupling gradients of their r
+// outputs, w = the W2^T fragment tiles, bits = the sign bytes of their a2 tiles, xin = the lanes their first layers saw.
+// g1: the lane's g1 (features 4 kq .. +3 of batch row m); gv: g_v = W1^T g1 of row m (every lane of the row holds all four).
+__device__ __forceinline__ void sub_node_bwd(const LDS_AS f32x4* par4, const KArgs& a, const UnitU (&u)[2], const f32x4 (&w)[2],
+                                             const int (&bits)[2], const float (&vin)[2][4], const float (&xin)[4], int kq,
+                                             f32x4 (&g1)[2], f32x4 (&gv)[2]) {
+    f32x4 g2[2], acc[2], pre[2];
+    {
+        f32x4 w3[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc = mfma4(w[i], g2[i], acc);
-    const LDS_AS f32x4* w1 = par4 + (u.w1v >> 2) + kq;
-    const f32x4 pre = wl_layer1(w1, xin);
-    f32x4 g = acc;
-    g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f; g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+        for (int n = 0; n < 2; ++n) {
+            const LDS_AS f32x4* w3p = par4 + ((a.sub_pf + u[n].w3v) >> 2) + kq;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) gv[o] = kq_sum(dot4(w1[4 * o], g, 0.f));
-    return g;
+            for (int o = 0; o < 4; ++o) w3[n][o] = w3p[4 * o];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            g2[n] = fma4(w3[n][3], vin[n][3], fma4(w3[n][2], vin[n][2], fma4(w3[n][1], vin[n][1], fma4(w3[n][0], vin[n][0], zero4()))));
+            mask_by_bits(g2[n], bits[n]);
+            acc[n] = zero4();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[n] = mfma4(w[n][i], g2[n][i], acc[n]);
+    __builtin_amdgcn_sched_barrier(0);          // (the first layer's vectors behind the MFMAs: 40 registers that need not live through them)
+    f32x4 w1[2][5];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const LDS_AS f32x4* w1p = par4 + (u[n].w1v >> 2) + kq;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) w1[n][k] = w1p[4 * k];
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        pre[n] = fma4(w1[n][3], xin[3], fma4(w1[n][2], xin[2], fma4(w1[n][1], xin[1], fma4(w1[n][0], xin[0], w1[n][4]))));   // (wl_layer1)
+    f32x4 p[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        f32x4 g = acc[n];
+        g.x = pre[n].x > 0.f ? g.x : 0.f; g.y = pre[n].y > 0.f ? g.y : 0.f; g.z = pre[n].z > 0.f ? g.z : 0.f; g.w = pre[n].w > 0.f ? g.w : 0.f;
+        g1[n] = g;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) p[n][o] = dot4(w1[n][o], g, 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) gv[n][o] = kq_sum(p[n][o]);
 }
 
-// dW1 | db1 of one subnet's tile from its g1 (hint_wl.hpp: transposed through the wavefront's scratch tile, four MFMAs over the
-// 16 rows) into the workgroup's first-layer gradient slab
-__device__ __forceinline__ void sub_dw1(const f32x4 g, float* scratch, const float* xs, int xld, const UnitU& u, GLOBAL_AS float* tw,
+// dW1 | db1 of both subnets' tiles from their g1 (hint_wl.hpp: transposed through the wavefront's two scratch tiles, four
+// MFMAs over the 16 rows each) into the workgroup's first-layer gradient slab; both in lockstep
+__device__ __forceinline__ void sub_dw1(const f32x4 (&g)[2], float* scratch, const float* xs, int xld, const UnitU (&u)[2], GLOBAL_AS float* tw,
                                         bool first_tile, int lane) {
     const int nl = lane & 15, kq = lane >> 4;
-    ((f32x4*)scratch)[lane] = g;
+    ((f32x4*)scratch)[lane] = g[0];
+    ((f32x4*)scratch)[64 + lane] = g[1];
     asm volatile("" ::: "memory");          // (the wavefront's own LDS traffic is in order)
     const float* g1p = scratch + (kq + 16 * (nl >> 2)) * 4 + (nl & 3);
-    const float* vp = xs + kq * xld + u.xoff + (nl < u.cin ? nl : 0);
-    const float one = nl == u.cin ? 1.f : 0.f;
-    float av[4], bv[4];
+    const float* vp = xs + kq * xld + u[0].xoff + (nl < u[0].cin ? nl : 0);       // (both subnets read the same lanes)
+    const float one = nl == u[0].cin ? 1.f : 0.f;
+    float av[2][4], bv[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { av[i] = g1p[16 * i]; bv[i] = vp[4 * i * xld]; }      // rows 4 i + kq
-    f32x4 dw = zero4();
+    for (int i = 0; i < 4; ++i) { av[0][i] = g1p[16 * i]; av[1][i] = g1p[256 + 16 * i]; bv[i] = vp[4 * i * xld]; }      // rows 4 i + kq
+    f32x4 dw[2] = {zero4(), zero4()};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dw = mfma4(nl < u.cin ? bv[i] : one, av[i], dw);
-    const int kcp = u.cin < 4 ? 4 : 8;
-    if (nl < u.h && 4 * kq < kcp) {
-        GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(tw + u.bias1 + nl * kcp + 4 * kq);
-        if (first_tile) *dst = dw; else *dst = *dst + dw;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) dw[n] = mfma4(nl < u[0].cin ? bv[i] : one, av[n][i], dw[n]);
+    const int kcp = u[0].cin < 4 ? 4 : 8;
+    if (nl < u[0].h && 4 * kq < kcp) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(tw + u[n].bias1 + nl * kcp + 4 * kq);
+            if (first_tile) *dst = dw[n]; else *dst = *dst + dw[n];
+        }
     }
 }
 
@@ -216,7 +278,7 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
     (void)sid;
     const int m = lane & 15, kq = lane >> 4;
     const LDS_AS f32x4* par4 = (const LDS_AS f32x4*)(lds + a.sub_par);
-    float* scratch = lds + a.sub_misc + wave * 256;
+    float* scratch = lds + a.sub_misc + wave * 512;             // two fragment tiles (the transposition of the subnets' g1)
     const float* tape = (const float*)blk.tape;
     float* wsGST = (float*)blk.wsGST;
     const size_t lvl = (size_t)a.B * a.d;
@@ -234,24 +296,22 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
     };
     auto tile_of = [&](int u) -> int { return lds_i32((const LDS_AS int32_t*)(T.units + u) + 4); };     // Unit::b2 (W2^T)
     auto byte_of = [&](int u) -> const GLOBAL_AS uint8_t* { return bits + (lds_i32((const LDS_AS int32_t*)(T.units + u) + 9) >> 4) * 64 + lane; };   // Unit::wcol
-    // ---- the wavefront's columns of the levels below the top one (lanes as the forward saw them, s): tape -> registers now,
-    //      -> xs / sb when the level starts ----
-    float lx[SUB_MAXG - 1][SUB_LV], ls[SUB_MAXG - 1][SUB_LV];
+    // ---- the wavefront's columns of the next level down (lanes as the forward saw them, s): tape -> registers while the level
+    //      above runs, -> xs / sb when the level starts ----
+    float lx[SUB_LV], ls[SUB_LV];
+    auto level_fetch = [&](int gidx) {
+        const int lv = lds_i32((const LDS_AS int32_t*)(T.groups + gidx) + 7);
+        const float* xsrc = lv == 0 ? (top ? tape + (size_t)(a.n_levels - 1) * lvl : x) : tape + (size_t)(lv - 1) * lvl;
+        const float* ssrc = tape + (size_t)(a.n_levels + lv) * lvl;
 #pragma unroll
-    for (int t = 0; t < SUB_MAXG - 1; ++t) {
-        if (t < a.n_sub - 1) {
-            const int level = lds_i32((const LDS_AS int32_t*)(T.groups + (a.n_sub - 2 - t)) + 7);
-            const float* xsrc = level == 0 ? (top ? tape + (size_t)(a.n_levels - 1) * lvl : x) : tape + (size_t)(level - 1) * lvl;
-            const float* ssrc = tape + (size_t)(a.n_levels + level) * lvl;
-#pragma unroll
-            for (int k = 0; k < SUB_LV; ++k) {
-                const int i = lane + 64 * k;
-                const int r = fdiv(i < ROWS * wc ? i : 0, inv_wc), j = (i < ROWS * wc ? i : 0) - r * wc;
-                const size_t o = (size_t)(row0 + r < a.B ? row0 + r : row0) * a.d + c0 + j;
-                lx[t][k] = xsrc[o]; ls[t][k] = ssrc[o];
-            }
+        for (int k = 0; k < SUB_LV; ++k) {
+            const int i = lane + 64 * k;
+            const int r = fdiv(i < ROWS * wc ? i : 0, inv_wc), j = (i < ROWS * wc ? i : 0) - r * wc;
+            const size_t o = (size_t)(row0 + r < a.B ? row0 + r : row0) * a.d + c0 + j;
+            lx[k] = xsrc[o]; ls[k] = ssrc[o];
         }
-    }
+    };
+    if (a.n_sub > 1) level_fetch(a.n_sub - 2);
     int ub, ue, level;
     range(a.n_sub - 1, ub, ue, level);
     f32x4 ws = zero4(), wtt = zero4();
@@ -264,21 +324,17 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
         if (!is_top) {
             // this level's lanes and s into the wavefront's columns of the tiles
 #pragma unroll
-            for (int t = 0; t < SUB_MAXG - 1; ++t) {
-                if (t == a.n_sub - 2 - q) {
-#pragma unroll
-                    for (int k = 0; k < SUB_LV; ++k) {
-                        const int i = lane + 64 * k;
-                        if (i < ROWS * wc) {
-                            const int r = fdiv(i, inv_wc), j = i - r * wc;
-                            const bool ok = row0 + r < a.B;
-                            xs[r * a.xld + c0 + j] = ok ? lx[t][k] : 0.f;
-                            sb[r * a.xld + c0 + j] = ok ? ls[t][k] : 0.f;
-                        }
-                    }
+            for (int k = 0; k < SUB_LV; ++k) {
+                const int i = lane + 64 * k;
+                if (i < ROWS * wc) {
+                    const int r = fdiv(i, inv_wc), j = i - r * wc;
+                    const bool ok = row0 + r < a.B;
+                    xs[r * a.xld + c0 + j] = ok ? lx[k] : 0.f;
+                    sb[r * a.xld + c0 + j] = ok ? ls[k] : 0.f;
                 }
             }
             wave_sync();
+            if (q > 0) level_fetch(q - 1);
         }
         for (int u = ub; u < ue; u += 2) {
             if (have != u) {
@@ -286,6 +342,7 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
                 sub_load_byte(bs, byte_of(u)); sub_load_byte(bt, byte_of(u + 1));
                 sub_wait<0>();
             }
+            STAMP(sid + 5)
             const bool has_next = u + 2 < ue || nb < ne;
             const int nu = u + 2 < ue ? u + 2 : nb;
             f32x4 nws = ws, nwt = wtt;
@@ -295,6 +352,7 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
                 sub_load_byte(nbs, byte_of(nu)); sub_load_byte(nbt, byte_of(nu + 1));
             }
             const UnitU us = load_unit(T.units + u), ut = load_unit(T.units + u + 1);
+            STAMP(sid + 6)
             if (!is_top) {
                 // coupling backward of the node: lane group kq < r takes the transformed lane xoff + ku + kq of batch row m
                 if (kq < us.r) {
@@ -315,26 +373,32 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
                 }
                 wave_sync();
             }
-            float vs[4], vt[4], xin[4];
+            STAMP(sid + 7)
+            float vst[2][4], xin[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int jr = k < us.r ? k : 0, kc = k < us.cin ? k : 0;
                 const float a0 = gst[m * a.gld + us.lcol + jr], a1 = gst[m * a.gld + ut.lcol + jr], a2 = xs[m * a.xld + us.xoff + kc];
-                vs[k] = k < us.r ? a0 : 0.f; vt[k] = k < us.r ? a1 : 0.f; xin[k] = k < us.cin ? a2 : 0.f;
+                vst[0][k] = k < us.r ? a0 : 0.f; vst[1][k] = k < us.r ? a1 : 0.f; xin[k] = k < us.cin ? a2 : 0.f;
             }
-            f32x4 gvs, gvt;
-            const f32x4 g1s = sub_unit_bwd(par4, a, us, ws, bs, vs, xin, kq, gvs);
-            const f32x4 g1t = sub_unit_bwd(par4, a, ut, wtt, bt, vt, xin, kq, gvt);
-            sub_dw1(g1s, scratch, xs, a.xld, us, tw, first_tile, lane);
-            sub_dw1(g1t, scratch, xs, a.xld, ut, tw, first_tile, lane);
+            const UnitU uu[2] = {us, ut};
+            const f32x4 ww[2] = {ws, wtt};
+            const int bb[2] = {bs, bt};
+            f32x4 g1[2], gvv[2];
+            sub_node_bwd(par4, a, uu, ww, bb, vst, xin, kq, g1, gvv);
+            const f32x4 gvs = gvv[0], gvt = gvv[1];
+            STAMP(sid + 8)
+            sub_dw1(g1, scratch, xs, a.xld, uu, tw, first_tile, lane);
             // g_v of the node's inputs: lane group kq < cin adds input kq of batch row m
             const float gsum = kq == 0 ? gvs.x + gvt.x : kq == 1 ? gvs.y + gvt.y : kq == 2 ? gvs.z + gvt.z : gvs.w + gvt.w;
             if (kq < us.cin) gs[m * a.xld + us.xoff + kq] += gsum;
+            STAMP(sid + 9)
             if (has_next) {
-                sub_wait<0>();
+                sub_wait<2>();          // (the node's two slab stores are younger than the prefetch)
                 ws = nws; wtt = nwt; bs = nbs; bt = nbt; have = nu;
             }
         }
+        STAMP(sid + 10)
         wave_sync();
         ub = nb; ue = ne; level = nlevel;
     }

@@ -50,7 +50,7 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
 }
 
 __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
-    const WJob* __restrict__ jobs, int n_jobs, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
+    const WJob* __restrict__ jobs, int n_jobs, int n_small, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
     int grid_pb, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
     int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c) {
     __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
@@ -58,24 +58,31 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
 
     // a chained launch holds grid_pb (a multiple of 8, so that the XCD mapping below holds for every
     // block) workgroups per block of the chain, of which the first n_jobs * splits have work
+    // The last n_small jobs of the list are single-tile jobs (deep levels of narrow trees: an 8 x 8 matrix): eight of them share a
+    // workgroup, one (job, split) per WAVEFRONT over all rows of the split - no combine, no barrier: a workgroup per such job
+    // spends its time in the fixed costs (MINIBOONE d = 43: 12 000 workgroups for 60 MFLOP)
+    const int n_big = n_jobs - n_small, items = n_big + (n_small + DW_WAVES - 1) / DW_WAVES;
     const int cbi = (int)blockIdx.x / grid_pb;
     const int bid = (int)blockIdx.x - cbi * grid_pb;
-    if (bid >= n_jobs * splits) return;
+    if (bid >= items * splits) return;
     const GBlock blk = chain_block(chain, one, cbi);
     const bool top = blk.perm != nullptr || cbi + cb0 > 0;        // (cb0: position of the launch's first block in its chain)
 
-    int jidx, split;
+    int item, split;
     if ((splits & 7) == 0) {          // XCD-aware: split s lives on XCD s % 8
         const int xcd = bid & 7, t = bid >> 3;
-        split = xcd + 8 * (t / n_jobs);
-        jidx = t % n_jobs;
+        split = xcd + 8 * (t / items);
+        item = t % items;
     } else {
-        split = bid / n_jobs;
-        jidx = bid % n_jobs;
+        split = bid / items;
+        item = bid % items;
     }
-    const WJob job = jobs[jidx];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = rfl(tid >> 6);
+    const bool solo = item >= n_big;
+    const int jidx = solo ? n_big + (item - n_big) * DW_WAVES + wave : item;
+    if (jidx >= n_jobs) return;         // (a spare wavefront of the last shared workgroup: that path has no barrier)
+    const WJob job = jobs[jidx];
     const int nl = lane & 15, kq = lane >> 4;
     const int ntm = job.mw, ntn = job.nw;
     const int b_begin = split * rows_per_wg;
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = zero4();
     float psum[3] = {0.f, 0.f, 0.f};
-    const int step = 16 * DW_WAVES;
+    const int step = solo ? 16 : 16 * DW_WAVES;
+    const int bb0 = b_begin + (solo ? 0 : wave * 16);
     const bool natural = job.psrc == WSRC_G2R;       // columns in natural order (no 12-byte loads to serve)
 
     if (natural) {
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
                         for (int tn = 0; tn < 3; ++tn)
                             if (tn < ntn) acc[tm][tn] = mfma4(p[tm][i], q[tn][i], acc[tm][tn]);
         };
-        int bb = b_begin + wave * 16;
+        int bb = bb0;
         if (bb < b_end) {
             In cur = load_in(bb);
             while (true) {
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
 
     // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs of block j
-    int bb = b_begin + wave * 16;
+    int bb = bb0;
     if (bb < b_end) {
         DW_LOAD(0, bb)
         while (true) {
@@ -216,6 +224,25 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
 #undef DW_LOAD
 #undef DW_MMA
+    }
+    if (solo) {
+        // one tile, one wavefront: straight to the split's slab
+        float* slab = (float*)blk.wsSlab + (size_t)split * param_floats;
+        const int n = nl;
+        if (ntn > 0 && n < job.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 4 * kq + i;
+                if (m < job.M) slab[job.wofs + (size_t)m * job.ldo + n] = acc[0][0][i];
+            }
+        }
+        if (job.bofs >= 0) {
+            float v = psum[0];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0 && nl < job.M) slab[job.bofs + nl] = v;
+        }
+        return;
     }
     // combine the wavefronts (fixed order)
 #pragma unroll
@@ -333,16 +360,16 @@ __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const
 
 namespace hint {
 
-hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int splits, const ChainBlock& one, const ChainBlock* chain,
+hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, const ChainBlock& one, const ChainBlock* chain,
                         int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
                         int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream) {
-    const int used = n_jobs * splits;
+    const int used = (n_jobs - n_small + (n_small + DW_WAVES - 1) / DW_WAVES) * splits;
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0)
         hipLaunchKernelGGL(hint_wgrad_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs,
-                           splits, one, chain, grid_pb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
+                           n_small, splits, one, chain, grid_pb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
                            a2_off, bits_a2_off, param_floats, x, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

