@@ -876,6 +876,32 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         return 2;
     }
 
+    if (P->n_sub > 0) {
+        // subtree groups: one row per unit, the wavefronts' units in unit order, the tape lanes a partition of [0, d)
+        const char* bad = nullptr;
+        for (int gi = 0; gi < P->n_sub && !bad; ++gi) {
+            const Group& g = groups[gi];
+            if (!(g.lean & 4) || rng[g.rng_begin + nw] != g.unit_end - g.unit_begin) bad = "rows of a subtree group";
+            int lastw = 0;
+            for (int ui = g.unit_begin; ui < g.unit_end && !bad; ++ui) {
+                const int w = node_wave[unit_node[ui]];
+                if (w < lastw || units[ui].NT != 1 || units[ui].cin > 4 || units[ui].r > 4) bad = "units of a subtree group";
+                lastw = w;
+            }
+        }
+        for (int gi = P->n_sub; gi < (int)groups.size() && !bad; ++gi) if (groups[gi].lean & 4) bad = "subtree groups are not the deepest";
+        int covered = 0;
+        for (int w = 0; w < nw && !bad; ++w) {
+            const int32_t* c = rng.data() + P->sub_cols + 4 * w;
+            if (c[1] - c[0] > 16 || (c[1] > c[0] && (c[2] > c[0] || c[3] < c[1]))) bad = "lanes of a subtree wavefront";
+            if (c[3] > c[2]) { if (c[2] != covered) bad = "tape lanes of the subtree wavefronts"; covered = c[3]; }
+        }
+        if (!bad && covered != d) bad = "tape lanes of the subtree wavefronts do not cover the block";
+        if (bad) {
+            delete P;
+            return fail("hint_plan_create: internal error (%s)", bad);
+        }
+    }
     if (const char* what = check_records(groups, units, recs_f, recs_b, rng, nw)) {
         delete P;
         return fail("hint_plan_create: internal error (%s)", what);
@@ -1039,6 +1065,7 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
         stats[0] = P->n_groups; stats[1] = P->n_levels; stats[2] = P->WT; stats[3] = P->ST;
         stats[4] = P->lds_fwd; stats[5] = P->lds_bwd; stats[6] = P->nw; stats[7] = P->n_wjobs;
         stats[8] = P->param_floats; stats[9] = P->packed_floats; stats[10] = P->n_units; stats[11] = P->abuf_tiles;
+        stats[12] = P->n_sub; stats[13] = P->wl; stats[14] = P->n_wsmall; stats[15] = 0;
     }
     delete P->alt4;
     delete P;                   // (host-only plans own no device memory)

@@ -1,12 +1,15 @@
 // Subtree groups of the general block kernels (hint_fwd.hip / hint_bwd.hip): the deepest levels of a wide tree, where
-// every subnet has 1..4 inputs, at most 4 outputs and at most two 16-feature tiles (MINIBOONE d = 43: the 24 nodes of
-// depth 3 and 4, hidden width 8), cost a general group's three phases and barriers per level although a level is a few
-// hundred FMAs - and below some depth the subtrees never exchange anything (hint.py:70-73,85-88: the children of a node
-// are independent).  So from that depth down (Group::lean bit 2, hint_plan.cpp) every wavefront takes whole subtrees and
-// runs their levels back to back on the wave-local row engine (hint_wl.hpp: first layer on the fly, h x h on the matrix
-// pipe, thin product behind it by FMAs + lane-group fold) with WAVE-local synchronisation only: its rows, then the
-// coupling of its own nodes on its own columns of the workgroup's lane tile, then the next level; one workgroup barrier
-// where the subtrees rejoin the general groups.  Tape, workspace and packed weights are unchanged (part B does not know).
+// every subnet has 1..4 inputs, at most 4 outputs and one 16-feature tile (MINIBOONE d = 43: the 24 nodes of depth 3 and
+// 4, hidden width 8), cost a general group's three phases and barriers per level although a level is a few hundred FMAs -
+// and below some depth the subtrees never exchange anything (hint.py:70-73,85-88: the children of a node are
+// independent).  So from that depth down (Group::lean bit 2, hint_plan.cpp) every wavefront takes whole subtrees and runs
+// their nodes back to back with WAVE-local synchronisation only, register resident: per node both subnets in lockstep
+// (first layer by FMAs from the staged thin vectors, h x h on the matrix pipe with the W2 tile fetched while the node before
+// ran, the thin product behind it by FMAs + lane-group fold: hint_wl.hpp's expressions), then the coupling of the node's
+// lanes on the wavefront's own columns of the workgroup's lane tile - nothing between lane tile and lane tile touches LDS
+// slabs or row records.  One workgroup barrier where the subtrees rejoin the general groups.  Tape, workspace and packed
+// weights are unchanged (part B does not know).  MINIBOONE x 10 blocks, 4096 rows: forward 386 -> 338 us, backward
+// 500 -> 445 us (the two levels cost the general kernels 39 k cycles per block and kernel, here 15 k / 20 k).
 #pragma once
 #include "hint_wl.hpp"
 

@@ -63,9 +63,11 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
 /* Host-only dry run of hint_plan_create (no device needed, nothing uploaded): builds the plan, lets the
  * planner verify its own schedule (every fragment tile of every group in exactly one wavefront's range of
  * either GEMM phase, slices and slabs consistent with the ranges) and reports what it came to:
- * stats[12] = { groups, levels, WT (activation columns), ST (coupling-gradient columns), LDS bytes forward,
+ * stats[16] = { groups, levels, WT (activation columns), ST (coupling-gradient columns), LDS bytes forward,
  * LDS bytes backward, wavefronts per workgroup, part-B tile jobs, parameter floats, packed floats, units,
- * fragment tiles of the widest group }.  For tests and tools; same return convention as hint_plan_create. */
+ * fragment tiles of the widest group, subtree groups (the deepest levels that run one subtree per wavefront; 0: none),
+ * 1 when the block runs on the wave-local kernels, single-tile part-B jobs that share workgroups, 0 }.
+ * For tests and tools; same return convention as hint_plan_create. */
 int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
                     int64_t* stats);
 void hint_plan_destroy(hint_plan* plan);

@@ -12,14 +12,15 @@ import hint_amd
 from hint_amd import _lib
 from hint_amd.hint import node_descs
 
-STAT = ["groups", "levels", "WT", "ST", "lds_fwd", "lds_bwd", "nw", "wjobs", "params", "packed", "units", "abuf_tiles"]
+STAT = ["groups", "levels", "WT", "ST", "lds_fwd", "lds_bwd", "nw", "wjobs", "params", "packed", "units", "abuf_tiles",
+        "sub_groups", "wave_local", "small_jobs", "reserved"]
 
 
 def check(tree, d, dc, clamp=4.0):
     lib = _lib.load()
     nodes = tree._flat_nodes()
     descs, params, offsets, total = node_descs(nodes)
-    stats = (C.c_int64 * 12)()
+    stats = (C.c_int64 * 16)()
     st = lib.hint_plan_check(descs, len(nodes), d, dc, clamp, stats)
     assert st == 0, lib.hint_last_error().decode()
     return dict(zip(STAT, list(stats))), nodes, total
@@ -89,7 +90,7 @@ def test_planner_rejects_malformed_trees():
     blk = hint_amd.HierarchicalAffineCouplingBlock([(6,)], c_internal=[16, 8])
     nodes = blk.tree._flat_nodes()
     descs, _, _, _ = node_descs(nodes)
-    stats = (C.c_int64 * 12)()
+    stats = (C.c_int64 * 16)()
     descs[1].off = 1                       # overlaps its sibling
     assert lib.hint_plan_check(descs, len(nodes), 6, 0, 4.0, stats) != 0
     assert b"overlap" in lib.hint_last_error()
@@ -97,3 +98,28 @@ def test_planner_rejects_malformed_trees():
     descs[0].r = 2                         # r != D - k
     assert lib.hint_plan_check(descs, len(nodes), 6, 0, 4.0, stats) != 0
     assert lib.hint_plan_check(descs, len(nodes), 600, 0, 4.0, stats) != 0     # more lanes than the kernels take
+
+
+@pytest.mark.parametrize("d,widths,sub_groups,wave_local", [
+    (43, [67, 33, 16, 8], 2, 0),             # cfg 5: depth 3 and 4 (8 subtrees of 3 nodes, hidden width 8) run one subtree per wavefront
+    (42, [67, 33, 16, 8], 2, 0),
+    (100, [224, 112, 56], 0, 0),             # cfg 4: its deep levels are 56 wide (four tiles): general groups
+    (100, [48, 24, 20, 12, 8, 8], None, 0),  # D = 3 leaves one level above the deepest D = 2 nodes: some wavefronts have an empty level
+    (26, [16, 16, 8, 8, 8], 3, 0),
+    (6, [140, 70, 35, 17], 0, 1),            # cfg 2: the whole tree on the wave-local kernels instead
+    (8, [128, 64, 32, 16], 0, 1),
+])
+def test_planner_subtree_groups(d, widths, sub_groups, wave_local):
+    """which trees get subtree groups (hint_sub.hpp): the planner checks their invariants itself (one row per unit, the
+    wavefronts' units in order, the tape lanes a partition of the block's lanes) and fails the plan otherwise"""
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths)
+    st, nodes, _ = check(blk.tree, d, 0)
+    assert st["wave_local"] == wave_local
+    if sub_groups is not None:
+        assert st["sub_groups"] == sub_groups
+    else:
+        assert 1 <= st["sub_groups"] <= 3
+    if st["sub_groups"]:
+        assert st["small_jobs"] > 0 and st["groups"] > st["sub_groups"]
+    else:
+        assert st["small_jobs"] == 0

@@ -100,7 +100,7 @@ _lib.check(lib.hint_chain_backward_parts(chain, x.data_ptr(), None, z.data_ptr()
 torch.cuda.synchronize()
 bw = buf.cpu().numpy().copy()
 lib.hint_debug_set_stamp_buffer(None)
-stats = (C.c_int64 * 12)()
+stats = (C.c_int64 * 16)()
 from hint_amd.hint import node_descs
 nodes = flow.blocks[0].tree._flat_nodes()
 descs, _, _, _ = node_descs(nodes)

@@ -42,7 +42,7 @@ stream = torch.cuda.current_stream().cuda_stream
 from hint_amd.hint import node_descs
 nodes = flow.blocks[0].tree._flat_nodes()
 descs, _, _, _ = node_descs(nodes)
-stats = (C.c_int64 * 12)()
+stats = (C.c_int64 * 16)()
 lib.hint_plan_check(descs, len(nodes), cfg["d"], 0, 4.0, stats)
 ng = int(stats[0])
 
