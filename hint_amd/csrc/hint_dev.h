@@ -227,7 +227,7 @@ struct KArgs {
 
 // ---- wave-local plans (hint_wl.hpp) ----
 constexpr int WL_PAR_REGS = 6;      // float4 per thread of the next block's staged parameters in flight
-constexpr int WL_PAR_REGS2 = 6;     // ... of the row-pair kernels (four measured no faster, and GAS d = 8 needs five)
+constexpr int WL_PAR_REGS2 = 5;     // ... of the row-pair kernels (GAS d = 8 needs five; six cost the forward 5 and the backward 6 more spilled registers)
 constexpr int WL_LV = 4;            // floats per lane of a [16, d] tile held in registers: d <= 16
 
 // where the WL kernels keep things in LDS (float offsets) and how the block's small parameters are staged
