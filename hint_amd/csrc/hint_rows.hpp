@@ -158,82 +158,128 @@ __device__ __forceinline__ void load_extra3(f32x4 (&dst)[NTT], const PhaseCtx& c
 // direction's thin blob (vector layout, inputs padded to four with zero vectors: no branches for the usual
 // K <= 4), staged in LDS once per block when it is small enough (STAGED).
 typedef int i32x4c __attribute__((ext_vector_type(4)));
-template <int KIND, bool STAGED>
-__device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins, int t0, int t1, int lane) {
+#ifndef HINT_THIN_RUN
+#define HINT_THIN_RUN 4
+#endif
+constexpr int THIN_RUN = HINT_THIN_RUN;       // tiles of a thin layer worked on together (4 or 6)
+// NTI tiles with the same inputs (tiles of one unit, or of the s and the t subnet of a node) in lockstep: the inputs are read
+// once and the tiles' dependent chains - record, vectors, FMAs / MFMAs, store - overlap instead of following each other
+// (a tile is 1.5-3 k cycles of latency and a few hundred of work)
+template <int KIND, bool STAGED, int NTI>
+__device__ __forceinline__ void thin_tiles(const PhaseCtx& c, const i32x4c (&rec)[NTI], int lane) {
     const int m = lane & 15, kq = lane >> 4;
-    for (int t = t0; t < t1; ++t) {
-        // (no look-ahead: a scalar load in flight would be waited for by every lgkmcnt wait of the tile's LDS reads)
-        const i32x4c rec = ((const CONST_AS i32x4c*)(unsigned long long)thins)[t];
-        const int K = rec.y & 0xff, kp = rec.w & 0xff;
-        const int vbase = rec.x + 4 * kq;                    // vector k of this lane's features: float offset vbase + 16 k
-        auto vec = [&](int k) -> f32x4 {
-            if (STAGED) return *(const LDS_AS f32x4*)(c.thin_l + vbase + 16 * k);
-            return *(const GLOBAL_AS f32x4*)(c.thin_g + vbase + 16 * k);
-        };
-        auto input = [&](int k) -> float {
-            if (KIND == K_FWD) {
-                const int ku = (rec.y >> 8) & 0xff, xoff = rec.y >> 16;
-                return k < ku ? c.xs[m * c.xld + xoff + k] : c.cs[m * c.cld + (k - ku)];
-            }
-            return c.gst[m * c.gld + (rec.y >> 16) + k];
-        };
-        f32x4 acc;
-        if ((rec.w >> 8) != 0) {
-            // wide layer: on the matrix pipe, out^T = W * in^T from fragment tiles of W (k-block kb = 1 KiB, lane l: W[16nt + (l&15)]
-            // [16kb + 4(l>>4) + i]); the B operand is gathered from the inputs (row l&15, input 16kb + 4(l>>4) + i; zero beyond K)
-            const GLOBAL_AS f32x4* wp = (const GLOBAL_AS f32x4*)(c.packed + (size_t)((rec.w >> 8) - 1) * 256) + lane;
-            const int KB = (K + 15) >> 4;
-            acc = KIND == K_FWD ? vec(kp) : zero4();
-            f32x4 w = wp[0];
-            for (int kb = 0; kb < KB; ++kb) {
-                const f32x4 wn = wp[(kb + 1 < KB ? kb + 1 : kb) * 64];
-                float b[4];
+    const int K = rec[0].y & 0xff, kp = rec[0].w & 0xff;
+    auto vec = [&](int n, int k) -> f32x4 {                  // vector k of this lane's features of tile n: float offset rec.x + 4 kq + 16 k
+        if (STAGED) return *(const LDS_AS f32x4*)(c.thin_l + rec[n].x + 4 * kq + 16 * k);
+        return *(const GLOBAL_AS f32x4*)(c.thin_g + rec[n].x + 4 * kq + 16 * k);
+    };
+    auto input = [&](int k) -> float {
+        if (KIND == K_FWD) {
+            const int ku = (rec[0].y >> 8) & 0xff, xoff = rec[0].y >> 16;
+            return k < ku ? c.xs[m * c.xld + xoff + k] : c.cs[m * c.cld + (k - ku)];
+        }
+        return c.gst[m * c.gld + (rec[0].y >> 16) + k];
+    };
+    f32x4 acc[NTI];
+    if ((rec[0].w >> 8) != 0) {
+        // wide layer: on the matrix pipe, out^T = W * in^T from fragment tiles of W (k-block kb = 1 KiB, lane l: W[16nt + (l&15)]
+        // [16kb + 4(l>>4) + i]); the B operand is gathered from the inputs (row l&15, input 16kb + 4(l>>4) + i; zero beyond K)
+        const GLOBAL_AS f32x4* wp[NTI];
+        f32x4 w[NTI];
+        const int KB = (K + 15) >> 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const int k = 16 * kb + 4 * kq + i; b[i] = input(k < K ? k : K - 1); b[i] = k < K ? b[i] : 0.f; }
+        for (int n = 0; n < NTI; ++n) {
+            wp[n] = (const GLOBAL_AS f32x4*)(c.packed + (size_t)((rec[n].w >> 8) - 1) * 256) + lane;
+            acc[n] = KIND == K_FWD ? vec(n, kp) : zero4();
+            w[n] = wp[n][0];
+        }
+        for (int kb = 0; kb < KB; ++kb) {
+            f32x4 wn[NTI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = mfma4(w[i], b[i], acc);
-                w = wn;
-            }
-        } else {
-        f32x4 w[4];
+            for (int n = 0; n < NTI; ++n) wn[n] = wp[n][(kb + 1 < KB ? kb + 1 : kb) * 64];
+            float b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int k = 16 * kb + 4 * kq + i; b[i] = input(k < K ? k : K - 1); b[i] = k < K ? b[i] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int n = 0; n < NTI; ++n) acc[n] = mfma4(w[n][i], b[i], acc[n]);
+#pragma unroll
+            for (int n = 0; n < NTI; ++n) w[n] = wn[n];
+        }
+    } else {
+        f32x4 w[NTI][4];
         float vin[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { w[k] = vec(k); vin[k] = k < K ? input(k) : 0.f; }
-        acc = KIND == K_FWD ? vec(kp) : zero4();
+        for (int k = 0; k < 4; ++k) {
+            vin[k] = k < K ? input(k) : 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc += w[k] * vin[k];
-        if (STAGED) {
-            // (eight inputs' reads in flight at a time: one at a time is a dependent LDS round trip per input)
-            constexpr int TL = 8;
-            for (int k = 4; k < K; k += TL) {
-                f32x4 wv[TL];
-                float iv[TL];
-#pragma unroll
-                for (int u = 0; u < TL; ++u) { const int kk = k + u < K ? k + u : K - 1; wv[u] = vec(kk); iv[u] = input(kk); }
-                __builtin_amdgcn_sched_barrier(0);      // (all sixteen reads first: hipcc otherwise waits for them pair by pair)
-#pragma unroll
-                for (int u = 0; u < TL; ++u) acc += wv[u] * (k + u < K ? iv[u] : 0.f);
-            }
-        } else {
-            // (from global memory: TB vectors in flight at a time; the padding terms add w * 0)
-            constexpr int TB = 8;
-            for (int k = 4; k < K; k += TB) {
-                f32x4 wv[TB];
-                float iv[TB];
-#pragma unroll
-                for (int u = 0; u < TB; ++u) { const int kk = k + u < K ? k + u : K - 1; wv[u] = vec(kk); iv[u] = k + u < K ? input(kk) : 0.f; }
-#pragma unroll
-                for (int u = 0; u < TB; ++u) acc += wv[u] * iv[u];
-            }
+            for (int n = 0; n < NTI; ++n) w[n][k] = vec(n, k);
         }
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            acc[n] = KIND == K_FWD ? vec(n, kp) : zero4();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[n] += w[n][k] * vin[k];
         }
-        if (KIND == K_FWD) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        ((LDS_AS f32x4*)c.abuf)[rec.z * 64 + lane] = acc;
+        // (inputs beyond four, at most eight: more go to the matrix pipe; their reads in flight together - one at a time is a
+        //  dependent round trip per input; the padding terms add w * 0)
+        constexpr int TL = 4;
+        for (int k = 4; k < K; k += TL) {
+            f32x4 wv[NTI][TL];
+            float iv[TL];
+#pragma unroll
+            for (int u = 0; u < TL; ++u) {
+                const int kk = k + u < K ? k + u : K - 1;
+                iv[u] = input(kk);
+#pragma unroll
+                for (int n = 0; n < NTI; ++n) wv[n][u] = vec(n, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (all reads first: hipcc otherwise waits for them pair by pair)
+#pragma unroll
+            for (int u = 0; u < TL; ++u)
+#pragma unroll
+                for (int n = 0; n < NTI; ++n) acc[n] += wv[n][u] * (k + u < K ? iv[u] : 0.f);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NTI; ++n) {
+        f32x4 v = acc[n];
+        if (KIND == K_FWD) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        ((LDS_AS f32x4*)c.abuf)[rec[n].z * 64 + lane] = v;
         if (KIND == K_FWD && HINT_STORE_ON) {
-            c.bits_a1[((c.wcol0 >> 4) + rec.z) * 64 + lane] = (uint8_t)sign_bits(acc);
+            c.bits_a1[((c.wcol0 >> 4) + rec[n].z) * 64 + lane] = (uint8_t)sign_bits(v);
             if (c.obuf == nullptr && c.out_thin != nullptr)      // (no LDS staging: the tile goes to the tape from here)
-                *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + c.wcol0 + 16 * rec.z) + (m * c.WT + 4 * kq)) = acc;
+                *(GLOBAL_AS f32x4*)(c.out_thin + ((size_t)c.row0 * c.WT + c.wcol0 + 16 * rec[n].z) + (m * c.WT + 4 * kq)) = v;
         }
+    }
+}
+template <int KIND, bool STAGED>
+__device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins, int t0, int t1, int lane) {
+    const CONST_AS i32x4c* recs = (const CONST_AS i32x4c*)(unsigned long long)thins;
+    int t = t0;
+    while (t < t1) {
+        // up to THIN_RUN consecutive tiles with the same inputs at a time
+        // (no look-ahead beyond them: a scalar load in flight would be waited for by every lgkmcnt wait of their LDS reads)
+        i32x4c r[THIN_RUN];
+#pragma unroll
+        for (int n = 0; n < THIN_RUN; ++n) r[n] = recs[t + n < t1 ? t + n : t];
+        int run = 1;
+#pragma unroll
+        for (int n = 1; n < THIN_RUN; ++n)
+            if (run == n && t + n < t1 && r[n].y == r[0].y && (r[n].w & 0xff) == (r[0].w & 0xff) && ((r[n].w >> 8) != 0) == ((r[0].w >> 8) != 0)) run = n + 1;
+#define HINT_THIN_CASE(N)                                                          \
+        if (run == (N)) {                                                          \
+            i32x4c rr[N];                                                          \
+            _Pragma("unroll") for (int n = 0; n < (N); ++n) rr[n] = r[n];          \
+            thin_tiles<KIND, STAGED, (N)>(c, rr, lane);                            \
+        }
+        HINT_THIN_CASE(1) else HINT_THIN_CASE(2) else HINT_THIN_CASE(3) else HINT_THIN_CASE(4)
+#if HINT_THIN_RUN >= 6
+        else HINT_THIN_CASE(5) else HINT_THIN_CASE(6)
+#endif
+#undef HINT_THIN_CASE
+        t += run;
     }
 }
 
