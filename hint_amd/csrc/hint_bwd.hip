@@ -14,6 +14,11 @@
 //       the accumulator the K-split partial of g_v into the row's slab            (run_rows<K_BWD>)
 // All weight gradients are batch reductions of (g1, g2, g_st) against (v, a1, a2): part B
 // (hint_wgrad.hip) computes them from the arrays written here.
+// rows of up to FOUR tiles in the general kernels (the wave-local ones keep three): a row's steps wait for L2 however few MFMAs
+// they hold, so fewer, wider rows - h = 56 as one row instead of 2 + 2 - halve what a unit costs (hint_plan.cpp: GEN_NTT)
+#ifndef HINT_NTT
+#define HINT_NTT 4
+#endif
 #include "hint_sub.hpp"
 
 using namespace hint;

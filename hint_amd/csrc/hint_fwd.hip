@@ -13,6 +13,9 @@
 //       fragment tiles in LDS), the second layer on the matrix pipe and, straight from its
 //       accumulator, the third layer's K-split partial (+ bias) into the row's slab   (run_rows<K_FWD>)
 //   P3  coupling: s, t = sum of the slabs; l' = exp(a) l + t; log-det
+// rows of up to FOUR tiles in the general kernels (the wave-local ones keep three): a row's steps wait for L2 however few MFMAs
+// they hold, so fewer, wider rows - h = 56 as one row instead of 2 + 2 - halve what a unit costs (hint_plan.cpp: GEN_NTT)
+#define HINT_NTT 4
 #include "hint_sub.hpp"
 
 using namespace hint;

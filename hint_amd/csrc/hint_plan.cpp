@@ -36,8 +36,12 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
                         int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream);
+hipError_t launch_bwd_n3(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
+                         int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
+                         float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);      // (hint_bwd3.hip: rows of <= 3 tiles)
 hipError_t set_max_lds_apply(int bytes);
 hipError_t set_max_lds_bwd(int bytes);
+hipError_t set_max_lds_bwd_n3(int bytes);
 hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
                            const ChainBlock* chain, int n_chain, const float* x, float* z, float* J, const float* J_in,
                            float* loss_acc, float noise, const unsigned long long* rng_state, float* x_noisy,
@@ -114,6 +118,7 @@ struct hint_plan {
     int n_sub = 0, sub_pf = 0, sub_pb = 0, sub_pbias = 0, sub_bsrc = 0, sub_cols = 0;
     int sub_slab_f = 0, sub_slab_b = 0;                 // floats of their slabs
     int sub_lds_f[3] = {0, 0, 0}, sub_lds_b[3] = {0, 0, 0};   // LDS float offsets: slabs, staged parameters, misc
+    int row_ntt = 0;            // tiles of the widest row (<= 3: the backward pass runs on hint_bwd_kernel_n3)
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
@@ -144,10 +149,11 @@ struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
 
 // The rows of a group: per unit at least ceil(NT / NTT) of them; more (narrower ones) while the group has fewer rows
 // than wavefronts.
-static std::vector<Row> split_rows(const std::vector<Unit>& units, const Group& g, int nw) {
+static constexpr int GEN_NTT = 4;       // tiles per row of the general kernels (hint_fwd.hip / hint_bwd.hip are compiled with HINT_NTT 4); NTT (3): the wave-local ones
+static std::vector<Row> split_rows(const std::vector<Unit>& units, const Group& g, int nw, int ntt_max) {
     std::vector<int> nrows(g.unit_end - g.unit_begin);
     int total = 0;
-    for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, NTT); total += nrows[ui - g.unit_begin]; }
+    for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { nrows[ui - g.unit_begin] = cdiv(units[ui].NT, ntt_max); total += nrows[ui - g.unit_begin]; }
     while (total < nw) {
         int best = -1; double bw = 0;
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {       // split where the rows are widest
@@ -329,7 +335,7 @@ static const char* check_records(const std::vector<Group>& groups, const std::ve
                     const int tb = (q.ocol - q.wcol) / 16;
                     int ui = -1;
                     for (int u = g.unit_begin; u < g.unit_end; ++u) if (units[u].tile0 == tile0) ui = u;
-                    if (ui < 0 || units[ui].NT != NT || ntt < 1 || ntt > NTT || tb < 0 || tb + ntt > NT) return "row record";
+                    if (ui < 0 || units[ui].NT != NT || ntt < 1 || ntt > GEN_NTT || tb < 0 || tb + ntt > NT) return "row record";
                     if ((q.flags >> 9) & 1) ++firsts[ui - g.unit_begin];
                     for (int j = 0; j < ntt; ++j) ++seen[tile0 + tb + j];
                 }
@@ -473,6 +479,15 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
         }
     }
+    // rows of three tiles for the trees the wave-local kernels may take, of four for the general kernels
+    int ntt_max = GEN_NTT;
+    {
+        bool narrow = dc == 0 && d <= 4 * WL_LV;
+        for (int i = 0; i < n_nodes; ++i)
+            if (nodes[i].k < 1 || nodes[i].k > 4 || nodes[i].r < 1 || nodes[i].r > 4) narrow = false;
+        if (narrow) ntt_max = NTT;
+        if (const char* e = std::getenv("HINT_GEN_NTT")) { const int v = std::atoi(e); if (v >= 1 && v <= GEN_NTT && !narrow) ntt_max = v; }
+    }
     int sub_off3 = 0, sub_offv = 0;       // the subtree groups' slabs: one area for all of them (the wavefronts are at different levels at any time)
     bool sub_closed = false;             // the first group above the subtree levels has been seen
 
@@ -596,7 +611,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->abuf_tiles = std::max(P->abuf_tiles, tiles);
         P->gld = std::max(P->gld, (sub ? gcol : g.gcols) | 1);      // (subtree groups: the columns of all of them side by side)
 
-        std::vector<Row> rows = split_rows(units, g, nw);
+        std::vector<Row> rows = split_rows(units, g, nw, ntt_max);
+        for (const Row& rw : rows) P->row_ntt = std::max(P->row_ntt, rw.ntt);
         int off3 = 0, offv = 0;
         g.tile_begin = (int)thin_f.size();
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
@@ -665,7 +681,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (P->n_sub > 0) {
         P->sub_cols = (int)rng.size();
         rng.insert(rng.end(), sub_cols_v.begin(), sub_cols_v.end());
-        P->sub_slab_f = sub_off3; P->sub_slab_b = sub_offv;
+        P->sub_slab_f = 0; P->sub_slab_b = 0;       // (the nodes' partial sums stay in registers: no slabs in LDS; the offsets above are unused)
     }
     P->n_groups = (int)groups.size();
     P->n_units = (int)units.size();
@@ -970,6 +986,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // of different sizes created in any order (or on several devices) cannot lower it for each other
     if (e == hipSuccess) e = set_max_lds_apply(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_bwd(LDS_ATTR);
+    if (e == hipSuccess) e = set_max_lds_bwd_n3(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_wl_apply(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_wl_bwd(LDS_ATTR);
     if (e != hipSuccess) {
@@ -1179,6 +1196,7 @@ int hint_plan_describe(const hint_plan* P, int32_t B, int32_t* out) {
     if (!P || !out || B < 0) return fail("hint_plan_describe: bad arguments");
     P = variant(P, B);
     out[0] = P->wl; out[1] = wl_nr_for(P, B); out[2] = P->nw; out[3] = P->lean;
+    out[4] = P->n_sub; out[5] = P->row_ntt; out[6] = 0; out[7] = 0;
     return 0;
 }
 
@@ -1306,8 +1324,8 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
         HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
     } else if (parts & 1) {
         // (the permutation matrices stay in global memory here: one d x d product per block)
-        HIP_TRY(launch_bwd(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c, g_z, g_J, g_x,
-                           g_c, gz_scale, gJ_const, s));
+        HIP_TRY((P->row_ntt <= 3 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
+                                                               g_z, g_J, g_x, g_c, gz_scale, gJ_const, s));
     }
     if (!(parts & 2)) return 0;
     int splits, rows_per_wg;

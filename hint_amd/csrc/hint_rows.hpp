@@ -433,7 +433,12 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
         const RowU nr = decode_rec(nrec);
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
         if (t == r0) { STAMP(c.sid + 9) }
-        if constexpr (NTT >= 3) {
+        if constexpr (NTT >= 4) {
+            if (cr.ntt >= 4) row_body<KIND, 4>(c, cr, nr, ring, lo, lane);
+            else if (cr.ntt == 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
+            else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
+            else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+        } else if constexpr (NTT == 3) {
             if (cr.ntt >= 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
             else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
             else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);

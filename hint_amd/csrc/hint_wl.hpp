@@ -106,7 +106,7 @@ template <int KIND, int NR>
 __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const RowU& nr, const GLOBAL_AS float* pkn,
                                        const GLOBAL_AS uint8_t* const (&bitsn)[2], f32x4 (&ring)[RING][NEL], f32x4 (&part)[NR],
                                        const LaneOff& lo, int lane) {
-    static_assert(RING == 2 && NTT == 3, "the WL rows alternate two ring slots of three tiles");
+    static_assert(KIND < 0 || (RING == 2 && NTT == 3), "the WL rows alternate two ring slots of three tiles");     // (checked where instantiated: the general kernels include this header for its helpers with NTT = 4)
     const int m = lane & 15, kq = lane >> 4;
     const int n1 = cr.n1, ntt = cr.ntt;
     STAMP(c.sid + 0)

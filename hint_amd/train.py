@@ -532,11 +532,11 @@ class FlowTrainer:
         """(forward, backward part A) kernel of a batch of B rows as rocprof prints them: the wave-local kernels for narrow
         trees (template arguments: direction / row tiles per workgroup), the general ones otherwise"""
         import ctypes as C
-        info = (C.c_int32 * 4)()
+        info = (C.c_int32 * 8)()
         _lib.check(self.lib.hint_plan_describe(self.engines[0].plan, B, info), "hint_plan_describe")
         if info[0]:
             return f"hint_wl_apply_kernel<false, {info[1]}>", f"hint_wl_bwd_kernel<{info[1]}>"
-        return "hint_apply_kernel<false>", "hint_bwd_kernel"
+        return "hint_apply_kernel<false>", ("hint_bwd_kernel_n3" if info[5] <= 3 else "hint_bwd_kernel")
 
     def _capture(self, x, c):
         self._check_arenas()

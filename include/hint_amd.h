@@ -100,7 +100,9 @@ int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
 /* Which kernels a batch of B rows runs on (diagnostics, bench labels): out[0] = 1 when the block runs on the wave-local
  * kernels (hint_wl_apply_kernel / hint_wl_bwd_kernel: every subnet has 1..4 inputs and at most 4 outputs), 0 for the
  * general ones (hint_apply_kernel / hint_bwd_kernel); out[1] = 16-row tiles per workgroup (1, or 2: row pairs);
- * out[2] = wavefronts per workgroup; out[3] = 1 when no a1 / g2 arrays exist (part B rebuilds them). */
+ * out[2] = wavefronts per workgroup; out[3] = 1 when no a1 / g2 arrays exist (part B rebuilds them); out[4] = subtree groups (the
+ * deepest levels that run one subtree per wavefront); out[5] = tiles of the widest row (<= 3: the general backward pass runs on
+ * hint_bwd_kernel_n3); out[6], out[7] = 0.  out must hold 8 values. */
 int hint_plan_describe(const hint_plan* plan, int32_t B, int32_t* out);
 
 /* Re-pack the flat parameters into `packed` (hint_plan_packed_floats floats).  Must be called

@@ -13,27 +13,29 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 SHAPES = [
-    (43, [67, 33, 16, 8], 37),                 # cfg 5 (configs/uci_data/miniboone_hint_10.py), ragged batch
-    (43, [67, 33, 16, 8], 4100),               # ... on the 4-wavefront variant: two subtrees per wavefront
-    (20, [40, 16, 8], 16),
-    (64, [16, 16, 16, 16], 70),                # three subtree levels, every wavefront busy in all of them
-    (26, [16, 16, 8, 8, 8], 16),               # wavefronts without nodes in the deepest level
-    (100, [48, 24, 20, 12, 8, 8], 33),         # 16 subtrees on 8 wavefronts; the deepest level only in every fourth
-    (100, [16, 16, 16, 16, 8, 8, 8], 16),
+    (43, [67, 33, 16, 8], 37, 2),               # cfg 5 (configs/uci_data/miniboone_hint_10.py), ragged batch
+    (43, [67, 33, 16, 8], 4100, 2),             # ... on the 4-wavefront variant: two subtrees per wavefront
+    (20, [40, 16, 8], 16, 1),
+    (64, [16, 16, 16, 16], 70, 0),             # three subtree levels, every wavefront busy in all of them
+    (26, [16, 16, 8, 8, 8], 16, 1),             # wavefronts without nodes in the deepest level
+    (100, [48, 24, 20, 12, 8, 8], 33, 1),         # 16 subtrees on 8 wavefronts; the deepest level only in every fourth
+    (100, [16, 16, 16, 16, 8, 8, 8], 16, 1),
 ]
 
 
-@pytest.mark.parametrize("d,widths,B", SHAPES, ids=lambda v: str(v).replace(" ", ""))
-def test_subtree_groups_vs_oracle(d, widths, B):
+@pytest.mark.parametrize("d,widths,B,min_sub", SHAPES, ids=lambda v: str(v).replace(" ", ""))
+def test_subtree_groups_vs_oracle(d, widths, B, min_sub):
     nodes = orc.build_nodes(d, [], widths)
     P = orc.init_params(nodes, seed=1, scale=None)
     x = torch.randn(B, d, generator=torch.Generator().manual_seed(5))
     blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=list(widths))
     blk.load_state_dict({k: v.clone() for k, v in P.items()})
     blk = blk.to(DEV)
-    info = (__import__("ctypes").c_int32 * 4)()
+    info = (__import__("ctypes").c_int32 * 8)()
     eng = blk.tree.engine(torch.device(DEV))
     assert eng.lib.hint_plan_describe(eng.plan, B, info) == 0 and info[0] == 0      # (the general kernels, not the wave-local ones)
+    print(f"d={d} widths={widths} B={B}: {info[4]} subtree groups, {info[2]} wavefronts")
+    assert info[4] >= min_sub
 
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     xg = x.clone().requires_grad_(True)
