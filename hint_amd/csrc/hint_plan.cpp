@@ -1014,7 +1014,9 @@ static int pick_nw(int d) {
 // groups do not fit either, fewer wavefronts per unit (fewer slabs)
 static int plan_for(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int nw, hint_plan** out) {
     for (int unit_waves = nw; unit_waves >= 1; unit_waves /= 2)
-        for (int tile_cap = 72; tile_cap >= 8; tile_cap -= 16) {
+        // (64 tiles = 16 rows of four: two per wavefront; 72 gave 18 rows - three for two of the wavefronts, everybody waits for them:
+        //  the d = 100 flows +4 %; HINT_TILE_CAP overrides)
+        for (int tile_cap = env_int("HINT_TILE_CAP") >= 8 ? env_int("HINT_TILE_CAP") : 64; tile_cap >= 8; tile_cap -= 16) {
             bool retry = false;
             const int st = build_plan(nodes, n_nodes, d, dc, clamp, nw, tile_cap, unit_waves, out, &retry);
             if (st != 2) return st;
