@@ -113,11 +113,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             const bool top = perm != nullptr || cb > 0;
             float* wsGST = (float*)blk.wsGST;
             if (a.n_sub > 0) sub_par_stage(a, blk.packed, lds, tid, nthreads);     // (the subtree groups' thin vectors and biases)
-            if (a.thin_lds > 0) {
+            if (a.thin_lds > 0 && a.thin_grp == 0) {
                 const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
                 for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
             }
-            if (a.thin_lds > 0 || a.n_sub > 0) __syncthreads();
+            if ((a.thin_lds > 0 && a.thin_grp == 0) || a.n_sub > 0) __syncthreads();
             PhaseCtx pc;
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
@@ -202,6 +202,13 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                             }
                         }
                     }
+                }
+                // (this group's thin vectors -> LDS when the block's are too many for it: read behind the barrier below)
+                bool thin_staged = a.thin_lds > 0;
+                if (a.thin_grp > 0 && !tail_only && slot >= a.n_sub) {
+                    pc.thin_l = thin_group_stage(thinb, a.thin_grp, blk.packed + a.thin_off, (const char*)a.thins + (size_t)a.total_tiles * sizeof(ThinRec),
+                                                 g.tile_begin, g.ntiles, a.total_tiles, a.thin_floats, tid, nthreads);
+                    thin_staged = pc.thin_l != nullptr;
                 }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
                 for (int idx = tid; idx < ROWS * a.d && tid < qthreads; idx += qthreads) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 {
                     const char* thb = (const char*)a.thins + (size_t)a.total_tiles * sizeof(ThinRec);
                     const int t0 = g.tile_begin + lds_i32(rng + a.nw + 1 + wave), t1 = g.tile_begin + lds_i32(rng + a.nw + 2 + wave);
-                    if (a.thin_lds > 0) thin_phase<K_BWD, true>(pc, thb, t0, t1, lane);
+                    if (thin_staged) thin_phase<K_BWD, true>(pc, thb, t0, t1, lane);
                     else thin_phase<K_BWD, false>(pc, thb, t0, t1, lane);
                 }
                 lds_barrier();

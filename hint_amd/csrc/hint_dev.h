@@ -209,6 +209,7 @@ struct KArgs {
     int32_t stage_out;             // 1: the rows leave their output tiles in LDS (obuf) and the element-wise phase streams them out; 0: no LDS for that, they store them themselves
     int32_t thin_off, thin_floats; // the direction's thin blob: float offset in the packed buffer, size (multiple of 4)
     int32_t thin_lds;              // float offset in LDS where the kernel stages it per block; 0: read it from global memory
+    int32_t thin_grp;              // > 0: the blob is too large for that - the buffer at thin_lds (thin_grp floats) takes one GROUP's vectors at a time
     int32_t perm_lds;              // float offset in LDS of the chain's d x d permutation matrices; 0: read them from global memory
     int64_t act_stride;            // floats between the a1 and a2 (g1 and g2) arrays
     float alpha;

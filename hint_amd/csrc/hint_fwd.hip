@@ -104,13 +104,13 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
             }
             if (a.n_sub > 0) sub_par_stage(a, blk.packed, lds, tid, nthreads);     // (the subtree groups' thin vectors and biases)
-            if (a.thin_lds > 0) {
+            if (a.thin_lds > 0 && a.thin_grp == 0) {
                 // this block's thin-layer weights (vector layout, a few KiB) into LDS: every wavefront re-reads them
                 // for its units, and all workgroups asking L2 for the same few lines at once is what made them slow
                 const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
                 for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
             }
-            if (a.thin_lds > 0 || a.n_sub > 0) __syncthreads();
+            if ((a.thin_lds > 0 && a.thin_grp == 0) || a.n_sub > 0) __syncthreads();
             PhaseCtx pc;
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
@@ -154,10 +154,17 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 (void)sid;
                 pc.sid = sid;
                 STAMP(sid + 0)
+                bool thin_staged = a.thin_lds > 0;
+                if (a.thin_grp > 0) {      // (the group's thin vectors: the block's are too many for the LDS)
+                    pc.thin_l = thin_group_stage(thinb, a.thin_grp, blk.packed + a.thin_off, a.thins, g.tile_begin, g.ntiles, a.total_tiles,
+                                                 a.thin_floats, tid, nthreads);
+                    thin_staged = pc.thin_l != nullptr;
+                    if (thin_staged) lds_barrier();
+                }
                 // ---- P1: first layer of every unit of the group on the vector ALU, the tiles shared out ----
                 {
                     const int t0 = g.tile_begin + lds_i32(rng + a.nw + 1 + wave), t1 = g.tile_begin + lds_i32(rng + a.nw + 2 + wave);
-                    if (a.thin_lds > 0) thin_phase<K_FWD, true>(pc, a.thins, t0, t1, lane);
+                    if (thin_staged) thin_phase<K_FWD, true>(pc, a.thins, t0, t1, lane);
                     else thin_phase<K_FWD, false>(pc, a.thins, t0, t1, lane);
                 }
                 STAMP(sid + 1)

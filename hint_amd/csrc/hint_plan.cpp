@@ -110,6 +110,7 @@ struct hint_plan {
     int tw_floats = 0;          // floats of one such slab
     int32_t* d_twmap = nullptr; // slab index -> offset in the flat parameter layout (or -1)
     int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
+    int thin_grp_f = 0, thin_grp_b = 0;     // > 0: LDS takes one group's thin vectors at a time (floats of the largest group's)
     int lds_fwd = 0, lds_bwd = 0;
     // wave-local plans (hint_wl.hpp): narrow trees run on hint_wl_apply_kernel / hint_wl_bwd_kernel
     int wl = 0, wl_nr2 = 0;     // wl_nr2: two 16-row tiles per workgroup on one weight stream fit the LDS as well
@@ -883,6 +884,26 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->thin_lds_b = P->lds_bwd / 4;
         P->lds_bwd += P->thin_b_floats * 4;
     }
+    // blobs too large for that (the d = 100 trees: 300 KB): one group's vectors at a time - a run of thin tiles reading them from L2
+    // costs 5 k cycles, from LDS 2 k (HINT_THIN_GRP=0: never)
+    {
+        // (the buffer: the largest group slice that fits; larger groups - the roots, whose wide thin layers run on the matrix pipe
+        //  and read one bias vector per tile - keep reading from L2)
+        const bool on = !(std::getenv("HINT_THIN_GRP") && std::atoi(std::getenv("HINT_THIN_GRP")) == 0) && !(std::getenv("HINT_THIN_LDS") && std::atoi(std::getenv("HINT_THIN_LDS")) == 0);
+        auto avail = [&](int lds) { return lds > LDS_LIMIT / 2 ? LDS_LIMIT - lds : LDS_LIMIT / 2 - lds; };
+        const int av_f = avail(P->lds_fwd) / 4, av_b = avail(P->lds_bwd) / 4;
+        int gmax_f = 0, gmax_b = 0;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const int t0 = groups[gi].tile_begin, t1 = t0 + groups[gi].ntiles;
+            if (t0 >= t1) continue;
+            const int f1 = t1 < (int)thin_f.size() ? thin_f[t1].voff : P->thin_f_floats, b1 = t1 < (int)thin_b.size() ? thin_b[t1].voff : P->thin_b_floats;
+            const int sf = (f1 - thin_f[t0].voff + 3) / 4 * 4, sb = (b1 - thin_b[t0].voff + 3) / 4 * 4;
+            if (sf <= av_f) gmax_f = std::max(gmax_f, sf);
+            if (sb <= av_b) gmax_b = std::max(gmax_b, sb);
+        }
+        if (on && P->thin_lds_f == 0 && gmax_f > 0) { P->thin_lds_f = P->lds_fwd / 4; P->thin_grp_f = gmax_f; P->lds_fwd += 4 * gmax_f; }
+        if (on && P->thin_lds_b == 0 && gmax_b > 0) { P->thin_lds_b = P->lds_bwd / 4; P->thin_grp_b = gmax_b; P->lds_bwd += 4 * gmax_b; }
+    }
     if (P->lds_bwd > LDS_LIMIT || P->lds_fwd > LDS_LIMIT) {
         const int need = std::max(P->lds_bwd, P->lds_fwd);
         const bool could_shrink = P->abuf_tiles > 0 && P->n_groups < (int)order.size();
@@ -1225,6 +1246,7 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.thin_off = backward ? P->thin_b_off : P->thin_f_off;
     a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
     a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;
+    a.thin_grp = backward ? P->thin_grp_b : P->thin_grp_f;
     a.act_stride = act_stride(P, B); a.bits_stride = bits_stride(P, B);
     a.fuse_dw1 = P->fuse_dw1; a.tw_floats = P->tw_floats; a.thin_slab_off = ws_thin_off(P, B);
     a.lean = P->lean; a.a2_off = P->lean ? 0 : a.act_stride; a.bits_off = (P->lean ? 1 : 2) * a.act_stride;

@@ -158,6 +158,19 @@ __device__ __forceinline__ void load_extra3(f32x4 (&dst)[NTT], const PhaseCtx& c
 // direction's thin blob (vector layout, inputs padded to four with zero vectors: no branches for the usual
 // K <= 4), staged in LDS once per block when it is small enough (STAGED).
 typedef int i32x4c __attribute__((ext_vector_type(4)));
+// One group's thin vectors -> the LDS buffer (blobs too large to stage whole): the group's tiles are [tile_begin, tile_begin + ntiles)
+// of this direction's records, their vectors one contiguous slice of the blob.  Returns the buffer's base for the records'
+// blob-relative offsets (a workgroup barrier follows), or nullptr when the slice is larger than the buffer (buf_floats).
+__device__ __forceinline__ const LDS_AS float* thin_group_stage(float* buf, int buf_floats, const GLOBAL_AS float* blob, const void* thins,
+                                                                int tile_begin, int ntiles, int total_tiles, int blob_floats, int tid, int nthreads) {
+    const CONST_AS i32x4c* recs = (const CONST_AS i32x4c*)(unsigned long long)thins;
+    const int v0 = recs[tile_begin].x;
+    const int v1 = tile_begin + ntiles < total_tiles ? recs[tile_begin + ntiles].x : blob_floats;
+    if (v1 - v0 > buf_floats) return nullptr;
+    const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blob + v0);
+    for (int i = tid; i < ((v1 - v0) >> 2); i += nthreads) ((f32x4*)buf)[i] = src[i];
+    return (const LDS_AS float*)buf - v0;
+}
 #ifndef HINT_THIN_RUN
 #define HINT_THIN_RUN 4
 #endif
