@@ -12,7 +12,7 @@
 // activations travel between wavefronts as 1 KiB "fragment tiles" in LDS (element [lane*4+i]),
 // written and read with one ds_*_b128 per lane.  The thin first layer (K = a few lanes) and g2
 // (K = r) are plain FMAs on the vector ALU in the same lane layout.  The unit of work is a ROW: up to
-// three adjacent 16-feature tiles of one unit (one subnet of one node) that share every B fragment;
+// NTT (three; four in the general kernels) adjacent 16-feature tiles of one unit (one subnet of one node) that share every B fragment;
 // the plan deals a group's rows to the wavefronts (balanced per SIMD) as per-wavefront record lists.
 #pragma once
 #include <stdint.h>
@@ -28,7 +28,7 @@ constexpr int TILE = 16;        // MFMA 16x16x4 f32 tile edge
 #define HINT_NTT 3
 #endif
 constexpr int MAX_NW = HINT_MAX_NW;   // wavefronts per workgroup (plan-time choice: 4, 8, ...)
-constexpr int NTT = HINT_NTT;         // fragment tiles per row (hint_rows.hpp)
+constexpr int NTT = HINT_NTT;         // fragment tiles per row (hint_rows.hpp): 3 by default (planner, wave-local kernels); hint_fwd.hip / hint_bwd.hip define 4
 constexpr int MAX_RT = 4;       // 16-wide tiles of a unit's output (r <= 64) and of its input (cin <= 64 + dc)
 constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (cin <= 192)
 constexpr int LV_REGS = 4;      // hint_bwd.hip holds a prefetched [16, d] tile in LV_REGS floats per thread: 16 * d <= LV_REGS * threads (the planner picks the wavefront count for it)
@@ -150,7 +150,7 @@ struct WJob {
 };
 static_assert(sizeof(WJob) == 128, "WJob must be 128 bytes");
 
-// Row record: everything a wavefront needs to know about one row - up to three adjacent fragment tiles
+// Row record: everything a wavefront needs to know about one row - up to NTT adjacent fragment tiles
 // [tb, tb+ntt) of one unit - in one direction; 16 x int32, read with one scalar load.  The steps of a
 // row, every one `ntt` elements wide: n1 main steps (weight tiles base1 + j*n1 + kb), one aux step (bias
 // vectors at packed + aux + 16 j, or the forward activation tiles at column ocol + 16 j), n2 tail steps

@@ -1,5 +1,5 @@
 // The GEMM engine of the block kernels.  One wavefront executes its list of ROWS of a group; a row
-// is up to three adjacent fragment tiles (16 output features x 16 batch rows each) of one unit
+// is up to NTT (three or four) adjacent fragment tiles (16 output features x 16 batch rows each) of one unit
 // that share every B fragment:
 //
 //   direction  thin layer (VALU, per unit)      main steps (A = weight tiles)   B operand      aux step            tail steps
@@ -18,7 +18,7 @@
 // The weight stream runs through a register ring of RING slots x 3 elements: every step consumes one
 // slot and first issues the 16-byte-per-lane global loads of the step RING - 1 ahead into the slot the
 // step before used (no copies of live values; a row's body is compiled for its tile count; the hand-over
-// to the next row always loads three elements, a narrower row's last tile again: an L1 hit) - weight
+// to the next row always loads NTT elements, a narrower row's last tile again: an L1 hit) - weight
 // tiles and the sign bytes of the forward activations that mask the backward tiles travel the same way.  That regularity is what lets hipcc keep the
 // loads in flight (counted vmcnt waits): a load under a branch makes its wait-count analysis assume
 // the worst on every path.  A row's stream is [main steps, padded with dummies to a multiple of
