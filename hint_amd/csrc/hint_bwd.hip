@@ -130,6 +130,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.bits_a2 = pc.bits_a1 + a.bits_stride;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
             pc.store = true;
+            pc.scratch = (LDS_AS float*)(lds + a.rowdw_lds + wave * 256);
+            pc.tw = blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
+            pc.first_tile = tile == (int)blockIdx.x;
 
             f32x4 ring[RING][NEL];
             {   // the weight stream (and the a2 tiles) of the root group's first row: started before its coupling phase
@@ -333,6 +336,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 STAMP(sid + 5)
                 if (a.fuse_dw1)          // the lanes this group's first layers read: kept for their weight gradients (computed across the next boundary)
                     for (int i = tid; i < ROWS * a.d; i += nthreads) { const int r = fdiv(i, inv_d), j = i - r * a.d; xo[r * a.xld + j] = xs[r * a.xld + j]; }
+                // (rows that compute dW1 | db1 themselves read the level's lanes to their end: nobody overwrites them before all are through)
+                if (lp_pending && a.rowdw_lds > 0 && g.lean && !g.staged) lds_barrier();
                 if (lp_pending) level_commit(lp, xs, sb, a.xld, a.d, tid, nthreads);
                 lds_barrier();
                 STAMP(sid + 6)

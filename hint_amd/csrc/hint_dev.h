@@ -168,7 +168,8 @@ struct RowRec {
     int32_t thin_b;     // wave-local plans: offset of the OTHER direction's thin vectors of the row's first tile (forward: W3^T, backward: W1 | b1)
     int32_t thin_k;     // forward: cin | ku << 8 | xoff << 16;  backward: r | lcol << 16
     int32_t flags;      // NT | thin << 8 (run the thin layer before this row) | first << 9 (the row holds the unit's tile 0: it stores the thin layer's tiles and adds b3)
-                        // | ulast << 10 (the wavefront's last row of the unit)
+                        // | ulast << 10 (the wavefront's last row of the unit) | rowdw << 11 (backward, general kernels: the row computes dW1 | db1 of its
+                        //   tiles itself - lean group whose outputs are not staged in LDS - and does not store g1; p1, p2 as in the wave-local plans)
     int32_t wcol;       // column of the unit's tile 0 in the [Bp][WT] arrays
     int32_t tb;         // first tile of the row inside its unit
     int32_t p1, p2;     // wave-local plans, backward: offset of the row's first feature in the workgroup's first-layer gradient slab; cin | xoff << 8 | h << 16
@@ -224,6 +225,7 @@ struct KArgs {
     int32_t sub_slab;              // LDS float offset of their slabs (this direction)
     int32_t sub_misc;              // LDS float offset: forward nw x 16 log-det partials; backward two 256-float scratch tiles per wavefront
     int32_t sub_cols;              // index in the ranges table of the wavefronts' lane bounds: four per wavefront (hint_plan.cpp)
+    int32_t rowdw_lds;             // backward: float offset in LDS of one scratch tile (256 floats) per wavefront for the rows that compute dW1 | db1 themselves; 0: none do
 };
 
 // ---- wave-local plans (hint_wl.hpp) ----

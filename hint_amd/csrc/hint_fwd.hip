@@ -122,6 +122,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
             pc.store = train;
+            pc.scratch = nullptr; pc.tw = nullptr; pc.first_tile = false;
 
             // the weight stream of a group's first row starts one phase early: before the block's first group
             // here, for the later ones right behind the rows of the group before (i.e. across its coupling phase)

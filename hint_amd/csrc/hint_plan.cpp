@@ -119,6 +119,7 @@ struct hint_plan {
     int n_sub = 0, sub_pf = 0, sub_pb = 0, sub_pbias = 0, sub_bsrc = 0, sub_cols = 0;
     int sub_slab_f = 0, sub_slab_b = 0;                 // floats of their slabs
     int sub_lds_f[3] = {0, 0, 0}, sub_lds_b[3] = {0, 0, 0};   // LDS float offsets: slabs, staged parameters, misc
+    int rowdw_lds = 0;          // backward: LDS float offset of the scratch tiles of the rows that compute dW1 | db1 themselves (0: none)
     int row_ntt = 0;            // tiles of the widest row (<= 3: the backward pass runs on hint_bwd_kernel_n3)
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
@@ -744,8 +745,17 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     const int sub_b_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_b) + sub_par_floats + nw * 512) : 0;
     const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + ROWS + MAX_NW) + sub_f_bytes;
     const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld) + sub_b_bytes;   // (+ the lanes of the level before: first-layer gradients)
-    P->stage_out = 0;
-    std::vector<char> unit_fused(units.size(), 0);       // lean and staged: dW1 / db1 come from the backward kernel
+    // Lean groups get their dW1 | db1 from the backward kernel: staged ones in a pass of their own (the g1 tiles wait in LDS),
+    // the others - too large to stage - row by row (RowRec flag rowdw: one scratch tile per wavefront), so that g1 never travels
+    // (HINT_ROW_DW1=0: only the staged ones).  The scratch tiles count against the LDS the staging decision sees: two passes.
+    const bool rowdw_on = !(std::getenv("HINT_ROW_DW1") && std::atoi(std::getenv("HINT_ROW_DW1")) == 0) && !wl &&
+                          !(std::getenv("HINT_FUSE_DW1") && std::atoi(std::getenv("HINT_FUSE_DW1")) == 0);
+    int rowdw_bytes = 0;
+    std::vector<char> unit_fused(units.size(), 0), unit_rowdw(units.size(), 0);
+    for (int pass = 0; pass < 2; ++pass) {
+    P->stage_out = 0; P->region_fwd = 0; P->region_bwd = 0;
+    std::fill(unit_fused.begin(), unit_fused.end(), 0); std::fill(unit_rowdw.begin(), unit_rowdw.end(), 0);
+    bool any_rowdw = false;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         Group& g = groups[gi];
         const long tiles = (long)g.ntiles * 256;
@@ -753,12 +763,22 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_fused[ui] = 1;
             continue;
         }
-        const bool staged = fixed_f + 4 * (2 * tiles + grp_slab_f[gi]) <= LDS_LIMIT && fixed_b + 4 * (2 * tiles + grp_slab_b[gi]) <= LDS_LIMIT;
+        const bool staged = fixed_f + 4 * (2 * tiles + grp_slab_f[gi]) <= LDS_LIMIT && fixed_b + rowdw_bytes + 4 * (2 * tiles + grp_slab_b[gi]) <= LDS_LIMIT;
+        g.lean &= ~2;
         if (staged) { g.lean |= 2; P->stage_out = 1; }
         P->region_fwd = std::max(P->region_fwd, (int)(tiles * (staged ? 2 : 1) + grp_slab_f[gi]));
         P->region_bwd = std::max(P->region_bwd, (int)(tiles * (staged ? 2 : 1) + grp_slab_b[gi]));
         if (staged && (g.lean & 1))
             for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_fused[ui] = 1;
+        if (!staged && (g.lean & 1) && rowdw_on) {
+            bool ok = true;
+            for (int ui = g.unit_begin; ui < g.unit_end; ++ui) if (units[ui].xoff > 255 || units[ui].h > 32767) ok = false;
+            if (ok) { any_rowdw = true; for (int ui = g.unit_begin; ui < g.unit_end; ++ui) { unit_fused[ui] = 1; unit_rowdw[ui] = 1; } }
+        }
+    }
+    if (pass == 0 && any_rowdw) { rowdw_bytes = 1024 * nw; continue; }      // (again, with the scratch tiles in the budget)
+    if (!any_rowdw) rowdw_bytes = 0;
+    break;
     }
     if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) std::fill(unit_fused.begin(), unit_fused.end(), 0);
     if (wl) {
@@ -852,6 +872,17 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
     }
 
+    if (rowdw_bytes > 0) {
+        for (size_t i = 0; i < recs_b.size(); ++i) {
+            const Unit& u = units[rec_unit[i]];
+            if (!unit_rowdw[rec_unit[i]]) continue;
+            RowRec& b = recs_b[i];
+            b.flags |= 1 << 11;
+            b.p1 = u.bias1 + b.tb * 16 * (u.cin < 4 ? 4 : 8);
+            b.p2 = u.cin | (u.xoff << 8) | (u.h << 16);
+        }
+    }
+
     std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
 
     // ---- meta blob staged in LDS by the kernels ----
@@ -863,6 +894,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (lops_lds) std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
     P->lds_fwd = (fixed_f - sub_f_bytes + 4 * P->region_fwd + 15) / 16 * 16;
     P->lds_bwd = (fixed_b - sub_b_bytes + 4 * P->region_bwd + 15) / 16 * 16;
+    if (rowdw_bytes > 0) { P->rowdw_lds = P->lds_bwd / 4; P->lds_bwd += rowdw_bytes; }
     if (P->n_sub > 0) {
         P->sub_lds_f[0] = P->lds_fwd / 4; P->sub_lds_f[1] = P->sub_lds_f[0] + pad4(P->sub_slab_f); P->sub_lds_f[2] = P->sub_lds_f[1] + sub_par_floats;
         P->sub_lds_b[0] = P->lds_bwd / 4; P->sub_lds_b[1] = P->sub_lds_b[0] + pad4(P->sub_slab_b); P->sub_lds_b[2] = P->sub_lds_b[1] + sub_par_floats;
@@ -1251,6 +1283,7 @@ static KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.fuse_dw1 = P->fuse_dw1; a.tw_floats = P->tw_floats; a.thin_slab_off = ws_thin_off(P, B);
     a.lean = P->lean; a.a2_off = P->lean ? 0 : a.act_stride; a.bits_off = (P->lean ? 1 : 2) * a.act_stride;
     a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
+    a.rowdw_lds = backward ? P->rowdw_lds : 0;
     a.n_sub = P->n_sub;
     if (P->n_sub > 0) {
         const int* o = backward ? P->sub_lds_b : P->sub_lds_f;

@@ -49,6 +49,7 @@ struct RowU {           // decoded record (all wave-uniform)
     int base1, base2, n1, n2, n3, ntt, aux, ocol, tile0, nquad, slab, bias3;
     int thin_w, thin_b, thin_k, NT, thin, first, wcol, tb;
     int ulast, p1, p2;      // (wave-local kernels, hint_wl.hpp)
+    int rowdw;              // (general backward kernel: dW1 | db1 of the row's tiles computed by the row)
 };
 __device__ __forceinline__ RowU decode_rec(const i32x16 r) {
     RowU u;
@@ -60,7 +61,7 @@ __device__ __forceinline__ RowU decode_rec(const i32x16 r) {
     u.thin_w = r[8]; u.thin_b = r[9]; u.thin_k = r[10];
     u.NT = r[11] & 0xff; u.thin = (r[11] >> 8) & 1; u.first = (r[11] >> 9) & 1;
     u.wcol = r[12]; u.tb = r[13];
-    u.ulast = (r[11] >> 10) & 1; u.p1 = r[14]; u.p2 = r[15];
+    u.ulast = (r[11] >> 10) & 1; u.p1 = r[14]; u.p2 = r[15]; u.rowdw = (r[11] >> 11) & 1;
     return u;
 }
 
@@ -89,6 +90,9 @@ struct PhaseCtx {
     int xld, cld, gld, WT, row0;
     int wcol0;                       // column of the group's first tile in the [Bp][WT] arrays
     int sid;                         // diagnostic builds: stamp id base of the phase
+    LDS_AS float* scratch;           // backward: one fragment tile of this wavefront (rows with the rowdw flag)
+    GLOBAL_AS float* tw;             // backward: this workgroup's first-layer gradient slab
+    bool first_tile;                 // backward: the workgroup's first row tile (plain stores into tw; later tiles add)
     bool store;                      // keep the outputs (training forward; always in the backward pass): the kernels stream them out of LDS after the phase
 };
 
@@ -380,7 +384,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         }
         act[j] = v;
         if (KIND == K_FWD && HINT_STORE_ON) c.bits_a2[((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
-        if (HINT_STORE_ON) {
+        if (HINT_STORE_ON && !(KIND == K_BWD && cr.rowdw)) {       // (a row that computes dW1 | db1 itself keeps its g1 on chip)
             if (c.obuf != nullptr) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
             else *(GLOBAL_AS f32x4*)(c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq)) = v;
         }
@@ -408,6 +412,35 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         if (q4 < cr.nquad) {
             LDS_AS f32x4* sp = (LDS_AS f32x4*)(slabp + (q4 * 16 + m) * 4);
             *sp = *sp + xb3[0];
+        }
+    }
+    if (KIND == K_BWD && cr.rowdw) {
+        // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f] of the row's tiles (lean group whose outputs are not
+        // staged in LDS: g1 would have to travel to part B otherwise): each tile transposed through the wavefront's scratch tile,
+        // four 16x16x4 MFMAs over the 16 rows (out^T[k][f]: a lane ends with four inputs of one feature), into the workgroup's slab
+        const int cin = cr.p2 & 0xff, xoff = (cr.p2 >> 8) & 0xff, hw = cr.p2 >> 16, kcp = cin < 4 ? 4 : 8;
+        const LDS_AS float* g1p = c.scratch + (kq + 16 * (m >> 2)) * 4 + (m & 3);
+        const LDS_AS float* vp = c.xs + kq * c.xld + xoff + (m < cin ? m : 0);
+        const float one = m == cin ? 1.f : 0.f;
+        float bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = vp[4 * i * c.xld];                  // rows 4 i + kq
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            ((LDS_AS f32x4*)c.scratch)[lane] = act[j];
+            asm volatile("" ::: "memory");              // (the wavefront's own LDS traffic is in order)
+            float av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = g1p[16 * i];
+            f32x4 dw = zero4();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw = mfma4(m < cin ? bv[i] : one, av[i], dw);
+            const int nvalid = hw - 16 * (cr.tb + j);
+            if (m < nvalid && 4 * kq < kcp) {
+                GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(c.tw + cr.p1 + (16 * j + m) * kcp + 4 * kq);
+                if (c.first_tile) *dst = dw; else *dst = *dst + dw;
+            }
+            asm volatile("" ::: "memory");
         }
     }
     STAMP(c.sid + 12)
