@@ -1251,7 +1251,7 @@ int hint_plan_describe(const hint_plan* P, int32_t B, int32_t* out) {
     if (!P || !out || B < 0) return fail("hint_plan_describe: bad arguments");
     P = variant(P, B);
     out[0] = P->wl; out[1] = wl_nr_for(P, B); out[2] = P->nw; out[3] = P->lean;
-    out[4] = P->n_sub; out[5] = P->row_ntt; out[6] = 0; out[7] = 0;
+    out[4] = P->n_sub; out[5] = P->row_ntt; out[6] = P->rowdw_lds > 0 ? 1 : 0; out[7] = 0;
     return 0;
 }
 
@@ -1381,7 +1381,7 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
         HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
     } else if (parts & 1) {
         // (the permutation matrices stay in global memory here: one d x d product per block)
-        HIP_TRY((P->row_ntt <= 3 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
+        HIP_TRY((P->row_ntt <= 3 && P->rowdw_lds == 0 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
                                                                g_z, g_J, g_x, g_c, gz_scale, gJ_const, s));
     }
     if (!(parts & 2)) return 0;

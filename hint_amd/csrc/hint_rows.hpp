@@ -96,6 +96,11 @@ struct PhaseCtx {
     bool store;                      // keep the outputs (training forward; always in the backward pass): the kernels stream them out of LDS after the phase
 };
 
+#ifdef HINT_NO_ROWDW          // (hint_bwd3.hip: the instance for plans without such rows)
+#define HINT_ROWDW_ON false
+#else
+#define HINT_ROWDW_ON true
+#endif
 #ifdef HINT_ABLATE_STORE      // diagnostic: no activation / gradient rows leave the kernel
 #define HINT_STORE_ON false
 #else
@@ -384,7 +389,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         }
         act[j] = v;
         if (KIND == K_FWD && HINT_STORE_ON) c.bits_a2[((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
-        if (HINT_STORE_ON && !(KIND == K_BWD && cr.rowdw)) {       // (a row that computes dW1 | db1 itself keeps its g1 on chip)
+        if (HINT_STORE_ON && !(KIND == K_BWD && HINT_ROWDW_ON && cr.rowdw)) {       // (a row that computes dW1 | db1 itself keeps its g1 on chip)
             if (c.obuf != nullptr) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
             else *(GLOBAL_AS f32x4*)(c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq)) = v;
         }
@@ -414,7 +419,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
             *sp = *sp + xb3[0];
         }
     }
-    if (KIND == K_BWD && cr.rowdw) {
+    if (KIND == K_BWD && HINT_ROWDW_ON && cr.rowdw) {
         // dW1[f][k] = sum_rows g1[row][f] v[row][k], db1[f] = sum_rows g1[row][f] of the row's tiles (lean group whose outputs are not
         // staged in LDS: g1 would have to travel to part B otherwise): each tile transposed through the wavefront's scratch tile,
         // four 16x16x4 MFMAs over the 16 rows (out^T[k][f]: a lane ends with four inputs of one feature), into the workgroup's slab
