@@ -127,7 +127,7 @@ __device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float
             // the next node (of the next level behind this level's last node)
             const bool has_next = u + 2 < ue || nb < ne;
             const int nu = u + 2 < ue ? u + 2 : nb;
-            f32x4 nws = ws, nwt = wtt;
+            f32x4 nws, nwt;             // (written by the untracked loads only: no value of the compiler's may share their registers before sub_wait)
             if (has_next) { sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64); }
             STAMP(sid + 3)
             const UnitU us = load_unit(T.units + u), ut = load_unit(T.units + u + 1);
@@ -348,8 +348,8 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
             STAMP(sid + 5)
             const bool has_next = u + 2 < ue || nb < ne;
             const int nu = u + 2 < ue ? u + 2 : nb;
-            f32x4 nws = ws, nwt = wtt;
-            int nbs = bs, nbt = bt;
+            f32x4 nws, nwt;             // (written by the untracked loads only: no value of the compiler's may share their registers before sub_wait)
+            int nbs, nbt;
             if (has_next) {
                 sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64);
                 sub_load_byte(nbs, byte_of(nu)); sub_load_byte(nbt, byte_of(nu + 1));
