@@ -985,7 +985,10 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         // arrays, and one wavefront walking 512 rows of a 9600-column array alone is slower (+6 %).  HINT_DW_SMALL=0 / 1 overrides.
         bool small_on = P->n_sub > 0;
         if (const char* e = std::getenv("HINT_DW_SMALL")) small_on = std::atoi(e) != 0;
-        auto is_small = [&](const WJob& j) { return small_on && j.mw <= 1 && j.nw <= 1; };
+        // (single-tile jobs that rebuild their operands read no wide array: for every tree on the general kernels - the d = 100 flows' part B
+        //  -4 %; the narrow trees of the wave-local kernels have a handful of them with long batches per split: GAS +5 %, left alone)
+        const bool nat_on = env_int("HINT_DW_SMALL_NAT") != -1 && !P->wl;
+        auto is_small = [&](const WJob& j) { return j.mw <= 1 && j.nw <= 1 && (small_on || (nat_on && j.psrc == WSRC_G2R)); };
         std::stable_partition(wjobs.begin(), wjobs.end(), [&](const WJob& j) { return !is_small(j); });
         P->n_wsmall = (int)std::count_if(wjobs.begin(), wjobs.end(), is_small);
     }

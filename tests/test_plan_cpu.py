@@ -119,7 +119,9 @@ def test_planner_subtree_groups(d, widths, sub_groups, wave_local):
         assert st["sub_groups"] == sub_groups
     else:
         assert 1 <= st["sub_groups"] <= 3
+    # part B's single-tile jobs share workgroups (one per wavefront): all of them in trees with subtree groups, those that rebuild
+    # their operands in every tree on the general kernels, none in the narrow trees of the wave-local kernels
     if st["sub_groups"]:
         assert st["small_jobs"] > 0 and st["groups"] > st["sub_groups"]
-    else:
+    elif wave_local:
         assert st["small_jobs"] == 0
