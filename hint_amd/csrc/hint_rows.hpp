@@ -391,7 +391,8 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         if (KIND == K_FWD && HINT_STORE_ON) c.bits_a2[((cr.ocol >> 4) + j) * 64 + lane] = (uint8_t)sign_bits(v);
         if (HINT_STORE_ON && !(KIND == K_BWD && HINT_ROWDW_ON && cr.rowdw)) {       // (a row that computes dW1 | db1 itself keeps its g1 on chip)
             if (c.obuf != nullptr) ((LDS_AS f32x4*)c.obuf)[(cr.tile0 + cr.tb + j) * 64 + lane] = v;
-            else *(GLOBAL_AS f32x4*)(c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq)) = v;
+            else    // (groups too large to stage: straight to the tape, non-temporal - it is read again a kernel later, by part B; -2 % at d = 100)
+                __builtin_nontemporal_store(v, (GLOBAL_AS f32x4*)(c.out_main + ((size_t)c.row0 * c.WT + cr.ocol + 16 * j) + (m * c.WT + 4 * kq)));
         }
     }
     // ---- tail steps: slab[q] = sum over the row's tiles of Wtail(q, tile) * act, the K-split partial of the thin
