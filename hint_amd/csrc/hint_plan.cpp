@@ -98,7 +98,7 @@ static thread_local bool g_host_only = false;    // hint_plan_check: build and v
 
 struct hint_plan {
     int device = -1;
-    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_units = 0, n_wjobs = 0, n_wsmall = 0, n_ptiles = 0, nw = 8;   // n_wsmall: single-tile jobs at the end of the job list (hint_wgrad.hip)
+    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_units = 0, n_wjobs = 0, n_wsmall = 0, wsorted = 0, n_ptiles = 0, nw = 8;   // n_wsmall: single-tile jobs at the end of the job list (hint_wgrad.hip)
     float alpha = 0.f;
     int64_t param_floats = 0, packed_floats = 0;
     int WT = 0, ST = 0;
@@ -997,6 +997,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             const auto nbig = std::count_if(wjobs.begin(), wjobs.end(), [&](const WJob& j) { return !is_small(j); });
             std::stable_sort(wjobs.begin(), wjobs.begin() + nbig, [](const WJob& x, const WJob& y) {
                 return x.mw * std::max(1, x.nw) > y.mw * std::max(1, y.nw); });
+            P->wsorted = env_int("HINT_DW_INTERLEAVE") != -1;
         }
         P->n_wsmall = (int)std::count_if(wjobs.begin(), wjobs.end(), is_small);
     }
@@ -1398,7 +1399,7 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
     if (!(parts & 2)) return 0;
     int splits, rows_per_wg;
     wgrad_splits(P, B, n_chain, &splits, &rows_per_wg);
-    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, P->n_wsmall, splits, one, chain, n_chain, cb0, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
+    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, P->wsorted ? -P->n_wsmall - 1 : P->n_wsmall, splits, one, chain, n_chain, cb0, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
                          rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
                          (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
                          accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),

@@ -62,8 +62,18 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     // workgroup, one (job, split) per WAVEFRONT over all rows of the split - no combine, no barrier: a workgroup per such job
     // spends its time in the fixed costs (MINIBOONE d = 43: 12 000 workgroups for 60 MFLOP)
     const int n_big = n_jobs - n_small, items = n_big + (n_small + DW_WAVES - 1) / DW_WAVES;
-    const int cbi = (int)blockIdx.x / grid_pb;
-    const int bid = (int)blockIdx.x - cbi * grid_pb;
+    // grid_pb > 0: the chain's blocks one after the other; < 0 (jobs sorted longest first: narrow trees): job j of ALL blocks
+    // next to each other, so that the order is longest-first over the whole launch
+    int cbi, bid;
+    if (grid_pb > 0) {
+        cbi = (int)blockIdx.x / grid_pb;
+        bid = (int)blockIdx.x - cbi * grid_pb;
+    } else {
+        const int n_chain = (int)gridDim.x / -grid_pb;
+        const int q = (int)blockIdx.x >> 3;
+        cbi = q % n_chain;
+        bid = (q / n_chain) * 8 + ((int)blockIdx.x & 7);
+    }
     if (bid >= items * splits) return;
     const GBlock blk = chain_block(chain, one, cbi);
     const bool top = blk.perm != nullptr || cbi + cb0 > 0;        // (cb0: position of the launch's first block in its chain)
@@ -365,11 +375,13 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
                         int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream) {
+    const bool interleave = n_small < 0;       // (flag in the sign: the planner sorted the jobs)
+    if (interleave) n_small = -n_small - 1;
     const int used = (n_jobs - n_small + (n_small + DW_WAVES - 1) / DW_WAVES) * splits;
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0)
         hipLaunchKernelGGL(hint_wgrad_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs,
-                           n_small, splits, one, chain, grid_pb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
+                           n_small, splits, one, chain, (interleave && n_chain > 1 && (splits & 7) == 0) ? -grid_pb : grid_pb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
                            a2_off, bits_a2_off, param_floats, x, c);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
