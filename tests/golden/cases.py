@@ -49,6 +49,12 @@ BLOCK_CASES = [
     dict(name="reshuffle_d9c2", d=9,   dc=2, c_internal=[20, 10, 6], init="uniform", reshuffle=True),
 ]
 
+# block cases that also pin the gradients THROUGH the inverse (rev=True is differentiable in the reference: hint.py:82-88):
+# revgrad_<name>.npz = d/dz, d/dc, d/dW of mean(0.5*|x|^2 - J) with (x, J) = block(z, rev=True), z = the case's input
+REV_GRAD_CASES = ["power8_unif", "gas8_unif", "mini43_unif", "plus100_c4", "cond_d6_c4", "cond_two_c",
+                  "splits1_d8", "minsplit3_d12", "cint_empty_d6", "clamp2_d6", "odd_d5", "tiny_d2",
+                  "reshuffle_d6", "reshuffle_d9c2"]
+
 # chained flows: (blocks chained by stored orthogonal matrices) + K Adam steps
 CHAIN_CASES = [
     dict(name="chain_power4", d=6, n_blocks=4, c_internal=[200, 100, 50, 25], B=64, steps=0),

@@ -19,7 +19,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from cases import (BLOCK_CASES, CHAIN_CASES, ROOT, checksum, make_block_inputs,  # noqa: E402
+from cases import (BLOCK_CASES, CHAIN_CASES, REV_GRAD_CASES, ROOT, checksum, make_block_inputs,  # noqa: E402
                    make_chain_inputs, norm_case)
 
 sys.path.insert(0, ROOT)
@@ -106,6 +106,31 @@ def gen_block(ref_hint, case):
     return out
 
 
+def gen_block_rev(ref_hint, case):
+    """gradients through the inverse direction (hint.py:82-88 under autograd), same parameters and inputs as gen_block"""
+    c = norm_case(case)
+    torch.manual_seed(0)
+    sys.modules["FrEIA.modules.orthogonal"].HouseholderPerm.rs = np.random.RandomState(len(case["name"]) + 7 * case["d"])
+    blk = build_ref_block(ref_hint, c)
+    shapes = check_contract(blk, c)
+    params, x_np, conds_np = make_block_inputs(case, shapes)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    z = torch.from_numpy(x_np).requires_grad_(True)
+    conds = [torch.from_numpy(a).requires_grad_(True) for a in conds_np]
+    (x,) = blk.forward([z], c=conds, rev=True)
+    J = blk.jacobian(None)
+    L = (0.5 * torch.sum(x ** 2, dim=1) - J).mean()
+    L.backward()
+    out = dict(x_inv=x.detach().numpy(), J_inv=J.detach().numpy(), L=np.float64(L.item()), gz=z.grad.numpy())
+    for i, cc in enumerate(conds):
+        out[f"gc{i}"] = cc.grad.numpy()
+    named = dict(blk.named_parameters())
+    for k in shapes:
+        out["g:" + k] = named[k].grad.numpy()
+    out["in_checksum"] = np.float64(checksum(list(params.values()) + [x_np] + conds_np))
+    return out
+
+
 def gen_chain(ref_hint, case):
     c = norm_case(dict(case, dc=0))
     torch.manual_seed(0)
@@ -162,6 +187,13 @@ def gen_chain(ref_hint, case):
 
 def main():
     ref_hint = import_reference()
+    for case in BLOCK_CASES:
+        if case["name"] in REV_GRAD_CASES:
+            out = gen_block_rev(ref_hint, case)
+            np.savez_compressed(os.path.join(HERE, f"revgrad_{case['name']}.npz"), **out)
+            print("revgrad", case["name"], "L=%.6f" % out["L"])
+    if len(sys.argv) > 1 and sys.argv[1] == "rev":          # only the fixtures above
+        return
     for case in BLOCK_CASES:
         out = gen_block(ref_hint, case)
         np.savez_compressed(os.path.join(HERE, f"block_{case['name']}.npz"), **out)

@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from oracle import hint_oracle as orc
-from util import BLOCK_CASES, CHAIN_CASES, case_perms, load_block_case, load_chain_case, rel_err, to_torch
+from util import (BLOCK_CASES, CHAIN_CASES, REV_GRAD_CASES, case_perms, load_block_case, load_chain_case, load_revgrad, rel_err,
+                  to_torch)
 
 TOL = dict(rtol=1e-5, atol=1e-5)
 
@@ -43,6 +44,29 @@ def test_block_forward_inverse_grads(case):
     np.testing.assert_allclose(Jr.numpy(), g["J_rev"], **TOL)
     assert rel_err(xi.numpy(), g["x_inv"]) < 1e-4
     np.testing.assert_allclose(Ji.numpy(), g["J_inv"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", [c for c in BLOCK_CASES if c["name"] in REV_GRAD_CASES], ids=lambda c: c["name"])
+def test_block_grads_through_inverse(case):
+    """rev=True under autograd (hint.py:82-88): d/dz, d/dc, d/dW of mean(0.5|x|^2 - J), (x, J) = block(z, rev=True)"""
+    c, nodes, shapes, params, z_np, conds_np, g = load_block_case(case)
+    r = load_revgrad(c, g)
+    P = to_torch(params)
+    for p in P.values():
+        p.requires_grad_(True)
+    z = torch.from_numpy(z_np).requires_grad_(True)
+    conds = [torch.from_numpy(a).requires_grad_(True) for a in conds_np]
+    perms = {k: torch.from_numpy(v) for k, v in case_perms(g).items()}
+    x, J = orc.block_apply(nodes, P, z, conds, rev=True, clamp=c["clamp"], perms=perms)
+    assert rel_err(x.detach().numpy(), r["x_inv"]) < 1e-4
+    L = (0.5 * torch.sum(x ** 2, dim=1) - J).mean()
+    assert abs(L.item() - float(r["L"])) <= 1e-4 * max(1.0, abs(float(r["L"])))
+    L.backward()
+    assert rel_err(z.grad.numpy(), r["gz"]) < 1e-4
+    for i, cc in enumerate(conds):
+        assert rel_err(cc.grad.numpy(), r[f"gc{i}"]) < 1e-4
+    for k in shapes:
+        assert rel_err(P[k].grad.numpy(), r["g:" + k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("case", BLOCK_CASES[:6], ids=lambda c: c["name"])

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from cases import (BLOCK_CASES, CHAIN_CASES, checksum, make_block_inputs,  # noqa: F401
+from cases import (BLOCK_CASES, CHAIN_CASES, REV_GRAD_CASES, checksum, make_block_inputs,  # noqa: F401
                    make_chain_inputs, norm_case)
 from oracle import hint_oracle as orc
 
@@ -22,6 +22,15 @@ def load_block_case(case):
         "regenerated inputs differ from the ones the golden vectors were computed on"
     assert list(g["keys"]) == list(shapes.keys())
     return c, nodes, shapes, params, x, conds, g
+
+
+def load_revgrad(c, g):
+    """golden gradients through the inverse of an already loaded block case (None if the case has none)"""
+    if c["name"] not in REV_GRAD_CASES:
+        return None
+    r = np.load(os.path.join(GOLDEN, f"revgrad_{c['name']}.npz"))
+    assert abs(float(r["in_checksum"]) - float(g["in_checksum"])) < 1e-6
+    return r
 
 
 def load_chain_case(case):
