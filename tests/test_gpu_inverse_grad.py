@@ -130,3 +130,26 @@ def test_flow_inverse_grads_vs_oracle_flow():
         named = dict(flow.blocks[i].named_parameters())
         for k, v in of.params[i].items():
             assert rel_err(named[k].grad.cpu().numpy(), v.grad.numpy()) < 1e-4, (i, k)
+
+
+@pytest.mark.parametrize("D,dc,h,B", [(5, 2, 16, 77), (100, 4, 224, 300), (1, 3, 8, 16)])
+def test_external_coupling_inverse_grads(D, dc, h, B):
+    """the conditional model's couplings (conditional_hint_4_full.py:76-89: k = 0, every lane transformed given y) through
+    the inverse under autograd, against the oracle's definition of the same node"""
+    import hint_amd
+    from test_gpu_conditional import oracle_nodes
+    torch.manual_seed(1)
+    mod = hint_amd.ExternalAffineCoupling([(D,)], dims_c=[(dc,)], F_args={"internal_size": h}).to(DEV)
+    z = torch.randn(B, D); c = torch.randn(B, dc)
+    zg = z.to(DEV).requires_grad_(True); cg = c.to(DEV).requires_grad_(True)
+    (x,) = mod([zg], c=[cg], rev=True); J = mod.jacobian(None, rev=True)
+    zo = z.clone().requires_grad_(True); co = c.clone().requires_grad_(True)
+    Po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xo, Jo = orc.block_apply(oracle_nodes(mod.tree, dc), Po, zo, [co], rev=True, clamp=mod.tree.clamp)
+    (0.5 * (x ** 2).sum(1) - J).mean().backward()
+    (0.5 * (xo ** 2).sum(1) - Jo).mean().backward()
+    assert rel_err(x.detach().cpu().numpy(), xo.detach().numpy()) < 1e-4
+    assert rel_err(zg.grad.cpu().numpy(), zo.grad.numpy()) < 1e-4
+    assert rel_err(cg.grad.cpu().numpy(), co.grad.numpy()) < 1e-4
+    for k, p in mod.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), Po[k].grad.numpy()) < 2e-4, k
