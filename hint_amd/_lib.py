@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HINT_AMD_LIB") or os.path.join(_HERE, "lib", "libhint_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HintAmdError(RuntimeError):
@@ -54,6 +54,9 @@ _PROTOS = {
     "hint_block_inverse_ex": (C.c_int, [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]),
     "hint_block_backward_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
                                                              C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "hint_plan_inverse_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
+    "hint_block_inverse_backward": (C.c_int, [C.c_void_p] * 9 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32,
+                                                                 C.c_void_p]),
     "hint_chain_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "hint_chain_set_block": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]),
     "hint_chain_commit": (C.c_int, [C.c_void_p]),

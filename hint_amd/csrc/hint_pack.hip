@@ -98,7 +98,63 @@ __global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, l
     if (t < n) p[t] = 0.f;
 }
 
+// ---- element-wise helpers of hint_block_inverse_backward (hint_plan.cpp): B x d lane tiles, `lower` marks the lanes a level
+//      transforms.  op 0: out = lower ? 1 : 0;  op 1: out = lower ? g / e : 0;  op 2: g = lower ? a : g - b ----
+__global__ __launch_bounds__(256) void hint_inv_lane_kernel(int op, float* out, const float* g,             // (op 2 runs in place: out == g)
+                                                            const float* __restrict__ a, const float* __restrict__ b,
+                                                            const uint8_t* __restrict__ lower, long n, int d) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool lo = lower[i % d] != 0;
+        float v;
+        if (op == 0) v = lo ? 1.f : 0.f;
+        else if (op == 1) v = lo ? g[i] / a[i] : 0.f;
+        else v = lo ? a[i] : g[i] - b[i];
+        out[i] = v;
+    }
+}
+
+// dst = (keep ? dst : 0) - src
+__global__ __launch_bounds__(256) void hint_inv_minus_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, int keep) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (keep ? dst[i] : 0.f) - src[i];
+}
+
+// y = x P (row tile by d x d matrix, d <= 128: the node permutations in front of a block; a few MFLOP)
+__global__ __launch_bounds__(256) void hint_inv_rowmat_kernel(const float* __restrict__ x, const float* __restrict__ P,
+                                                              float* __restrict__ y, long n, int d) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long row = i / d;
+        const int j = (int)(i - row * d);
+        float acc = 0.f;
+        for (int k = 0; k < d; ++k) acc = fmaf(x[row * d + k], P[(long)k * d + j], acc);
+        y[i] = acc;
+    }
+}
+
 namespace hint {
+
+static inline unsigned small_grid(long n, int num_cu) {
+    long blocks = (n + 255) / 256;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > (long)num_cu * 8 ? (long)num_cu * 8 : blocks));
+}
+
+hipError_t launch_inv_lane(int op, float* out, const float* g, const float* a, const float* b, const uint8_t* lower, long n, int d,
+                           int num_cu, hipStream_t stream) {
+    hipLaunchKernelGGL(hint_inv_lane_kernel, dim3(small_grid(n, num_cu)), dim3(256), 0, stream, op, out, g, a, b, lower, n, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_inv_minus(float* dst, const float* src, long n, int keep, int num_cu, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(hint_inv_minus_kernel, dim3(small_grid(n, num_cu)), dim3(256), 0, stream, dst, src, n, keep);
+    return hipGetLastError();
+}
+
+hipError_t launch_inv_rowmat(const float* x, const float* P, float* y, long n, int d, int num_cu, hipStream_t stream) {
+    hipLaunchKernelGGL(hint_inv_rowmat_kernel, dim3(small_grid(n, num_cu)), dim3(256), 0, stream, x, P, y, n, d);
+    return hipGetLastError();
+}
 
 hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
                        long bias_off, const float* params, float* packed, hipStream_t stream) {

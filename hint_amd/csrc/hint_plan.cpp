@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,10 @@ hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, con
 hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
                             unsigned long long* rng_state, float* opt_state, hipStream_t stream);
 hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
+hipError_t launch_inv_lane(int op, float* out, const float* g, const float* a, const float* b, const uint8_t* lower, long n, int d,
+                           int num_cu, hipStream_t stream);
+hipError_t launch_inv_minus(float* dst, const float* src, long n, int keep, int num_cu, hipStream_t stream);
+hipError_t launch_inv_rowmat(const float* x, const float* P, float* y, long n, int d, int num_cu, hipStream_t stream);
 hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
                         const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
                         const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
@@ -137,6 +142,13 @@ struct hint_plan {
     // the same block planned for 4 wavefronts per workgroup (two workgroups per CU: one row tile's serial phases overlap
     // the other's GEMM phases) - used for batches of more row tiles than CUs; owned by this plan; may be absent
     hint_plan* alt4 = nullptr;
+    // hint_block_inverse_backward: the node table the plan was made from and, built at the first call, one plan per tree
+    // level (its nodes as a forest of depth 0) with the lanes each level transforms
+    std::vector<hint_node_desc> nodes;
+    float clamp = 0.f;
+    std::mutex inv_mu;
+    std::vector<hint_plan*> inv_levels;         // deepest level last
+    uint8_t* d_inv_lower = nullptr;             // [levels][d]
 };
 
 static inline int plan_lds(const hint_plan* P, bool backward, int nr = 1) {
@@ -1136,6 +1148,8 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
         }
         g_err = keep;
     }
+    (*out)->nodes.assign(nodes, nodes + n_nodes);
+    (*out)->clamp = clamp;
     return 0;
 }
 
@@ -1159,6 +1173,8 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
 void hint_plan_destroy(hint_plan* P) {
     if (!P) return;
     hint_plan_destroy(P->alt4);
+    for (hint_plan* L : P->inv_levels) hint_plan_destroy(L);
+    (void)hipFree(P->d_inv_lower);
     (void)hipFree(P->d_meta);
     (void)hipFree(P->d_lops);
     (void)hipFree(P->d_recs);
@@ -1464,11 +1480,12 @@ int hint_block_backward(const hint_plan* P, const float* params, const float* pa
                                   workspace, workspace_bytes, nullptr, 1.0f, 0.0f, B, stream);
 }
 
-int hint_block_backward_ex(const hint_plan* P, const float* params, const float* packed, const float* x,
-                           const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
-                           float* g_c, float* g_params, int32_t accumulate, void* workspace,
-                           size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
-                           int32_t B, void* stream) {
+// parts: bit 0 the row-parallel kernel, bit 1 the weight gradients (run_backward)
+static int block_backward(const hint_plan* P, const float* params, const float* packed, const float* x,
+                          const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
+                          float* g_c, float* g_params, int32_t accumulate, void* workspace,
+                          size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
+                          int32_t B, int parts, void* stream) {
     if (!P || !params || !packed || (!x && !perm) || !g_x || !g_params) return fail("hint_block_backward: null argument");
     if (perm && !tape) return fail("hint_block_backward_ex: a fused permutation needs the tape of hint_block_forward_ex");
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
@@ -1490,7 +1507,144 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
     bind_tape(P, B, const_cast<float*>(tape), &one);
     one.gparams = g_params;
     split_workspace(P, B, workspace, &one);
-    return run_backward(P, one, nullptr, nullptr, 1, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, 3, s);
+    return run_backward(P, one, nullptr, nullptr, 1, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, parts, s);
+}
+
+int hint_block_backward_ex(const hint_plan* P, const float* params, const float* packed, const float* x,
+                           const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
+                           float* g_c, float* g_params, int32_t accumulate, void* workspace,
+                           size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
+                           int32_t B, void* stream) {
+    return block_backward(P, params, packed, x, tape, c, g_z, g_J, g_x, g_c, g_params, accumulate, workspace, workspace_bytes,
+                          perm, gz_scale, gJ_const, B, 3, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward of the INVERSE direction (hint.py:82-88 under autograd), level by level on the block kernels.
+// With y_L = x (times the node permutations) and y_l = level_l(y_{l+1}) the forward direction rebuilds, deepest level
+// first, what the inverse saw at every node; the inverse coupling's derivative is the forward coupling's with the roles
+// turned round:  g_z2 = g_x2 / e(s);  (g_s, g_t) and with them every subnet, weight and condition gradient of the level
+// are MINUS what the forward's backward returns for the upstream pair (g_z2, g_J);  g_z1 = g_x1 - (its gradient on the
+// conditioning lanes).  e(s) itself is the lane gradient of a row-parallel backward launch with g = 1 on the level's
+// transformed lanes (1 * e: exact).
+// ---------------------------------------------------------------------------------------
+static int inv_levels(const hint_plan* Pc) {
+    hint_plan* P = const_cast<hint_plan*>(Pc);
+    std::lock_guard<std::mutex> lock(P->inv_mu);
+    if (!P->inv_levels.empty()) return 0;
+    int depth = 0;
+    for (const hint_node_desc& n : P->nodes) depth = std::max(depth, n.depth + 1);
+    std::vector<hint_plan*> levels;
+    std::vector<uint8_t> lower;
+    for (int lev = 0; lev < depth; ++lev) {
+        std::vector<hint_node_desc> sel;
+        for (hint_node_desc n : P->nodes)
+            if (n.depth == lev) { n.depth = 0; sel.push_back(n); }
+        if (sel.empty()) continue;
+        hint_plan* L = nullptr;
+        if (hint_plan_create(sel.data(), (int32_t)sel.size(), P->d, P->dc, P->clamp, &L) != 0) {
+            for (hint_plan* q : levels) hint_plan_destroy(q);
+            return 1;                       // (hint_plan_create's message stands)
+        }
+        levels.push_back(L);
+        lower.resize(levels.size() * (size_t)P->d, 0);
+        for (const hint_node_desc& n : sel)
+            for (int j = n.off + n.k; j < n.off + n.D; ++j) lower[(levels.size() - 1) * (size_t)P->d + j] = 1;
+    }
+    if (hipMalloc((void**)&P->d_inv_lower, lower.size()) != hipSuccess ||
+        hipMemcpy(P->d_inv_lower, lower.data(), lower.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        for (hint_plan* q : levels) hint_plan_destroy(q);
+        (void)hipFree(P->d_inv_lower);
+        P->d_inv_lower = nullptr;
+        return fail("hint_block_inverse_backward: device allocation failed");
+    }
+    P->inv_levels = levels;
+    return 0;
+}
+
+struct InvWs { size_t y0, y1, g, e, t, gin, J, gc, tape, packed, gneg, bws, bws_bytes, total_bytes; };
+static InvWs inv_ws(const hint_plan* P, int B) {
+    auto al = [](size_t floats) { return (floats + 3) & ~(size_t)3; };
+    const size_t lane = al((size_t)B * P->d);
+    InvWs w{};
+    size_t off = 0, tape = 0, packed = 0;
+    w.y0 = off; off += lane;  w.y1 = off; off += lane;  w.g = off; off += lane;  w.e = off; off += lane;
+    w.t = off; off += lane;   w.gin = off; off += lane;
+    w.J = off; off += al((size_t)B);
+    w.gc = off; off += al((size_t)B * P->dc);
+    for (const hint_plan* L : P->inv_levels) {
+        tape = std::max(tape, (size_t)hint_plan_tape_floats(L, B));
+        packed = std::max(packed, (size_t)hint_plan_packed_floats(L));
+        w.bws_bytes = std::max(w.bws_bytes, hint_plan_workspace_bytes(L, B));
+    }
+    w.tape = off; off += al(tape);
+    w.packed = off; off += al(packed);
+    w.gneg = off; off += al((size_t)P->param_floats);
+    w.bws = off; off += al((w.bws_bytes + 3) / 4);
+    w.total_bytes = off * sizeof(float);
+    return w;
+}
+
+size_t hint_plan_inverse_workspace_bytes(const hint_plan* P, int32_t B) {
+    if (!P || B <= 0 || inv_levels(P) != 0) return 0;
+    return inv_ws(P, B).total_bytes;
+}
+
+int hint_block_inverse_backward(const hint_plan* P, const float* params, const float* x, const float* c, const float* g_x,
+                                const float* g_J, float* g_z, float* g_c, float* g_params, int32_t accumulate,
+                                void* workspace, size_t workspace_bytes, const float* perm, int32_t B, void* stream) {
+    if (!P || !params || !x || !g_z || !g_params) return fail("hint_block_inverse_backward: null argument");
+    if (P->dc > 0 && !c) return fail("hint_block_inverse_backward: plan has dc=%d but c is NULL", P->dc);
+    if (B < 0) return fail("negative batch");
+    if (((uintptr_t)g_params & 15) != 0) return fail("hint_block_inverse_backward: g_params must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
+        return 0;
+    }
+    if (inv_levels(P) != 0) return 1;
+    const InvWs w = inv_ws(P, B);
+    if (!workspace || workspace_bytes < w.total_bytes)
+        return fail("hint_block_inverse_backward: workspace too small (%zu < %zu)", workspace_bytes, w.total_bytes);
+    if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_inverse_backward: workspace must be 16-byte aligned");
+    float* W = (float*)workspace;
+    const long n = (long)B * P->d;
+    const int cu = P->num_cu;
+    float* ybuf[2] = {W + w.y0, W + w.y1};
+    float *g = W + w.g, *e = W + w.e, *t = W + w.t, *gin = W + w.gin, *gc = W + w.gc, *gneg = W + w.gneg;
+    const float* y = x;
+    int cur = 0;
+    if (g_x == nullptr) HIP_TRY(launch_zero(g, n, cu, s));
+    if (perm != nullptr) {              // x = y P^T behind the inverse (hint.py:93-94): y = x P, g_y = g_x P
+        HIP_TRY(launch_inv_rowmat(x, perm, ybuf[0], n, P->d, cu, s));
+        y = ybuf[0];
+        cur = 1;
+        if (g_x != nullptr) HIP_TRY(launch_inv_rowmat(g_x, perm, g, n, P->d, cu, s));
+    } else if (g_x != nullptr) {
+        HIP_TRY(hipMemcpyAsync(g, g_x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(launch_zero(gneg, (long)P->param_floats, cu, s));
+    if (g_c != nullptr) HIP_TRY(launch_zero(g_c, (long)B * P->dc, cu, s));
+    for (size_t li = P->inv_levels.size(); li-- > 0;) {
+        const hint_plan* L = P->inv_levels[li];
+        const uint8_t* lower = P->d_inv_lower + li * (size_t)P->d;
+        float* yup = ybuf[cur];
+        if (hint_block_pack(L, params, W + w.packed, stream) != 0) return 1;
+        if (hint_block_forward(L, params, W + w.packed, y, c, yup, W + w.J, W + w.tape, B, stream) != 0) return 1;
+        HIP_TRY(launch_inv_lane(0, t, nullptr, nullptr, nullptr, lower, n, P->d, cu, s));
+        if (block_backward(L, params, W + w.packed, y, W + w.tape, c, t, nullptr, e, nullptr, gneg, 1, W + w.bws, w.bws_bytes,
+                           nullptr, 1.f, 0.f, B, 1, stream) != 0) return 1;
+        HIP_TRY(launch_inv_lane(1, t, g, e, nullptr, lower, n, P->d, cu, s));
+        if (block_backward(L, params, W + w.packed, y, W + w.tape, c, t, g_J, gin, g_c ? gc : nullptr, gneg, 1, W + w.bws,
+                           w.bws_bytes, nullptr, 1.f, 0.f, B, 3, stream) != 0) return 1;
+        HIP_TRY(launch_inv_lane(2, g, g, t, gin, lower, n, P->d, cu, s));
+        if (g_c != nullptr) HIP_TRY(launch_inv_minus(g_c, gc, (long)B * P->dc, 1, cu, s));
+        y = yup;
+        cur ^= 1;
+    }
+    HIP_TRY(hipMemcpyAsync(g_z, g, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_inv_minus(g_params, gneg, (long)P->param_floats, accumulate ? 1 : 0, cu, s));
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

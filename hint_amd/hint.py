@@ -77,7 +77,6 @@ class _Engine:
         self.dc = tree.condition_length
         nodes = tree._flat_nodes()
         descs, self.params, self.offsets, cursor = node_descs(nodes)
-        self._descs, self._levels, self.clamp = descs, None, float(tree.clamp)
         self.total = max(cursor, _ALIGN)
         # two trees with equal keys get identical plans (they can share chained launches)
         self.shape_key = (self.d, self.dc, float(tree.clamp),
@@ -281,76 +280,26 @@ class _Engine:
 
 
     # ---- backward of the INVERSE direction (hint.py:82-88 under autograd) ------------------------------
-    def _level_engines(self):
-        """one plan per tree level (its nodes as a forest of depth 0, the other lanes passed through), all over the
-        block's own parameter arena: the inverse's backward runs the levels one at a time, deepest first"""
-        if self._levels is None:
-            depth = max(n.depth for n in self._descs) + 1
-            self._levels = [_LevelEngine(self, [n for n in self._descs if n.depth == lev]) for lev in range(depth)]
-        return self._levels
-
     def inverse_backward(self, x, c, gx, gJ, need_gc: bool):
-        """gradients of (x, J) = block(z, rev=True) given x, the upstream g_x [B,d] / g_J [B] (either may be None):
-        -> (g_z, g_c or None, flat parameter gradient).
-
-        With y_L = x (times the node permutations) and y_l = level_l(y_{l+1}) the forward direction rebuilds, from the
-        deepest level up, exactly what the inverse saw (its lanes, s and hidden activations at every node), and per
-        level the inverse's derivative is the forward coupling's with the roles turned round:
-            g_z2 = g_x2 / e(s)                      (e(s) read off a backward launch with g = 1 on the transformed lanes)
-            (g_s, g_t) = -(forward coupling's (g_s, g_t) at upstream g_z2, g_J)
-        so the subnet / weight gradients of a level are MINUS what hint_block_backward returns for (g_z2, g_J), and
-        g_z1 = g_x1 - (its lane gradient on the conditioning lanes).  Three launches of the block kernels per level;
-        nothing is computed outside them but the division, the sign and the lane select."""
-        B, dev = x.shape[0], x.device
-        total_g = torch.zeros(self.total, dtype=torch.float32, device=dev)
-        gc_tot = torch.zeros_like(c) if (c is not None and need_gc) else None
-        g = gx.clone() if gx is not None else torch.zeros_like(x)
-        if B == 0:
-            return g, gc_tot, total_g
+        """gradients of (x, J) = block(z, rev=True) given its output x and the upstream g_x [B,d] / g_J [B] (either may be
+        None): -> (g_z, g_c or None, flat parameter gradient).  hint_block_inverse_backward runs the tree level by level
+        on the block kernels (include/hint_amd.h)."""
+        B = x.shape[0]
+        gz = torch.empty_like(x)
+        gc = torch.empty_like(c) if (c is not None and need_gc) else None
+        g_params = torch.empty(self.total, dtype=torch.float32, device=x.device)
         perm = self.total_perm()
-        y = x
-        if perm is not None:            # x = y P^T behind the inverse (hint.py:93-94): y = x P, g_y = g_x P
-            y = (x @ perm).contiguous()
-            g = (g @ perm).contiguous()
-        junk = torch.empty(self.total, dtype=torch.float32, device=dev)
-        for lev in reversed(self._level_engines()):
-            lev.arena = self.arena
-            lev.pack()
-            y_up, _, tape = lev.apply(y, c, rev=False, with_tape=True)
-            ones = lev.lower.to(torch.float32).expand(B, -1).contiguous()
-            e, _, _ = lev.backward(y, tape, c, ones, None, False, g_params=junk, accumulate=False)
-            gz2 = torch.where(lev.lower, g / e, torch.zeros_like(g))
-            gin, gcl, _ = lev.backward(y, tape, c, gz2, gJ, need_gc, g_params=total_g, accumulate=True)
-            g = torch.where(lev.lower, gz2, g - gin)
-            if gc_tot is not None:
-                gc_tot -= gcl
-            y = y_up
-        return g, gc_tot, total_g.neg_()
-
-
-class _LevelEngine(_Engine):
-    """the nodes of ONE depth of a block as a plan of their own (same parameter offsets: it reads the block's arena and
-    writes its nodes' slices of a block-sized gradient buffer); `lower` marks the lanes the level transforms"""
-
-    def __init__(self, parent: _Engine, descs):
-        self.lib, self.device, self.d, self.dc, self.total = parent.lib, parent.device, parent.d, parent.dc, parent.total
-        table = (NodeDesc * len(descs))()
-        lower = torch.zeros(self.d, dtype=torch.bool)
-        for i, n in enumerate(descs):
-            C.memmove(C.byref(table[i]), C.byref(n), C.sizeof(NodeDesc))
-            table[i].depth = 0
-            lower[n.off + n.k:n.off + n.D] = True
-        self.lower = lower.to(self.device).view(1, self.d)
-        handle = C.c_void_p()
+        ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.hint_plan_create(table, len(descs), self.d, self.dc, parent.clamp, C.byref(handle)),
-                       "hint_plan_create")
-        self.plan = handle
-        self.arena = None
-        self.packed = None
-        self._perm_nodes = []
-        self._perm_total = None
-        self._levels = None
+            nbytes = self.lib.hint_plan_inverse_workspace_bytes(self.plan, B) if B > 0 else 0
+            if B > 0 and nbytes == 0:
+                _lib.check(1, "hint_plan_inverse_workspace_bytes")
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+            st = self.lib.hint_block_inverse_backward(self.plan, self.arena.data_ptr(), x.data_ptr(), ptr(c), ptr(gx), ptr(gJ),
+                                                      gz.data_ptr(), ptr(gc), g_params.data_ptr(), 0, ws.data_ptr(), nbytes,
+                                                      ptr(perm), B, self._stream())
+        _lib.check(st, "hint_block_inverse_backward")
+        return gz, gc, g_params
 
 
 class _RevCouplingFn(torch.autograd.Function):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HINT_AMD_ABI_VERSION 3
+#define HINT_AMD_ABI_VERSION 4
 
 /* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
  * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],
@@ -150,6 +150,26 @@ int hint_block_backward(const hint_plan* plan, const float* params, const float*
                         const float* g_J, float* g_x, float* g_c, float* g_params,
                         int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t B,
                         void* stream);
+
+/* Backward of hint_block_inverse / hint_block_inverse_ex: what autograd derives when `rev=True` runs with gradients
+ * (hint.py:82-88 and the recursion of :85-88 are differentiable torch ops; train_unconditional.py:152-153 only samples
+ * under no_grad, so no reference loop needs it - it is here for users of the module who do).
+ *   x        [B,d] the OUTPUT of the inverse call (with the same perm, if any); c as given to it.
+ *   g_x, g_J upstream gradients of the inverse's outputs (either may be NULL = zeros).
+ *   g_z [B,d], g_c [B,dc] (may be NULL), g_params (flat, same layout as params; overwritten when accumulate == 0, added
+ *   to otherwise; 16-byte aligned) receive the gradients.
+ *   perm     the matrix given to hint_block_inverse_ex (x = block^-1(z) @ perm^T), or NULL.
+ * Runs level by level on the block kernels, deepest level first: the forward direction rebuilds from x what the
+ * inverse saw at every node, and each level's derivative is the forward coupling's with the roles turned round
+ * (g_z2 = g_x2 / e(s), all subnet gradients with the opposite sign; derivation: DESIGN.md section 1).  The first call
+ * on a plan builds one plan per tree level (device tables; not stream-ordered, like hint_plan_create).
+ * workspace: hint_plan_inverse_workspace_bytes(plan, B) bytes of 16-byte aligned device scratch (that call builds the
+ * level plans as well; returns 0 on failure, see hint_last_error). */
+size_t hint_plan_inverse_workspace_bytes(const hint_plan* plan, int32_t B);
+int hint_block_inverse_backward(const hint_plan* plan, const float* params, const float* x, const float* c,
+                                const float* g_x, const float* g_J, float* g_z, float* g_c, float* g_params,
+                                int32_t accumulate, void* workspace, size_t workspace_bytes, const float* perm,
+                                int32_t B, void* stream);
 
 /* Chained forms used by the flow container / trainer (hint_amd/flow.py, hint_amd/train.py): the
  * work FrEIA's graph does between two blocks is folded into the block kernels.

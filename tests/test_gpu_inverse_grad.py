@@ -153,3 +153,48 @@ def test_external_coupling_inverse_grads(D, dc, h, B):
     assert rel_err(cg.grad.cpu().numpy(), co.grad.numpy()) < 1e-4
     for k, p in mod.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), Po[k].grad.numpy()) < 2e-4, k
+
+
+def test_inverse_backward_entry_point_contract():
+    """hint_block_inverse_backward directly: accumulate adds to g_params, NULL upstream gradients mean zeros, a short
+    workspace and a missing condition are refused, an empty batch clears the gradient"""
+    import ctypes as C
+    from hint_amd import _lib
+    d, dc, widths, B = 9, 2, [19, 11, 3], 50
+    c = dict(d=d, dims_c=[(dc,)], c_internal=widths, clamp=4.0, max_splits=-1, min_split_size=2)
+    blk = make_block(c)
+    z = torch.randn(B, d, device=DEV); cond = torch.randn(B, dc, device=DEV)
+    with torch.no_grad():
+        (x,) = blk([z], c=[cond], rev=True)
+    eng = blk.tree.engine(torch.device(DEV))
+    lib = eng.lib
+    nbytes = lib.hint_plan_inverse_workspace_bytes(eng.plan, B)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    gx = torch.randn(B, d, device=DEV); gJ = torch.randn(B, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(gx, gJ, G, acc, nb=nbytes, cptr=cond.data_ptr(), rows=B):
+        gz = torch.empty(B, d, device=DEV); gc = torch.empty(B, dc, device=DEV)
+        st = lib.hint_block_inverse_backward(eng.plan, eng.arena.data_ptr(), x.data_ptr(), cptr,
+                                             gx.data_ptr() if gx is not None else None, gJ.data_ptr() if gJ is not None else None,
+                                             gz.data_ptr(), gc.data_ptr(), G.data_ptr(), acc, ws.data_ptr(), nb, None, rows, stream)
+        torch.cuda.synchronize()
+        return st, gz, gc
+    G1 = torch.full((eng.total,), 7.0, device=DEV)
+    st, gz1, gc1 = call(gx, gJ, G1, 0)
+    assert st == 0
+    G2 = G1.clone()
+    st, gz2, gc2 = call(gx, gJ, G2, 1)
+    assert st == 0 and torch.equal(gz1, gz2) and torch.equal(gc1, gc2)
+    assert torch.allclose(G2, 2 * G1, rtol=1e-6, atol=1e-7)
+    # linear in the upstream pair: (g_x, 0) + (0, g_J) = (g_x, g_J)
+    Ga, Gb = torch.empty_like(G1), torch.empty_like(G1)
+    _, gza, _ = call(gx, None, Ga, 0)
+    _, gzb, _ = call(None, gJ, Gb, 0)
+    assert rel_err((gza + gzb).cpu().numpy(), gz1.cpu().numpy()) < 1e-5
+    assert rel_err((Ga + Gb).cpu().numpy(), G1.cpu().numpy()) < 1e-5
+    assert call(gx, gJ, G2, 0, nb=nbytes - 16)[0] != 0 and b"workspace" in lib.hint_last_error()
+    assert call(gx, gJ, G2, 0, cptr=None)[0] != 0
+    st, _, _ = call(gx, gJ, G2, 0, rows=0)
+    assert st == 0 and float(G2.abs().max()) == 0.0
