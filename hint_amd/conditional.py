@@ -198,7 +198,7 @@ class ConditionalFlowTrainer:
         # 1/sqrt(1-beta2^t), ...}, rng_state[1] = step count; the re-pack launch's prologue advances them
         self.opt_state = torch.tensor([lr, betas[0], betas[1], 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
         self.rng_state = torch.zeros(2, dtype=torch.int64, device=dev)
-        self._zero = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)     # hint_block_forward_ex: the two loss sums
 
     @property
     def lr(self) -> float:
@@ -234,7 +234,7 @@ class ConditionalFlowTrainer:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             if prologue:      # also: step counter += 1, Adam's bias corrections of that step -> opt_state
-                st = self.lib.hint_pack_group_run_ex(self._pack_group, self._zero.data_ptr(), self._zero.numel(),
+                st = self.lib.hint_pack_group_run_ex(self._pack_group, self.loss_acc.data_ptr(), self.loss_acc.numel(),
                                                      self.rng_state.data_ptr(), self.opt_state.data_ptr(), stream)
             else:
                 st = self.lib.hint_pack_group_run(self._pack_group, stream)
@@ -298,46 +298,56 @@ class ConditionalFlowTrainer:
         return True
 
     def _iteration(self, x: torch.Tensor, y: torch.Tensor, on_device_adam: bool):
+        """Both lanes forward and backward as direct launches.  What FrEIA's graph does between the couplings is folded
+        into them (hint_block_*_ex): the x lane's fixed permutation rides in front of hac_x, the log-dets accumulate
+        through J_in, the two loss sums come from the last couplings' launches (loss_acc), dL/dz = z / B and
+        dL/dJ = -1/B are applied on load.  Left to torch: the y lane's 4 x 4 permutation (the permuted y is also the
+        x lane's condition) and the sum of the two gradients that meet in y."""
         flow, B = self.flow, x.shape[0]
-        self._pack_all(prologue=on_device_adam)
+        self._pack_all(prologue=on_device_adam)         # (its prologue clears loss_acc)
+        if not on_device_adam:
+            self.loss_acc.zero_()
         if self.noise > 0:
             x = x.add(torch.randn_like(x), alpha=self.noise)
         eng = dict(zip([(k, i) for k, i, _ in self.mods], self.engines))
         sl = dict(zip([(k, i) for k, i, _ in self.mods], self.slices))
         saved = {}
-        Jx = torch.zeros(B, dtype=torch.float32, device=x.device)
-        Jy = torch.zeros_like(Jx)
-        for i in range(flow.n_blocks):                              # ---- forward, both lanes ----
+        nb = flow.n_blocks
+        Jx = Jy = None
+        for i in range(nb):                                         # ---- forward, both lanes ----
+            front = None
             if i > 0:
                 y = y @ flow.perm_y[i].W
-                x = x @ flow.perm_x[i].W
-            xin = x
-            x, j, tape = eng[("hac_x", i)].apply(xin, None, rev=False, with_tape=True)
-            saved[("hac_x", i)] = (xin, tape, None); Jx = Jx + j
-            xin = x
-            x, j, tape = eng[("ac_y_to_x", i)].apply(xin, y, rev=False, with_tape=True)
-            saved[("ac_y_to_x", i)] = (xin, tape, y); Jx = Jx + j
-            yin = y
-            y, j, tape = eng[("ac_y", i)].apply(yin, None, rev=False, with_tape=True)
-            saved[("ac_y", i)] = (yin, tape, None); Jy = Jy + j
+                front = flow.perm_x[i].W
+            acc = self.loss_acc if i == nb - 1 else None
+
+            def fwd(kind, inp, c, front, J_in, acc):
+                e = eng[(kind, i)]
+                out, J, tape = e.forward_chain(inp, c, e.compose_perm(front), J_in, acc, True)
+                saved[(kind, i)] = (inp, tape, c, front)
+                return out, J
+            x, Jx = fwd("hac_x", x, None, front, Jx, None)
+            x, Jx = fwd("ac_y_to_x", x, y, None, Jx, acc)
+            y, Jy = fwd("ac_y", y, None, None, Jy, acc)
         zx, zy = x, y
-        l0 = 0.5 * (zx.pow(2).sum(1).mean() + zy.pow(2).sum(1).mean())
-        l1 = -(Jx + Jy).mean()
-        gx, gy = zx / B, zy / B                                     # dL/dz
-        gJ = torch.full((B,), -1.0 / B, dtype=torch.float32, device=x.device)
-        for i in reversed(range(flow.n_blocks)):                    # ---- backward ----
-            def bwd(kind, g, need_gc=False):
-                xin, tape, c = saved[(kind, i)]
+        sums = self.loss_acc.sum(dim=0)
+        l0, l1 = sums[0] / B, -sums[1] / B
+        gx, gy = zx, zy                                             # dL/dz = z / B: the scale is applied on load
+        for i in reversed(range(nb)):                               # ---- backward ----
+            scale = 1.0 / B if i == nb - 1 else 1.0
+
+            def bwd(kind, g, need_gc=False, scale=1.0):
+                xin, tape, c, front = saved[(kind, i)]
                 a, b = sl[(kind, i)]
-                gin, gc, _ = eng[(kind, i)].backward(xin, tape, c, g.contiguous(), gJ, need_gc, self.G[a:b], accumulate=True)
+                gin, gc, _ = eng[(kind, i)].backward(xin, tape, c, g, None, need_gc, self.G[a:b], accumulate=True, front=front,
+                                                     gz_scale=scale, gJ_const=-1.0 / B)
                 return gin, gc
-            gy, _ = bwd("ac_y", gy)
-            gx, gc = bwd("ac_y_to_x", gx, need_gc=True)
+            gy, _ = bwd("ac_y", gy, scale=scale)
+            gx, gc = bwd("ac_y_to_x", gx, need_gc=True, scale=scale)
             gy = gy + gc                                            # the condition of ac_y_to_x_i is the y lane
-            gx, _ = bwd("hac_x", gx)
+            gx, _ = bwd("hac_x", gx)                                # (comes back through the x lane's permutation)
             if i > 0:
                 gy = gy @ flow.perm_y[i].W.t()
-                gx = gx @ flow.perm_x[i].W.t()
         if on_device_adam:                      # step factors come from opt_state (prologue above): capturable
             scale = self._dp.allreduce_sum_(self.G, self.group)       # (no-op without a process group)
             with torch.cuda.device(self.device):

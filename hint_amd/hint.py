@@ -253,7 +253,10 @@ class _Engine:
         return gx
 
     def backward(self, x, tape, c, gz, gJ, need_gc: bool, g_params: Optional[torch.Tensor] = None,
-                 accumulate: bool = False):
+                 accumulate: bool = False, front: Optional[torch.Tensor] = None, gz_scale: float = 1.0,
+                 gJ_const: float = 0.0):
+        """front: the fixed matrix in front of the block the forward call was given (forward_chain's perm before
+        compose_perm), so that g_x comes back through it; gz_scale / gJ_const as in hint_block_backward_ex"""
         B = x.shape[0]
         gx = torch.empty_like(x)
         gc = torch.empty_like(c) if (c is not None and need_gc) else None
@@ -266,7 +269,7 @@ class _Engine:
             return gx, gc, g_params
         nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
-        perm = self.total_perm()
+        perm = self.compose_perm(front)
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_backward_ex(
                 self.plan, self.arena.data_ptr(), self.packed.data_ptr(), x.data_ptr(),
@@ -274,10 +277,9 @@ class _Engine:
                 gz.data_ptr() if gz is not None else None, gJ.data_ptr() if gJ is not None else None,
                 gx.data_ptr(), gc.data_ptr() if gc is not None else None, g_params.data_ptr(),
                 1 if accumulate else 0, ws.data_ptr(), nbytes, perm.data_ptr() if perm is not None else None,
-                1.0, 0.0, B, self._stream())
+                float(gz_scale), float(gJ_const), B, self._stream())
         _lib.check(st, "hint_block_backward")
         return gx, gc, g_params
-
 
     # ---- backward of the INVERSE direction (hint.py:82-88 under autograd) ------------------------------
     def inverse_backward(self, x, c, gx, gJ, need_gc: bool):
