@@ -64,6 +64,8 @@ _PROTOS = {
     "hint_chain_forward_noisy": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hint_chain_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "hint_chain_destroy": (None, [C.c_void_p]),
+    "hint_chain_backward_adam": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p]
+                                 + [C.c_float] * 6 + [C.c_void_p]),
     "hint_chain_backward_parts": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "hint_chain_wgrad_range": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hint_chain_inverse": (C.c_int, [C.c_void_p] * 7),

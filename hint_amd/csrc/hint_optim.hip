@@ -12,7 +12,7 @@
 // With zero_grads the kernel also clears the gradient arena it has just consumed, so the next
 // step's backward kernels can accumulate into it without a separate memset.
 // Pure HBM streaming: 16 B/lane loads and stores, 4 arrays read + 3 (4) written = 28-32 B/param.
-#include <hip/hip_runtime.h>
+#include "hint_adam.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -30,13 +30,9 @@ __global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, f
         f32x4 pp = ((f32x4*)p)[i], gg = ((f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float gj = gg[j] * gscale;
-            gj = fminf(fmaxf(gj, -gclamp), gclamp);
-            gj = gj + wd * pp[j];
-            mm[j] = b1 * mm[j] + (1.f - b1) * gj;
-            vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
-            const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
-            pp[j] = pp[j] - lr_t * (mm[j] / denom);
+            float pj = pp[j], mj = mm[j], vj = vv[j];
+            hint::adam_update(pj, mj, vj, gg[j], lr_t, b1, b2, inv_sqrt_bc2, eps, wd, gscale, gclamp);
+            pp[j] = pj; mm[j] = mj; vv[j] = vj;
         }
         ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
         if (zero_grads) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -45,13 +41,9 @@ __global__ __launch_bounds__(256) void hint_adam_kernel(float* __restrict__ p, f
     const long tail0 = n4 * 4;
     const long t = tail0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
-        float gj = g[t] * gscale;
-        gj = fminf(fmaxf(gj, -gclamp), gclamp);
-        gj = gj + wd * p[t];
-        const float mj = b1 * m[t] + (1.f - b1) * gj;
-        const float vj = b2 * v[t] + (1.f - b2) * gj * gj;
-        m[t] = mj; v[t] = vj;
-        p[t] = p[t] - lr_t * (mj / (sqrtf(vj) * inv_sqrt_bc2 + eps));
+        float pj = p[t], mj = m[t], vj = v[t];
+        hint::adam_update(pj, mj, vj, g[t], lr_t, b1, b2, inv_sqrt_bc2, eps, wd, gscale, gclamp);
+        p[t] = pj; m[t] = mj; v[t] = vj;
         if (zero_grads) g[t] = 0.f;
     }
 }

@@ -18,6 +18,7 @@
 
 #include "../../include/hint_amd.h"
 #include "hint_dev.h"
+#include "hint_adam.hpp"
 
 namespace hint {
 hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
@@ -40,7 +41,7 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
-                        int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream);
+                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, hipStream_t stream);
 hipError_t launch_bwd_n3(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
                          int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                          float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);      // (hint_bwd3.hip: rows of <= 3 tiles)
@@ -1397,7 +1398,8 @@ static int grid_for(const hint_plan* P, int B) {
 // one block or a chain
 static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, const ChainBlock* chain_host, int n_chain,
                         int cb0, const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
-                        float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s) {
+                        float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s,
+                        const AdamFuse* adam = nullptr) {
     if ((parts & 1) && P->wl) {
         KArgs a = make_args(P, B, true);
         const int nr = wl_nr_for(P, B);
@@ -1419,7 +1421,7 @@ static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBl
                          rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
                          (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
                          accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),
-                         P->num_cu, s));
+                         P->num_cu, adam, s));
     return 0;
 }
 
@@ -1797,6 +1799,30 @@ int hint_chain_wgrad_range(const hint_chain* C, const float* x, const float* c, 
 int hint_chain_backward(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
                         float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate, void* stream) {
     return hint_chain_backward_parts(C, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, accumulate, 3, stream);
+}
+
+int hint_chain_backward_adam(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
+                             float* g_x, float* g_c, float gz_scale, float gJ_const, float* params, float* exp_avg,
+                             float* exp_avg_sq, int64_t n, const float* opt_state, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_scale, float grad_clamp, void* stream) {
+    if (!C || !g_z || !g_x || !params || !exp_avg || !exp_avg_sq || !opt_state) return fail("hint_chain_backward_adam: null argument");
+    if (!C->committed) return fail("hint_chain_backward_adam: hint_chain_commit() has not been called");
+    const hint_plan* P = C->plan;
+    if (P->dc > 0 && !c) return fail("hint_chain_backward_adam: plan has dc=%d but c is NULL", P->dc);
+    if (!x && !C->host[0].perm) return fail("hint_chain_backward_adam: x is NULL but the first block has no fused permutation");
+    if ((((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
+        return fail("hint_chain_backward_adam: the arenas must be 16-byte aligned");
+    for (int i = 0; i < C->n; ++i) {
+        const ChainBlock& b = C->host[i];
+        if (!b.wsG1 || !b.actA1 || !b.gparams) return fail("hint_chain_backward_adam: block %d was set without workspace / g_params", i);
+        const int64_t off = b.params - params;
+        if (off < 0 || off + P->param_floats > n || (off & 3) != 0)
+            return fail("hint_chain_backward_adam: block %d's parameters are not a 16-byte aligned slice of the arena [params, params + n)", i);
+    }
+    AdamFuse ad{params, exp_avg, exp_avg_sq, opt_state, beta1, beta2, eps, weight_decay, grad_scale,
+                grad_clamp > 0.f ? grad_clamp : 3.0e38f};
+    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, 1, 3,
+                        (hipStream_t)stream, &ad);
 }
 
 void hint_chain_destroy(hint_chain* C) {

@@ -16,6 +16,7 @@
 // Deterministic: every (tile, split) writes its partial to the split's own slab with plain stores and
 // hint_wreduce_kernel adds the slabs in a fixed order - no float atomics anywhere.
 #include "hint_device.hpp"
+#include "hint_adam.hpp"
 
 using namespace hint;
 
@@ -303,13 +304,19 @@ __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const
                                                            const uint8_t* __restrict__ real, int64_t param_floats,
                                                            int splits, int accumulate, int blocks_pb,
                                                            const int32_t* __restrict__ twmap, int tw_floats,
-                                                           int64_t thin_slab_off, int thin_slabs, int thin_blocks) {
+                                                           int64_t thin_slab_off, int thin_slabs, int thin_blocks, AdamFuse ad) {
+    // ad.p != nullptr (hint_chain_backward_adam): the gradient goes straight into the clamp + Adam step of its parameter - the
+    // gradient arena is neither read nor written (it stays zero, as hint_adam_step's zero_grads leaves it)
     const int per_block = blocks_pb + thin_blocks;
     const int cbi = (int)blockIdx.x / per_block;
     const int bid = (int)blockIdx.x - cbi * per_block;
     const GBlock blk = chain_block(chain, one, cbi);
     const float* slab = (const float*)blk.wsSlab;
     float* g = (float*)blk.gparams;
+    const bool fuse = ad.p != nullptr;
+    const int64_t aoff = fuse ? (const float*)blk.params - ad.p : 0;     // the block's slice of the arenas
+    float lr_t = 0.f, bc2 = 0.f;
+    if (fuse) { lr_t = ad.st[3]; bc2 = ad.st[4]; }
     if (bid >= blocks_pb) {
         // first-layer gradients of a lean plan: one slab per workgroup of the backward kernel.  32 slab elements per
         // block, 8 threads each: thread q adds slabs q, q+8, .. (eight loads in flight), the eight partials are
@@ -339,7 +346,9 @@ __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const
                     float r = part[0][tl];
 #pragma unroll
                     for (int u = 1; u < 8; ++u) r += part[u][tl];
-                    g[dst] = accumulate ? g[dst] + r : r;
+                    if (fuse) adam_update(ad.p[aoff + dst], ad.m[aoff + dst], ad.v[aoff + dst], r, lr_t, ad.b1, ad.b2, bc2, ad.eps, ad.wd,
+                                          ad.gscale, ad.gclamp);
+                    else g[dst] = accumulate ? g[dst] + r : r;
                 }
             }
             __syncthreads();
@@ -351,6 +360,26 @@ __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const
         const uchar4 rl = ((const uchar4*)real)[i4];      // 1: from part B's slabs; 2: from the backward kernel's (above); 0: padding
         f32x4 s = zero4();
         for (int sp = 0; sp < splits; ++sp) s += ((const f32x4*)(slab + (size_t)sp * param_floats))[i4];
+        if (fuse) {
+            f32x4* pp = (f32x4*)(ad.p + aoff) + i4; f32x4* pm = (f32x4*)(ad.m + aoff) + i4; f32x4* pv = (f32x4*)(ad.v + aoff) + i4;
+            f32x4 p4 = *pp, m4 = *pm, v4 = *pv;
+            const unsigned char r4[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r4[j] == 1) {
+                    float pj = p4[j], mj = m4[j], vj = v4[j];
+                    adam_update(pj, mj, vj, 0.f + s[j], lr_t, ad.b1, ad.b2, bc2, ad.eps, ad.wd, ad.gscale, ad.gclamp);
+                    p4[j] = pj; m4[j] = mj; v4[j] = vj;
+                }
+            if (rl.x != 2 && rl.y != 2 && rl.z != 2 && rl.w != 2) {
+                *pp = p4; *pm = m4; *pv = v4;
+            } else {                                    // (elements of the other path are not touched here)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r4[j] == 1) { ((float*)pp)[j] = p4[j]; ((float*)pm)[j] = m4[j]; ((float*)pv)[j] = v4[j]; }
+            }
+            continue;
+        }
         f32x4 o = accumulate ? ((const f32x4*)g)[i4] : zero4();
         if (rl.x == 1) o.x += s.x;
         if (rl.y == 1) o.y += s.y;
@@ -374,7 +403,7 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
-                        int64_t thin_slab_off, int thin_slabs, int num_cu, hipStream_t stream) {
+                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, hipStream_t stream) {
     const bool interleave = n_small < 0;       // (flag in the sign: the planner sorted the jobs)
     if (interleave) n_small = -n_small - 1;
     const int used = (n_jobs - n_small + (n_small + DW_WAVES - 1) / DW_WAVES) * splits;
@@ -390,7 +419,8 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
     blocks_pb = blocks_pb < 1 ? 1 : (blocks_pb > cap && cap >= 1 ? cap : blocks_pb);
     const int thin_blocks = twmap != nullptr ? (tw_floats + 31) / 32 : 0;
     hipLaunchKernelGGL(hint_wreduce_kernel, dim3((blocks_pb + thin_blocks) * n_chain), dim3(256), 0, stream, one, chain, real,
-                       param_floats, splits, accumulate, blocks_pb, twmap, tw_floats, thin_slab_off, thin_slabs, thin_blocks);
+                       param_floats, splits, accumulate, blocks_pb, twmap, tw_floats, thin_slab_off, thin_slabs, thin_blocks,
+                       adam ? *adam : AdamFuse{});
     return hipGetLastError();
 }
 

@@ -281,6 +281,14 @@ class FlowTrainer:
                         torch.distributed.all_reduce(self.G[:cut], op=torch.distributed.ReduceOp.SUM, group=self.group)
                         torch.cuda.current_stream(self.device).wait_stream(self._side)
                         self._reduced = True      # step() must not reduce again
+                elif with_adam and not self._allreduce_in_graph and os.environ.get("HINT_FUSE_ADAM", "1") != "0":
+                    # one process: the clamp + Adam step rides in the weight gradients' final reduction (the gradient arena
+                    # stays zero, as the separate optimizer launch leaves it)
+                    _lib.check(self.lib.hint_chain_backward_adam(
+                        chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(), None, 1.0 / B, -1.0 / B,
+                        self.P.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n_floats, self.opt_state.data_ptr(),
+                        self.betas[0], self.betas[1], self.eps, self.wd, 1.0, self.grad_clamp, stream), "hint_chain_backward_adam")
+                    with_adam = False
                 else:
                     _lib.check(self.lib.hint_chain_backward(chain, xn.data_ptr(), cp, z.data_ptr(), None, gx.data_ptr(),
                                                             None, 1.0 / B, -1.0 / B, 1, stream), "hint_chain_backward")

@@ -250,6 +250,15 @@ int hint_chain_wgrad_range(const hint_chain* chain, const float* x, const float*
  * (the reference's rev=True sign, hint.py:83).  x may alias z. */
 int hint_chain_inverse(const hint_chain* chain, const float* z, const float* c, float* x, float* J,
                        const float* J_in, void* stream);
+/* hint_chain_backward with the optimizer folded into the weight gradients' final reduction (one process: nothing sits
+ * between backward and the step - train_unconditional.py:137-144): every parameter element takes its clamp + Adam step
+ * (hint_adam_step_dev's arithmetic, bit for bit) the moment its gradient is summed, and the gradient arena is neither read
+ * nor written.  params / exp_avg / exp_avg_sq: arenas of n floats that hold every block's parameter slice (the blocks'
+ * params pointers must point into [params, params + n)); elements outside the blocks' slices are not touched. */
+int hint_chain_backward_adam(const hint_chain* chain, const float* x, const float* c, const float* g_z, const float* g_J,
+                             float* g_x, float* g_c, float gz_scale, float gJ_const, float* params, float* exp_avg,
+                             float* exp_avg_sq, int64_t n, const float* opt_state, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_scale, float grad_clamp, void* stream);
 void hint_chain_destroy(hint_chain* chain);
 
 /* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces

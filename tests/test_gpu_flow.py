@@ -289,3 +289,24 @@ def test_module_copies_and_pickles_after_first_use(tmp_path):
         for p in twin.parameters():
             p.mul_(0.5)
         assert torch.equal(flow(x), z) and not torch.equal(twin(x), z)
+
+
+@pytest.mark.parametrize("d,widths,nb,B", [(6, [140, 70, 35, 17], 3, 1000), (43, [67, 33, 16, 8], 2, 300), (9, [19, 11, 3], 4, 4113)])
+def test_optimizer_folded_into_the_reduction_takes_the_same_steps(d, widths, nb, B, monkeypatch):
+    """hint_chain_backward_adam (the captured step of a one-process trainer) against the separate reduction + optimizer
+    launches: the same weights and Adam moments bit for bit after five steps, the gradient arena left at zero"""
+    x = torch.randn(B, d, generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HINT_FUSE_ADAM", fused)
+        torch.manual_seed(0)
+        flow = hint_amd.HintFlow(d, nb, widths).to("cuda:0")
+        tr = hint_amd.FlowTrainer(flow, use_graph=True, seed=1)           # (in-kernel noise: the same counter-based draws in both runs)
+        for _ in range(5):
+            tr.step(x)
+        torch.cuda.synchronize()
+        out[fused] = (tr.P.clone(), tr.M.clone(), tr.V.clone(), tr.G.clone())
+    for a, b in zip(out["1"][:3], out["0"][:3]):
+        assert torch.equal(a, b)
+    assert float(out["1"][3].abs().max()) == 0.0 and float(out["0"][3].abs().max()) == 0.0
+    assert not torch.equal(out["1"][0], torch.zeros_like(out["1"][0]))
