@@ -215,8 +215,44 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
         }                                                                                  \
     }
 
-    // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs of block j
     int bb = bb0;
+    if (solo && ntm == 1) {
+        // A single-tile job on one wavefront is a chain of memory latencies (four MFMAs per 16-row block): eight blocks per step,
+        // all their loads in flight at once, an accumulator each (acc[3][3] has nine), added up in a fixed order behind the loop.
+        // What is left of the split (fewer than eight blocks) runs through the loop below.
+        constexpr int NS = 8;
+        const int pc = pcj[0], qc = qcj[0];
+        float ps8[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) ps8[t] = 0.f;
+        while (bb + 16 * NS <= b_end) {
+            float sa[NS][4], sq[NS][4];
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row_ = bb + 16 * t + 4 * i + kq;
+                    sa[t][i] = ps.p[(size_t)min(row_, prow_max) * ps.ld + pc];
+                    sq[t][i] = ntn > 0 ? qs.p[(size_t)min(row_, qrow_max) * qs.ld + qc] : 0.f;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    ps8[t] += sa[t][i];
+                    acc[t / 3][t % 3] = mfma4(sa[t][i], sq[t][i], acc[t / 3][t % 3]);
+                }
+            bb += 16 * NS;
+        }
+#pragma unroll
+        for (int t = 1; t < NS; ++t) {
+            acc[0][0] += acc[t / 3][t % 3];
+            acc[t / 3][t % 3] = zero4();
+            ps8[0] += ps8[t];
+        }
+        psum[0] += ps8[0];
+    }
+    // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs of block j
     if (bb < b_end) {
         DW_LOAD(0, bb)
         while (true) {
