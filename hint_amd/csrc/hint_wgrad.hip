@@ -50,6 +50,9 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
     return r;
 }
 
+// SMALL: the job list ends in single-tile jobs that share workgroups (n_small > 0); plans without them (the wave-local ones)
+// run the instance that holds none of that code
+template <bool SMALL>
 __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     const WJob* __restrict__ jobs, int n_jobs, int n_small, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
     int grid_pb, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = rfl(tid >> 6);
-    const bool solo = item >= n_big;
+    const bool solo = SMALL && item >= n_big;
     const int jidx = solo ? n_big + (item - n_big) * DW_WAVES + wave : item;
     if (jidx >= n_jobs) return;         // (a spare wavefront of the last shared workgroup: that path has no barrier)
     const WJob job = jobs[jidx];
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
 
     int bb = bb0;
-    if (solo && ntm == 1) {
+    if (SMALL && solo && ntm == 1) {
         // A single-tile job on one wavefront is a chain of memory latencies (four MFMAs per 16-row block): eight blocks per step,
         // all their loads in flight at once, an accumulator each (acc[3][3] has nine), added up in a fixed order behind the loop.
         // What is left of the split (fewer than eight blocks) runs through the loop below.
@@ -444,10 +447,17 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
     if (interleave) n_small = -n_small - 1;
     const int used = (n_jobs - n_small + (n_small + DW_WAVES - 1) / DW_WAVES) * splits;
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
-    if (used > 0)
-        hipLaunchKernelGGL(hint_wgrad_kernel, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs,
-                           n_small, splits, one, chain, (interleave && n_chain > 1 && (splits & 7) == 0) ? -grid_pb : grid_pb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride,
-                           a2_off, bits_a2_off, param_floats, x, c);
+    if (used > 0) {
+        const int gpb = (interleave && n_chain > 1 && (splits & 7) == 0) ? -grid_pb : grid_pb;
+        if (n_small > 0)
+            hipLaunchKernelGGL(hint_wgrad_kernel<true>, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits,
+                               one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off,
+                               param_floats, x, c);
+        else
+            hipLaunchKernelGGL(hint_wgrad_kernel<false>, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits,
+                               one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off,
+                               param_floats, x, c);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int blocks_pb = (int)((param_floats / 4 + 255) / 256);
