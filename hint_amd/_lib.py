@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HINT_AMD_LIB") or os.path.join(_HERE, "lib", "libhint_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HintAmdError(RuntimeError):
@@ -29,6 +29,7 @@ _lib = None
 _PROTOS = {
     "hint_abi_version": (C.c_int, []),
     "hint_last_error": (C.c_char_p, []),
+    "hint_build_info": (C.c_char_p, []),
     "hint_plan_create": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.POINTER(C.c_void_p)]),
     "hint_plan_check": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,

@@ -192,6 +192,17 @@ class ConditionalFlowTrainer:
             e.bind_external_arena(self.P[a:b])
             e.ensure_arena()
             e.pack()
+        if dp.world_info(group)[1] > 1:
+            # data-parallel replicas start from rank 0's weights AND buffers (the fixed permutations are drawn per process:
+            # replicas with different matrices would sum gradients of different functions) - as FlowTrainer does
+            src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
+            torch.distributed.broadcast(self.P, src=src, group=group)
+            for buf in flow.buffers():
+                if buf.is_cuda and buf.numel() > 0:
+                    torch.distributed.broadcast(buf, src=src, group=group)
+            for e in self.engines:
+                e._perm_key = None          # (composed permutations are rebuilt from the received matrices)
+                e.pack()
         self._pack_group, self._pack_key = None, None
         self.last = None
         # device-side step state (see FlowTrainer): opt_state = {lr, beta1, beta2, lr/(1-beta1^t),
@@ -239,6 +250,15 @@ class ConditionalFlowTrainer:
             else:
                 st = self.lib.hint_pack_group_run(self._pack_group, stream)
         self._lib.check(st, "hint_pack_group_run")
+
+    def allreduce_plan(self) -> str:
+        """what the step does with the gradient arena between backward and optimizer (for bench.py's config line)"""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return "none (one process)"
+        world = self._dp.world_info(self.group)[1]
+        where = "captured in the step's hipGraph" if self._graph is not None else "issued from the host"
+        return (f"one all-reduce (sum) of the flat fp32 gradient arena ({self.n_floats} floats) over {world} ranks "
+                f"({torch.distributed.get_backend(self.group)}); {where}")
 
     def _graphable(self) -> bool:
         """one process, or a data-parallel job over RCCL (whose all-reduce is captured with the step)"""

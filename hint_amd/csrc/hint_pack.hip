@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void hint_zero_kernel(float* __restrict__ p, l
     if (t < n) p[t] = 0.f;
 }
 
-// ---- element-wise helpers of hint_block_inverse_backward (hint_plan.cpp): B x d lane tiles, `lower` marks the lanes a level
+// ---- element-wise helpers of hint_block_inverse_backward (hint_invgrad.cpp): B x d lane tiles, `lower` marks the lanes a level
 //      transforms.  op 0: out = lower ? 1 : 0;  op 1: out = lower ? g / e : 0;  op 2: g = lower ? a : g - b ----
 __global__ __launch_bounds__(256) void hint_inv_lane_kernel(int op, float* out, const float* g,             // (op 2 runs in place: out == g)
                                                             const float* __restrict__ a, const float* __restrict__ b,

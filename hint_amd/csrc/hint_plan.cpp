@@ -1,163 +1,19 @@
-// Host side of the C ABI (include/hint_amd.h): turns the node list of one coupling tree (the
+// The planner (host side of the C ABI, include/hint_amd.h): turns the node list of one coupling tree (the
 // structure /root/reference/hint.py:25-54 builds recursively) into a static schedule in device
 // memory - groups of same-depth nodes, their units (one subnet of one node each), the split of every
-// group's fragment tiles over the wavefronts, the packed-weight layout, the weight-gradient jobs -
-// and launches the kernels of hint_fwd.hip / hint_bwd.hip / hint_wgrad.hip / hint_pack.hip /
-// hint_optim.hip.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/hint_amd.h"
-#include "hint_dev.h"
-#include "hint_adam.hpp"
-
-namespace hint {
-hipError_t launch_pack(const PackSeg* segs, const int2* ptiles, int n_tiles, const int32_t* bmap, int n_bias,
-                       long bias_off, const float* params, float* packed, hipStream_t stream);
-hipError_t launch_pack_many(const PackItem* items, int n_items, int grid, float* zero_buf, int zero_floats,
-                            unsigned long long* rng_state, float* opt_state, hipStream_t stream);
-hipError_t launch_zero(float* p, long n, int num_cu, hipStream_t stream);
-hipError_t launch_inv_lane(int op, float* out, const float* g, const float* a, const float* b, const uint8_t* lower, long n, int d,
-                           int num_cu, hipStream_t stream);
-hipError_t launch_inv_minus(float* dst, const float* src, long n, int keep, int num_cu, hipStream_t stream);
-hipError_t launch_inv_rowmat(const float* x, const float* P, float* y, long n, int d, int num_cu, hipStream_t stream);
-hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
-                        const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
-                        const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
-                        float* x_noisy, hipStream_t stream);
-hipError_t launch_bwd(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
-                      int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
-                      float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);
-hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, const ChainBlock& one, const ChainBlock* chain,
-                        int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
-                        int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
-                        const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
-                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, hipStream_t stream);
-hipError_t launch_bwd_n3(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
-                         int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
-                         float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);      // (hint_bwd3.hip: rows of <= 3 tiles)
-hipError_t set_max_lds_apply(int bytes);
-hipError_t set_max_lds_bwd(int bytes);
-hipError_t set_max_lds_bwd_n3(int bytes);
-hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
-                           const ChainBlock* chain, int n_chain, const float* x, float* z, float* J, const float* J_in,
-                           float* loss_acc, float noise, const unsigned long long* rng_state, float* x_noisy,
-                           hipStream_t stream);
-hipError_t launch_wl_bwd(const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
-                         const ChainBlock* chain, int n_chain, const float* x, const float* g_z, const float* g_J,
-                         float* g_x, float gz_scale, float gJ_const, hipStream_t stream);
-hipError_t set_max_lds_wl_apply(int bytes);
-hipError_t set_max_lds_wl_bwd(int bytes);
-hipError_t launch_adam(float* p, float* g, float* m, float* v, long n, float lr_t, float b1, float b2,
-                       float inv_sqrt_bc2, float eps, float wd, float gscale, float gclamp, int zero_grads,
-                       int num_cu, const float* dev_state, hipStream_t stream);
-}  // namespace hint
+// group's fragment tiles over the wavefronts, the packed-weight layout, the weight-gradient jobs.
+// The launches live in hint_abi.cpp / hint_chain.cpp / hint_invgrad.cpp.
+#include "hint_host.hpp"
 
 using namespace hint;
 
-static thread_local std::string g_err;
-
-static int fail(const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return 1;
-}
-
-#define HIP_TRY(expr)                                                              \
-    do {                                                                           \
-        hipError_t e_ = (expr);                                                    \
-        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline int pad4(int v) { return (v + 3) & ~3; }
-
-#ifdef HINT_STAMPS
-static constexpr int LDS_LIMIT = 160 * 1024 - 33 * 1024;   // the diagnostic build's static stamp array shares the 160 KiB
-#else
-static constexpr int LDS_LIMIT = 160 * 1024;
-#endif
-static constexpr int LDS_ATTR = LDS_LIMIT;
 #ifndef HINT_THIN_MFMA_MIN
 #define HINT_THIN_MFMA_MIN 8
 #endif
 static constexpr int THIN_MFMA_MIN = HINT_THIN_MFMA_MIN;          // thin layers with more inputs than this use the matrix pipe (fragment tiles of W1 / W3^T)
 static constexpr int THIN_LDS_MAX = 24 * 1024;   // a block's thin-layer vectors are staged in LDS up to this size
-static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
-static constexpr int WS_SLACK = 64;              // floats of slack behind every [Bp][W] array
 static constexpr int MAX_TAIL = 8;               // hint_rows.hpp: tail accumulators
-static unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only (hint_debug_set_stamp_buffer)
 static thread_local bool g_host_only = false;    // hint_plan_check: build and verify the plan, touch no device
-
-struct hint_plan {
-    int device = -1;
-    int d = 0, dc = 0, n_nodes = 0, n_groups = 0, n_levels = 0, n_units = 0, n_wjobs = 0, n_wsmall = 0, wsorted = 0, n_ptiles = 0, nw = 8;   // n_wsmall: single-tile jobs at the end of the job list (hint_wgrad.hip)
-    float alpha = 0.f;
-    int64_t param_floats = 0, packed_floats = 0;
-    int WT = 0, ST = 0;
-    int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
-    int region_fwd = 0, region_bwd = 0;   // LDS floats of the per-group region [tiles | staged output tiles | slabs]
-    int stage_out = 1;
-    int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
-    int fuse_dw1 = 0;           // lean plans with LDS-staged outputs: dW1, db1 come from the backward kernel (per-workgroup slabs), g1 stays on chip
-    int tw_floats = 0;          // floats of one such slab
-    int32_t* d_twmap = nullptr; // slab index -> offset in the flat parameter layout (or -1)
-    int thin_f_off = 0, thin_f_floats = 0, thin_b_off = 0, thin_b_floats = 0, thin_lds_f = 0, thin_lds_b = 0;
-    int thin_grp_f = 0, thin_grp_b = 0;     // > 0: LDS takes one group's thin vectors at a time (floats of the largest group's)
-    int lds_fwd = 0, lds_bwd = 0;
-    // wave-local plans (hint_wl.hpp): narrow trees run on hint_wl_apply_kernel / hint_wl_bwd_kernel
-    int wl = 0, wl_nr2 = 0;     // wl_nr2: two 16-row tiles per workgroup on one weight stream fit the LDS as well
-    WlArgs wl_f[2]{}, wl_b[2]{};  // [nr - 1]
-    // subtree groups (hint_sub.hpp): the deepest n_sub groups run one subtree per wavefront
-    int n_sub = 0, sub_pf = 0, sub_pb = 0, sub_pbias = 0, sub_bsrc = 0, sub_cols = 0;
-    int sub_slab_f = 0, sub_slab_b = 0;                 // floats of their slabs
-    int sub_lds_f[3] = {0, 0, 0}, sub_lds_b[3] = {0, 0, 0};   // LDS float offsets: slabs, staged parameters, misc
-    int rowdw_lds = 0;          // backward: LDS float offset of the scratch tiles of the rows that compute dW1 | db1 themselves (0: none)
-    int row_ntt = 0;            // tiles of the widest row (<= 3: the backward pass runs on hint_bwd_kernel_n3)
-    int num_cu = 256;
-    int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
-    void* d_meta = nullptr;
-    LaneOp* d_lops = nullptr;
-    RowRec* d_recs = nullptr;
-    ThinRec* d_thins = nullptr;
-    int total_tiles = 0;
-    int total_rows = 0;
-    int32_t* d_bmap = nullptr;
-    uint8_t* d_real = nullptr;
-    WJob* d_wjobs = nullptr;
-    PackSeg* d_segs = nullptr;
-    int2* d_ptiles = nullptr;
-    // the same block planned for 4 wavefronts per workgroup (two workgroups per CU: one row tile's serial phases overlap
-    // the other's GEMM phases) - used for batches of more row tiles than CUs; owned by this plan; may be absent
-    hint_plan* alt4 = nullptr;
-    // hint_block_inverse_backward: the node table the plan was made from and, built at the first call, one plan per tree
-    // level (its nodes as a forest of depth 0) with the lanes each level transforms
-    std::vector<hint_node_desc> nodes;
-    float clamp = 0.f;
-    std::mutex inv_mu;
-    std::vector<hint_plan*> inv_levels;         // deepest level last
-    uint8_t* d_inv_lower = nullptr;             // [levels][d]
-};
-
-static inline int plan_lds(const hint_plan* P, bool backward, int nr = 1) {
-    if (P->wl) return 4 * (backward ? P->wl_b[nr - 1].off_perm : P->wl_f[nr - 1].off_perm);
-    return backward ? P->lds_bwd : P->lds_fwd;
-}
-
-static int env_int(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; }
 
 // A row of a group's GEMM phase: up to NTT adjacent fragment tiles [tb, tb + ntt) of one unit
 struct Row { int unit, tb, ntt, slab3, slabv; long cost; };
@@ -1105,9 +961,6 @@ static int plan_for(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
 
 extern "C" {
 
-int hint_abi_version(void) { return HINT_AMD_ABI_VERSION; }
-const char* hint_last_error(void) { return g_err.c_str(); }
-
 int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
                      hint_plan** out) {
     if (!nodes || n_nodes <= 0 || d <= 0 || dc < 0 || !out) return fail("hint_plan_create: bad arguments");
@@ -1135,7 +988,7 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
     // batches of more row tiles than CUs run two 4-wavefront workgroups per CU instead of one 8-wavefront workgroup
     // after the other (when the block fits twice and the backward kernel's register-held lane tile allows 256 threads)
     if (nw == 8 && !std::getenv("HINT_NW") && ROWS * d <= LV_REGS * 64 * 4) {
-        const std::string keep = g_err;
+        const std::string keep = last_error_ref();
         hint_plan* alt = nullptr;
         if (plan_for(nodes, n_nodes, d, dc, clamp, 4, &alt) == 0) {
             const hint_plan* P = *out;
@@ -1147,7 +1000,7 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
             else if (g_host_only) delete alt;
             else hint_plan_destroy(alt);
         }
-        g_err = keep;
+        last_error_ref() = keep;
     }
     (*out)->nodes.assign(nodes, nodes + n_nodes);
     (*out)->clamp = clamp;
@@ -1187,696 +1040,6 @@ void hint_plan_destroy(hint_plan* P) {
     (void)hipFree(P->d_segs);
     (void)hipFree(P->d_ptiles);
     delete P;
-}
-
-// the plan variant a batch of B rows runs on, and (wave-local plans) how many 16-row tiles a workgroup takes:
-//   up to one row tile per CU                  the 8-wavefront plan, one tile per workgroup
-//   more                                       wave-local plans: ROW PAIRS - two tiles on one weight stream (hint_wl.hpp) - on the
-//                                              8-wavefront plan; beyond two pairs per CU on the 4-wavefront plan (two workgroups
-//                                              per CU) when that fits the LDS twice
-//                                              other plans: the 4-wavefront plan, one tile per workgroup
-static const hint_plan* variant(const hint_plan* P, int B) {
-    if (!P || !P->alt4) return P;
-    const int ntiles = (B + ROWS - 1) / ROWS;
-    if (ntiles <= P->num_cu) return P;
-    static const int nr_forced = env_int("HINT_WL_NR");
-    if (P->wl && P->wl_nr2 && nr_forced != 1) {
-        const hint_plan* A = P->alt4;
-        const bool alt_twice = A->wl && A->wl_nr2 && std::max(plan_lds(A, false, 2), plan_lds(A, true, 2)) + 4096 <= LDS_LIMIT / 2;
-        return (alt_twice && ntiles > 4 * P->num_cu) ? A : P;
-    }
-    return P->alt4;
-}
-static int wl_nr_for(const hint_plan* Pv, int B) {       // Pv: the variant already picked
-    if (!Pv->wl || !Pv->wl_nr2) return 1;
-    static const int nr_forced = env_int("HINT_WL_NR");
-    if (nr_forced == 1 || nr_forced == 2) return nr_forced;
-    return (B + ROWS - 1) / ROWS > Pv->num_cu ? 2 : 1;
-}
-
-int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
-// + 4 KiB of slack behind the bias region (a padded row's dummy steps load up to three tiles past its last)
-int64_t hint_plan_packed_floats(const hint_plan* P) { return P ? P->packed_floats + P->n_bias + 1024 : -1; }
-
-static inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
-
-// Tape layout (floats): [lane tiles: L x B x d][s: L x B x d][pad to 4][a1: Bp x WT + slack][a2: same]
-//                       [sign bytes of a1: Bp/16 x WT/16 x 64 bytes][of a2: same]
-// (lean plans: no a1 array)
-static inline int64_t tape_act_off(const hint_plan* P, int B) {
-    return (2 * (int64_t)P->n_levels * B * P->d + 3) / 4 * 4;
-}
-static inline int64_t act_stride(const hint_plan* P, int B) { return (int64_t)rows_padded(B) * P->WT + WS_SLACK; }
-static inline int64_t bits_stride(const hint_plan* P, int B) { return (int64_t)rows_padded(B) / ROWS * (P->WT / 16) * 64; }   // bytes
-
-int64_t hint_plan_tape_floats(const hint_plan* P, int32_t B) {
-    if (!P || B < 0) return -1;
-    P = variant(P, B);
-    return tape_act_off(P, B) + (P->lean ? 1 : 2) * act_stride(P, B) + 2 * bits_stride(P, B) / 4;
-}
-
-// batch split of part B: a multiple of 8 splits (one XCD each), enough workgroups to cover the chip,
-// every workgroup reducing at least 128 rows
-static void wgrad_splits(const hint_plan* P, int B, int n_chain, int* splits_out, int* rows_out) {
-    const long Bp = rows_padded(B);
-    int splits = 8;
-    while ((long)splits * P->n_wjobs * n_chain < (long)P->num_cu && Bp / (splits * 2) >= 128) splits *= 2;
-    static const int forced = env_int("HINT_DW_SPLITS");          // (experiments)
-    if (forced > 0 && Bp / forced >= 16) splits = forced;
-    int rows_per_wg = (int)((Bp + splits - 1) / splits);
-    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
-    if ((long)rows_per_wg * (splits - 1) >= Bp)   // tiny batches: fewer, non-empty splits
-        splits = (int)((Bp + rows_per_wg - 1) / rows_per_wg);
-    *splits_out = splits;
-    *rows_out = rows_per_wg;
-}
-
-// Workspace layout (floats): [g1: Bp x WT + slack][g2: same][g_st: Bp x ST + slack, padded to 4][slabs: splits x param_floats]
-static inline int64_t ws_gst_off(const hint_plan* P, int B) { return (P->lean ? 1 : 2) * act_stride(P, B); }      // (lean plans: no g2 array)
-static inline int64_t ws_slab_off(const hint_plan* P, int B) {
-    return ws_gst_off(P, B) + ((int64_t)rows_padded(B) * P->ST + WS_SLACK + 3) / 4 * 4;
-}
-
-static int grid_for(const hint_plan* P, int B);
-// the backward kernel's first-layer gradient slabs (fuse_dw1) follow part B's slabs: [workgroup][tw_floats]
-static inline int64_t ws_thin_off(const hint_plan* P, int B) {        // floats from the part-B slabs' start
-    int splits, rows;
-    wgrad_splits(P, B, 1, &splits, &rows);        // (a chain never uses more splits than a single block)
-    return (int64_t)splits * P->param_floats;
-}
-
-size_t hint_plan_workspace_bytes(const hint_plan* P, int32_t B) {
-    if (!P || B <= 0) return 0;
-    P = variant(P, B);
-    const int64_t thin = P->fuse_dw1 ? (int64_t)grid_for(P, B) * P->tw_floats : 0;
-    return (size_t)(ws_slab_off(P, B) + ws_thin_off(P, B) + thin) * sizeof(float);
-}
-
-int32_t hint_plan_lds_bytes(const hint_plan* P, int32_t backward) {
-    return P ? plan_lds(P, backward != 0) : -1;
-}
-
-int hint_plan_describe(const hint_plan* P, int32_t B, int32_t* out) {
-    if (!P || !out || B < 0) return fail("hint_plan_describe: bad arguments");
-    P = variant(P, B);
-    out[0] = P->wl; out[1] = wl_nr_for(P, B); out[2] = P->nw; out[3] = P->lean;
-    out[4] = P->n_sub; out[5] = P->row_ntt; out[6] = P->rowdw_lds > 0 ? 1 : 0; out[7] = 0;
-    return 0;
-}
-
-// LDS bytes of the launch: the plan's, plus the chain's permutation matrices when they fit behind it
-static int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a) {
-    const long extra = (long)n_blocks * P->d * P->d * (long)sizeof(float);
-    a->perm_lds = 0;
-    const int cap = env_int("HINT_PERM_LDS_MAX") > 0 ? env_int("HINT_PERM_LDS_MAX") : PERM_LDS_MAX;
-    if (env_int("HINT_PLAN_DUMP")) fprintf(stderr, "[hint plan] lds %d + perms %ld (cap %d)\n", lds_plan, extra, cap);
-    if (!any_perm || extra > cap || lds_plan + extra > LDS_LIMIT) return lds_plan;
-    a->perm_lds = lds_plan / (int)sizeof(float);
-    return lds_plan + (int)extra;
-}
-static KArgs make_args(const hint_plan* P, int B, bool backward) {
-    KArgs a{};
-    a.meta = P->d_meta; a.meta_bytes = P->meta_bytes; a.recs = P->d_recs; a.total_rows = P->total_rows; a.thins = P->d_thins; a.total_tiles = P->total_tiles;
-    a.units_off = P->units_off; a.tmap_off = P->tmap_off; a.ents_off = P->ents_off; a.rng_off = P->rng_off;
-    a.lops_off = P->lops_off; a.lops = P->d_lops;
-    a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;
-    a.d = P->d; a.dc = P->dc; a.xld = P->xld; a.cld = P->cld;
-    a.abuf_tiles = P->abuf_tiles; a.slab_floats = backward ? P->slab_bwd : P->slab_fwd; a.gld = P->gld;
-    a.region_floats = backward ? P->region_bwd : P->region_fwd;
-    a.WT = P->WT; a.ST = P->ST; a.perm_lds = 0; a.stage_out = P->stage_out;
-    a.thin_off = backward ? P->thin_b_off : P->thin_f_off;
-    a.thin_floats = backward ? P->thin_b_floats : P->thin_f_floats;
-    a.thin_lds = backward ? P->thin_lds_b : P->thin_lds_f;
-    a.thin_grp = backward ? P->thin_grp_b : P->thin_grp_f;
-    a.act_stride = act_stride(P, B); a.bits_stride = bits_stride(P, B);
-    a.fuse_dw1 = P->fuse_dw1; a.tw_floats = P->tw_floats; a.thin_slab_off = ws_thin_off(P, B);
-    a.lean = P->lean; a.a2_off = P->lean ? 0 : a.act_stride; a.bits_off = (P->lean ? 1 : 2) * a.act_stride;
-    a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
-    a.rowdw_lds = backward ? P->rowdw_lds : 0;
-    a.n_sub = P->n_sub;
-    if (P->n_sub > 0) {
-        const int* o = backward ? P->sub_lds_b : P->sub_lds_f;
-        a.sub_slab = o[0]; a.sub_par = o[1]; a.sub_misc = o[2];
-        a.sub_pf = P->sub_pf; a.sub_pb = P->sub_pb; a.sub_par_f4 = (P->sub_pf + P->sub_pb + P->sub_pbias) / 4;
-        a.sub_bsrc = P->sub_bsrc; a.sub_bias_src = (int)P->packed_floats; a.sub_cols = P->sub_cols;
-    }
-    return a;
-}
-
-int hint_block_pack(const hint_plan* P, const float* params, float* packed, void* stream) {
-    if (!P || !params || !packed) return fail("hint_block_pack: null argument");
-    HIP_TRY(launch_pack(P->d_segs, P->d_ptiles, P->n_ptiles, P->d_bmap, P->n_bias, (long)P->packed_floats, params,
-                        packed, (hipStream_t)stream));
-    return 0;
-}
-
-struct hint_pack_group {
-    PackItem* d_items = nullptr;
-    int n = 0, grid = 0;
-};
-
-int hint_pack_group_create(const hint_plan* const* plans, const float* const* params, float* const* packed,
-                           int32_t n, hint_pack_group** out) {
-    if (!plans || !params || !packed || n <= 0 || !out) return fail("hint_pack_group_create: bad arguments");
-    std::vector<PackItem> items(n);
-    int grid = 0;
-    for (int i = 0; i < n; ++i) {
-        const hint_plan* P = plans[i];
-        if (!P || !params[i] || !packed[i]) return fail("hint_pack_group_create: null entry %d", i);
-        PackItem& q = items[i];
-        q.segs = P->d_segs; q.ptiles = P->d_ptiles; q.bmap = P->d_bmap; q.params = params[i]; q.packed = packed[i];
-        q.bias_off = P->packed_floats; q.n_tiles = P->n_ptiles; q.n_bias = P->n_bias; q.grid_begin = grid; q.pad = 0;
-        grid += P->n_ptiles + (P->n_bias + 255) / 256;
-    }
-    hint_pack_group* G = new hint_pack_group();
-    G->n = n; G->grid = grid;
-    hipError_t e = hipMalloc((void**)&G->d_items, items.size() * sizeof(PackItem));
-    if (e == hipSuccess) e = hipMemcpy(G->d_items, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(G->d_items); delete G; return fail("hint_pack_group_create: %s", hipGetErrorString(e)); }
-    *out = G;
-    return 0;
-}
-
-int hint_pack_group_run(const hint_pack_group* G, void* stream) {
-    return hint_pack_group_run_ex(G, nullptr, 0, nullptr, nullptr, stream);
-}
-
-int hint_pack_group_run_ex(const hint_pack_group* G, float* zero_buf, int32_t zero_floats, uint64_t* rng_state,
-                           float* opt_state, void* stream) {
-    if (!G) return fail("hint_pack_group_run: null group");
-    if (zero_floats < 0 || (zero_floats > 0 && !zero_buf)) return fail("hint_pack_group_run_ex: bad zero buffer");
-    if (opt_state && !rng_state) return fail("hint_pack_group_run_ex: opt_state needs the step counter of rng_state");
-    HIP_TRY(launch_pack_many(G->d_items, G->n, G->grid, zero_buf, zero_floats, (unsigned long long*)rng_state,
-                             opt_state, (hipStream_t)stream));
-    return 0;
-}
-
-void hint_pack_group_destroy(hint_pack_group* G) {
-    if (!G) return;
-    (void)hipFree(G->d_items);
-    delete G;
-}
-
-static void split_workspace(const hint_plan* P, int B, void* workspace, ChainBlock* b) {
-    b->wsG1 = (float*)workspace;
-    b->wsGST = b->wsG1 + ws_gst_off(P, B);
-    b->wsSlab = b->wsG1 + ws_slab_off(P, B);
-}
-
-// the hidden activations live inside the tape (the training forward writes them)
-static void bind_tape(const hint_plan* P, int B, float* tape, ChainBlock* b) {
-    b->tape = tape;
-    b->actA1 = tape ? tape + tape_act_off(P, B) : nullptr;
-}
-
-static int grid_for(const hint_plan* P, int B) {
-    const int ntiles = (B + ROWS - 1) / ROWS, nr = wl_nr_for(P, B);
-    return std::min((ntiles + nr - 1) / nr, P->num_cu * 8);
-}
-
-// part A (row-parallel, bit 0 of `parts`) and part B (weight gradients, bit 1) of the backward pass of
-// one block or a chain
-static int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, const ChainBlock* chain_host, int n_chain,
-                        int cb0, const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
-                        float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s,
-                        const AdamFuse* adam = nullptr) {
-    if ((parts & 1) && P->wl) {
-        KArgs a = make_args(P, B, true);
-        const int nr = wl_nr_for(P, B);
-        WlArgs w = P->wl_b[nr - 1];
-        bool any_perm = one.perm != nullptr;
-        if (chain_host) for (int i = 0; i < n_chain; ++i) any_perm = any_perm || chain_host[i].perm != nullptr;
-        const int lds = lds_with_perms(P, plan_lds(P, true, nr), n_chain, any_perm, &a);
-        w.off_perm = a.perm_lds;
-        HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
-    } else if (parts & 1) {
-        // (the permutation matrices stay in global memory here: one d x d product per block)
-        HIP_TRY((P->row_ntt <= 3 && P->rowdw_lds == 0 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
-                                                               g_z, g_J, g_x, g_c, gz_scale, gJ_const, s));
-    }
-    if (!(parts & 2)) return 0;
-    int splits, rows_per_wg;
-    wgrad_splits(P, B, n_chain, &splits, &rows_per_wg);
-    HIP_TRY(launch_wgrad(P->d_wjobs, P->n_wjobs, P->wsorted ? -P->n_wsmall - 1 : P->n_wsmall, splits, one, chain, n_chain, cb0, P->WT, P->ST, P->d, P->dc, P->n_levels, B,
-                         rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
-                         (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
-                         accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),
-                         P->num_cu, adam, s));
-    return 0;
-}
-
-static int apply(const hint_plan* P, bool rev, const float* params, const float* packed, const float* x,
-                 const float* c, float* z, float* J, float* tape, const float* perm, const float* J_in,
-                 float* loss_acc, int32_t B, void* stream) {
-    const char* what = rev ? "inverse" : "forward";
-    if (!P || !params || !packed || !x || !z || !J) return fail("hint_block_%s: null argument", what);
-    if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", what, P->dc);
-    if (B < 0) return fail("negative batch");
-    if (B == 0) return 0;
-    P = variant(P, B);
-    ChainBlock one{};
-    one.params = params; one.packed = packed; one.perm = perm;
-    bind_tape(P, B, rev ? nullptr : tape, &one);
-    KArgs a = make_args(P, B, false);
-    const int nr = wl_nr_for(P, B);
-    const int lds = lds_with_perms(P, plan_lds(P, false, nr), 1, perm != nullptr, &a);
-    if (P->wl) {
-        WlArgs w = P->wl_f[nr - 1];
-        w.off_perm = a.perm_lds;
-        HIP_TRY(launch_wl_apply(rev, a, w, lds, grid_for(P, B), one, nullptr, 1, x, z, J, J_in, loss_acc, 0.f, nullptr, nullptr,
-                                (hipStream_t)stream));
-        return 0;
-    }
-    HIP_TRY(launch_apply(rev, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
-                         nullptr, nullptr, (hipStream_t)stream));
-    return 0;
-}
-
-int hint_block_forward(const hint_plan* P, const float* params, const float* packed, const float* x,
-                       const float* c, float* z, float* J, float* tape, int32_t B, void* stream) {
-    return apply(P, false, params, packed, x, c, z, J, tape, nullptr, nullptr, nullptr, B, stream);
-}
-
-int hint_block_forward_ex(const hint_plan* P, const float* params, const float* packed, const float* x,
-                          const float* c, float* z, float* J, float* tape, const float* perm,
-                          const float* J_in, float* loss_acc, int32_t B, void* stream) {
-    return apply(P, false, params, packed, x, c, z, J, tape, perm, J_in, loss_acc, B, stream);
-}
-
-int hint_block_inverse(const hint_plan* P, const float* params, const float* packed, const float* z,
-                       const float* c, float* x, float* J, int32_t B, void* stream) {
-    return apply(P, true, params, packed, z, c, x, J, nullptr, nullptr, nullptr, nullptr, B, stream);
-}
-
-int hint_block_inverse_ex(const hint_plan* P, const float* params, const float* packed, const float* z,
-                          const float* c, float* x, float* J, const float* perm, const float* J_in,
-                          int32_t B, void* stream) {
-    return apply(P, true, params, packed, z, c, x, J, nullptr, perm, J_in, nullptr, B, stream);
-}
-
-int hint_block_backward(const hint_plan* P, const float* params, const float* packed, const float* x,
-                        const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
-                        float* g_c, float* g_params, int32_t accumulate, void* workspace,
-                        size_t workspace_bytes, int32_t B, void* stream) {
-    return hint_block_backward_ex(P, params, packed, x, tape, c, g_z, g_J, g_x, g_c, g_params, accumulate,
-                                  workspace, workspace_bytes, nullptr, 1.0f, 0.0f, B, stream);
-}
-
-// parts: bit 0 the row-parallel kernel, bit 1 the weight gradients (run_backward)
-static int block_backward(const hint_plan* P, const float* params, const float* packed, const float* x,
-                          const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
-                          float* g_c, float* g_params, int32_t accumulate, void* workspace,
-                          size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
-                          int32_t B, int parts, void* stream) {
-    if (!P || !params || !packed || (!x && !perm) || !g_x || !g_params) return fail("hint_block_backward: null argument");
-    if (perm && !tape) return fail("hint_block_backward_ex: a fused permutation needs the tape of hint_block_forward_ex");
-    if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
-    if (!tape && B > 0) return fail("hint_block_backward: tape is NULL (the backward pass reads the forward's lane tiles, s values and activations from it)");
-    if (B < 0) return fail("negative batch");
-    hipStream_t s = (hipStream_t)stream;
-    if (B == 0) {
-        if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
-        return 0;
-    }
-    P = variant(P, B);
-    if (!workspace || workspace_bytes < hint_plan_workspace_bytes(P, B))
-        return fail("hint_block_backward: workspace too small (%zu < %zu)", workspace_bytes,
-                    hint_plan_workspace_bytes(P, B));
-    if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_backward: workspace must be 16-byte aligned");
-    if (((uintptr_t)g_params & 15) != 0) return fail("hint_block_backward: g_params must be 16-byte aligned");
-    ChainBlock one{};
-    one.params = params; one.packed = packed; one.perm = perm;
-    bind_tape(P, B, const_cast<float*>(tape), &one);
-    one.gparams = g_params;
-    split_workspace(P, B, workspace, &one);
-    return run_backward(P, one, nullptr, nullptr, 1, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, B, accumulate ? 1 : 0, parts, s);
-}
-
-int hint_block_backward_ex(const hint_plan* P, const float* params, const float* packed, const float* x,
-                           const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
-                           float* g_c, float* g_params, int32_t accumulate, void* workspace,
-                           size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
-                           int32_t B, void* stream) {
-    return block_backward(P, params, packed, x, tape, c, g_z, g_J, g_x, g_c, g_params, accumulate, workspace, workspace_bytes,
-                          perm, gz_scale, gJ_const, B, 3, stream);
-}
-
-// ---------------------------------------------------------------------------------------
-// backward of the INVERSE direction (hint.py:82-88 under autograd), level by level on the block kernels.
-// With y_L = x (times the node permutations) and y_l = level_l(y_{l+1}) the forward direction rebuilds, deepest level
-// first, what the inverse saw at every node; the inverse coupling's derivative is the forward coupling's with the roles
-// turned round:  g_z2 = g_x2 / e(s);  (g_s, g_t) and with them every subnet, weight and condition gradient of the level
-// are MINUS what the forward's backward returns for the upstream pair (g_z2, g_J);  g_z1 = g_x1 - (its gradient on the
-// conditioning lanes).  e(s) itself is the lane gradient of a row-parallel backward launch with g = 1 on the level's
-// transformed lanes (1 * e: exact).
-// ---------------------------------------------------------------------------------------
-static int inv_levels(const hint_plan* Pc) {
-    hint_plan* P = const_cast<hint_plan*>(Pc);
-    std::lock_guard<std::mutex> lock(P->inv_mu);
-    if (!P->inv_levels.empty()) return 0;
-    int depth = 0;
-    for (const hint_node_desc& n : P->nodes) depth = std::max(depth, n.depth + 1);
-    std::vector<hint_plan*> levels;
-    std::vector<uint8_t> lower;
-    for (int lev = 0; lev < depth; ++lev) {
-        std::vector<hint_node_desc> sel;
-        for (hint_node_desc n : P->nodes)
-            if (n.depth == lev) { n.depth = 0; sel.push_back(n); }
-        if (sel.empty()) continue;
-        hint_plan* L = nullptr;
-        if (hint_plan_create(sel.data(), (int32_t)sel.size(), P->d, P->dc, P->clamp, &L) != 0) {
-            for (hint_plan* q : levels) hint_plan_destroy(q);
-            return 1;                       // (hint_plan_create's message stands)
-        }
-        levels.push_back(L);
-        lower.resize(levels.size() * (size_t)P->d, 0);
-        for (const hint_node_desc& n : sel)
-            for (int j = n.off + n.k; j < n.off + n.D; ++j) lower[(levels.size() - 1) * (size_t)P->d + j] = 1;
-    }
-    if (hipMalloc((void**)&P->d_inv_lower, lower.size()) != hipSuccess ||
-        hipMemcpy(P->d_inv_lower, lower.data(), lower.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        for (hint_plan* q : levels) hint_plan_destroy(q);
-        (void)hipFree(P->d_inv_lower);
-        P->d_inv_lower = nullptr;
-        return fail("hint_block_inverse_backward: device allocation failed");
-    }
-    P->inv_levels = levels;
-    return 0;
-}
-
-struct InvWs { size_t y0, y1, g, e, t, gin, J, gc, tape, packed, gneg, bws, bws_bytes, total_bytes; };
-static InvWs inv_ws(const hint_plan* P, int B) {
-    auto al = [](size_t floats) { return (floats + 3) & ~(size_t)3; };
-    const size_t lane = al((size_t)B * P->d);
-    InvWs w{};
-    size_t off = 0, tape = 0, packed = 0;
-    w.y0 = off; off += lane;  w.y1 = off; off += lane;  w.g = off; off += lane;  w.e = off; off += lane;
-    w.t = off; off += lane;   w.gin = off; off += lane;
-    w.J = off; off += al((size_t)B);
-    w.gc = off; off += al((size_t)B * P->dc);
-    for (const hint_plan* L : P->inv_levels) {
-        tape = std::max(tape, (size_t)hint_plan_tape_floats(L, B));
-        packed = std::max(packed, (size_t)hint_plan_packed_floats(L));
-        w.bws_bytes = std::max(w.bws_bytes, hint_plan_workspace_bytes(L, B));
-    }
-    w.tape = off; off += al(tape);
-    w.packed = off; off += al(packed);
-    w.gneg = off; off += al((size_t)P->param_floats);
-    w.bws = off; off += al((w.bws_bytes + 3) / 4);
-    w.total_bytes = off * sizeof(float);
-    return w;
-}
-
-size_t hint_plan_inverse_workspace_bytes(const hint_plan* P, int32_t B) {
-    if (!P || B <= 0 || inv_levels(P) != 0) return 0;
-    return inv_ws(P, B).total_bytes;
-}
-
-int hint_block_inverse_backward(const hint_plan* P, const float* params, const float* x, const float* c, const float* g_x,
-                                const float* g_J, float* g_z, float* g_c, float* g_params, int32_t accumulate,
-                                void* workspace, size_t workspace_bytes, const float* perm, int32_t B, void* stream) {
-    if (!P || !params || !x || !g_z || !g_params) return fail("hint_block_inverse_backward: null argument");
-    if (P->dc > 0 && !c) return fail("hint_block_inverse_backward: plan has dc=%d but c is NULL", P->dc);
-    if (B < 0) return fail("negative batch");
-    if (((uintptr_t)g_params & 15) != 0) return fail("hint_block_inverse_backward: g_params must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    if (B == 0) {
-        if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
-        return 0;
-    }
-    if (inv_levels(P) != 0) return 1;
-    const InvWs w = inv_ws(P, B);
-    if (!workspace || workspace_bytes < w.total_bytes)
-        return fail("hint_block_inverse_backward: workspace too small (%zu < %zu)", workspace_bytes, w.total_bytes);
-    if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_inverse_backward: workspace must be 16-byte aligned");
-    float* W = (float*)workspace;
-    const long n = (long)B * P->d;
-    const int cu = P->num_cu;
-    float* ybuf[2] = {W + w.y0, W + w.y1};
-    float *g = W + w.g, *e = W + w.e, *t = W + w.t, *gin = W + w.gin, *gc = W + w.gc, *gneg = W + w.gneg;
-    const float* y = x;
-    int cur = 0;
-    if (g_x == nullptr) HIP_TRY(launch_zero(g, n, cu, s));
-    if (perm != nullptr) {              // x = y P^T behind the inverse (hint.py:93-94): y = x P, g_y = g_x P
-        HIP_TRY(launch_inv_rowmat(x, perm, ybuf[0], n, P->d, cu, s));
-        y = ybuf[0];
-        cur = 1;
-        if (g_x != nullptr) HIP_TRY(launch_inv_rowmat(g_x, perm, g, n, P->d, cu, s));
-    } else if (g_x != nullptr) {
-        HIP_TRY(hipMemcpyAsync(g, g_x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
-    HIP_TRY(launch_zero(gneg, (long)P->param_floats, cu, s));
-    if (g_c != nullptr) HIP_TRY(launch_zero(g_c, (long)B * P->dc, cu, s));
-    for (size_t li = P->inv_levels.size(); li-- > 0;) {
-        const hint_plan* L = P->inv_levels[li];
-        const uint8_t* lower = P->d_inv_lower + li * (size_t)P->d;
-        float* yup = ybuf[cur];
-        if (hint_block_pack(L, params, W + w.packed, stream) != 0) return 1;
-        if (hint_block_forward(L, params, W + w.packed, y, c, yup, W + w.J, W + w.tape, B, stream) != 0) return 1;
-        HIP_TRY(launch_inv_lane(0, t, nullptr, nullptr, nullptr, lower, n, P->d, cu, s));
-        if (block_backward(L, params, W + w.packed, y, W + w.tape, c, t, nullptr, e, nullptr, gneg, 1, W + w.bws, w.bws_bytes,
-                           nullptr, 1.f, 0.f, B, 1, stream) != 0) return 1;
-        HIP_TRY(launch_inv_lane(1, t, g, e, nullptr, lower, n, P->d, cu, s));
-        if (block_backward(L, params, W + w.packed, y, W + w.tape, c, t, g_J, gin, g_c ? gc : nullptr, gneg, 1, W + w.bws,
-                           w.bws_bytes, nullptr, 1.f, 0.f, B, 3, stream) != 0) return 1;
-        HIP_TRY(launch_inv_lane(2, g, g, t, gin, lower, n, P->d, cu, s));
-        if (g_c != nullptr) HIP_TRY(launch_inv_minus(g_c, gc, (long)B * P->dc, 1, cu, s));
-        y = yup;
-        cur ^= 1;
-    }
-    HIP_TRY(hipMemcpyAsync(g_z, g, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_inv_minus(g_params, gneg, (long)P->param_floats, accumulate ? 1 : 0, cu, s));
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------
-// chained launches: the blocks of a flow (same plan, own parameters) in one kernel each for the
-// forward pass, backward part A and backward part B (+ its slab reduction)
-// ---------------------------------------------------------------------------------------
-struct hint_chain {
-    const hint_plan* plan = nullptr;
-    int n = 0, B = 0;
-    bool committed = false;
-    std::vector<ChainBlock> host;
-    std::vector<char> set;
-    ChainBlock* d_table = nullptr;
-};
-
-static bool chain_any_perm(const hint_chain* C) {
-    for (const ChainBlock& b : C->host) if (b.perm != nullptr) return true;
-    return false;
-}
-
-int hint_chain_create(const hint_plan* P, int32_t n_blocks, int32_t B, hint_chain** out) {
-    if (!P || !out) return fail("hint_chain_create: null argument");
-    if (n_blocks < 1 || B < 1) return fail("hint_chain_create: n_blocks and B must be >= 1");
-    hint_chain* C = new hint_chain();
-    C->plan = variant(P, B); C->n = n_blocks; C->B = B;      // (the variant planned for this many row tiles)
-    C->host.assign(n_blocks, ChainBlock{});
-    C->set.assign(n_blocks, 0);
-    if (hipMalloc((void**)&C->d_table, sizeof(ChainBlock) * (size_t)n_blocks) != hipSuccess) {
-        delete C;
-        return fail("hint_chain_create: hipMalloc failed");
-    }
-    *out = C;
-    return 0;
-}
-
-int hint_chain_set_block(hint_chain* C, int32_t i, const float* params, const float* packed, const float* perm,
-                         float* tape, void* workspace, size_t workspace_bytes, float* g_params) {
-    if (!C || !params || !packed) return fail("hint_chain_set_block: null argument");
-    if (i < 0 || i >= C->n) return fail("hint_chain_set_block: block %d out of range (chain has %d)", i, C->n);
-    const hint_plan* P = C->plan;
-    if (!tape && workspace)
-        return fail("hint_chain_set_block: a trainable chain block needs a tape");
-    ChainBlock b{};
-    b.params = params; b.packed = packed; b.perm = perm; b.gparams = g_params;
-    bind_tape(P, C->B, tape, &b);
-    if (workspace) {
-        if (!g_params) return fail("hint_chain_set_block: workspace without g_params");
-        if (workspace_bytes < hint_plan_workspace_bytes(P, C->B))
-            return fail("hint_chain_set_block: workspace too small (%zu < %zu)", workspace_bytes,
-                        hint_plan_workspace_bytes(P, C->B));
-        if (((uintptr_t)workspace & 15) != 0) return fail("hint_chain_set_block: workspace must be 16-byte aligned");
-        if (((uintptr_t)g_params & 15) != 0) return fail("hint_chain_set_block: g_params must be 16-byte aligned");
-        split_workspace(P, C->B, workspace, &b);
-    }
-    C->host[i] = b;
-    C->set[i] = 1;
-    C->committed = false;
-    return 0;
-}
-
-int hint_chain_commit(hint_chain* C) {
-    if (!C) return fail("hint_chain_commit: null argument");
-    for (int i = 0; i < C->n; ++i)
-        if (!C->set[i]) return fail("hint_chain_commit: block %d was never set", i);
-    HIP_TRY(hipMemcpy(C->d_table, C->host.data(), sizeof(ChainBlock) * (size_t)C->n, hipMemcpyHostToDevice));
-    C->committed = true;
-    return 0;
-}
-
-int hint_chain_forward(const hint_chain* C, const float* x, const float* c, float* z, float* J, const float* J_in,
-                       float* loss_acc, void* stream) {
-    return hint_chain_forward_noisy(C, x, c, z, J, J_in, loss_acc, 0.f, nullptr, nullptr, stream);
-}
-
-int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c, float* z, float* J,
-                             const float* J_in, float* loss_acc, float noise, const uint64_t* rng_state,
-                             float* x_noisy, void* stream) {
-    if (!C || !x || !z || !J) return fail("hint_chain_forward: null argument");
-    if (!C->committed) return fail("hint_chain_forward: hint_chain_commit() has not been called");
-    const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
-    KArgs a = make_args(P, C->B, false);
-    const int nr = wl_nr_for(P, C->B);
-    const int lds = lds_with_perms(P, plan_lds(P, false, nr), C->n, chain_any_perm(C), &a);
-    if (P->wl) {
-        WlArgs w = P->wl_f[nr - 1];
-        w.off_perm = a.perm_lds;
-        HIP_TRY(launch_wl_apply(false, a, w, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, z, J, J_in, loss_acc, noise,
-                                (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
-        return 0;
-    }
-    HIP_TRY(launch_apply(false, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, c, z, J,
-                         J_in, loss_acc, noise, (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
-    return 0;
-}
-
-int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, float* x, float* J, const float* J_in,
-                       void* stream) {
-    if (!C || !z || !x || !J) return fail("hint_chain_inverse: null argument");
-    if (!C->committed) return fail("hint_chain_inverse: hint_chain_commit() has not been called");
-    const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_inverse: plan has dc=%d but c is NULL", P->dc);
-    KArgs a = make_args(P, C->B, false);
-    const int nr = wl_nr_for(P, C->B);
-    const int lds = lds_with_perms(P, plan_lds(P, false, nr), C->n, chain_any_perm(C), &a);
-    if (P->wl) {
-        WlArgs w = P->wl_f[nr - 1];
-        w.off_perm = a.perm_lds;
-        HIP_TRY(launch_wl_apply(true, a, w, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, x, J, J_in, nullptr, 0.f,
-                                nullptr, nullptr, (hipStream_t)stream));
-        return 0;
-    }
-    HIP_TRY(launch_apply(true, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, c, x, J, J_in, nullptr, 0.f,
-                         nullptr, nullptr, (hipStream_t)stream));
-    return 0;
-}
-
-int hint_chain_backward_parts(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
-                              float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate,
-                              int32_t parts, void* stream) {
-    if (!C || !g_z || !g_x) return fail("hint_chain_backward: null argument");
-    if (!C->committed) return fail("hint_chain_backward: hint_chain_commit() has not been called");
-    const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_backward: plan has dc=%d but c is NULL", P->dc);
-    if (!x && !C->host[0].perm) return fail("hint_chain_backward: x is NULL but the first block has no fused permutation");
-    for (int i = 0; i < C->n; ++i)
-        if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
-            return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
-    if ((parts & 3) == 0) return fail("hint_chain_backward_parts: parts must select part A (1), part B (2) or both (3)");
-    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
-                        accumulate ? 1 : 0, parts & 3, (hipStream_t)stream);
-}
-
-int hint_chain_wgrad_range(const hint_chain* C, const float* x, const float* c, int32_t accumulate, int32_t block_begin,
-                           int32_t block_end, void* stream) {
-    if (!C) return fail("hint_chain_wgrad_range: null argument");
-    if (!C->committed) return fail("hint_chain_wgrad_range: hint_chain_commit() has not been called");
-    if (block_begin < 0 || block_end > C->n || block_begin >= block_end)
-        return fail("hint_chain_wgrad_range: blocks [%d, %d) out of range (chain has %d)", block_begin, block_end, C->n);
-    const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_wgrad_range: plan has dc=%d but c is NULL", P->dc);
-    if (!x && !C->host[0].perm) return fail("hint_chain_wgrad_range: x is NULL but the first block has no fused permutation");
-    for (int i = block_begin; i < block_end; ++i)
-        if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
-            return fail("hint_chain_wgrad_range: block %d was set without workspace / g_params", i);
-    return run_backward(P, C->host[block_begin], C->d_table + block_begin, C->host.data() + block_begin, block_end - block_begin,
-                        block_begin, x, c, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, C->B, accumulate ? 1 : 0, 2, (hipStream_t)stream);
-}
-
-int hint_chain_backward(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
-                        float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate, void* stream) {
-    return hint_chain_backward_parts(C, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, accumulate, 3, stream);
-}
-
-int hint_chain_backward_adam(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
-                             float* g_x, float* g_c, float gz_scale, float gJ_const, float* params, float* exp_avg,
-                             float* exp_avg_sq, int64_t n, const float* opt_state, float beta1, float beta2, float eps,
-                             float weight_decay, float grad_scale, float grad_clamp, void* stream) {
-    if (!C || !g_z || !g_x || !params || !exp_avg || !exp_avg_sq || !opt_state) return fail("hint_chain_backward_adam: null argument");
-    if (!C->committed) return fail("hint_chain_backward_adam: hint_chain_commit() has not been called");
-    const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_backward_adam: plan has dc=%d but c is NULL", P->dc);
-    if (!x && !C->host[0].perm) return fail("hint_chain_backward_adam: x is NULL but the first block has no fused permutation");
-    if ((((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
-        return fail("hint_chain_backward_adam: the arenas must be 16-byte aligned");
-    for (int i = 0; i < C->n; ++i) {
-        const ChainBlock& b = C->host[i];
-        if (!b.wsG1 || !b.actA1 || !b.gparams) return fail("hint_chain_backward_adam: block %d was set without workspace / g_params", i);
-        const int64_t off = b.params - params;
-        if (off < 0 || off + P->param_floats > n || (off & 3) != 0)
-            return fail("hint_chain_backward_adam: block %d's parameters are not a 16-byte aligned slice of the arena [params, params + n)", i);
-    }
-    AdamFuse ad{params, exp_avg, exp_avg_sq, opt_state, beta1, beta2, eps, weight_decay, grad_scale,
-                grad_clamp > 0.f ? grad_clamp : 3.0e38f};
-    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, 1, 3,
-                        (hipStream_t)stream, &ad);
-}
-
-void hint_chain_destroy(hint_chain* C) {
-    if (!C) return;
-    (void)hipFree(C->d_table);
-    delete C;
-}
-
-#ifdef HINT_STAMPS
-// diagnostic builds only (make stamps): device buffer of MAX_NW x 256 uint64 that workgroup 0 of the block
-// kernels fills with shader-clock stamps of its phase boundaries; not part of the shipped ABI
-int hint_debug_set_stamp_buffer(void* device_buffer) { g_stamp_buf = (unsigned long long*)device_buffer; return 0; }
-#endif
-
-static int adam_num_cu() {
-    static int num_cu = 0;
-    if (num_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-        if (num_cu <= 0) num_cu = 256;
-    }
-    return num_cu;
-}
-
-int hint_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                   float grad_clamp, int32_t zero_grads, void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail("hint_adam_step: null argument");
-    if (n < 0 || step < 1) return fail("hint_adam_step: n must be >= 0 and step >= 1");
-    if (n == 0) return 0;
-    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
-        return fail("hint_adam_step: buffers must be 16-byte aligned");
-    // bias corrections in double like torch.optim.Adam's python scalars
-    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    HIP_TRY(launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, (float)((double)lr / bc1), beta1, beta2,
-                        (float)(1.0 / std::sqrt(bc2)), eps, weight_decay, grad_scale,
-                        grad_clamp > 0.f ? grad_clamp : 3.0e38f, zero_grads ? 1 : 0, adam_num_cu(), nullptr,
-                        (hipStream_t)stream));
-    return 0;
-}
-
-int hint_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                       const float* opt_state, float beta1, float beta2, float eps, float weight_decay,
-                       float grad_scale, float grad_clamp, int32_t zero_grads, void* stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !opt_state) return fail("hint_adam_step_dev: null argument");
-    if (n < 0) return fail("hint_adam_step_dev: n must be >= 0");
-    if (n == 0) return 0;
-    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
-        return fail("hint_adam_step_dev: buffers must be 16-byte aligned");
-    HIP_TRY(launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, 0.f, beta1, beta2, 0.f, eps, weight_decay,
-                        grad_scale, grad_clamp > 0.f ? grad_clamp : 3.0e38f, zero_grads ? 1 : 0, adam_num_cu(),
-                        opt_state, (hipStream_t)stream));
-    return 0;
 }
 
 }  // extern "C"

@@ -107,12 +107,14 @@ class FlowTrainer:
                                       device=dev)
         self._adam_in_graph = False
         self._allreduce_in_graph = False
-        # data-parallel jobs all-reduce the gradient arena in TWO buckets: the second half of the blocks (whose part B runs
-        # first) while the weight gradients of the first half are still being computed ("launch it on a side
-        # stream as soon as backward finishes"); HINT_DP_BUCKETS=1: one bucket behind the whole backward pass
+        # data-parallel jobs all-reduce the gradient arena in ONE bucket behind the backward pass (north_star: "a
+        # single RCCL all-reduce of gradients per step").  HINT_DP_BUCKETS=2: two buckets - the second half of the blocks
+        # (whose part B then runs as a launch of its own, first) goes out on a side stream while the weight gradients of
+        # the first half are still being computed; never measured with more than one rank, hence not the default
         nb = len(self.engines)
-        self._split = nb // 2 if (self._chainable and nb >= 2 and os.environ.get("HINT_DP_BUCKETS", "2") != "1") else 0
+        self._split = nb // 2 if (self._chainable and nb >= 2 and os.environ.get("HINT_DP_BUCKETS", "1") == "2") else 0
         self._side = None
+        self._warming = False       # _capture's warm-up passes issue no collectives (a re-capture on one rank must not hang the others)
 
     @property
     def lr(self) -> float:
@@ -268,7 +270,8 @@ class FlowTrainer:
                                                                   None, 1.0 / B, -1.0 / B, 1, 1, stream), "hint_chain_backward_parts")
                     _lib.check(self.lib.hint_chain_wgrad_range(chain, xn.data_ptr(), cp, 1, h, n, stream), "hint_chain_wgrad_range")
                     # (inside a graph capture only when the collectives are captured as well)
-                    overlap = self._dp_overlap() and (self._allreduce_in_graph or not torch.cuda.is_current_stream_capturing())
+                    overlap = self._dp_overlap() and not self._warming and \
+                        (self._allreduce_in_graph or not torch.cuda.is_current_stream_capturing())
                     if overlap:
                         if self._side is None:
                             self._side = torch.cuda.Stream(device=self.device)
@@ -536,6 +539,19 @@ class FlowTrainer:
         names = ["hint_pack_many_kernel", fwd, bwd, "hint_wgrad_kernel+hint_wreduce_kernel", "allreduce+hint_adam_kernel"]
         return {n: ev[i].elapsed_time(ev[i + 1]) * 1e3 for i, n in enumerate(names)}
 
+    def allreduce_plan(self) -> str:
+        """what the step does with the gradient arena between backward and optimizer (for bench.py's config line)"""
+        world = dp.world_info(self.group)[1]
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if not dist_on:
+            return "none (one process: clamp + Adam ride in the weight gradients' final reduction)"
+        backend = torch.distributed.get_backend(self.group)
+        where = "captured in the step's hipGraph" if self._allreduce_in_graph else "issued from the host after the graph replay"
+        if self._split > 0:
+            return (f"two buckets over {world} ranks ({backend}): blocks [{self._split}, {len(self.engines)}) first, beside the "
+                    f"rest of part B (HINT_DP_BUCKETS=2); {where}")
+        return f"one all-reduce (sum) of the flat fp32 gradient arena ({self.n_floats} floats) over {world} ranks ({backend}); {where}"
+
     def kernel_names(self, B: int):
         """(forward, backward part A) kernel of a batch of B rows as rocprof prints them: the wave-local kernels for narrow
         trees (template arguments: direction / row tiles per workgroup), the general ones otherwise"""
@@ -552,9 +568,13 @@ class FlowTrainer:
         sc = c.clone() if c is not None else None
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):          # warm-up on a side stream (allocator, plan LDS attrs)
-            for _ in range(2):
-                self._fwd_bwd(sx, sc)
+        self._warming = True
+        try:
+            with torch.cuda.stream(side):      # warm-up on a side stream (allocator, plan LDS attrs); no collectives
+                for _ in range(2):
+                    self._fwd_bwd(sx, sc)
+        finally:
+            self._warming = False
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.G.zero_()                         # the warm-up runs accumulated into the gradient arena
         torch.cuda.synchronize(self.device)

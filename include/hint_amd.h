@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HINT_AMD_ABI_VERSION 4
+#define HINT_AMD_ABI_VERSION 5
 
 /* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
  * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],
@@ -282,6 +282,9 @@ int hint_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_a
 
 int hint_abi_version(void);
 const char* hint_last_error(void);
+/* what the library binary was built with: "libhint_amd abi N, gfx950, HIP x.y.z, clang ..." (static string; the HIP
+ * runtime of the machine that loads it may differ - bench.py prints both) */
+const char* hint_build_info(void);
 
 #ifdef __cplusplus
 }

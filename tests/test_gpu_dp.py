@@ -149,7 +149,14 @@ def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
     try:
         tr1, got1 = run(copy.deepcopy(flow0))
         assert tr1._allreduce_in_graph and tr1._adam_in_graph
-        assert tr1._split == 1 and tr1._side is not None      # two buckets, the first one's all-reduce on the side stream, captured
+        assert tr1._split == 0 and "one all-reduce" in tr1.allreduce_plan()      # the default: ONE bucket, captured
+        os.environ["HINT_DP_BUCKETS"] = "2"
+        try:
+            tr3, got3 = run(copy.deepcopy(flow0))
+        finally:
+            del os.environ["HINT_DP_BUCKETS"]
+        assert tr3._allreduce_in_graph and tr3._adam_in_graph
+        assert tr3._split == 1 and tr3._side is not None      # two buckets, the first one's all-reduce on the side stream, captured
         tr2, got2 = run(copy.deepcopy(flow0), break_capture=True)
         assert not tr2._allreduce_in_graph and not tr2._adam_in_graph
         ctr, cgot = run_cond()                               # the conditional two-lane trainer: same capture
@@ -158,4 +165,5 @@ def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
         dist.destroy_process_group()
     assert np.allclose(got1, want, rtol=1e-5, atol=1e-6), (got1, want)
     assert np.allclose(got2, want, rtol=1e-5, atol=1e-6), (got2, want)
+    assert np.allclose(got3, want, rtol=1e-5, atol=1e-6), (got3, want)
     assert np.allclose(cgot, cwant, rtol=1e-5, atol=1e-6), (cgot, cwant)
