@@ -183,3 +183,78 @@ def test_conditional_trainer_equals_reference_loop_on_module_path(use_graph):
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     for k in sd1:
         assert rel_err(sd2[k].cpu().numpy(), sd1[k].cpu().numpy()) < 1e-3, k
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_conditional_trainer_full_size_matches_oracle_training(use_graph):
+    """The FAST path at the full size of conditional_hint_4_full.py:58-94 (x d = 100, y d = 4, width 224, 4 blocks): three
+    iterations of ConditionalFlowTrainer - the launches with the x lane's permutation, the running log-dets, the loss sums
+    and the loss gradient folded in (hint_block_*_ex), eager and as one hipGraph replay per step - against the statements
+    of train_conditional.py:120-150 on the two-lane graph assembled from oracle blocks (CPU autograd + torch.optim.Adam).
+    Per step: loss pair within 1e-4, x_jac (train_conditional.py:50-55) within 1e-4; final weights within 1e-3 per tensor
+    (norm-wise) and no element further off than a sign flip of Adam's update could take it."""
+    torch.manual_seed(5)
+    nx, ny, nb, hidden, B, steps, lr = 100, 4, 4, 224, 256, 3, 0.01 * 3e-2
+    m = hint_amd.ConditionalHintFlow(nx, ny, nb, hidden).to(DEV)
+    gw = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.data = (0.03 * torch.randn(p.shape, generator=gw)).to(DEV)     # train_conditional.py:160-162 idiom, larger scale
+    gx = torch.Generator().manual_seed(6)
+    xs = [torch.randn(B, nx, generator=gx) for _ in range(steps)]
+    ys = [torch.randn(B, ny, generator=gx) for _ in range(steps)]
+
+    mods = []
+    for i in range(nb):
+        mods += [(f"hac_x.{i}", m.hac_x[i], 0), (f"ac_y_to_x.{i}", m.ac_y_to_x[i], ny), (f"ac_y.{i}", m.ac_y[i], 0)]
+    Po = {name: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sub.state_dict().items()} for name, sub, _ in mods}
+    nodes = {name: oracle_nodes(sub.tree, dc) for name, sub, dc in mods}
+    clamp = {name: sub.tree.clamp for name, sub, _ in mods}
+    Wy = [m.perm_y[i].W.cpu() if i > 0 else None for i in range(nb)]
+    Wx = [m.perm_x[i].W.cpu() if i > 0 else None for i in range(nb)]
+    plist = [p for d_ in Po.values() for p in d_.values()]
+    optim = torch.optim.Adam(plist, lr=lr, betas=(0.9, 0.95), eps=1e-4, weight_decay=1.86e-5)
+    ref_losses, ref_xjac = [], []
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, nt))
+    try:
+        for x, y in zip(xs, ys):
+            optim.zero_grad()
+            xo, yo = x, y
+            jx = jy = 0
+            for i in range(nb):
+                if i > 0:
+                    yo = yo @ Wy[i]; xo = xo @ Wx[i]
+                n = f"hac_x.{i}"; xo, j = orc.block_apply(nodes[n], Po[n], xo, [], clamp=clamp[n]); jx = jx + j
+                n = f"ac_y_to_x.{i}"; xo, j = orc.block_apply(nodes[n], Po[n], xo, [yo], clamp=clamp[n]); jx = jx + j
+                n = f"ac_y.{i}"; yo, j = orc.block_apply(nodes[n], Po[n], yo, [], clamp=clamp[n]); jy = jy + j
+            z = torch.cat([xo, yo], dim=-1)
+            batch_losses = [0.5 * torch.sum(z ** 2, dim=1).mean(), -(jx + jy).mean()]      # train_conditional.py:132-143
+            sum(batch_losses).backward()
+            for p in plist:
+                p.grad.data.clamp_(-5.00, 5.00)
+            optim.step()
+            ref_losses.append([float(l) for l in batch_losses])
+            ref_xjac.append(jx.detach().clone())
+    finally:
+        torch.set_num_threads(nt)
+
+    tr = hint_amd.ConditionalFlowTrainer(m, noise=0.0, use_graph=use_graph, lr=lr)
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        l0, l1 = tr.step(x.to(DEV), y.to(DEV))
+        got = [float(l0), float(l1)]
+        np.testing.assert_allclose(got, ref_losses[k], rtol=1e-4, atol=1e-5, err_msg=f"step {k}")
+        Jx = tr.last[2].detach().cpu()
+        scale = max(1.0, float(ref_xjac[k].abs().max()))
+        assert float((Jx - ref_xjac[k]).abs().max()) <= 1e-4 * scale, (k, float((Jx - ref_xjac[k]).abs().max()), scale)
+    assert (tr._graph is not None) == use_graph
+    sd = {name: sub.state_dict() for name, sub, _ in mods}
+    worst = 0.0
+    for name, _, _ in mods:
+        for key, ref in Po[name].items():
+            a, b = sd[name][key].detach().cpu().double(), ref.detach().double()
+            rel = float((a - b).norm() / b.norm().clamp(min=1e-12))
+            worst = max(worst, rel)
+            assert rel <= 1e-3, (name, key, rel)
+            assert float((a - b).abs().max()) <= 2.2 * lr * steps, (name, key, float((a - b).abs().max()))
+    print(f"conditional full size ({'graph' if use_graph else 'eager'}): worst per-tensor weight deviation {worst:.2e}")

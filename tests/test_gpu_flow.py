@@ -36,6 +36,16 @@ def test_chain_forward_nll_matches_reference():
     assert (xr - x).abs().max().item() < 1e-4
 
 
+def check_update(initial, final, final_ref, what):
+    """the MOVEMENT of a tensor over the fixture's steps against the reference's: the weights themselves barely move (five
+    Adam steps of 3e-4), so a tolerance on the weights alone would not see a gradient of the wrong sign in a small tensor -
+    the update vector does (a flipped sign turns it round: relative deviation 2)"""
+    upd = np.asarray(final, dtype=np.float64) - np.asarray(initial, dtype=np.float64)
+    ref = np.asarray(final_ref, dtype=np.float64) - np.asarray(initial, dtype=np.float64)
+    dev = np.linalg.norm(upd - ref) / max(np.linalg.norm(ref), 1e-30)
+    assert dev < 5e-2, (what, dev)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_trainer_reproduces_reference_adam_steps(use_graph):
     """K=5 steps of train_unconditional.py:120-144 (noise off) from fixed weights: per-step
@@ -53,6 +63,7 @@ def test_trainer_reproduces_reference_adam_steps(use_graph):
         for k, v in blk.state_dict().items():
             assert rel_err(v.cpu().numpy(), g[f"final:{bi}:{k}"]) < 1e-3, (bi, k)
             np.testing.assert_allclose(v.cpu().numpy(), g[f"final:{bi}:{k}"], rtol=2e-3, atol=3e-5)
+            check_update(params[bi][k], v.cpu().numpy(), g[f"final:{bi}:{k}"], (bi, k))
 
 
 @pytest.mark.parametrize("reshuffle", [False, True])
@@ -122,6 +133,7 @@ def test_reference_training_loop_body_on_module_path():
     for bi, blk in enumerate(model.blocks):
         for k, v in blk.state_dict().items():
             assert rel_err(v.cpu().numpy(), g[f"final:{bi}:{k}"]) < 1e-3, (bi, k)
+            check_update(params[bi][k], v.cpu().numpy(), g[f"final:{bi}:{k}"], (bi, k))
 
 
 @pytest.mark.parametrize("d,dc,widths,perm_first,n_blocks,B,reshuffle", [
