@@ -375,6 +375,8 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
 // diagnostic builds only (make stamps): device buffer of MAX_NW x 256 uint64 that workgroup 0 of the block
 // kernels fills with shader-clock stamps of its phase boundaries; not part of the shipped ABI
 int hint_debug_set_stamp_buffer(void* device_buffer) { g_stamp_buf = (unsigned long long*)device_buffer; return 0; }
+// ... and one of [workgroups of a part-B launch][wavefronts][8] uint64 for hint_wgrad_kernel (tools/stamps_dw.py); NULL: off
+int hint_debug_set_dw_stamp_buffer(void* device_buffer) { hint::set_dw_stamps((unsigned long long*)device_buffer); return 0; }
 #endif
 
 static int adam_num_cu() {

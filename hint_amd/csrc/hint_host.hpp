@@ -150,6 +150,10 @@ inline int plan_lds(const hint_plan* P, bool backward, int nr = 1) {
 }
 inline int rows_padded(int B) { return (B + ROWS - 1) / ROWS * ROWS; }
 
+#ifdef HINT_STAMPS
+void set_dw_stamps(unsigned long long* p);      // hint_wgrad.hip (diagnostic build)
+#endif
+
 // hint_abi.cpp
 const hint_plan* variant(const hint_plan* P, int B);
 int wl_nr_for(const hint_plan* Pv, int B);

@@ -25,21 +25,42 @@ using namespace hint;
 #endif
 constexpr int DW_WAVES = HINT_DW_WAVES;
 
-struct SrcRef { const float* p; int ld; int rows; };
+#ifndef HINT_DW_BOUND
+#define HINT_DW_BOUND , 4
+#endif
 
-__device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bool top, const float* __restrict__ x,
-                                       const float* __restrict__ c, int WT, int ST, int d, int dc, int n_levels, int B, int Bp,
+// Diagnostic build only (-DHINT_STAMPS, `make stamps`): every wavefront of part B leaves DW_STAMP_IDS shader-clock stamps of its
+// phase boundaries in a global buffer [workgroup][wavefront][id] (hint_debug_set_dw_stamp_buffer; tools/stamps_dw.py reads them)
+#ifdef HINT_STAMPS
+constexpr int DW_STAMP_IDS = 8;
+static unsigned long long* h_dw_stamps = nullptr;
+namespace hint { void set_dw_stamps(unsigned long long* p) { h_dw_stamps = p; } }
+#define DW_STAMP(ID) { if (dw_stamps != nullptr) dw_st[ID] = __builtin_amdgcn_s_memtime(); }
+#define DW_STAMP_WAIT(ID) { if (dw_stamps != nullptr) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dw_st[ID] = __builtin_amdgcn_s_memtime(); } }
+#define DW_STAMP_FLUSH() { if (dw_stamps != nullptr && (threadIdx.x & 63) == 0) { \
+    unsigned long long* o_ = dw_stamps + ((size_t)blockIdx.x * DW_WAVES + (threadIdx.x >> 6)) * DW_STAMP_IDS; \
+    for (int i_ = 0; i_ < DW_STAMP_IDS; ++i_) o_[i_] = dw_st[i_]; } }
+#else
+#define DW_STAMP(ID) {}
+#define DW_STAMP_WAIT(ID) {}
+#define DW_STAMP_FLUSH() {}
+#endif
+
+struct SrcRef { const GLOBAL_AS float* p; int ld; int rows; };     // (global address space kept: a generic pointer is read with flat_load, whose waits drain both counters)
+
+__device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bool top, const GLOBAL_AS float* __restrict__ x,
+                                       const GLOBAL_AS float* __restrict__ c, int WT, int ST, int d, int dc, int n_levels, int B, int Bp,
                                        int64_t act_stride, int64_t a2_off) {
     SrcRef r;
     r.rows = Bp;
     switch (src) {
-        case WSRC_G1: r.p = (const float*)blk.wsG1; r.ld = WT; break;
-        case WSRC_G2: r.p = (const float*)blk.wsG1 + act_stride; r.ld = WT; break;
-        case WSRC_GST: r.p = (const float*)blk.wsGST; r.ld = ST; break;
-        case WSRC_A1: r.p = (const float*)blk.actA1; r.ld = WT; break;
-        case WSRC_A2: r.p = (const float*)blk.actA1 + a2_off; r.ld = WT; break;
+        case WSRC_G1: r.p = blk.wsG1; r.ld = WT; break;
+        case WSRC_G2: r.p = blk.wsG1 + act_stride; r.ld = WT; break;
+        case WSRC_GST: r.p = blk.wsGST; r.ld = ST; break;
+        case WSRC_A1: r.p = blk.actA1; r.ld = WT; break;
+        case WSRC_A2: r.p = blk.actA1 + a2_off; r.ld = WT; break;
         case WSRC_X: {
-            const float* tape = (const float*)blk.tape;
+            const GLOBAL_AS float* tape = blk.tape;
             const size_t lvl = (size_t)B * d;
             r.p = level == 0 ? (top ? tape + (size_t)(n_levels - 1) * lvl : x) : tape + (size_t)(level - 1) * lvl;
             r.ld = d; r.rows = B;
@@ -50,13 +71,270 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
     return r;
 }
 
+// ---- the row loops of a (job, split), one instance per tile shape ----
+// On gfx950 vector-ALU instructions do NOT hide under the matrix pipe: a SIMD's time is 32 cycles per MFMA PLUS ~4-5 per VALU
+// instruction, whatever the number of wavefronts (tools/mfma_valu_bench.hip).  Round 3's loops issued 136 VALU instructions per
+// step beside 25-42 MFMAs - address arithmetic of the loads, relu, masks, column sums: 45 % of the kernel's time.  So every load
+// here goes through a BUFFER descriptor that the scalar unit re-bases per 16-row step (the per-lane offset is loop invariant,
+// rows behind the operand's last read as zero by the descriptor's bound), and the element-wise work is cut to what the
+// arithmetic needs: 4 v_max per a1 tile, 8 (bit-field extract + and) per g2 tile, 4 adds per tile for the bias gradient.
+#ifndef HINT_DW_LEAN_RING
+#define HINT_DW_LEAN_RING 3
+#endif
+constexpr int DW_LEAN_RING = HINT_DW_LEAN_RING;
+constexpr int BUF_FLAGS = 0x00020000;           // raw buffer, 32-bit data format (gfx9 family)
+constexpr int BUF_OOB = 0x7ffffff0;             // a per-lane offset past any descriptor's bound: the load returns zero
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+struct DwCtx { int nl, kq, step, bb0, b_end; };
+struct LeanSrc { const GLOBAL_AS float* prm; SrcRef vs; const GLOBAL_AS float* gst; const GLOBAL_AS uint8_t* bits; int ntiles, ST; };
+struct GenSrc { SrcRef ps, qs; int pc0, qc0, pcj[3], qcj[3]; };
+
+// descriptor of rows [bb, bb + 16) of a row-major operand, `valid` of them inside the operand (the others read as zero).  Only the
+// last 16-row block of a batch can be partial, so `valid` is 16 or a value computed ONCE per loop (rows_valid): a clamp inside the
+// loop becomes a v_med3 - there is no scalar one - and with it the descriptor a per-lane value that hipcc wraps in a waterfall loop
+__device__ __forceinline__ int rows_valid(const SrcRef& sr, int bb) {
+    return rfl(max(0, min(sr.rows - bb, 16)));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const SrcRef& sr, int bb, int valid) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(sr.p + (size_t)bb * sr.ld), 0, valid * sr.ld * 4, BUF_FLAGS);
+}
+// relu in ONE instruction: fmaxf() is canonicalise + max for the sake of signalling NaNs; the matrix pipe's outputs need none
+__device__ __forceinline__ float relu1(float x) {
+#pragma clang fp reassociate(on)
+    return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f);
+}
+// (by-value helpers: __builtin_bit_cast applied to a vector ELEMENT expression - v.z, v[i] - reads element 0 with this clang)
+__device__ __forceinline__ float as_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ int as_i32(float f) { return __builtin_bit_cast(int, f); }
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, int voff) {
+    return as_f32(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+// lean dW2 (hint_dev.h: WSRC_G2R x WSRC_A1R): per 16-row step one float of v, one of g_st and NTM words of a2 sign bytes per lane;
+// a1 = relu(v W1^T + b1) and g2 = relu'(a2) (g_st W3) are one K <= 4 MFMA per tile, whose result layout is the operand layout of
+// the products over the row subsets {4 kq + i}
+template <int NTM, int NTN>
+__device__ __forceinline__ void dw_lean(f32x4 (&acc)[3][3], float (&psum)[3], const WJob& job, const LeanSrc& ls, const DwCtx& cx) {
+    const int nl = cx.nl, kq = cx.kq;
+    float w1b[NTN], w3b[NTM];
+    f32x4 b1v[NTN];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+        const int fq = job.qcol - job.r_wcol + 16 * t + nl;
+        w1b[t] = (kq < job.r_cin && fq < job.r_h) ? ls.prm[job.r_w1 + (size_t)fq * job.r_cin + kq] : 0.f;
+        const float b1 = fq < job.r_h ? ls.prm[job.r_b1 + fq] : 0.f;
+        b1v[t] = f32x4{b1, b1, b1, b1};
+    }
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+        const int fp = job.pcol - job.r_wcol + 16 * t + nl;
+        w3b[t] = (kq < job.r_r && fp < job.r_h) ? ls.prm[job.r_w3 + (size_t)kq * job.r_h + fp] : 0.f;
+    }
+    // loop-invariant per-lane offsets: the lanes without an input (kq >= cin / r) read past the bound = zero
+    const int voff_v = kq < job.r_cin ? (nl * ls.vs.ld + job.r_xoff + kq) * 4 : BUF_OOB;
+    const int voff_g = kq < job.r_r ? (nl * ls.ST + job.r_gcol + kq) * 4 : BUF_OOB;
+    const int voff_b = 16 * (nl >> 2) + 4 * kq;
+    int bit[4];                                   // where the lane's four mask bits sit in its word of sign bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bit[i] = (nl & 3) + 8 * i;
+    SrcRef gsr; gsr.p = ls.gst; gsr.ld = ls.ST; gsr.rows = 0x7fffffff;
+    const int nsteps = (cx.b_end - cx.bb0 + cx.step - 1) / cx.step;
+    if (nsteps <= 0) return;
+    const int last_bb = cx.bb0 + (nsteps - 1) * cx.step;
+    const int v_last = rows_valid(ls.vs, last_bb);
+    struct In { float v, g; unsigned s[NTM]; };
+    auto load_in = [&](int BB) {
+        In in;
+        in.v = buf_f32(rows_rsrc(ls.vs, BB, BB == last_bb ? v_last : 16), voff_v);
+        in.g = buf_f32(rows_rsrc(gsr, BB, 16), voff_g);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(ls.bits + ((size_t)(BB >> 4) * ls.ntiles + (job.pcol >> 4)) * 64), 0, NTM * 64, BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) in.s[t] = __builtin_amdgcn_raw_buffer_load_b32(rb, voff_b + 64 * t, 0, 0);
+        return in;
+    };
+    auto mma = [&](const In& in) {
+        f32x4 p[NTM], q[NTN];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) q[t] = mfma4(in.v, w1b[t], b1v[t]);
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) p[t] = mfma4(in.g, w3b[t], zero4());
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[t][i] = relu1(q[t][i]);
+#pragma unroll
+        for (int t = 0; t < NTM; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // relu'(a2): the mask bit sign-extended to 0 / -1 and and-ed onto the float (two instructions per element)
+                const int m = __builtin_amdgcn_sbfe((int)in.s[t], bit[i], 1);
+                p[t][i] = as_f32((unsigned)(as_i32(p[t][i]) & m));
+            }
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) psum[t] += (p[t].x + p[t].y) + (p[t].z + p[t].w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) acc[tm][tn] = mfma4(p[tm][i], q[tn][i], acc[tm][tn]);
+    };
+    // a ring of DW_LEAN_RING input sets (2 + NTM registers each): the loads of step j + RING - 1 are issued in front of step j's
+    // products (never under a branch: past the end of the split the last block is re-loaded), so that a set has RING - 1 steps to arrive
+    constexpr int RING = DW_LEAN_RING;
+    In ring[RING];
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r) ring[r] = load_in(min(cx.bb0 + r * cx.step, last_bb));
+    int bb = cx.bb0 + (RING - 1) * cx.step;
+    for (int j = 0; j < nsteps; j += RING) {
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            if (j + r < nsteps) {
+                ring[(r + RING - 1) % RING] = load_in(min(bb, last_bb));
+                bb += cx.step;
+                mma(ring[r]);
+            }
+        }
+    }
+}
+
+// the general products: P columns [pcol, pcol + 16 NTM) x Q columns [qcol, qcol + 16 NTN) over the rows of the split (NTN = 0: the
+// column sums of P only); PVEC / QVEC: a full 48-column group inside its array - one 12-byte load per lane and row
+template <int NTM, int NTN, bool PVEC, bool QVEC>
+__device__ __forceinline__ void dw_gen(f32x4 (&acc)[3][3], float (&psum)[3], const GenSrc& gs, const DwCtx& cx) {
+    constexpr int NQ = NTN > 0 ? NTN : 1;
+    struct Op { float a[4][NTM], b[4][NQ]; };
+    const int kq = cx.kq;
+    // loop-invariant per-lane byte offsets inside the 16-row window of a step (row 4 i + kq, the lane's column(s))
+    int poff[4][PVEC ? 1 : NTM], qoff[4][QVEC ? 1 : NQ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * i + kq;
+#pragma unroll
+        for (int j = 0; j < (PVEC ? 1 : NTM); ++j) poff[i][j] = (row * gs.ps.ld + (PVEC ? gs.pc0 : gs.pcj[j])) * 4;
+#pragma unroll
+        for (int j = 0; j < (QVEC ? 1 : NQ); ++j) qoff[i][j] = (row * gs.qs.ld + (QVEC ? gs.qc0 : gs.qcj[j])) * 4;
+    }
+    const int nsteps = (cx.b_end - cx.bb0 + cx.step - 1) / cx.step;
+    if (nsteps <= 0) return;
+    const int last_bb = cx.bb0 + (nsteps - 1) * cx.step;
+    const int p_last = rows_valid(gs.ps, last_bb), q_last = rows_valid(gs.qs, last_bb);
+    auto load_op = [&](int BB) {
+        Op o;
+        const __amdgpu_buffer_rsrc_t rp = rows_rsrc(gs.ps, BB, BB == last_bb ? p_last : 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (PVEC) {
+                const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rp, poff[i][0], 0, 0);
+                o.a[i][0] = as_f32(t.x);
+                if (NTM > 1) o.a[i][1 % NTM] = as_f32(t.y);
+                if (NTM > 2) o.a[i][2 % NTM] = as_f32(t.z);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) o.a[i][j] = buf_f32(rp, poff[i][PVEC ? 0 : j]);
+            }
+        }
+        if (NTN > 0) {
+            const __amdgpu_buffer_rsrc_t rq = rows_rsrc(gs.qs, BB, BB == last_bb ? q_last : 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (QVEC) {
+                    const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rq, qoff[i][0], 0, 0);
+                    o.b[i][0] = as_f32(t.x);
+                    if (NQ > 1) o.b[i][1 % NQ] = as_f32(t.y);
+                    if (NQ > 2) o.b[i][2 % NQ] = as_f32(t.z);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NTN; ++j) o.b[i][j] = buf_f32(rq, qoff[i][QVEC ? 0 : j]);
+                }
+            }
+        }
+        return o;
+    };
+    auto mma = [&](const Op& o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tm = 0; tm < NTM; ++tm) {
+                psum[tm] += o.a[i][tm];
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) acc[tm][tn] = mfma4(o.a[i][tm], o.b[i][tn], acc[tm][tn]);
+            }
+    };
+    int bb = cx.bb0;
+    if (bb >= cx.b_end) return;
+    Op A = load_op(bb);
+    while (true) {
+        const int nb1 = bb + cx.step;
+        const bool last1 = nb1 >= cx.b_end;
+        const Op Bn = load_op(last1 ? bb : nb1);
+        mma(A);
+        if (last1) break;
+        const int nb2 = nb1 + cx.step;
+        const bool last2 = nb2 >= cx.b_end;
+        A = load_op(last2 ? nb1 : nb2);
+        mma(Bn);
+        if (last2) break;
+        bb = nb2;
+    }
+}
+
+// A single-tile job on one wavefront is a chain of memory latencies (four MFMAs per 16-row block): eight blocks per step,
+// all their loads in flight at once, an accumulator each (acc[3][3] has nine), added up in a fixed order behind the loop.
+// What is left of the split (fewer than eight blocks) runs through dw_gen: cx.bb0 is advanced to it.
+__device__ __forceinline__ void dw_solo8(f32x4 (&acc)[3][3], float (&psum)[3], const GenSrc& gs, DwCtx& cx, int ntn) {
+    constexpr int NS = 8;
+    const int pc = gs.pcj[0], qc = gs.qcj[0], kq = cx.kq;
+    float ps8[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) ps8[t] = 0.f;
+    int bb = cx.bb0;
+    while (bb + 16 * NS <= cx.b_end) {
+        float sa[NS][4], sq[NS][4];
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row_ = bb + 16 * t + 4 * i + kq;
+                sa[t][i] = gs.ps.p[(size_t)min(row_, gs.ps.rows - 1) * gs.ps.ld + pc];
+                sq[t][i] = ntn > 0 ? gs.qs.p[(size_t)min(row_, gs.qs.rows - 1) * gs.qs.ld + qc] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                ps8[t] += sa[t][i];
+                acc[t / 3][t % 3] = mfma4(sa[t][i], sq[t][i], acc[t / 3][t % 3]);
+            }
+        bb += 16 * NS;
+    }
+#pragma unroll
+    for (int t = 1; t < NS; ++t) {
+        acc[0][0] += acc[t / 3][t % 3];
+        acc[t / 3][t % 3] = zero4();
+        ps8[0] += ps8[t];
+    }
+    psum[0] += ps8[0];
+    cx.bb0 = bb;
+}
+
+
 // SMALL: the job list ends in single-tile jobs that share workgroups (n_small > 0); plans without them (the wave-local ones)
 // run the instance that holds none of that code
 template <bool SMALL>
-__global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
+__global__ __launch_bounds__(DW_WAVES * 64 HINT_DW_BOUND) void hint_wgrad_kernel(
     const WJob* __restrict__ jobs, int n_jobs, int n_small, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
     int grid_pb, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
-    int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c) {
+    int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* __restrict__ x, const float* __restrict__ c
+#ifdef HINT_STAMPS
+    , unsigned long long* dw_stamps
+#endif
+    ) {
+#ifdef HINT_STAMPS
+    unsigned long long dw_st[DW_STAMP_IDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    DW_STAMP(0)
     __shared__ float red[DW_WAVES][9][64][4];   // 72 KiB
     __shared__ float bred[DW_WAVES][3][16];
 
@@ -80,6 +358,8 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     }
     if (bid >= items * splits) return;
     const GBlock blk = chain_block(chain, one, cbi);
+    const GLOBAL_AS float* xg = (const GLOBAL_AS float*)x;
+    const GLOBAL_AS float* cg = (const GLOBAL_AS float*)c;
     const bool top = blk.perm != nullptr || cbi + cb0 > 0;        // (cb0: position of the launch's first block in its chain)
 
     int item, split;
@@ -97,6 +377,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
     const int jidx = solo ? n_big + (item - n_big) * DW_WAVES + wave : item;
     if (jidx >= n_jobs) return;         // (a spare wavefront of the last shared workgroup: that path has no barrier)
     const WJob job = jobs[jidx];
+    DW_STAMP_WAIT(1)        // block pointers and job record have arrived
     const int nl = lane & 15, kq = lane >> 4;
     const int ntm = job.mw, ntn = job.nw;
     const int b_begin = split * rows_per_wg;
@@ -108,190 +389,101 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = zero4();
     float psum[3] = {0.f, 0.f, 0.f};
-    const int step = solo ? 16 : 16 * DW_WAVES;
-    const int bb0 = b_begin + (solo ? 0 : wave * 16);
     const bool natural = job.psrc == WSRC_G2R;       // columns in natural order (no 12-byte loads to serve)
+    DwCtx cx;
+    cx.nl = nl; cx.kq = kq;
+    cx.step = solo ? 16 : 16 * DW_WAVES;
+    cx.bb0 = b_begin + (solo ? 0 : wave * 16);
+    cx.b_end = b_end;
 
+    // The loops are instantiated per tile shape (ntm x ntn known at compile time: every MFMA of a step in ONE basic block, the
+    // next step's loads in flight across it with counted waits).  With the shape a run-time value every MFMA sat under its
+    // own scalar branch and behind a vmcnt(0): the step's loads were waited for in front of its first product (round 3:
+    // matrix pipe busy 49 % of the kernel).
     if (natural) {
         // ---- lean dW2: both operands rebuilt from the thin layers' inputs ----
-        const float* prm = (const float*)blk.params;
-        const SrcRef vs = wsrc(WSRC_X, job.qlevel, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
-        const float* gst = (const float*)blk.wsGST;
-        const uint8_t* bits = (const uint8_t*)blk.actA1 + bits_a2_off;           // a2 sign bytes [row tile][tile][64]
-        const int ntiles = WT >> 4;
-        float w1b[3], b1c[3], w3b[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int fq = job.qcol - job.r_wcol + 16 * t + nl, fp = job.pcol - job.r_wcol + 16 * t + nl;
-            w1b[t] = (kq < job.r_cin && fq < job.r_h) ? prm[job.r_w1 + (size_t)fq * job.r_cin + kq] : 0.f;
-            b1c[t] = fq < job.r_h ? prm[job.r_b1 + fq] : 0.f;
-            w3b[t] = (kq < job.r_r && fp < job.r_h) ? prm[job.r_w3 + (size_t)kq * job.r_h + fp] : 0.f;
-        }
-        const int vcol = job.r_xoff + min(kq, job.r_cin - 1), gcol = job.r_gcol + min(kq, job.r_r - 1);
-        const unsigned bofs = 16 * (nl >> 2) + 4 * kq, bsh = nl & 3;
-        struct In { float v, g; unsigned s[3]; };
-        auto load_in = [&](int BB) {
-            In in;
-            in.v = vs.p[(size_t)min(BB + nl, vs.rows - 1) * vs.ld + vcol];
-            in.g = gst[(size_t)(BB + nl) * ST + gcol];
-            const uint8_t* bp = bits + ((size_t)(BB >> 4) * ntiles + (job.pcol >> 4)) * 64 + bofs;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) in.s[t] = t < ntm ? *(const unsigned*)(bp + 64 * t) : 0u;
-            return in;
-        };
-        auto mma = [&](const In& in) {
-            const float va = kq < job.r_cin ? in.v : 0.f, ga = kq < job.r_r ? in.g : 0.f;
-            f32x4 p[3], q[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if (t < ntn) {
-                    f32x4 b = {b1c[t], b1c[t], b1c[t], b1c[t]};
-                    q[t] = mfma4(va, w1b[t], b);
-                    q[t].x = fmaxf(q[t].x, 0.f); q[t].y = fmaxf(q[t].y, 0.f); q[t].z = fmaxf(q[t].z, 0.f); q[t].w = fmaxf(q[t].w, 0.f);
-                }
-                if (t < ntm) {
-                    p[t] = mfma4(ga, w3b[t], zero4());
-                    const unsigned sw = in.s[t] >> bsh;
-                    p[t].x = (sw & 1u) ? p[t].x : 0.f; p[t].y = (sw & 0x100u) ? p[t].y : 0.f;
-                    p[t].z = (sw & 0x10000u) ? p[t].z : 0.f; p[t].w = (sw & 0x1000000u) ? p[t].w : 0.f;
-                    psum[t] += (p[t].x + p[t].y) + (p[t].z + p[t].w);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int tm = 0; tm < 3; ++tm)
-                    if (tm < ntm)
-#pragma unroll
-                        for (int tn = 0; tn < 3; ++tn)
-                            if (tn < ntn) acc[tm][tn] = mfma4(p[tm][i], q[tn][i], acc[tm][tn]);
-        };
-        int bb = bb0;
-        if (bb < b_end) {
-            In cur = load_in(bb);
-            while (true) {
-                const int nb = bb + step;
-                const bool last = nb >= b_end;
-                const In nxt = load_in(last ? bb : nb);
-                mma(cur);
-                if (last) break;
-                cur = nxt; bb = nb;
-            }
+        LeanSrc ls;
+        ls.prm = blk.params;
+        ls.vs = wsrc(WSRC_X, job.qlevel, blk, top, xg, cg, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
+        ls.gst = blk.wsGST;
+        ls.bits = (const GLOBAL_AS uint8_t*)blk.actA1 + bits_a2_off;           // a2 sign bytes [row tile][tile][64]
+        ls.ntiles = WT >> 4; ls.ST = ST;
+        switch (ntm * 4 + ntn) {
+#define DW_CASE(M_, N_) case M_ * 4 + N_: dw_lean<M_, N_>(acc, psum, job, ls, cx); break;
+            DW_CASE(1, 1) DW_CASE(1, 2) DW_CASE(1, 3) DW_CASE(2, 1) DW_CASE(2, 2) DW_CASE(2, 3) DW_CASE(3, 1) DW_CASE(3, 2)
+            default: dw_lean<3, 3>(acc, psum, job, ls, cx); break;
+#undef DW_CASE
         }
     } else {
-    const SrcRef ps = wsrc(job.psrc, 0, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
-    const SrcRef qs = wsrc(job.qsrc, job.qlevel, blk, top, x, c, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
-
-    // lane nl holds columns col0 + w*nl + {0..w-1} of its operand (the permutation of columns inside
-    // the up-to-48-wide group is undone at write-out).  Full 48-column groups inside the array: one
-    // 12-byte load per k-step; otherwise element loads clamped to the operand's last column (products
-    // of clamped columns are never written).
-    typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
-    const int pc0 = job.pcol + ntm * nl, qc0 = job.qcol + ntn * nl;
-    const bool pvec = ntm == 3 && job.pcol + 47 <= job.pmax;
-    const bool qvec = ntn == 3 && job.qcol + 47 <= job.qmax;
-    int pcj[3], qcj[3];
+        GenSrc gs;
+        gs.ps = wsrc(job.psrc, 0, blk, top, xg, cg, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
+        gs.qs = wsrc(job.qsrc, job.qlevel, blk, top, xg, cg, WT, ST, d, dc, n_levels, B, Bp, act_stride, a2_off);
+        // lane nl holds columns col0 + w*nl + {0..w-1} of its operand (the permutation of columns inside
+        // the up-to-48-wide group is undone at write-out).  Full 48-column groups inside the array: one
+        // 12-byte load per k-step; otherwise element loads clamped to the operand's last column (products
+        // of clamped columns are never written).
+        const int pc0 = job.pcol + ntm * nl, qc0 = job.qcol + ntn * nl;
+        const bool pvec = ntm == 3 && job.pcol + 47 <= job.pmax;
+        const bool qvec = ntn == 3 && job.qcol + 47 <= job.qmax;
+        gs.pc0 = pc0; gs.qc0 = qc0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { pcj[j] = min(pc0 + j, job.pmax); qcj[j] = min(qc0 + j, max(job.qmax, 0)); }
-    const int prow_max = ps.rows - 1, qrow_max = qs.rows - 1;
-
-    f32x3u av[2][4], bv[2][4];
-#define DW_LOAD(BUF, BB)                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-        const int row_ = (BB) + 4 * i + kq;                                                \
-        const size_t pr_ = (size_t)min(row_, prow_max) * ps.ld;                            \
-        const size_t qr_ = (size_t)min(row_, qrow_max) * qs.ld;                            \
-        if (pvec) av[BUF][i] = *(const f32x3u*)(ps.p + pr_ + pc0);                         \
-        else { av[BUF][i].x = ps.p[pr_ + pcj[0]]; av[BUF][i].y = ps.p[pr_ + pcj[1]]; av[BUF][i].z = ps.p[pr_ + pcj[2]]; } \
-        if (ntn > 0) {                                                                     \
-            if (qvec) bv[BUF][i] = *(const f32x3u*)(qs.p + qr_ + qc0);                     \
-            else { bv[BUF][i].x = qs.p[qr_ + qcj[0]]; bv[BUF][i].y = qs.p[qr_ + qcj[1]]; bv[BUF][i].z = qs.p[qr_ + qcj[2]]; } \
-        }                                                                                  \
-    }
-#define DW_MMA(BUF)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-        _Pragma("unroll") for (int tm = 0; tm < 3; ++tm) {                                 \
-            psum[tm] += av[BUF][i][tm];                                                    \
-            if (tm < ntm)                                                                  \
-                _Pragma("unroll") for (int tn = 0; tn < 3; ++tn)                           \
-                    if (tn < ntn) acc[tm][tn] = mfma4(av[BUF][i][tm], bv[BUF][i][tn], acc[tm][tn]); \
-        }                                                                                  \
-    }
-
-    int bb = bb0;
-    if (SMALL && solo && ntm == 1) {
-        // A single-tile job on one wavefront is a chain of memory latencies (four MFMAs per 16-row block): eight blocks per step,
-        // all their loads in flight at once, an accumulator each (acc[3][3] has nine), added up in a fixed order behind the loop.
-        // What is left of the split (fewer than eight blocks) runs through the loop below.
-        constexpr int NS = 8;
-        const int pc = pcj[0], qc = qcj[0];
-        float ps8[NS];
-#pragma unroll
-        for (int t = 0; t < NS; ++t) ps8[t] = 0.f;
-        while (bb + 16 * NS <= b_end) {
-            float sa[NS][4], sq[NS][4];
-#pragma unroll
-            for (int t = 0; t < NS; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row_ = bb + 16 * t + 4 * i + kq;
-                    sa[t][i] = ps.p[(size_t)min(row_, prow_max) * ps.ld + pc];
-                    sq[t][i] = ntn > 0 ? qs.p[(size_t)min(row_, qrow_max) * qs.ld + qc] : 0.f;
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int t = 0; t < NS; ++t) {
-                    ps8[t] += sa[t][i];
-                    acc[t / 3][t % 3] = mfma4(sa[t][i], sq[t][i], acc[t / 3][t % 3]);
-                }
-            bb += 16 * NS;
-        }
-#pragma unroll
-        for (int t = 1; t < NS; ++t) {
-            acc[0][0] += acc[t / 3][t % 3];
-            acc[t / 3][t % 3] = zero4();
-            ps8[0] += ps8[t];
-        }
-        psum[0] += ps8[0];
-    }
-    // double-buffered over 16-row blocks: the loads of block j+1 are in flight during the MFMAs of block j
-    if (bb < b_end) {
-        DW_LOAD(0, bb)
-        while (true) {
-            const int nb1 = bb + step;
-            const bool last1 = nb1 >= b_end;
-            if (!last1) { DW_LOAD(1, nb1) }
-            DW_MMA(0)
-            if (last1) break;
-            const int nb2 = nb1 + step;
-            const bool last2 = nb2 >= b_end;
-            if (!last2) { DW_LOAD(0, nb2) }
-            DW_MMA(1)
-            if (last2) break;
-            bb = nb2;
-        }
-    }
-#undef DW_LOAD
-#undef DW_MMA
-    }
-    if (solo) {
-        // one tile, one wavefront: straight to the split's slab
-        float* slab = (float*)blk.wsSlab + (size_t)split * param_floats;
-        const int n = nl;
-        if (ntn > 0 && n < job.N) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = 4 * kq + i;
-                if (m < job.M) slab[job.wofs + (size_t)m * job.ldo + n] = acc[0][0][i];
+        for (int j = 0; j < 3; ++j) { gs.pcj[j] = min(pc0 + j, job.pmax); gs.qcj[j] = min(qc0 + j, max(job.qmax, 0)); }
+        if (SMALL && solo && ntm == 1 && ntn <= 1) dw_solo8(acc, psum, gs, cx, ntn);
+        const int shape = ntm * 4 + ntn;
+        if (pvec && qvec) dw_gen<3, 3, true, true>(acc, psum, gs, cx);
+        else if (pvec) {
+            switch (ntn) {
+                case 0: dw_gen<3, 0, true, false>(acc, psum, gs, cx); break;
+                case 1: dw_gen<3, 1, true, false>(acc, psum, gs, cx); break;
+                case 2: dw_gen<3, 2, true, false>(acc, psum, gs, cx); break;
+                default: dw_gen<3, 3, true, false>(acc, psum, gs, cx); break;
+            }
+        } else if (qvec) {
+            switch (ntm) {
+                case 1: dw_gen<1, 3, false, true>(acc, psum, gs, cx); break;
+                case 2: dw_gen<2, 3, false, true>(acc, psum, gs, cx); break;
+                default: dw_gen<3, 3, false, true>(acc, psum, gs, cx); break;
+            }
+        } else {
+            switch (shape) {
+#define DW_CASE(M_, N_) case M_ * 4 + N_: dw_gen<M_, N_, false, false>(acc, psum, gs, cx); break;
+                DW_CASE(1, 0) DW_CASE(1, 1) DW_CASE(1, 2) DW_CASE(1, 3) DW_CASE(2, 0) DW_CASE(2, 1) DW_CASE(2, 2) DW_CASE(2, 3)
+                DW_CASE(3, 0) DW_CASE(3, 1) DW_CASE(3, 2)
+                default: dw_gen<3, 3, false, false>(acc, psum, gs, cx); break;
+#undef DW_CASE
             }
         }
+    }
+    DW_STAMP_WAIT(2)        // the rows of the split are done
+    if (solo) {
+        // one (job, split) per wavefront: straight to the split's slab
+        GLOBAL_AS float* slab = blk.wsSlab + (size_t)split * param_floats;
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 3; ++tn) {
+                if (tm >= ntm || tn >= ntn) continue;
+                const int n = natural ? 16 * tn + nl : ntn * nl + tn;              // undo the column permutation of the loads
+                if (n >= job.N) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = natural ? 16 * tm + 4 * kq + i : ntm * (4 * kq + i) + tm;
+                    if (m < job.M) slab[job.wofs + (size_t)m * job.ldo + n] = acc[tm][tn][i];
+                }
+            }
         if (job.bofs >= 0) {
-            float v = psum[0];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (kq == 0 && nl < job.M) slab[job.bofs + nl] = v;
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                if (tm >= ntm) continue;
+                float v = psum[tm];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int m = natural ? 16 * tm + nl : ntm * nl + tm;
+                if (kq == 0 && m < job.M) slab[job.bofs + m] = v;
+            }
         }
+        DW_STAMP_WAIT(5)
+        DW_STAMP_FLUSH()
         return;
     }
     // combine the wavefronts (fixed order)
@@ -308,8 +500,10 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
             if (kq == 0) bred[wave][tm][nl] = v;
         }
     }
+    DW_STAMP(3)
     __syncthreads();
-    float* slab = (float*)blk.wsSlab + (size_t)split * param_floats;
+    DW_STAMP(4)             // every wavefront of the workgroup has left its partials
+    GLOBAL_AS float* slab = blk.wsSlab + (size_t)split * param_floats;
     for (int idx = tid; idx < 9 * 64; idx += DW_WAVES * 64) {
         const int t = idx >> 6, l = idx & 63;
         const int tm = t / 3, tn = t - 3 * tm;
@@ -335,6 +529,8 @@ __global__ __launch_bounds__(DW_WAVES * 64) void hint_wgrad_kernel(
             slab[job.bofs + m] = v;
         }
     }
+    DW_STAMP_WAIT(5)
+    DW_STAMP_FLUSH()
 }
 
 // g[i] (+)= sum over the splits' slabs, in split order, for every real parameter element i (the
@@ -445,6 +641,9 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, hipStream_t stream) {
     const bool interleave = n_small < 0;       // (flag in the sign: the planner sorted the jobs)
     if (interleave) n_small = -n_small - 1;
+#ifdef HINT_DW_SOLO_ALL
+    n_small = n_jobs;                          // (experiment: one (job, split) per wavefront for every job)
+#endif
     const int used = (n_jobs - n_small + (n_small + DW_WAVES - 1) / DW_WAVES) * splits;
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0) {
@@ -452,11 +651,19 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
         if (n_small > 0)
             hipLaunchKernelGGL(hint_wgrad_kernel<true>, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits,
                                one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off,
-                               param_floats, x, c);
+                               param_floats, x, c
+#ifdef HINT_STAMPS
+                               , h_dw_stamps
+#endif
+                               );
         else
             hipLaunchKernelGGL(hint_wgrad_kernel<false>, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits,
                                one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off,
-                               param_floats, x, c);
+                               param_floats, x, c
+#ifdef HINT_STAMPS
+                               , h_dw_stamps
+#endif
+                               );
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

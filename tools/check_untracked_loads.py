@@ -26,7 +26,7 @@ import sys
 
 VMEM = re.compile(r"^(global_|buffer_|scratch_|flat_)")
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
-CAP = 32          # younger counts saturate here (no wait in the sources asks for more)
+CAP = 8           # younger counts saturate here (no wait in the sources asks for more)
 
 
 def regs_of(text):
@@ -78,9 +78,10 @@ def parse(path):
         if not body:
             continue
         op = body.split()[0]
-        cur.append(dict(line=ln, op=op, text=body, inline=inline, labels=pending_labels))
+        cur.append(dict(line=ln, op=op, text=body, inline=inline, labels=pending_labels, regs=frozenset(regs_of(body)),
+                        vmem=bool(VMEM.match(op))))
         pending_labels = []
-    return funcs
+    return [(n, f) for n, f in funcs if n.startswith("_Z") or n.startswith("hint_")]
 
 
 def check_function(fname, name, ins):
@@ -89,7 +90,7 @@ def check_function(fname, name, ins):
         for lab in it["labels"]:
             label_at[lab] = i
     errors = []
-    starts = [i for i, it in enumerate(ins) if it["inline"] and VMEM.match(it["op"]) and "load" in it["op"]]
+    starts = [i for i, it in enumerate(ins) if it["inline"] and it.get("vmem") and "load" in it["op"]]
     if not starts:
         return 0, errors
     seen = set()
@@ -116,8 +117,8 @@ def check_function(fname, name, ins):
                 facts = facts | {(nm, val)}
                 i += 1
                 continue
-            is_untracked = it["inline"] and VMEM.match(op) and "load" in op
-            touched = regs_of(text)
+            is_untracked = it["inline"] and it["vmem"] and "load" in op
+            touched = it["regs"]
             if is_untracked:
                 dst = regs_of(text.split(",")[0])
                 src = regs_of(",".join(text.split(",")[1:]))
@@ -147,7 +148,7 @@ def check_function(fname, name, ins):
                     errors.append(f"{fname}:{it['line']}: `{text}` touches {r[0]}{r[1]} of the untracked load at line {ln} "
                                   f"before a wait that covers it ({y} younger vector-memory operations so far; {name})")
                     pending = tuple(p for p in pending if p[0] != ln)
-            if VMEM.match(op):
+            if it["vmem"]:
                 pending = tuple((ln, regs, min(CAP, y + 1)) for (ln, regs, y) in pending)
             if op == "s_endpgm":
                 for (ln, regs, y) in pending:
