@@ -20,8 +20,12 @@
 
 using namespace hint;
 
+// wavefronts per workgroup: they split the rows of a (job, split) and combine in LDS.  Two since round 4 (eight before): a
+// wavefront's fixed costs - records, parameters, the partials' trip through LDS, the stores - are paid once per 16 row steps
+// instead of once per 4, and eight small workgroups per CU are at different points of their lives where two large ones went
+// through their phases together (cfg 2: 82 -> 75 us, the d = 100 flows 658 -> 519; 4: 75 / 551; 1: 77 / 510, MINIBOONE 201 against 180)
 #ifndef HINT_DW_WAVES
-#define HINT_DW_WAVES 8
+#define HINT_DW_WAVES 2
 #endif
 constexpr int DW_WAVES = HINT_DW_WAVES;
 
