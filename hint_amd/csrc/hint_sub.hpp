@@ -85,9 +85,14 @@ __device__ __forceinline__ void sub_node_fwd(const LDS_AS f32x4* par4, const KAr
 // lanes by the lane groups kq < r - everything between the lane tile and the lane tile stays in registers.  Leaves the
 // wavefront's share of the log-det of batch row l & 15 in LDS (a.sub_misc + 16 wave + row); the caller adds them up behind
 // its barrier.
-template <bool REV>
-__device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float* lds, const GBlock& blk, float* xs, bool train,
-                                          int row0, int wave, int lane, int sid) {
+// TRAIN (the tape is written) is a template parameter, the prefetch and its wait are unconditional, and every store the wait
+// count relies on is issued whatever the lanes' predicates: the hand-counted waits are then provable on the generated assembly
+// path by path (tools/check_untracked_loads.py, `make asm`) - a count that holds only because two `if (train)` agree, or
+// because a predicated store happens to have an active lane, is not.
+template <bool REV, bool TRAIN>
+__device__ __forceinline__ void sub_apply_t(const KArgs& a, const Tables& T, float* lds, const GBlock& blk, float* xs,
+                                            int row0, int wave, int lane, int sid) {
+    constexpr bool train = TRAIN;
     (void)sid;
     const int m = lane & 15, kq = lane >> 4;
     const LDS_AS f32x4* par4 = (const LDS_AS f32x4*)(lds + a.sub_par);
@@ -124,11 +129,12 @@ __device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float
                 sub_load(ws, wt + (size_t)tile_of(u) * 64); sub_load(wtt, wt + (size_t)tile_of(u + 1) * 64);
                 sub_wait<0>();
             }
-            // the next node (of the next level behind this level's last node)
+            // the next node (of the next level behind this level's last node; behind the last one of all: this node's tiles again -
+            // the loads are never under a branch)
             const bool has_next = u + 2 < ue || nb < ne;
-            const int nu = u + 2 < ue ? u + 2 : nb;
+            const int nu = u + 2 < ue ? u + 2 : (nb < ne ? nb : u);
             f32x4 nws, nwt;             // (written by the untracked loads only: no value of the compiler's may share their registers before sub_wait)
-            if (has_next) { sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64); }
+            sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64);
             STAMP(sid + 3)
             const UnitU us = load_unit(T.units + u), ut = load_unit(T.units + u + 1);
             STAMP(sid + 4)
@@ -162,10 +168,9 @@ __device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float
                 xs[m * a.xld + xcol] = xn;
             }
             STAMP(sid + 7)
-            if (has_next) {
-                if (train) sub_wait<4>(); else sub_wait<0>();
-                ws = nws; wtt = nwt; have = nu;
-            }
+            // (training: the node's four tape stores - two sign-byte rows, two a2 tiles, none of them predicated - are younger than the prefetch)
+            sub_wait<TRAIN ? 4 : 0>();
+            if (has_next) { ws = nws; wtt = nwt; have = nu; }
         }
         wave_sync();
         // training: the wavefront's lanes as they stand after the level (tape[level][B][d])
@@ -187,6 +192,13 @@ constexpr int SUB_LV = 4;       // floats per lane of a wavefront's columns of a
 
 __device__ __forceinline__ void sub_load_byte(int& dst, const GLOBAL_AS uint8_t* p) {
     asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+
+template <bool REV>
+__device__ __forceinline__ void sub_apply(const KArgs& a, const Tables& T, float* lds, const GBlock& blk, float* xs, bool train,
+                                          int row0, int wave, int lane, int sid) {
+    if (!REV && train) sub_apply_t<REV, !REV>(a, T, lds, blk, xs, row0, wave, lane, sid);
+    else sub_apply_t<REV, false>(a, T, lds, blk, xs, row0, wave, lane, sid);
 }
 
 // Both subnets of a subtree node, backward, in lockstep (hint_wl.hpp's expressions): vin = the coupling gradients of their r
@@ -243,8 +255,11 @@ __device__ __forceinline__ void sub_node_bwd(const LDS_AS f32x4* par4, const KAr
 
 // dW1 | db1 of both subnets' tiles from their g1 (hint_wl.hpp: transposed through the wavefront's two scratch tiles, four
 // MFMAs over the 16 rows each) into the workgroup's first-layer gradient slab; both in lockstep
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 sub_as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }      // (whole vectors by value: see hint_wgrad.hip as_f32)
+__device__ __forceinline__ u32x4 sub_as_u32x4(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
 __device__ __forceinline__ void sub_dw1(const f32x4 (&g)[2], float* scratch, const float* xs, int xld, const UnitU (&u)[2], GLOBAL_AS float* tw,
-                                        bool first_tile, int lane) {
+                                        int tw_floats, bool first_tile, int lane) {
     const int nl = lane & 15, kq = lane >> 4;
     ((f32x4*)scratch)[lane] = g[0];
     ((f32x4*)scratch)[64 + lane] = g[1];
@@ -260,13 +275,20 @@ __device__ __forceinline__ void sub_dw1(const f32x4 (&g)[2], float* scratch, con
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int n = 0; n < 2; ++n) dw[n] = mfma4(nl < u[0].cin ? bv[i] : one, av[n][i], dw[n]);
+    // through a buffer descriptor of the workgroup's slab: the lanes without an element get an offset past its bound (their store is
+    // dropped, their load reads zero), so that the two stores are ISSUED for every node - sub_bwd's hand-counted wait relies on them
     const int kcp = u[0].cin < 4 ? 4 : 8;
-    if (nl < u[0].h && 4 * kq < kcp) {
+    const bool mine = nl < u[0].h && 4 * kq < kcp;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tw, 0, tw_floats * 4, 0x00020000);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            GLOBAL_AS f32x4* dst = (GLOBAL_AS f32x4*)(tw + u[n].bias1 + nl * kcp + 4 * kq);
-            if (first_tile) *dst = dw[n]; else *dst = *dst + dw[n];
+    for (int n = 0; n < 2; ++n) {
+        const int off = mine ? (u[n].bias1 + nl * kcp + 4 * kq) * 4 : 0x7ffffff0;
+        f32x4 v = dw[n];
+        if (!first_tile) {
+            const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            v += sub_as_f32x4(o);
         }
+        __builtin_amdgcn_raw_buffer_store_b128(sub_as_u32x4(v), rs, off, 0, 0);
     }
 }
 
@@ -347,13 +369,11 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
             }
             STAMP(sid + 5)
             const bool has_next = u + 2 < ue || nb < ne;
-            const int nu = u + 2 < ue ? u + 2 : nb;
+            const int nu = u + 2 < ue ? u + 2 : (nb < ne ? nb : u);      // (behind the last node of all: this node's again - never under a branch)
             f32x4 nws, nwt;             // (written by the untracked loads only: no value of the compiler's may share their registers before sub_wait)
             int nbs, nbt;
-            if (has_next) {
-                sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64);
-                sub_load_byte(nbs, byte_of(nu)); sub_load_byte(nbt, byte_of(nu + 1));
-            }
+            sub_load(nws, wt + (size_t)tile_of(nu) * 64); sub_load(nwt, wt + (size_t)tile_of(nu + 1) * 64);
+            sub_load_byte(nbs, byte_of(nu)); sub_load_byte(nbt, byte_of(nu + 1));
             const UnitU us = load_unit(T.units + u), ut = load_unit(T.units + u + 1);
             STAMP(sid + 6)
             if (!is_top) {
@@ -391,15 +411,13 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
             sub_node_bwd(par4, a, uu, ww, bb, vst, xin, kq, g1, gvv);
             const f32x4 gvs = gvv[0], gvt = gvv[1];
             STAMP(sid + 8)
-            sub_dw1(g1, scratch, xs, a.xld, uu, tw, first_tile, lane);
+            sub_dw1(g1, scratch, xs, a.xld, uu, tw, a.tw_floats, first_tile, lane);
             // g_v of the node's inputs: lane group kq < cin adds input kq of batch row m
             const float gsum = kq == 0 ? gvs.x + gvt.x : kq == 1 ? gvs.y + gvt.y : kq == 2 ? gvs.z + gvt.z : gvs.w + gvt.w;
             if (kq < us.cin) gs[m * a.xld + us.xoff + kq] += gsum;
             STAMP(sid + 9)
-            if (has_next) {
-                sub_wait<2>();          // (the node's two slab stores are younger than the prefetch)
-                ws = nws; wtt = nwt; bs = nbs; bt = nbt; have = nu;
-            }
+            sub_wait<2>();              // (the node's two slab stores - buffer stores, issued whatever the lanes' predicates - are younger than the prefetch)
+            if (has_next) { ws = nws; wtt = nwt; bs = nbs; bt = nbt; have = nu; }
         }
         STAMP(sid + 10)
         wave_sync();

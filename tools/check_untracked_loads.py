@@ -125,6 +125,9 @@ def check_function(fname, name, ins):
                 for (ln, regs, y) in pending:
                     if regs & (dst | src):
                         errors.append(f"{fname}:{it['line']}: `{text}` touches v-registers of the untracked load at line {ln} still in flight ({name})")
+                if any(ln == it["line"] for (ln, _, _) in pending):
+                    errors.append(f"{fname}:{it['line']}: `{text}` is issued again while its previous issue is still in flight ({name})")
+                    break
                 pending = tuple((ln, regs, min(CAP, y + 1)) for (ln, regs, y) in pending) + ((it["line"], frozenset(dst), 0),)
                 i += 1
                 continue
