@@ -42,6 +42,17 @@ __device__ __forceinline__ float kq_sum(float v) {
     return __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
 }
 
+typedef unsigned wl_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 wl_as_f32x4(wl_u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+// relu'(.) from four sign bits: bit i sign-extended to 0 / -1 and and-ed onto element i (two instructions per element)
+__device__ __forceinline__ void wl_mask_by_bits(f32x4& v, int bits) {
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __int_as_float(__float_as_int(e[i]) & __builtin_amdgcn_sbfe(bits, i, 1));
+    v = f32x4{o[0], o[1], o[2], o[3]};
+}
+
 // The first-layer pre-activation of features 4 kq .. +3 of a tile (vector layout: five float4 per tile and lane group,
 // inputs 0..3 then the bias; inputs beyond cin are zero vectors): bias first, then the inputs in order - the order of
 // the MFMA chain with which part B rebuilds a1 (hint_wgrad.hip), and the same expression forward and backward, so
@@ -74,24 +85,31 @@ struct WlCtx {
     bool train, first_tile;
 };
 
+// (through buffer descriptors: the tile index is wave-uniform, so the scalar unit does the address arithmetic - offset operand of
+//  the load - and the per-lane part, lane * 16, is loop invariant.  Vector-ALU instructions do not hide under the matrix pipe on
+//  gfx950 - tools/mfma_valu_bench.hip - and a 64-bit per-lane address cost one per tile and step)
 template <int KIND, int NR>
 __device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float* pk, const GLOBAL_AS uint8_t* const (&bits)[2],
                                         const RowU& r, int kb, const LaneOff& lo) {
-    const GLOBAL_AS char* p = (const GLOBAL_AS char*)pk + lo.w;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)pk, 0, -1, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NTT; ++j) {
         const int jj = j < r.ntt ? j : r.ntt - 1;
 #ifdef HINT_WL_ABL_W        // diagnostic: every k-block reads the row's first tiles again (L1 hits): what the weight stream's latency costs
-        dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj + (kb & 0)) * 1024);
+        dst[j] = wl_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rw, (int)lo.w, (r.base1 + jj + (kb & 0)) * 1024, 0));
 #else
-        dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj * r.n1 + kb) * 1024);
+        dst[j] = wl_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rw, (int)lo.w, (r.base1 + jj * r.n1 + kb) * 1024, 0));
 #endif
     }
     if (KIND == K_BWD) {
         const int kc = kb < r.n1 ? kb : r.n1 - 1;
-        const int o = ((r.wcol >> 4) + kc) * 64 + lo.l;
-        dst[NTT].x = __int_as_float((int)bits[0][o]);
-        if (NR == 2) dst[NTT].y = __int_as_float((int)bits[1][o]);
+        const int o = ((r.wcol >> 4) + kc) * 64;
+        const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc((void*)bits[0], 0, -1, 0x00020000);
+        dst[NTT].x = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b8(rb0, (int)lo.l, o, 0));
+        if (NR == 2) {
+            const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)bits[1], 0, -1, 0x00020000);
+            dst[NTT].y = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b8(rb1, (int)lo.l, o, 0));
+        }
     }
 }
 
@@ -111,46 +129,45 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     const int n1 = cr.n1, ntt = cr.ntt;
     STAMP(c.sid + 0)
     // the unit's thin-layer inputs of this lane's batch row: forward the lanes feeding the subnet, backward g_s | g_t
-    float vin[NR][4];
+    // ... as the B operand of the thin layer's MFMA: lane (m, kq) supplies input kq of batch row m
+    float vk[NR];
 #pragma unroll
     for (int h = 0; h < NR; ++h) {
         const int K = cr.thin_k & 0xff;
         const LDS_AS float* src = KIND == K_FWD ? c.xs[h] + m * c.xld + (cr.thin_k >> 16) : c.gst[h] + m * c.gld + (cr.thin_k >> 16);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const float v = src[k < K ? k : 0]; vin[h][k] = k < K ? v : 0.f; }
+        const float v = src[kq < K ? kq : 0];
+        vk[h] = kq < K ? v : 0.f;
     }
-    // forward: W1 vectors of k-block kb at tq[20 kb + 4 k] (bias: k = 4); backward: W3^T vectors at tq[16 kb + 4 j]
-    const LDS_AS f32x4* tq = (const LDS_AS f32x4*)(c.par + cr.thin_w) + kq;
+    // forward: W1 vectors of k-block kb at tf[(5 kb + k) 16 + feature] (bias: k = 4); backward: W3^T vectors at tf[(4 kb + j) 16 + feature]
+    const LDS_AS float* tf = c.par + cr.thin_w;
     f32x4 acc[NR][NTT];
 #pragma unroll
     for (int h = 0; h < NR; ++h)
 #pragma unroll
         for (int j = 0; j < NTT; ++j) acc[h][j] = zero4();
 
-    // The B operand of k-block kb, before the backward's mask, is software-pipelined two steps deep so that no step waits
-    // for the LDS: step kb issues the reads of the thin vectors of k-block kb + 2 (five / four float4 per lane), turns the
-    // vectors of kb + 1 (read a step ago) into the operand of the next step - 16 FMAs (+ ReLU) per row tile, issued between
-    // this step's MFMAs - and multiplies with the operand computed a step ago.
-    constexpr int NQ = KIND == K_FWD ? 5 : 4;
-    f32x4 qv[NQ];
+    // The B operand of k-block kb - a1 = relu(W1 v + b1) forward, g2 (before its mask) = W3^T g_st backward, four features per lane -
+    // is ONE MFMA of its own since round 4 (K = the unit's <= 4 inputs: A = the thin layer's vectors of the k-block, one float per
+    // lane; B = vk; C = the bias quad): 16 FMAs on the vector ALU cost 72 cycles of the SIMD beside the matrix pipe, the MFMA 32,
+    // and the LDS reads shrink from five float4 to a float and a float4.  The MFMA adds bias, input 0, .., 3 in that order, as the
+    // FMA chain did and as part B's rebuild and the backward's wl_layer1 do: the ReLU decisions still agree bit for bit.
+    // Software-pipelined two steps deep: step kb issues the LDS reads of k-block kb + 2, turns the operands of kb + 1 (read a step
+    // ago) into the B fragment of the next step, and multiplies with the fragment computed a step ago (two buffers: no copies).
+    constexpr int KV = KIND == K_FWD ? 5 : 4;
+    float qa = 0.f;
+    f32x4 qb = zero4();
     auto q_load = [&](int kb) {
-        const LDS_AS f32x4* q = tq + (KIND == K_FWD ? 20 : 16) * kb;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) qv[k] = q[4 * k];
+        qa = tf[(KV * kb + kq) * 16 + m];
+        if (KIND == K_FWD) qb = *(const LDS_AS f32x4*)(tf + (KV * kb + 4) * 16 + 4 * kq);
     };
     auto q_frag = [&](int h) -> f32x4 {
-#ifdef HINT_WL_ABL_THIN     // diagnostic: no thin-layer arithmetic in the k-loop
-        return f32x4{vin[h][0], vin[h][1], vin[h][2], vin[h][3]};
-#endif
-        // (forward: bias first, then the inputs in order - wl_layer1's expression; backward: from zero)
-        const f32x4 a0 = KIND == K_FWD ? qv[4] : zero4();
-        const f32x4 r = fma4(qv[3], vin[h][3], fma4(qv[2], vin[h][2], fma4(qv[1], vin[h][1], fma4(qv[0], vin[h][0], a0))));
+        const f32x4 r = mfma4(qa, vk[h], qb);
         return KIND == K_FWD ? relu4(r) : r;
     };
+    f32x4 bq[2][NR];
     q_load(0);
-    f32x4 b4n[NR];
 #pragma unroll
-    for (int h = 0; h < NR; ++h) b4n[h] = q_frag(h);
+    for (int h = 0; h < NR; ++h) bq[0][h] = q_frag(h);
     q_load(1);
     STAMP(c.sid + 1)
     // Program order of a step is pinned with empty asm statements that "use" the accumulators and clobber memory: the
@@ -163,18 +180,16 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
         else asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[NR - 1][0]), "+v"(acc[NR - 1][1]), "+v"(acc[NR - 1][2]) : : "memory"); \
     }
 #define WL_MFMA(J)                                                                                      \
-    _Pragma("unroll") for (int h_ = 0; h_ < NR; ++h_) acc[h_][J] = mfma4(ring[S_][J][i_], b4[h_][i_], acc[h_][J]);
+    _Pragma("unroll") for (int h_ = 0; h_ < NR; ++h_) acc[h_][J] = mfma4(ring[S_][J][i_], bq[S_][h_][i_], acc[h_][J]);
 #define WL_STEP(KB, S, LIVE, PK, BITS, NR_, NKB, PREFETCH)                                              \
     {                                                                                                   \
         constexpr int S_ = (S);                                                                         \
         if (PREFETCH) wl_load<KIND, NR>(ring[(S_ + 1) & 1], PK, BITS, NR_, NKB, lo);                    \
         WL_PIN()                                                                                        \
         if (LIVE) {                                                                                     \
-            f32x4 b4[NR];                                                                               \
             _Pragma("unroll") for (int h = 0; h < NR; ++h) {                                            \
-                b4[h] = b4n[h];                                                                         \
-                if (KIND == K_BWD) mask_by_bits(b4[h], __float_as_int(h == 0 ? ring[S_][NTT].x : ring[S_][NTT].y)); \
-                b4n[h] = q_frag(h);                 /* k-block KB + 1 (behind the row's last one: never used) */ \
+                if (KIND == K_BWD) wl_mask_by_bits(bq[S_][h], __float_as_int(h == 0 ? ring[S_][NTT].x : ring[S_][NTT].y)); \
+                bq[S_ ^ 1][h] = q_frag(h);          /* k-block KB + 1 (behind the row's last one: never used) */ \
             }                                                                                           \
             q_load((KB) + 2);                                                                           \
             if (ntt >= 3) {                                                                             \
