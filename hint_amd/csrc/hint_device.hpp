@@ -173,7 +173,11 @@ __device__ __forceinline__ void perm_store(const f32x4 (&acc)[PERM_TQ], float* o
 }
 
 // sum_k row[k] * w[k * stride]: a row of the lane tile times a column (or row) of a fixed d x d matrix
-__device__ __forceinline__ float perm_dot(const float* row, const float* __restrict__ w, int stride, int d) {
+// (WP: the matrix pointer WITH its address space - LDS_AS when the chain's matrices ride in LDS, GLOBAL_AS otherwise: one
+//  pointer that may be either is read with flat_load, whose wait drains the vector-memory AND the LDS counter - at every block
+//  boundary of the wave-local kernels that was the weight stream's hand-over)
+template <typename WP>
+__device__ __forceinline__ float perm_dot(const float* row, WP w, int stride, int d) {
     float acc = 0.f;
     int k = 0;
     for (; k + 8 <= d; k += 8) {

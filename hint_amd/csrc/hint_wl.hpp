@@ -30,6 +30,12 @@ __device__ __forceinline__ float dot4(const f32x4 w, const f32x4 v, float a) {
     return fmaf(w.w, v.w, fmaf(w.z, v.z, fmaf(w.y, v.y, fmaf(w.x, v.x, a))));
 }
 __device__ __forceinline__ f32x4 relu4(const f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
+// relu of a matrix-pipe result in ONE instruction per element: fmaxf() of a value the compiler cannot prove canonical is
+// canonicalise + max (signalling NaNs); v_med3_f32(x, 0, 3e38) needs neither
+__device__ __forceinline__ f32x4 relu4m(const f32x4 v) {
+    return f32x4{__builtin_amdgcn_fmed3f(v.x, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(v.y, 0.f, 3.0e38f),
+                 __builtin_amdgcn_fmed3f(v.z, 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(v.w, 0.f, 3.0e38f)};
+}
 // sum over the four lane groups (lanes l, l^16, l^32, l^48): every lane ends with the same bits
 __device__ __forceinline__ float kq_sum(float v) {
     // v_permlane32_swap: upper half of the first <-> lower half of the second; v_permlane16_swap: odd rows of the first <->
@@ -162,7 +168,7 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
     };
     auto q_frag = [&](int h) -> f32x4 {
         const f32x4 r = mfma4(qa, vk[h], qb);
-        return KIND == K_FWD ? relu4(r) : r;
+        return KIND == K_FWD ? relu4m(r) : r;
     };
     f32x4 bq[2][NR];
     q_load(0);

@@ -272,12 +272,12 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 STAMP(sid + 4)
             }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
-                const float* wm = a.perm_lds > 0 ? ptab + cb * pdd : perm;
 #pragma unroll
                 for (int h = 0; h < NR; ++h)
                     for (int i = lane; i < ROWS * a.d; i += 64) {
                         const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        GO(h)[r * a.xld + j] = perm_dot(GS(h) + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
+                        GO(h)[r * a.xld + j] = a.perm_lds > 0 ? perm_dot(GS(h) + r * a.xld, (const LDS_AS float*)(ptab + cb * pdd) + j * a.d, 1, a.d)
+                                                               : perm_dot(GS(h) + r * a.xld, (const GLOBAL_AS float*)perm + (size_t)j * a.d, 1, a.d);
                     }
                 gcur = tl - gcur;
             }

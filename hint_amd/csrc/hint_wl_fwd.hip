@@ -110,12 +110,12 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             const int tsel = cb & (a.nw - 1);          // the wavefront that writes this block's small tape entries
             if (!REV && perm != nullptr) {
                 // fused fixed permutation in front of the block (power_hint_8.py:59-62): x' = x W
-                const float* wm = a.perm_lds > 0 ? ptab + bi * pdd : perm;
 #pragma unroll
                 for (int h = 0; h < NR; ++h)
                     for (int i = lane; i < ROWS * a.d; i += 64) {
                         const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        XO(h)[r * a.xld + j] = perm_dot(XS(h) + r * a.xld, wm + j, a.d, a.d);
+                        XO(h)[r * a.xld + j] = a.perm_lds > 0 ? perm_dot(XS(h) + r * a.xld, (const LDS_AS float*)(ptab + bi * pdd) + j, a.d, a.d)
+                                                               : perm_dot(XS(h) + r * a.xld, (const GLOBAL_AS float*)perm + j, a.d, a.d);
                     }
                 xcur = xflip - xcur;
             }
@@ -241,12 +241,12 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 STAMP(sid + 5)
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
-                const float* wm = a.perm_lds > 0 ? ptab + bi * pdd : perm;
 #pragma unroll
                 for (int h = 0; h < NR; ++h)
                     for (int i = lane; i < ROWS * a.d; i += 64) {
                         const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        XO(h)[r * a.xld + j] = perm_dot(XS(h) + r * a.xld, wm + (size_t)j * a.d, 1, a.d);
+                        XO(h)[r * a.xld + j] = a.perm_lds > 0 ? perm_dot(XS(h) + r * a.xld, (const LDS_AS float*)(ptab + bi * pdd) + j * a.d, 1, a.d)
+                                                               : perm_dot(XS(h) + r * a.xld, (const GLOBAL_AS float*)perm + (size_t)j * a.d, 1, a.d);
                     }
                 xcur = xflip - xcur;
             }
