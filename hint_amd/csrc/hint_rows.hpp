@@ -119,43 +119,52 @@ __device__ __forceinline__ void mask_by_bits(f32x4& v, int bits) {
 
 // the first N weight elements of main step kb of row r (tile j of a narrower row: its last tile again); backward:
 // also the sign byte of the a2 tile of k-block kb (element NTT, in .x), which masks the step's B fragment
+// (through buffer descriptors since round 4: the tile index is wave-uniform, so the scalar unit does the address arithmetic - the
+//  offset operand of the load - and the per-lane part, lane * 16, is loop invariant; vector-ALU instructions do not hide under the
+//  matrix pipe on gfx950, and a 64-bit per-lane address cost one or two per tile and step)
+typedef unsigned rows_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 rows_as_f32x4(rows_u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc_of(const GLOBAL_AS void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000);
+}
 template <int KIND, int N>
 __device__ __forceinline__ void load_main3(f32x4 (&dst)[NEL], const PhaseCtx& c, const RowU& r, int kb, const LaneOff& lo) {
-    const GLOBAL_AS char* p = (const GLOBAL_AS char*)c.packed + lo.w;
+    const __amdgpu_buffer_rsrc_t rw = rows_rsrc_of(c.packed);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int jj = j < r.ntt ? j : r.ntt - 1;
-        dst[j] = *(const GLOBAL_AS f32x4*)(p + (size_t)(r.base1 + jj * r.n1 + kb) * 1024);
+        dst[j] = rows_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rw, (int)lo.w, (r.base1 + jj * r.n1 + kb) * 1024, 0));
     }
     if (KIND == K_BWD) {
         const int kc = kb < r.n1 ? kb : r.n1 - 1;
-        dst[NTT].x = __int_as_float((int)c.bits_a2[((r.wcol >> 4) + kc) * 64 + lo.l]);
+        dst[NTT].x = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b8(rows_rsrc_of(c.bits_a2), (int)lo.l, ((r.wcol >> 4) + kc) * 64, 0));
     }
 }
 // the first N elements of extra step e: 0 = aux (bias vectors / forward activation tiles), 1 .. n2 = tail
 // weight tiles, then n3 bias vectors of the last layer; anything beyond re-loads the aux elements
 template <int KIND, int N>
 __device__ __forceinline__ void load_extra3(f32x4 (&dst)[NTT], const PhaseCtx& c, const RowU& r, int e, const LaneOff& lo) {
-    const GLOBAL_AS char* base;
-    unsigned off, step;
+    int base, off, step;            // byte offsets inside the packed buffer: base + jj * step (scalar), off (per lane)
     if (e >= 1 && e <= r.n2) {
-        base = (const GLOBAL_AS char*)c.packed + (size_t)(r.base2 + (e - 1) * r.n1) * 1024; off = lo.w; step = 1024;
+        base = (r.base2 + (e - 1) * r.n1) * 1024; off = (int)lo.w; step = 1024;
     } else if (e > r.n2 && e <= r.n2 + r.n3) {
-        base = (const GLOBAL_AS char*)c.packed + (size_t)(r.bias3 + 16 * (e - 1 - r.n2)) * 4; off = lo.b; step = 0;
+        base = (r.bias3 + 16 * (e - 1 - r.n2)) * 4; off = (int)lo.b; step = 0;
     } else if (KIND == K_FWD) {
-        base = (const GLOBAL_AS char*)c.packed + (size_t)r.aux * 4; off = lo.b; step = 64;
+        base = r.aux * 4; off = (int)lo.b; step = 64;
     } else {            // backward aux: the sign bytes of the row's a1 tiles (in .x)
+        const __amdgpu_buffer_rsrc_t rb = rows_rsrc_of(c.bits_a1);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const int jj = j < r.ntt ? j : r.ntt - 1;
-            dst[j].x = __int_as_float((int)c.bits_a1[((r.ocol >> 4) + jj) * 64 + lo.l]);
+            dst[j].x = __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b8(rb, (int)lo.l, ((r.ocol >> 4) + jj) * 64, 0));
         }
         return;
     }
+    const __amdgpu_buffer_rsrc_t rw = rows_rsrc_of(c.packed);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int jj = j < r.ntt ? j : r.ntt - 1;
-        dst[j] = *(const GLOBAL_AS f32x4*)(base + (size_t)(jj * step) + off);
+        dst[j] = rows_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rw, off, base + jj * step, 0));
     }
 }
 
