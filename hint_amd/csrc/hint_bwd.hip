@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         const float ea = expf(aa);
                         const float l = xs[row * a.xld + col];            // lower input of the node
                         const float ga = gval * ea * l + gj[row];           // g_a (a feeds both l' and J)
-                        const float gsv = ga * a.alpha / (1.f + s * s);     // g_s
+                        const float gsv = ga * a.alpha * __builtin_amdgcn_rcpf(1.f + s * s);     // g_s (v_rcp_f32, 1 ulp: an IEEE division is ten vector instructions)
                         gst[row * a.gld + cp_ls] = gsv;
                         gst[row * a.gld + cp_lt] = gval;                    // g_t = g_l'
                         float* go = wsGST + (size_t)(row0 + row) * a.ST;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                         if (!REV && tape != nullptr && row0 + row < a.B)
                             tape[((size_t)(a.n_levels + g.level) * a.B + row0 + row) * a.d + xcol] = s;
                         if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
-                        else      { *px = ((*px) - t) / expf(aa); part -= aa; }
+                        else      { *px = ((*px) - t) * __builtin_amdgcn_rcpf(expf(aa)); part -= aa; }      // (v_rcp_f32, 1 ulp, instead of a ten-instruction division)
                     }
                     // deterministic butterfly over the nsub adjacent lanes that share a batch row
                     if (nsub == 16) { part += __shfl_xor(part, 8, 16); part += __shfl_xor(part, 4, 16); }

@@ -164,7 +164,7 @@ __device__ __forceinline__ void sub_apply_t(const KArgs& a, const Tables& T, flo
                 if (!REV && tape != nullptr && row0 + m < a.B) tape[(size_t)(a.n_levels + level) * lvl + (size_t)(row0 + m) * a.d + xcol] = sv;
                 float xn;
                 if (!REV) { xn = expf(aa) * xold + tv; jpart += aa; }
-                else      { xn = (xold - tv) / expf(aa); jpart -= aa; }
+                else      { xn = (xold - tv) * __builtin_amdgcn_rcpf(expf(aa)); jpart -= aa; }
                 xs[m * a.xld + xcol] = xn;
             }
             STAMP(sid + 7)
@@ -386,7 +386,7 @@ __device__ __forceinline__ void sub_bwd(const KArgs& a, const Tables& T, float* 
                     const float ea = expf(aa);
                     const float l = xs[m * a.xld + xcol];                 // lower input of the node
                     const float ga = gval * ea * l + gj[m];               // g_a (a feeds both l' and J)
-                    const float gsv = ga * a.alpha / (1.f + sv * sv);     // g_s
+                    const float gsv = ga * a.alpha * __builtin_amdgcn_rcpf(1.f + sv * sv);     // g_s (v_rcp_f32, 1 ulp)
                     gst[m * a.gld + us.lcol + kq] = gsv;
                     gst[m * a.gld + ut.lcol + kq] = gval;                 // g_t = g_l'
                     float* go = wsGST + (size_t)(row0 + m) * a.ST;

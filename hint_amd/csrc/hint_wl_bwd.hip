@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                             const float ea = expf(aa);
                             const float l = XSP(h)[row * a.xld + col];          // lower input of the node
                             const float ga = gval[h] * ea * l + gj[h * ROWS + row];   // g_a (a feeds both l' and J)
-                            const float gsv = ga * a.alpha / (1.f + s * s);     // g_s
+                            const float gsv = ga * a.alpha * __builtin_amdgcn_rcpf(1.f + s * s);     // g_s (v_rcp_f32, 1 ulp: an IEEE division is ten vector instructions)
                             GSTP(h)[row * a.gld + cp_ls] = gsv;
                             GSTP(h)[row * a.gld + cp_lt] = gval[h];             // g_t = g_l'
                             if (wave == tsel && row0[h] < ntiles * ROWS) {

@@ -50,8 +50,9 @@ st = buf.cpu().numpy().reshape(NWG, NW, IDS)
 used = st[:, :, 0] != 0
 nwg = int(used.any(axis=1).sum())
 w = st[used]                       # [waves, ids]
-t0 = w[:, 0].min()
-span = w[:, 5].max() - t0
+w = w[(w[:, 5] != 0) & (w[:, 1] != 0)]
+t0 = int(w[:, 0].min())
+span = int(w[:, 5].max()) - t0
 print(f"{name}: part B + reduction {us:.1f} us between events; {nwg} workgroups, {len(w)} wavefronts with work; "
       f"first stamp to last {span} ticks ({span / us:.1f} ticks per us)")
 labels = ["records arrive (block pointers, job)", "row loop (incl. its parameter / first-input latency)", "partials -> LDS",
