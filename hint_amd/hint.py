@@ -39,6 +39,21 @@ def linear_subnet_constructor(c_in, c_out, c_internal):
                          nn.Linear(c_internal, c_out))
 
 
+def _checked_subnet(net, c_in, c_out):
+    """a subnet the HIP kernels can run: nn.Sequential(Linear(c_in, h), ReLU, Linear(h, h), ReLU, Linear(h, c_out)), all with
+    bias (what linear_subnet_constructor builds, hint.py:10-13); NotImplementedError otherwise"""
+    ok = isinstance(net, nn.Sequential) and len(net) == 5 and all(isinstance(net[i], nn.Linear) for i in (0, 2, 4)) \
+        and all(type(net[i]) is nn.ReLU for i in (1, 3)) and all(net[i].bias is not None for i in (0, 2, 4))
+    if ok:
+        h = net[0].out_features
+        ok = net[0].in_features == c_in and net[2].in_features == h and net[2].out_features == h \
+            and net[4].in_features == h and net[4].out_features == c_out
+    if not ok:
+        raise NotImplementedError("subnet_constructor must return nn.Sequential(Linear(c_in, h), ReLU(), Linear(h, h), ReLU(), "
+                                  "Linear(h, c_out)) - the subnet of hint.py:10-13 is the only one implemented in HIP")
+    return net
+
+
 def conv_subnet_constructor(c_in, c_out, c_internal):
     raise NotImplementedError("conv subnets (hint.py:15-18) are out of scope: no reference config uses conv=True")
 
@@ -397,8 +412,6 @@ class HierarchicalAffineCouplingTree(nn.Module):
         super().__init__()
         if conv:
             raise NotImplementedError("conv=True (hint.py:15-18,29) is out of scope")
-        if subnet_constructor is not None and subnet_constructor is not linear_subnet_constructor:
-            raise NotImplementedError("only linear_subnet_constructor (hint.py:10-13) is implemented in HIP")
         if len(tuple(data_shape)) != 1:
             raise NotImplementedError("only flat [B, d] data is supported")
         self.data_shape = tuple(data_shape)
@@ -415,8 +428,16 @@ class HierarchicalAffineCouplingTree(nn.Module):
         self.split_idx = D // 2 if _split_idx is None else int(_split_idx)
         self.conditional = len(dims_c) > 0
         self.condition_length = sum(dims_c[i][0] for i in range(len(dims_c)))
-        self.s = linear_subnet_constructor(self.split_idx + self.condition_length, D - self.split_idx, widths[0])
-        self.t = linear_subnet_constructor(self.split_idx + self.condition_length, D - self.split_idx, widths[0])
+        # hint.py:27-32,44-45: a custom `subnet_constructor(c_in, c_out, c_internal)` is called as the reference calls it; the
+        # kernels implement ONE subnet - Linear-ReLU-Linear-ReLU-Linear with one hidden width (hint.py:10-13) - so whatever it
+        # returns must have exactly that structure (its initialisation, names inside the Sequential and dtype handling are its
+        # own); anything else raises
+        make = linear_subnet_constructor if subnet_constructor is None else subnet_constructor
+        c_in, c_out = self.split_idx + self.condition_length, D - self.split_idx
+        self.s = _checked_subnet(make(c_in, c_out, widths[0]), c_in, c_out)
+        self.t = _checked_subnet(make(c_in, c_out, widths[0]), c_in, c_out)
+        if self.s[0].out_features != self.t[0].out_features:
+            raise NotImplementedError("the s and t subnets of a node must have the same hidden width")
         if D >= 2 * min_split_size and max_splits != 0 and _split_idx is None:   # hint.py:47
             self.leaf = False
             self.upper = HierarchicalAffineCouplingTree((self.split_idx,), dims_c, conv, subnet_constructor,

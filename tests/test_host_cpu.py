@@ -71,6 +71,27 @@ def test_unsupported_options_fail_loudly():
         hint_amd.HierarchicalAffineCouplingBlock([(6,)], conv=True)
     with pytest.raises(NotImplementedError):
         hint_amd.HierarchicalAffineCouplingBlock([(6,)], subnet_constructor=lambda a, b, c: None)
+    with pytest.raises(NotImplementedError):          # a subnet of another shape than hint.py:10-13
+        hint_amd.HierarchicalAffineCouplingBlock([(6,)], subnet_constructor=lambda a, b, c: torch.nn.Sequential(torch.nn.Linear(a, b)))
+
+
+def test_custom_subnet_constructor_of_the_reference_shape_is_taken():
+    """hint.py:27-32: subnet_constructor(c_in, c_out, c_internal) is called per subnet; one that returns the reference's own
+    Linear-ReLU-Linear-ReLU-Linear (here with another initialisation) is adopted - same state_dict keys, its own weights"""
+    calls = []
+
+    def make(c_in, c_out, c_internal):
+        calls.append((c_in, c_out, c_internal))
+        net = hint_amd.linear_subnet_constructor(c_in, c_out, c_internal)
+        for p in net.parameters():
+            torch.nn.init.constant_(p, 0.25)
+        return net
+
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(6,)], subnet_constructor=make, c_internal=[16, 8])
+    ref = hint_amd.HierarchicalAffineCouplingBlock([(6,)], c_internal=[16, 8])
+    assert list(blk.state_dict().keys()) == list(ref.state_dict().keys())
+    assert calls[0] == (3, 3, 16) and calls[1] == (3, 3, 16) and (1, 2, 8) in calls and len(calls) == 6
+    assert all(float(v.min()) == 0.25 == float(v.max()) for v in blk.state_dict().values())
 
 
 def test_reshuffle_composes_to_one_orthogonal_matrix():
