@@ -123,7 +123,7 @@ struct LaneOp {
     int16_t sc_unit, sc_k;  // s unit (global index) of the node of the previous group that takes this lane as input k; -1: none
     int16_t cp_ls, cp_lt;   // column of g_s / g_t of this lane in the LDS coupling-gradient buffer; cp_ls = -1: lane not transformed
     int16_t cp_gs, cp_gt;   // the same columns in the global [Bp][ST] array
-    int32_t pad;
+    int32_t pad;            // entry k of a boundary: the boundary's k-th ACTIVE lane (sc_unit >= 0 or cp_ls >= 0) | their number << 16
 };
 static_assert(sizeof(LaneOp) == 16, "LaneOp must be 16 bytes");
 

@@ -182,6 +182,12 @@ static std::vector<LaneOp> build_lane_ops(std::vector<Group>& groups, const std:
                 }
             lops[(size_t)b * d + col] = op;
         }
+        // the boundary's ACTIVE lanes (something to add or a coupling gradient to form), compacted: entry k's `pad` holds the k-th
+        // active lane | count << 16 - the wave-local backward kernel walks 16 rows x count lanes instead of 16 x d
+        int cnt = 0;
+        for (int col = 0; col < d; ++col)
+            if (lops[(size_t)b * d + col].sc_unit >= 0 || lops[(size_t)b * d + col].cp_ls >= 0) lops[(size_t)b * d + cnt++].pad = col;
+        for (int k = 0; k < d; ++k) lops[(size_t)b * d + k].pad = (k < cnt ? lops[(size_t)b * d + k].pad : 0) | (cnt << 16);
         if (b < n_groups) groups[b].lop_begin = b * d;
     }
     return lops;

@@ -164,13 +164,22 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 (void)sid;
                 STAMP(sid + 0)
                 // ---- scatter of the previous group's g_v + coupling backward of this one, on the wavefront's own tiles ----
-                for (int idx = lane; idx < ROWS * a.d; idx += 64) {
-                    const int row = fdiv(idx, inv_d), col = idx - row * a.d;
+                // (only the boundary's ACTIVE lanes - something to add, or a coupling gradient to form: LaneOp::pad lists them -,
+                //  16 rows x nact elements: the lanes a boundary leaves alone cost a full pass of the loop for nothing - at d = 6 the
+                //  three boundaries of a block have 3, 5 and 2 active lanes of 6)
+                const int nact = a.lops_off >= 0 ? (int)((unsigned)lds_i32((const LDS_AS int32_t*)(T.lops + lop0) + 3) >> 16)
+                                                 : (int)((unsigned)rfl(((const GLOBAL_AS i32x4*)a.lops)[lop0].w) >> 16);
+                const float inv_act = frcp(nact > 0 ? nact : 1);
+                for (int idx = lane; idx < ROWS * nact; idx += 64) {
+                    const int row = fdiv(idx, inv_act), kk = idx - row * nact;
+                    int col;
                     unsigned w0, w1, w2;
                     if (a.lops_off >= 0) {
+                        col = ((const LDS_AS int32_t*)(T.lops + lop0 + kk))[3] & 0xffff;
                         const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
                         w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
                     } else {
+                        col = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + kk].w & 0xffff;
                         const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + col];
                         w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
                     }
