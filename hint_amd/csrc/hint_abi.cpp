@@ -90,9 +90,21 @@ int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm
     a->perm_lds = 0;
     const int cap = env_int("HINT_PERM_LDS_MAX") > 0 ? env_int("HINT_PERM_LDS_MAX") : PERM_LDS_MAX;
     if (env_int("HINT_PLAN_DUMP")) fprintf(stderr, "[hint plan] lds %d + perms %ld (cap %d)\n", lds_plan, extra, cap);
-    if (!any_perm || extra > cap || lds_plan + extra > LDS_LIMIT) return lds_plan;
-    a->perm_lds = lds_plan / (int)sizeof(float);
-    return lds_plan + (int)extra;
+    int total = lds_plan;
+    if (any_perm && extra <= cap && lds_plan + extra <= LDS_LIMIT) {
+        a->perm_lds = lds_plan / (int)sizeof(float);
+        total += (int)extra;
+    }
+    // the general kernels warm the L2 with the weights of what comes two phases later (hint_device.hpp prefetch_consumer): loads
+    // straight into a 256-byte sink behind everything else (HINT_PF=0: never)
+    a->sink_lds = 0;
+    const bool pf_off = std::getenv("HINT_PF") && env_int("HINT_PF") == 0;
+    if (!P->wl && !pf_off && total + 256 <= LDS_LIMIT) {
+        a->sink_lds = total / (int)sizeof(float);
+        total += 256;
+    }
+    if (env_int("HINT_PLAN_DUMP")) fprintf(stderr, "[hint plan] packed lines %d: sink at %d, lds %d\n", a->packed_lines, a->sink_lds, total);
+    return total;
 }
 KArgs make_args(const hint_plan* P, int B, bool backward) {
     KArgs a{};
@@ -114,6 +126,8 @@ KArgs make_args(const hint_plan* P, int B, bool backward) {
     a.alpha = P->alpha; a.B = B; a.stamps = g_stamp_buf;
     a.rowdw_lds = backward ? P->rowdw_lds : 0;
     a.n_sub = P->n_sub;
+    a.packed_tiles = (int)(P->packed_floats / 256);
+    a.packed_lines = (int)(((P->packed_floats + P->n_bias) * 4 + 127) / 128);
     if (P->n_sub > 0) {
         const int* o = backward ? P->sub_lds_b : P->sub_lds_f;
         a.sub_slab = o[0]; a.sub_par = o[1]; a.sub_misc = o[2];

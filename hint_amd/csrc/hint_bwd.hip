@@ -112,10 +112,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             const float* tape = (const float*)blk.tape;
             const bool top = perm != nullptr || cb > 0;
             float* wsGST = (float*)blk.wsGST;
-            if (a.n_sub > 0) sub_par_stage(a, blk.packed, lds, tid, nthreads);     // (the subtree groups' thin vectors and biases)
-            if (a.thin_lds > 0 && a.thin_grp == 0) {
-                const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
-                for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
+            {   // the subtree groups' parameters and the block's thin-layer vectors -> LDS (every wavefront re-reads them for its units,
+                // and all workgroups asking L2 for the same few lines at once is what made them slow)
+                const bool thin_blk = a.thin_lds > 0 && a.thin_grp == 0;
+                block_stage(a, blk.packed, lds, thin_blk ? a.thin_floats >> 2 : 0, tid, nthreads);
             }
             if ((a.thin_lds > 0 && a.thin_grp == 0) || a.n_sub > 0) __syncthreads();
             PhaseCtx pc;
@@ -334,6 +334,20 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 5)
+                if (a.sink_lds > 0 && wave == a.nw - 1) {       // (L2 warm-up two consumers ahead: hint_device.hpp prefetch_consumer; backward order: root first)
+                    const int ngen = a.n_groups - a.n_sub, pos = a.n_groups - slot;
+                    auto pf = [&](int q) {
+                        const GLOBAL_AS float* pk = blk.packed;
+                        if (q > ngen) {
+                            if (cb == 0) return;
+                            q -= ngen + 1;
+                            pk = nblk.packed;
+                        }
+                        prefetch_consumer<false>(a, T, pk, q, lds + a.sink_lds, lane);
+                    };
+                    pf(pos + 2);
+                    if (pos == 1) pf(2);                        // (the head has no phase of its own)
+                }
                 if (a.fuse_dw1)          // the lanes this group's first layers read: kept for their weight gradients (computed across the next boundary)
                     for (int i = tid; i < ROWS * a.d; i += nthreads) { const int r = fdiv(i, inv_d), j = i - r * a.d; xo[r * a.xld + j] = xs[r * a.xld + j]; }
                 // (rows that compute dW1 | db1 themselves read the level's lanes to their end: nobody overwrites them before all are through)

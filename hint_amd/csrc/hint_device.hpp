@@ -277,6 +277,45 @@ __device__ __forceinline__ Tables make_tables(const KArgs& a, float* lds) {
     t.lops = (const LDS_AS LaneOp*)(mbase + (a.lops_off >= 0 ? a.lops_off : 0));
     return t;
 }
+
+// ---- L2 warm-up of the packed weights, a phase or two ahead of their use ----
+// Every workgroup carries its 16 rows through the same blocks and groups at about the same time, so the first touch of a group's
+// weights is an L2 miss for all 32 workgroups of an XCD at once (eight XCDs with an L2 each; workgroups are dealt round robin:
+// XCD = blockIdx & 7), and a block's tape traffic has pushed the weights out of the L2 - often out of the memory-side cache - since
+// the launch before.  ONE wavefront of every workgroup therefore touches what comes two consumers later: the workgroups of an XCD
+// share the range's 128-byte lines out among themselves, one line per lane, loaded straight into a 256-byte sink in LDS nobody
+// reads (`global_load_lds_dword`: no register waits for it; the wavefront's later loads do - vector-memory operations retire in
+// order - so the caller is a wavefront with slack in front of a barrier).
+// The consumers of a block in packed order: position 0 = [thin blobs | tiles of the subtree groups] + the biases at the buffer's
+// end ("head": what block_stage and the subtree phase read), position 1 + i = the fragment tiles of general group i (forward
+// order) or of general group ngen - 1 - i (backward / inverse order: root first).  MINIBOONE x 10: forward 341 -> 309 us,
+// backward 452 -> 426; the d = 100 flows 745 -> 670 / 898 -> 880; h = 512: 1215 -> 989 / 1327 -> 1250 with whole blocks a block ahead.
+__device__ __forceinline__ void prefetch_range(const GLOBAL_AS float* base, int l0, int l1, float* sink, int lane) {
+    const int wgs = (int)(gridDim.x >> 3);
+    const int per_xcd = wgs < 32 ? (wgs > 0 ? wgs : 1) : 32;
+    const int share = (int)(blockIdx.x >> 3);
+    if (share >= per_xcd) return;
+    for (int b0 = l0; b0 < l1; b0 += per_xcd * 64) {
+        const int line = b0 + share + per_xcd * lane;
+        if (line < l1)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)((const GLOBAL_AS char*)base + (size_t)line * 128), (LDS_AS void*)sink, 4, 0, 0);
+    }
+}
+template <bool FWD_ORDER>
+__device__ __forceinline__ void prefetch_consumer(const KArgs& a, const Tables& T, const GLOBAL_AS float* packed, int pos, float* sink, int lane) {
+    auto first_tile = [&](int g) -> int {        // first packed tile of group g's units (Unit::f2 of its first unit); behind the last group: the tiles' end
+        if (g >= a.n_groups) return a.packed_tiles;
+        const int ub = rfl(*((const LDS_AS int32_t*)(T.groups + g)));
+        return rfl(*((const LDS_AS int32_t*)(T.units + ub) + 1));
+    };
+    if (pos == 0) {
+        prefetch_range(packed, 0, 8 * first_tile(a.n_sub), sink, lane);
+        prefetch_range(packed, 8 * a.packed_tiles, a.packed_lines, sink, lane);
+    } else {
+        const int g = FWD_ORDER ? a.n_sub + pos - 1 : a.n_groups - pos;
+        prefetch_range(packed, 8 * first_tile(g), 8 * first_tile(g + 1), sink, lane);
+    }
+}
 __device__ __forceinline__ void copy_meta(const KArgs& a, float* lds, int tid, int nthreads) {
     const int n16 = a.meta_bytes >> 4;
     LDS_AS i32x4* dst = (LDS_AS i32x4*)lds;

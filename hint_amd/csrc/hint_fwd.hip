@@ -89,28 +89,36 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             float* tape = (float*)blk.tape;
             float* actA1 = (float*)blk.actA1;
             const bool train = !REV && actA1 != nullptr;
+            STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 9)
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
                 const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
                 f32x4 pacc[PERM_TQ];
                 perm_mfma<false>(pacc, XS, a.xld, w, a.d, wave, a.nw, lane);
+                STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 10)
                 perm_store(pacc, XO, a.xld, a.d, wave, a.nw, lane);
                 xcur = xflip - xcur;
                 __syncthreads();
+                STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 11)
+#ifndef HINT_ABL_TAPE
                 if (tape != nullptr)      // the permuted input is what the backward pass starts from
+#else
+                if (tape != nullptr && a.B < 0)
+#endif
                     store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
             } else if (!REV && cb > 0 && tape != nullptr) {
                 // inner block of a chain without a permutation: its input exists nowhere else
                 store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
             }
-            if (a.n_sub > 0) sub_par_stage(a, blk.packed, lds, tid, nthreads);     // (the subtree groups' thin vectors and biases)
-            if (a.thin_lds > 0 && a.thin_grp == 0) {
-                // this block's thin-layer weights (vector layout, a few KiB) into LDS: every wavefront re-reads them
-                // for its units, and all workgroups asking L2 for the same few lines at once is what made them slow
-                const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blk.packed + a.thin_off);
-                for (int i = tid; i < (a.thin_floats >> 2); i += nthreads) ((f32x4*)thinb)[i] = src[i];
+            STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 12)
+            {   // the subtree groups' parameters and the block's thin-layer vectors -> LDS (every wavefront re-reads them for its units,
+                // and all workgroups asking L2 for the same few lines at once is what made them slow)
+                const bool thin_blk = a.thin_lds > 0 && a.thin_grp == 0;
+                block_stage(a, blk.packed, lds, thin_blk ? a.thin_floats >> 2 : 0, tid, nthreads);
             }
+            STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 13)
             if ((a.thin_lds > 0 && a.thin_grp == 0) || a.n_sub > 0) __syncthreads();
+            STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 14)
             PhaseCtx pc;
             pc.packed = blk.packed;
             pc.thin_l = a.thin_lds > 0 ? (const LDS_AS float*)thinb : nullptr;
@@ -128,10 +136,20 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             // here, for the later ones right behind the rows of the group before (i.e. across its coupling phase)
             f32x4 ring[RING][NEL];
             const int ngen = a.n_groups - a.n_sub;        // the general groups: [n_sub, n_groups)
+            auto pf = [&](int pos) {                      // consumer `pos` of this block's sequence [head | general groups in this direction's order], or of the next block's
+                const GLOBAL_AS float* pk = blk.packed;
+                if (pos > ngen) {
+                    if (cb + 1 >= n_chain) return;
+                    pos -= ngen + 1;
+                    pk = HINT_CB(REV ? bi - 1 : bi + 1).packed;
+                }
+                prefetch_consumer<!REV>(a, T, pk, pos, lds + a.sink_lds, lane);
+            };
             if (!REV && a.n_sub > 0) {
                 // the deepest levels: one subtree per wavefront, no workgroup barrier until they rejoin (hint_sub.hpp)
                 STAMP((cb * a.n_groups + ngen) * 16 + 0)
                 sub_apply<false>(a, T, lds, blk, XS, train, row0, wave, lane, (cb * a.n_groups + ngen) * 16);
+                if (a.sink_lds > 0 && wave == 0) pf(2);       // (the first wavefronts are through their subtrees 2-4 k cycles before the last)
                 STAMP((cb * a.n_groups + ngen) * 16 + 1)
                 lds_barrier();
                 STAMP((cb * a.n_groups + ngen) * 16 + 2)
@@ -187,6 +205,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 STAMP(sid + 3)
                 lds_barrier();
                 STAMP(sid + 4)
+                if (a.sink_lds > 0 && wave == a.nw - 1) {       // (L2 warm-up two consumers ahead: hint_device.hpp prefetch_consumer)
+                    pf(gi + 3);
+                    if (gi == 0 && (REV || a.n_sub == 0)) pf(2);        // (the head has no phase of its own here)
+                }
                 // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) on the first wavefront(s):
                 //      16 rows x nsub lanes; the others meanwhile send both hidden activations of the group to the
                 //      tape (training), out of LDS, whole lines per batch row ----

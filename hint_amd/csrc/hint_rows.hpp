@@ -186,7 +186,14 @@ __device__ __forceinline__ const LDS_AS float* thin_group_stage(float* buf, int 
     const int v1 = tile_begin + ntiles < total_tiles ? recs[tile_begin + ntiles].x : blob_floats;
     if (v1 - v0 > buf_floats) return nullptr;
     const GLOBAL_AS f32x4* src = (const GLOBAL_AS f32x4*)(blob + v0);
-    for (int i = tid; i < ((v1 - v0) >> 2); i += nthreads) ((f32x4*)buf)[i] = src[i];
+    const int n4 = (v1 - v0) >> 2;
+    for (int base = tid; base < n4; base += 8 * nthreads) {      // (eight loads in flight before the first LDS store: hint_sub.hpp block_stage)
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (base + k * nthreads < n4) v[k] = src[base + k * nthreads];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (base + k * nthreads < n4) ((f32x4*)buf)[base + k * nthreads] = v[k];
+    }
     return (const LDS_AS float*)buf - v0;
 }
 #ifndef HINT_THIN_RUN

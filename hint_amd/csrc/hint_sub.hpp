@@ -18,13 +18,31 @@ namespace hint {
 // LDS traffic of one wavefront is processed in order: what it wrote it can read back; the compiler must not reorder
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// the subtree units' thin vectors and biases -> LDS: [forward vectors | backward vectors | biases] (what the rows' records index)
-__device__ __forceinline__ void sub_par_stage(const KArgs& a, const GLOBAL_AS float* packed, float* lds, int tid, int nthreads) {
-    f32x4* dst = (f32x4*)(lds + a.sub_par);
-    for (int i = tid; i < a.sub_par_f4; i += nthreads) {
-        const int f = 4 * i;
-        const int src = f < a.sub_pf ? f : f < a.sub_pf + a.sub_pb ? f - a.sub_pf + a.sub_bsrc : f - a.sub_pf - a.sub_pb + a.sub_bias_src;
-        dst[i] = *(const GLOBAL_AS f32x4*)(packed + src);
+// What a block's phases read out of LDS instead of L2, global -> LDS by the whole workgroup at the top of the block: the subtree
+// units' thin vectors and biases [forward vectors | backward vectors | biases] (what the rows' records index; n_sub > 0) and the
+// block's thin-layer vectors (thin_n4 float4 from thin_src; 0: none).  One index space, up to STAGE_INFLIGHT loads per thread
+// issued before the first LDS store: a load -> store loop pays the L2 latency once per iteration (MINIBOONE: 5 + 2 iterations,
+// 11 k cycles per block and kernel; batched 3 k).
+constexpr int STAGE_INFLIGHT = 8;
+__device__ __forceinline__ void block_stage(const KArgs& a, const GLOBAL_AS float* packed, float* lds, int thin_n4, int tid, int nthreads) {
+    const int n_sub4 = a.n_sub > 0 ? a.sub_par_f4 : 0;
+    const int total = n_sub4 + thin_n4;
+    // (no branches: the threads past the end repeat the last element - the same value to the same address)
+    for (int base = 0; base < total; base += STAGE_INFLIGHT * nthreads) {
+        f32x4 v[STAGE_INFLIGHT];
+        int dst[STAGE_INFLIGHT];
+#pragma unroll
+        for (int k = 0; k < STAGE_INFLIGHT; ++k) {
+            int i = base + k * nthreads + tid;
+            i = i < total ? i : total - 1;
+            const int f = 4 * i, ft = 4 * (i - n_sub4);
+            const int src = i >= n_sub4 ? a.thin_off + ft
+                          : f < a.sub_pf ? f : f < a.sub_pf + a.sub_pb ? f - a.sub_pf + a.sub_bsrc : f - a.sub_pf - a.sub_pb + a.sub_bias_src;
+            dst[k] = i >= n_sub4 ? a.thin_lds + ft : a.sub_par + f;
+            v[k] = *(const GLOBAL_AS f32x4*)(packed + src);
+        }
+#pragma unroll
+        for (int k = 0; k < STAGE_INFLIGHT; ++k) *(f32x4*)(lds + dst[k]) = v[k];
     }
 }
 

@@ -99,6 +99,8 @@ _lib.check(lib.hint_chain_backward_parts(chain, x.data_ptr(), None, z.data_ptr()
                                          1, 1, stream), "bwd")
 torch.cuda.synchronize()
 bw = buf.cpu().numpy().copy()
+if os.environ.get("STAMPS_NPZ"):        # raw stamps for offline analysis: [wave][id]
+    np.savez(os.environ["STAMPS_NPZ"], fw=fw.reshape(NW, IDS), bw=bw.reshape(NW, IDS))
 lib.hint_debug_set_stamp_buffer(None)
 stats = (C.c_int64 * 16)()
 from hint_amd.hint import node_descs
