@@ -96,7 +96,10 @@ int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm
         total += (int)extra;
     }
     // the general kernels warm the L2 with the weights of what comes two phases later (hint_device.hpp prefetch_consumer): loads
-    // straight into a 256-byte sink behind everything else (HINT_PF=0: never)
+    // straight into a 256-byte sink behind everything else (HINT_PF=0: never).  Not the wave-local kernels: the same touch a block
+    // ahead is worth 6 us of 109 (forward) and 2 of 133 (backward) at cfg 2, but the call site - wherever it was put - costs their
+    // register allocation 10 / 8 us (SGPR spills in the level loop), and from the block's top the issuing wavefront's own loads
+    // wait for it (+14 / +9 us)
     a->sink_lds = 0;
     const bool pf_off = std::getenv("HINT_PF") && env_int("HINT_PF") == 0;
     if (!P->wl && !pf_off && total + 256 <= LDS_LIMIT) {
