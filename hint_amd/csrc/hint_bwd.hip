@@ -115,7 +115,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             {   // the subtree groups' parameters and the block's thin-layer vectors -> LDS (every wavefront re-reads them for its units,
                 // and all workgroups asking L2 for the same few lines at once is what made them slow)
                 const bool thin_blk = a.thin_lds > 0 && a.thin_grp == 0;
-                block_stage(a, blk.packed, lds, thin_blk ? a.thin_floats >> 2 : 0, tid, nthreads);
+                // (the subtree parameters as well, although their phase is the block's last: staged in front of it, behind the boundary's
+                //  element-wise work, they cost MINIBOONE's backward 5 us more)
+                block_stage(a, blk.packed, lds, true, thin_blk ? a.thin_floats >> 2 : 0, tid, nthreads);
             }
             if ((a.thin_lds > 0 && a.thin_grp == 0) || a.n_sub > 0) __syncthreads();
             PhaseCtx pc;

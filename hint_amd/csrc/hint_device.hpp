@@ -107,9 +107,15 @@ __device__ __forceinline__ void load_tile(float* dst, int ld, const float* __res
     }
     const float* p = src + (size_t)row0 * width;
     const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
-    for (int i = tid; i < ROWS * width; i += nthreads) {
-        const int r = fdiv(i, inv);
-        dst[r * ld + (i - r * width)] = (i < nvalid) ? p[i] : 0.f;
+    // (two elements per thread and turn, both loads in flight: d = 43 on 512 threads is one turn instead of two latencies)
+    const int n = ROWS * width;
+    for (int i = tid; i < n; i += 2 * nthreads) {
+        const int i2 = i + nthreads;
+        const bool ok2 = i2 < n;
+        const float v = (i < nvalid) ? p[i] : 0.f, v2 = (ok2 && i2 < nvalid) ? p[i2] : 0.f;
+        const int r = fdiv(i, inv), r2 = fdiv(ok2 ? i2 : i, inv);
+        dst[r * ld + (i - r * width)] = v;
+        if (ok2) dst[r2 * ld + (i2 - r2 * width)] = v2;
     }
 }
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* src, int ld, int width, int row0,
@@ -117,9 +123,13 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
     float* p = dst + (size_t)row0 * width;
     const int nvalid = (B - row0 < ROWS ? B - row0 : ROWS) * width;
     const float inv = frcp(width);
-    for (int i = tid; i < nvalid; i += nthreads) {
-        const int r = fdiv(i, inv);
-        p[i] = src[r * ld + (i - r * width)];
+    for (int i = tid; i < nvalid; i += 2 * nthreads) {
+        const int i2 = i + nthreads;
+        const bool ok2 = i2 < nvalid;
+        const int r = fdiv(i, inv), r2 = fdiv(ok2 ? i2 : i, inv);
+        const float v = src[r * ld + (i - r * width)], v2 = src[r2 * ld + ((ok2 ? i2 : i) - r2 * width)];
+        p[i] = v;
+        if (ok2) p[i2] = v2;
     }
 }
 

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             {   // the subtree groups' parameters and the block's thin-layer vectors -> LDS (every wavefront re-reads them for its units,
                 // and all workgroups asking L2 for the same few lines at once is what made them slow)
                 const bool thin_blk = a.thin_lds > 0 && a.thin_grp == 0;
-                block_stage(a, blk.packed, lds, thin_blk ? a.thin_floats >> 2 : 0, tid, nthreads);
+                const bool thin_late = !REV && a.n_sub > 0;          // (behind the subtree phase: below)
+                block_stage(a, blk.packed, lds, true, thin_blk && !thin_late ? a.thin_floats >> 2 : 0, tid, nthreads);
             }
             STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 13)
             if ((a.thin_lds > 0 && a.thin_grp == 0) || a.n_sub > 0) __syncthreads();
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 STAMP((cb * a.n_groups + ngen) * 16 + 0)
                 sub_apply<false>(a, T, lds, blk, XS, train, row0, wave, lane, (cb * a.n_groups + ngen) * 16);
                 if (a.sink_lds > 0 && wave == 0) pf(2);       // (the first wavefronts are through their subtrees 2-4 k cycles before the last)
+                if (a.thin_lds > 0 && a.thin_grp == 0) block_stage(a, blk.packed, lds, false, a.thin_floats >> 2, tid, nthreads);
                 STAMP((cb * a.n_groups + ngen) * 16 + 1)
                 lds_barrier();
                 STAMP((cb * a.n_groups + ngen) * 16 + 2)

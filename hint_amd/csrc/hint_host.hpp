@@ -78,7 +78,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int pad4(int v) { return (v + 3) & ~3; }
 
 #ifdef HINT_STAMPS
-static constexpr int LDS_LIMIT = 160 * 1024 - 33 * 1024;   // the diagnostic build's static stamp array shares the 160 KiB
+static constexpr int LDS_LIMIT = 160 * 1024 - 32 * 1024 - 512;   // the diagnostic build's static stamp array shares the 160 KiB
 #else
 static constexpr int LDS_LIMIT = 160 * 1024;
 #endif

@@ -24,8 +24,10 @@ __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)
 // issued before the first LDS store: a load -> store loop pays the L2 latency once per iteration (MINIBOONE: 5 + 2 iterations,
 // 11 k cycles per block and kernel; batched 3 k).
 constexpr int STAGE_INFLIGHT = 8;
-__device__ __forceinline__ void block_stage(const KArgs& a, const GLOBAL_AS float* packed, float* lds, int thin_n4, int tid, int nthreads) {
-    const int n_sub4 = a.n_sub > 0 ? a.sub_par_f4 : 0;
+// (sub / thin_n4 = 0: without that part - the two are wanted at different times: forward, the subtree phase comes first and the thin
+//  vectors are staged behind it, in front of its barrier, where the early wavefronts wait anyway; backward the other way round)
+__device__ __forceinline__ void block_stage(const KArgs& a, const GLOBAL_AS float* packed, float* lds, bool sub, int thin_n4, int tid, int nthreads) {
+    const int n_sub4 = (sub && a.n_sub > 0) ? a.sub_par_f4 : 0;
     const int total = n_sub4 + thin_n4;
     // (no branches: the threads past the end repeat the last element - the same value to the same address)
     for (int base = 0; base < total; base += STAGE_INFLIGHT * nthreads) {
