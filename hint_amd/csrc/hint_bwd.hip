@@ -349,6 +349,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     };
                     pf(pos + 2);
                     if (pos == 1) pf(2);                        // (the head has no phase of its own)
+                    if (slot == a.n_sub && perm != nullptr) prefetch_range((const GLOBAL_AS float*)perm, 0, (a.d * a.d * 4 + 127) >> 7, lds + a.sink_lds, lane);   // (the matrix behind the block)
                 }
                 if (a.fuse_dw1)          // the lanes this group's first layers read: kept for their weight gradients (computed across the next boundary)
                     for (int i = tid; i < ROWS * a.d; i += nthreads) { const int r = fdiv(i, inv_d), j = i - r * a.d; xo[r * a.xld + j] = xs[r * a.xld + j]; }

@@ -142,7 +142,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 if (pos > ngen) {
                     if (cb + 1 >= n_chain) return;
                     pos -= ngen + 1;
-                    pk = HINT_CB(REV ? bi - 1 : bi + 1).packed;
+                    const GBlock nb = HINT_CB(REV ? bi - 1 : bi + 1);
+                    pk = nb.packed;
+                    // (with the next block's head: the d x d matrix in front of it, when it is read from global memory)
+                    if (!REV && pos == 0 && a.perm_lds == 0 && nb.perm != nullptr) prefetch_range(nb.perm, 0, (pdd * 4 + 127) >> 7, lds + a.sink_lds, lane);
                 }
                 prefetch_consumer<!REV>(a, T, pk, pos, lds + a.sink_lds, lane);
             };
