@@ -19,6 +19,9 @@
 #ifndef HINT_NTT
 #define HINT_NTT 4
 #endif
+#ifndef HINT_PF_DIST
+#define HINT_PF_DIST 2
+#endif
 #include "hint_sub.hpp"
 
 using namespace hint;
@@ -347,8 +350,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         }
                         prefetch_consumer<false>(a, T, pk, q, lds + a.sink_lds, lane);
                     };
-                    pf(pos + 2);
-                    if (pos == 1) pf(2);                        // (the head has no phase of its own)
+                    pf(pos + HINT_PF_DIST);
+                    if (pos == 1) for (int q = 2; q <= HINT_PF_DIST; ++q) pf(q);      // (the head has no phase of its own)
                     if (slot == a.n_sub && perm != nullptr) prefetch_range((const GLOBAL_AS float*)perm, 0, (a.d * a.d * 4 + 127) >> 7, lds + a.sink_lds, lane);   // (the matrix behind the block)
                 }
                 if (a.fuse_dw1)          // the lanes this group's first layers read: kept for their weight gradients (computed across the next boundary)

@@ -16,6 +16,9 @@
 // rows of up to FOUR tiles in the general kernels (the wave-local ones keep three): a row's steps wait for L2 however few MFMAs
 // they hold, so fewer, wider rows - h = 56 as one row instead of 2 + 2 - halve what a unit costs (hint_plan.cpp: GEN_NTT)
 #define HINT_NTT 4
+#ifndef HINT_PF_DIST
+#define HINT_PF_DIST 2
+#endif
 #include "hint_sub.hpp"
 
 using namespace hint;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 // the deepest levels: one subtree per wavefront, no workgroup barrier until they rejoin (hint_sub.hpp)
                 STAMP((cb * a.n_groups + ngen) * 16 + 0)
                 sub_apply<false>(a, T, lds, blk, XS, train, row0, wave, lane, (cb * a.n_groups + ngen) * 16);
-                if (a.sink_lds > 0 && wave == 0) pf(2);       // (the first wavefronts are through their subtrees 2-4 k cycles before the last)
+                if (a.sink_lds > 0 && wave == 0) pf(HINT_PF_DIST);       // (the first wavefronts are through their subtrees 2-4 k cycles before the last)
                 if (a.thin_lds > 0 && a.thin_grp == 0) block_stage(a, blk.packed, lds, false, a.thin_floats >> 2, tid, nthreads);
                 STAMP((cb * a.n_groups + ngen) * 16 + 1)
                 lds_barrier();
@@ -211,8 +214,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 lds_barrier();
                 STAMP(sid + 4)
                 if (a.sink_lds > 0 && wave == a.nw - 1) {       // (L2 warm-up two consumers ahead: hint_device.hpp prefetch_consumer)
-                    pf(gi + 3);
-                    if (gi == 0 && (REV || a.n_sub == 0)) pf(2);        // (the head has no phase of its own here)
+                    pf(gi + 1 + HINT_PF_DIST);
+                    if (gi == 0 && (REV || a.n_sub == 0)) pf(HINT_PF_DIST);        // (the head has no phase of its own here)
+                    if (gi == 0) for (int q = 2; q < HINT_PF_DIST; ++q) pf(q);
                 }
                 // ---- P3: element-wise affine coupling + log-det partial sums (hint.py:79-83) on the first wavefront(s):
                 //      16 rows x nsub lanes; the others meanwhile send both hidden activations of the group to the
