@@ -188,3 +188,35 @@ def test_weight_gradients_are_deterministic(d, dc, n_blocks, widths, B):
         runs.append(tr.G.clone())
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2])
     assert runs[0].abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("d,dc,n_blocks,widths,B", [(43, 0, 3, [67, 33, 16, 8], 200), (100, 0, 2, [224, 112, 56], 96),
+                                                    (100, 4, 2, [224, 112, 56], 48)])
+def test_l2_prefetch_changes_no_result(d, dc, n_blocks, widths, B, monkeypatch):
+    """the general kernels' L2 warm-up (hint_device.hpp prefetch_consumer: loads into an LDS sink nobody reads, two
+    consumers ahead) is a hint: losses, z, log-dets and gradients with it (default) and without it (HINT_PF=0, read at
+    every launch) are bit-identical - subtree plan (cfg 5 shape), general plan (cfg 4's x lane), with a condition"""
+    torch.manual_seed(11)
+    flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc).to(DEV)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.copy_(0.04 * torch.randn_like(p))
+    x = torch.randn(B, d, device=DEV)
+    c = torch.randn(B, dc, device=DEV) if dc else None
+    tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
+    tr._check_arenas()
+    outs = []
+    for pf in ("0", None, "0"):
+        if pf is None:
+            monkeypatch.delenv("HINT_PF", raising=False)
+        else:
+            monkeypatch.setenv("HINT_PF", pf)
+        tr.G.zero_()
+        tr._fwd_bwd(x, c)
+        torch.cuda.synchronize()
+        outs.append([tr.G.clone(), tr.loss_acc.clone()])      # flat gradient; the two loss sums (0.5 |z|^2, log-det) of the forward
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]).all() and outs[0][0].abs().sum().item() > 0
