@@ -211,7 +211,7 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
                                 (hipStream_t)stream));
         return 0;
     }
-    HIP_TRY(launch_apply(rev, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
+    HIP_TRY(launch_apply(rev, P->has_fly != 0, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
 }

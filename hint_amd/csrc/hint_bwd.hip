@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.bits_a1 = (GLOBAL_AS uint8_t*)(blk.actA1 + a.bits_off) + (size_t)(row0 >> 4) * (a.WT >> 4) * 64;
             pc.bits_a2 = pc.bits_a1 + a.bits_stride;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = a.gld; pc.WT = a.WT; pc.row0 = row0;
-            pc.store = true;
+            pc.store = true; pc.fly = false;
             pc.scratch = (LDS_AS float*)(lds + a.rowdw_lds + wave * 256);
             pc.tw = blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
             pc.first_tile = tile == (int)blockIdx.x;

@@ -93,7 +93,7 @@ int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c
                                 (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
         return 0;
     }
-    HIP_TRY(launch_apply(false, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, c, z, J,
+    HIP_TRY(launch_apply(false, P->has_fly != 0, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, x, c, z, J,
                          J_in, loss_acc, noise, (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
     return 0;
 }
@@ -114,7 +114,7 @@ int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, floa
                                 nullptr, nullptr, (hipStream_t)stream));
         return 0;
     }
-    HIP_TRY(launch_apply(true, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, c, x, J, J_in, nullptr, 0.f,
+    HIP_TRY(launch_apply(true, P->has_fly != 0, a, lds, grid_for(P, C->B), C->host[0], C->d_table, C->n, z, c, x, J, J_in, nullptr, 0.f,
                          nullptr, nullptr, (hipStream_t)stream));
     return 0;
 }

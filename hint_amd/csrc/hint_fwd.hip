@@ -19,11 +19,17 @@
 #ifndef HINT_PF_DIST
 #define HINT_PF_DIST 2
 #endif
+#ifndef HINT_FLY_ON
+#define HINT_FLY_ON true
+#endif
 #include "hint_sub.hpp"
 
 using namespace hint;
 
-template <bool REV>
+// FLYK: the instance for plans with lean general groups (hint_plan::has_fly) - their rows make the first layer themselves, no
+// thin phase (hint_rows.hpp row_body FLY); plans without such groups keep the instance without that code (its mere presence cost
+// MINIBOONE's forward 20 us of 300)
+template <bool REV, bool FLYK>
 __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
     KArgs a, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ z,
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             pc.bits_a2 = train ? pc.bits_a1 + a.bits_stride : nullptr;
             pc.cs = (const LDS_AS float*)cs; pc.gst = nullptr;
             pc.xld = a.xld; pc.cld = a.cld; pc.gld = 0; pc.WT = a.WT; pc.row0 = row0;
-            pc.store = train;
+            pc.store = train; pc.fly = false;
             pc.scratch = nullptr; pc.tw = nullptr; pc.first_tile = false;
 
             // the weight stream of a group's first row starts one phase early: before the block's first group
@@ -188,14 +194,16 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                     thin_staged = pc.thin_l != nullptr;
                     if (thin_staged) lds_barrier();
                 }
-                // ---- P1: first layer of every unit of the group on the vector ALU, the tiles shared out ----
-                {
+                // ---- P1: first layer of every unit of the group on the vector ALU, the tiles shared out - not for a lean group with its
+                //      thin vectors in LDS: its rows make their a1 fragments themselves (hint_rows.hpp row_body FLY) ----
+                pc.fly = FLYK && g.lean && thin_staged && HINT_FLY_ON;
+                if (!pc.fly) {
                     const int t0 = g.tile_begin + lds_i32(rng + a.nw + 1 + wave), t1 = g.tile_begin + lds_i32(rng + a.nw + 2 + wave);
                     if (thin_staged) thin_phase<K_FWD, true>(pc, a.thins, t0, t1, lane);
                     else thin_phase<K_FWD, false>(pc, a.thins, t0, t1, lane);
+                    STAMP(sid + 1)
+                    lds_barrier();
                 }
-                STAMP(sid + 1)
-                lds_barrier();
                 STAMP(sid + 2)
                 // ---- P2: second layer, third layer partials; the last row hands the weight ring to the wavefront's
                 //      first row of the next group (its loads fly across the coupling and thin phases) ----
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
                         if (n0 < n1) rnext = gn.row_begin + n0;
                     }
-                    rows_run<K_FWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
+                    rows_run<K_FWD, FLYK>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 3)
@@ -229,6 +237,13 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                         if (!g.lean) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         stream_tiles(actA1 + a.a2_off, obuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                     }
+                }
+                if (FLYK && train && pc.fly) {
+                    // the sign bytes of the group's a1 tiles, left in its a1 region by the rows: 64 bytes per tile, consecutive tiles
+                    const int soff = nthreads > ncpl ? ncpl : 0;
+                    GLOBAL_AS i32x4* dst = (GLOBAL_AS i32x4*)(pc.bits_a1 + (size_t)(g.wcol0 >> 4) * 64);
+                    if (tid >= soff)
+                        for (int i = tid - soff; i < g.ntiles * 4; i += nthreads - soff) dst[i] = ((const LDS_AS i32x4*)abuf)[i];
                 }
                 if (tid < ncpl) {
                     const int sub = tid & (nsub - 1), row = nsub == 4 ? tid >> 2 : tid >> 4;
@@ -311,24 +326,28 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
 
 namespace hint {
 
-hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
+hipError_t launch_apply(bool rev, bool fly, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
                         const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
                         const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
                         float* x_noisy, hipStream_t stream) {
-    if (rev)
-        hipLaunchKernelGGL(hint_apply_kernel<true>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, one, chain,
-                           n_chain, x, c, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr,
-                           (float*)nullptr);
-    else
-        hipLaunchKernelGGL(hint_apply_kernel<false>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, one, chain,
-                           n_chain, x, c, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
+#define HINT_LAUNCH_APPLY(REV, FLYK, ...) hipLaunchKernelGGL((hint_apply_kernel<REV, FLYK>), dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, one, chain, n_chain, __VA_ARGS__)
+    if (rev) {
+        if (fly) HINT_LAUNCH_APPLY(true, true, x, c, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr, (float*)nullptr);
+        else HINT_LAUNCH_APPLY(true, false, x, c, z, J, J_in, (float*)nullptr, 0.f, (const unsigned long long*)nullptr, (float*)nullptr);
+    } else {
+        if (fly) HINT_LAUNCH_APPLY(false, true, x, c, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
+        else HINT_LAUNCH_APPLY(false, false, x, c, z, J, J_in, loss_acc, noise, rng_state, x_noisy);
+    }
+#undef HINT_LAUNCH_APPLY
     return hipGetLastError();
 }
 
 hipError_t set_max_lds_apply(int bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)hint_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)hint_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)hint_apply_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)hint_apply_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)hint_apply_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)hint_apply_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return e;
 }
 
 }  // namespace hint

@@ -31,7 +31,7 @@ hipError_t launch_inv_lane(int op, float* out, const float* g, const float* a, c
                            int num_cu, hipStream_t stream);
 hipError_t launch_inv_minus(float* dst, const float* src, long n, int keep, int num_cu, hipStream_t stream);
 hipError_t launch_inv_rowmat(const float* x, const float* P, float* y, long n, int d, int num_cu, hipStream_t stream);
-hipError_t launch_apply(bool rev, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
+hipError_t launch_apply(bool rev, bool fly, const KArgs& a, int lds_bytes, int grid, const ChainBlock& one,
                         const ChainBlock* chain, int n_chain, const float* x, const float* c, float* z, float* J,
                         const float* J_in, float* loss_acc, float noise, const unsigned long long* rng_state,
                         float* x_noisy, hipStream_t stream);
@@ -101,6 +101,7 @@ struct hint_plan {
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
     int region_fwd = 0, region_bwd = 0;   // LDS floats of the per-group region [tiles | staged output tiles | slabs]
     int stage_out = 1;
+    int has_fly = 0;            // some general (not subtree) group is lean: the forward kernel's instance whose rows make such groups' first layer themselves
     int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
     int fuse_dw1 = 0;           // lean plans with LDS-staged outputs: dW1, db1 come from the backward kernel (per-workgroup slabs), g1 stays on chip
     int tw_floats = 0;          // floats of one such slab

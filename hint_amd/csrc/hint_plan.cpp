@@ -589,6 +589,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)g.lean;
         if (!g.lean) P->lean = 0;
+        if (g.lean && !sub_bit) P->has_fly = 1;
         g.lean |= sub_bit;
     }
     // ---- wave-local plans (hint_wl.hpp): every group lean, narrow lane tile, the block's thin vectors and biases small

@@ -94,6 +94,7 @@ struct PhaseCtx {
     GLOBAL_AS float* tw;             // backward: this workgroup's first-layer gradient slab
     bool first_tile;                 // backward: the workgroup's first row tile (plain stores into tw; later tiles add)
     bool store;                      // keep the outputs (training forward; always in the backward pass): the kernels stream them out of LDS after the phase
+    bool fly;                        // forward, lean group with its thin vectors in LDS: no thin phase - the rows make their B fragments (a1 tiles) themselves
 };
 
 #ifdef HINT_NO_ROWDW          // (hint_bwd3.hip: the instance for plans without such rows)
@@ -326,9 +327,15 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
 // extra elements - bias vectors / forward activation tiles, the tail product's first weight tiles, the first
 // last-layer bias vector - are fetched when the row starts and wait in registers of their own; further tail
 // steps (r or cin beyond 16) fetch theirs when they run.
-template <int KIND, int NA>
+// FLY (forward, PhaseCtx::fly): the row's B fragments - the a1 tiles of its unit, 1..4 inputs - are not read from LDS but made on
+// the spot, one K <= 4 MFMA each from the unit's thin vectors staged in LDS (the wave-local kernels' first layer, hint_wl.hpp
+// wl_row: A = W1[feature l&15][input l>>4] = the tile's four 16-float vectors read at + lane, B = the row's inputs, C = b1);
+// the unit's first row leaves their sign bytes.  The d = 100 trees' lean groups spent 6-7 k of their 25 k cycles in the thin
+// phase and its barrier for 64 tiles of 16 FMAs per lane.
+template <int KIND, int NA, bool FLY = false>
 __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, const RowU& nr, f32x4 (&ring)[RING][NEL],
                                          const LaneOff& lo, int lane) {
+    static_assert(!FLY || KIND == K_FWD, "only the forward rows make their own B fragments");
     const int m = lane & 15, kq = lane >> 4;
     const LDS_AS f32x4* abuf4 = (const LDS_AS f32x4*)c.abuf + lane;
     const int n1 = cr.n1;
@@ -337,8 +344,23 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     f32x4 acc[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) acc[j] = zero4();
+    // (FLY: tile kb's vectors at thin_w + 80 kb - four weight vectors and the bias vector of 16 floats)
+    const LDS_AS float* tf = c.thin_l + cr.thin_w;
+    float vin = 0.f;
+    if (FLY) { const int cin = cr.thin_k & 0xff, xoff = cr.thin_k >> 16; const float v = c.xs[m * c.xld + xoff + (kq < cin ? kq : 0)]; vin = kq < cin ? v : 0.f; }
+    auto bfrag = [&](int kb) -> f32x4 {
+        if (!FLY) return abuf4[(cr.tile0 + kb) * 64];
+        const float qa = tf[80 * kb + lane];
+        const f32x4 qb = *(const LDS_AS f32x4*)(tf + 80 * kb + 64 + 4 * kq);
+        f32x4 v = mfma4(qa, vin, qb);
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        // (the sign bytes go to the group's - otherwise unused - a1 region in LDS; the element-wise phase streams them out: a global
+        //  store among the ring's loads would hold every later load back until it is acknowledged)
+        if (HINT_STORE_ON && cr.first) ((LDS_AS uint8_t*)c.abuf)[(cr.tile0 + kb) * 64 + lane] = (uint8_t)sign_bits(v);
+        return v;
+    };
     f32x4 bb[2];
-    bb[0] = abuf4[cr.tile0 * 64];
+    bb[0] = bfrag(0);
     bb[1] = zero4();
 
     // One main step of static slot S: k-block KB with the slot's weight fragments (backward: element NTT = the sign
@@ -351,7 +373,7 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
         load_main3<KIND, NLOAD>(ring[((S) + DIST) % RING], c, NR, NKB, lo);                             \
         f32x4 b4 = bb[(S) & 1];                                                                         \
         const int kn = (KB) + 1 < n1 ? (KB) + 1 : (KB);                                                 \
-        bb[((S) + 1) & 1] = abuf4[(cr.tile0 + kn) * 64];                                                \
+        bb[((S) + 1) & 1] = bfrag(kn < n1 ? kn : n1 - 1);      /* (dummy steps: the last tile again) */ \
         if (LIVE) {                                                                                     \
             if (KIND == K_BWD) {                                                                        \
                 mask_by_bits(b4, __float_as_int(ring[S][NTT].x));                                       \
@@ -482,7 +504,7 @@ __device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING
 }
 // rnext: the record whose first main steps the LAST row hands the ring over to - the wavefront's first row of the
 // next group of the block - or -1 (then it re-loads its own: never used)
-template <int KIND>
+template <int KIND, bool FLYK = false>
 __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int rnext, int lane) {
     if (r0 >= r1) {
         if (rnext >= 0) rows_begin<KIND>(c, ring, rnext, rnext + 1, lane);     // nothing to do here, but the next group has work
@@ -501,7 +523,19 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
         const RowU nr = decode_rec(nrec);
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
         if (t == r0) { STAMP(c.sid + 9) }
-        if constexpr (NTT >= 4) {
+        if constexpr (NTT >= 4 && KIND == K_FWD && FLYK) {
+            if (c.fly) {
+                if (cr.ntt >= 4) row_body<KIND, 4, true>(c, cr, nr, ring, lo, lane);
+                else if (cr.ntt == 3) row_body<KIND, 3, true>(c, cr, nr, ring, lo, lane);
+                else if (cr.ntt == 2) row_body<KIND, 2, true>(c, cr, nr, ring, lo, lane);
+                else row_body<KIND, 1, true>(c, cr, nr, ring, lo, lane);
+            } else {
+                if (cr.ntt >= 4) row_body<KIND, 4>(c, cr, nr, ring, lo, lane);
+                else if (cr.ntt == 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
+                else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
+                else row_body<KIND, 1>(c, cr, nr, ring, lo, lane);
+            }
+        } else if constexpr (NTT >= 4) {
             if (cr.ntt >= 4) row_body<KIND, 4>(c, cr, nr, ring, lo, lane);
             else if (cr.ntt == 3) row_body<KIND, 3>(c, cr, nr, ring, lo, lane);
             else if (cr.ntt == 2) row_body<KIND, 2>(c, cr, nr, ring, lo, lane);
