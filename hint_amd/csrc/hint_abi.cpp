@@ -255,7 +255,7 @@ int hint_plan_describe(const hint_plan* P, int32_t B, int32_t* out) {
     if (!P || !out || B < 0) return fail("hint_plan_describe: bad arguments");
     P = variant(P, B);
     out[0] = P->wl; out[1] = wl_nr_for(P, B); out[2] = P->nw; out[3] = P->lean;
-    out[4] = P->n_sub; out[5] = P->row_ntt; out[6] = P->rowdw_lds > 0 ? 1 : 0; out[7] = 0;
+    out[4] = P->n_sub; out[5] = P->row_ntt; out[6] = P->rowdw_lds > 0 ? 1 : 0; out[7] = P->has_fly;
     return 0;
 }
 

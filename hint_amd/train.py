@@ -560,7 +560,8 @@ class FlowTrainer:
         _lib.check(self.lib.hint_plan_describe(self.engines[0].plan, B, info), "hint_plan_describe")
         if info[0]:
             return f"hint_wl_apply_kernel<false, {info[1]}>", f"hint_wl_bwd_kernel<{info[1]}>"
-        return "hint_apply_kernel<false>", ("hint_bwd_kernel_n3" if info[5] <= 3 and not info[6] else "hint_bwd_kernel")
+        return (f"hint_apply_kernel<false, {'true' if info[7] else 'false'}>",
+                "hint_bwd_kernel_n3" if info[5] <= 3 and not info[6] else "hint_bwd_kernel")
 
     def _capture(self, x, c):
         self._check_arenas()

@@ -103,7 +103,8 @@ int32_t hint_plan_lds_bytes(const hint_plan* plan, int32_t backward);
  * out[2] = wavefronts per workgroup; out[3] = 1 when no a1 / g2 arrays exist (part B rebuilds them); out[4] = subtree groups (the
  * deepest levels that run one subtree per wavefront); out[5] = tiles of the widest row (<= 3: the general backward pass runs on
  * hint_bwd_kernel_n3, unless out[6]); out[6] = 1 when rows of the backward kernel compute first-layer weight gradients themselves;
- * out[7] = 0.  out must hold 8 values. */
+ * out[7] = 1 when some general group is lean: forward and inverse run on hint_apply_kernel<REV, true>, whose rows make such groups'
+ * first layer themselves (no thin phase), else on hint_apply_kernel<REV, false>.  out must hold 8 values. */
 int hint_plan_describe(const hint_plan* plan, int32_t B, int32_t* out);
 
 /* Re-pack the flat parameters into `packed` (hint_plan_packed_floats floats).  Must be called
