@@ -173,7 +173,7 @@ int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* ch
         HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
     } else if (parts & 1) {
         // (the permutation matrices stay in global memory here: one d x d product per block)
-        HIP_TRY((P->row_ntt <= 3 && P->rowdw_lds == 0 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
+        HIP_TRY((P->has_fly && !env_int("HINT_NO_BWD_FLY") ? launch_bwd_fly : P->row_ntt <= 3 && P->rowdw_lds == 0 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
                                                                g_z, g_J, g_x, g_c, gz_scale, gJ_const, s));
     }
     if (!(parts & 2)) return 0;

@@ -26,6 +26,11 @@
 
 using namespace hint;
 
+#ifdef HINT_BWD_FLY       // (hint_bwd_fly.hip: the instance for plans with lean general groups - their rows make g2' themselves, no thin phase)
+constexpr bool BWD_FLYK = true;
+#else
+constexpr bool BWD_FLYK = false;
+#endif
 
 struct LevelPrefetch { float x[LV_REGS], s[LV_REGS]; int nvalid; };
 // (the loads only: nothing here may look at the loaded values - a select on them would be a wait for HBM in the
@@ -314,14 +319,16 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 }
                 const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 STAMP(sid + 3)
-                // ---- Q2: g2' = W3^T g_st of every unit of the group on the vector ALU, the tiles shared out ----
-                {
+                // ---- Q2: g2' = W3^T g_st of every unit of the group on the vector ALU, the tiles shared out - not for a lean group with
+                //      its thin vectors in LDS in the instance whose rows make those fragments themselves (hint_rows.hpp row_body FLY) ----
+                pc.fly = BWD_FLYK && g.lean && thin_staged;
+                if (!pc.fly) {
                     const char* thb = (const char*)a.thins + (size_t)a.total_tiles * sizeof(ThinRec);
                     const int t0 = g.tile_begin + lds_i32(rng + a.nw + 1 + wave), t1 = g.tile_begin + lds_i32(rng + a.nw + 2 + wave);
                     if (thin_staged) thin_phase<K_BWD, true>(pc, thb, t0, t1, lane);
                     else thin_phase<K_BWD, false>(pc, thb, t0, t1, lane);
+                    lds_barrier();
                 }
-                lds_barrier();
                 STAMP(sid + 4)
                 // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
                 pc.out_thin = g.lean ? nullptr : (GLOBAL_AS float*)(blk.wsG1 + a.act_stride);
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
                         if (n0 < n1) rnext = gn.row_begin + n0;
                     }
-                    rows_run<K_BWD>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
+                    rows_run<K_BWD, BWD_FLYK>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 5)

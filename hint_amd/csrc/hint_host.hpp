@@ -49,6 +49,10 @@ hipError_t launch_bwd_n3(const KArgs& a, int lds_bytes, int grid, const ChainBlo
 hipError_t set_max_lds_apply(int bytes);
 hipError_t set_max_lds_bwd(int bytes);
 hipError_t set_max_lds_bwd_n3(int bytes);
+hipError_t launch_bwd_fly(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
+                          int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
+                          float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);     // (hint_bwd_fly.hip: plans with lean general groups)
+hipError_t set_max_lds_bwd_fly(int bytes);
 hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
                            const ChainBlock* chain, int n_chain, const float* x, float* z, float* J, const float* J_in,
                            float* loss_acc, float noise, const unsigned long long* rng_state, float* x_noisy,

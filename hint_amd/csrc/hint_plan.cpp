@@ -928,6 +928,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (e == hipSuccess) e = set_max_lds_apply(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_bwd(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_bwd_n3(LDS_ATTR);
+    if (e == hipSuccess) e = set_max_lds_bwd_fly(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_wl_apply(LDS_ATTR);
     if (e == hipSuccess) e = set_max_lds_wl_bwd(LDS_ATTR);
     if (e != hipSuccess) {

@@ -327,7 +327,7 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
 // extra elements - bias vectors / forward activation tiles, the tail product's first weight tiles, the first
 // last-layer bias vector - are fetched when the row starts and wait in registers of their own; further tail
 // steps (r or cin beyond 16) fetch theirs when they run.
-// FLY (forward, PhaseCtx::fly): the row's B fragments - the a1 tiles of its unit, 1..4 inputs - are not read from LDS but made on
+// FLY (PhaseCtx::fly; backward: the hint_bwd_fly.hip instance, B fragment = g2' = W3^T g_st): the row's B fragments - the a1 tiles of its unit, 1..4 inputs - are not read from LDS but made on
 // the spot, one K <= 4 MFMA each from the unit's thin vectors staged in LDS (the wave-local kernels' first layer, hint_wl.hpp
 // wl_row: A = W1[feature l&15][input l>>4] = the tile's four 16-float vectors read at + lane, B = the row's inputs, C = b1);
 // the unit's first row leaves their sign bytes.  The d = 100 trees' lean groups spent 6-7 k of their 25 k cycles in the thin
@@ -335,7 +335,6 @@ __device__ __forceinline__ void thin_phase(const PhaseCtx& c, const void* thins,
 template <int KIND, int NA, bool FLY = false>
 __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, const RowU& nr, f32x4 (&ring)[RING][NEL],
                                          const LaneOff& lo, int lane) {
-    static_assert(!FLY || KIND == K_FWD, "only the forward rows make their own B fragments");
     const int m = lane & 15, kq = lane >> 4;
     const LDS_AS f32x4* abuf4 = (const LDS_AS f32x4*)c.abuf + lane;
     const int n1 = cr.n1;
@@ -347,9 +346,12 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     // (FLY: tile kb's vectors at thin_w + 80 kb - four weight vectors and the bias vector of 16 floats)
     const LDS_AS float* tf = c.thin_l + cr.thin_w;
     float vin = 0.f;
-    if (FLY) { const int cin = cr.thin_k & 0xff, xoff = cr.thin_k >> 16; const float v = c.xs[m * c.xld + xoff + (kq < cin ? kq : 0)]; vin = kq < cin ? v : 0.f; }
+    if (FLY && KIND == K_FWD) { const int cin = cr.thin_k & 0xff, xoff = cr.thin_k >> 16; const float v = c.xs[m * c.xld + xoff + (kq < cin ? kq : 0)]; vin = kq < cin ? v : 0.f; }
+    if (FLY && KIND == K_BWD) { const int r = cr.thin_k & 0xff, lcol = cr.thin_k >> 16; const float v = c.gst[m * c.gld + lcol + (kq < r ? kq : 0)]; vin = kq < r ? v : 0.f; }
     auto bfrag = [&](int kb) -> f32x4 {
         if (!FLY) return abuf4[(cr.tile0 + kb) * 64];
+        // (backward: g2' = W3^T g_st of the tile, unmasked - four 16-float vectors per tile, no bias vector)
+        if (KIND == K_BWD) return mfma4(tf[64 * kb + lane], vin, zero4());
         const float qa = tf[80 * kb + lane];
         const f32x4 qb = *(const LDS_AS f32x4*)(tf + 80 * kb + 64 + 4 * kq);
         f32x4 v = mfma4(qa, vin, qb);
@@ -523,7 +525,7 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
         const RowU nr = decode_rec(nrec);
         nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
         if (t == r0) { STAMP(c.sid + 9) }
-        if constexpr (NTT >= 4 && KIND == K_FWD && FLYK) {
+        if constexpr (NTT >= 4 && FLYK) {
             if (c.fly) {
                 if (cr.ntt >= 4) row_body<KIND, 4, true>(c, cr, nr, ring, lo, lane);
                 else if (cr.ntt == 3) row_body<KIND, 3, true>(c, cr, nr, ring, lo, lane);
