@@ -224,6 +224,25 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     thin_staged = pc.thin_l != nullptr;
                 }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
+#ifdef HINT_BWD_FLY
+                // (this instance's trees keep the lane table in global memory: the boundary's ACTIVE lanes only, from the compacted copy -
+                //  16 x 40-60 elements instead of 16 x 100 in front of the deep groups, whose eight small nodes touch that many lanes)
+                const bool lop_c = a.lops_off < 0;
+                const int nact = lop_c ? rfl(((const GLOBAL_AS i32x4*)a.lopsc)[lop0].w >> 16) : a.d;
+                const float inv_n = lop_c ? frcp(nact > 0 ? nact : 1) : inv_d;
+                for (int idx = tid; idx < ROWS * nact && tid < qthreads; idx += qthreads) {
+                    const int row = fdiv(idx, inv_n);
+                    int col = idx - row * nact;
+                    unsigned w0, w1, w2;
+                    if (!lop_c) {
+                        const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
+                        w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
+                    } else {
+                        const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lopsc)[lop0 + col];
+                        w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
+                        col = lq.w & 0xffff;
+                    }
+#else
                 for (int idx = tid; idx < ROWS * a.d && tid < qthreads; idx += qthreads) {
                     const int row = fdiv(idx, inv_d), col = idx - row * a.d;
                     unsigned w0, w1, w2;
@@ -234,6 +253,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + col];
                         w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
                     }
+#endif
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
                     const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);

@@ -188,6 +188,7 @@ struct ThinRec {
 struct KArgs {
     const void* meta;              // [groups | units | tmap | ents | ranges | laneops] contiguous, copied to LDS at kernel start
     const void* lops;              // LaneOp[(n_groups + 1) * d] in global memory (used when lops_off < 0: table too big for LDS)
+    const void* lopsc;             // the same table with every boundary's ACTIVE lanes first: entry k = the ops of the k-th active lane, pad = its column | count << 16 (hint_bwd_fly.hip)
     const void* thins;             // ThinRec[2][total_tiles]: forward records, then backward records, tiles in (group, unit) order
     int32_t total_tiles;
     const void* recs;              // RowRec[2][total_rows]: forward records, then backward records, rows in (group, wavefront, unit) order

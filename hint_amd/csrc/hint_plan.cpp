@@ -906,6 +906,22 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
     if (e == hipSuccess) e = upload((void**)&P->d_lops, lops.data(), lops.size() * sizeof(LaneOp));
+    {
+        // per boundary the active lanes' entries first (entry k's pad names the k-th active lane: build_lane_ops), their column in pad
+        std::vector<LaneOp> lc(lops.size());
+        const int nb = (int)(lops.size() / (size_t)d);
+        for (int b = 0; b < nb; ++b) {
+            const int cnt = lops[(size_t)b * d].pad >> 16;
+            for (int k = 0; k < d; ++k) {
+                LaneOp op{};
+                op.sc_unit = -1; op.cp_ls = -1;
+                if (k < cnt) { const int col = lops[(size_t)b * d + k].pad & 0xffff; op = lops[(size_t)b * d + col]; op.pad = col; }
+                op.pad = (op.pad & 0xffff) | (cnt << 16);
+                lc[(size_t)b * d + k] = op;
+            }
+        }
+        if (e == hipSuccess) e = upload((void**)&P->d_lopsc, lc.data(), lc.size() * sizeof(LaneOp));
+    }
     if (e == hipSuccess) {
         std::vector<ThinRec> both(thin_f);
         both.insert(both.end(), thin_b.begin(), thin_b.end());
@@ -1039,6 +1055,7 @@ void hint_plan_destroy(hint_plan* P) {
     (void)hipFree(P->d_inv_lower);
     (void)hipFree(P->d_meta);
     (void)hipFree(P->d_lops);
+    (void)hipFree(P->d_lopsc);
     (void)hipFree(P->d_recs);
     (void)hipFree(P->d_thins);
     (void)hipFree(P->d_bmap);
