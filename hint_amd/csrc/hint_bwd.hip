@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 // (this instance's trees keep the lane table in global memory: the boundary's ACTIVE lanes only, from the compacted copy -
                 //  16 x 40-60 elements instead of 16 x 100 in front of the deep groups, whose eight small nodes touch that many lanes)
                 const bool lop_c = a.lops_off < 0;
-                const int nact = lop_c ? rfl(((const GLOBAL_AS i32x4*)a.lopsc)[lop0].w >> 16) : a.d;
+                const int nact = lop_c ? lds_i32(T.rng + a.lop_cnt + (tail_only ? a.n_groups : slot)) : a.d;
                 const float inv_n = lop_c ? frcp(nact > 0 ? nact : 1) : inv_d;
                 for (int idx = tid; idx < ROWS * nact && tid < qthreads; idx += qthreads) {
                     const int row = fdiv(idx, inv_n);

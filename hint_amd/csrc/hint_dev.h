@@ -227,6 +227,7 @@ struct KArgs {
     int32_t sub_misc;              // LDS float offset: forward nw x 16 log-det partials; backward two 256-float scratch tiles per wavefront
     int32_t sub_cols;              // index in the ranges table of the wavefronts' lane bounds: four per wavefront (hint_plan.cpp)
     int32_t packed_tiles, packed_lines;    // a block's packed buffer: 256-float tiles of [thin blobs | fragment tiles]; 128-byte lines with the biases behind them
+    int32_t lop_cnt;               // index in the ranges table of the backward boundaries' active-lane counts (boundary b = in front of group b; n_groups: the tail's)
     int32_t sink_lds;              // float offset in LDS of a 64-float sink for the L2 prefetch (hint_device.hpp prefetch_consumer); 0: no prefetch
     int32_t rowdw_lds;             // backward: float offset in LDS of one scratch tile (256 floats) per wavefront for the rows that compute dW1 | db1 themselves; 0: none do
 };

@@ -560,6 +560,10 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         rng.insert(rng.end(), sub_cols_v.begin(), sub_cols_v.end());
         P->sub_slab_f = 0; P->sub_slab_b = 0;       // (the nodes' partial sums stay in registers: no slabs in LDS; the offsets above are unused)
     }
+    // the backward lane tables (one boundary per group + the tail's); every boundary's count of active lanes rides in the ranges table
+    std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
+    P->lop_cnt = (int)rng.size();
+    for (size_t b = 0; b <= groups.size(); ++b) rng.push_back(lops[b * (size_t)d].pad >> 16);
     P->n_groups = (int)groups.size();
     P->n_units = (int)units.size();
     P->WT = wcol;
@@ -759,7 +763,6 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
     }
 
-    std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
 
     // ---- meta blob staged in LDS by the kernels ----
     std::vector<char> meta(P->meta_bytes, 0);
