@@ -99,7 +99,8 @@ int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm
     // straight into a 256-byte sink behind everything else (HINT_PF=0: never).  Not the wave-local kernels: the same touch a block
     // ahead is worth 6 us of 109 (forward) and 2 of 133 (backward) at cfg 2, but the call site - wherever it was put - costs their
     // register allocation 10 / 8 us (SGPR spills in the level loop), and from the block's top the issuing wavefront's own loads
-    // wait for it (+14 / +9 us)
+    // wait for it (+14 / +9 us); as straight-line code - a `buffer_load ... lds` every wavefront always issues, with an out-of-bound
+    // offset for the lanes that are not to touch anything - +2 / +6 us
     a->sink_lds = 0;
     const bool pf_off = std::getenv("HINT_PF") && env_int("HINT_PF") == 0;
     if (!P->wl && !pf_off && total + 256 <= LDS_LIMIT) {
