@@ -8,7 +8,7 @@ gradient deviates are looked up in the oracle: a row is ACCEPTED as a kink row o
 pre-activations lies within KINK_EPS = 1e-5 (x the row's largest pre-activation, at least 1) of zero - the
 distance float32 summation order can move it across.  Such rows are printed (index, the pre-activation,
 its deviation) and dropped, at most KINK_ROWS = 3 per case; anything else fails the sweep.
-   python tools/fuzz_parity.py [n_cases] [seed] [wide]"""
+   python tools/fuzz_parity.py [n_cases] [seed] [wide | deep | lean]"""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -55,6 +55,15 @@ for case in range(n_cases):
         widths = [rng.choice([16, 24, 33, 48, 67]) for _ in range(rng.randint(1, 2))] + [rng.choice([3, 8, 12, 16]) for _ in range(depth - 1)]
         dc = rng.choice([0, 0, 0, 0, 2])
         B = rng.choice([1, 16, 33, 257, 4112])
+    if len(sys.argv) > 3 and sys.argv[3] == "lean":
+        # wide trees whose deep levels are general groups of small nodes with 17..100 hidden units: the kernel instances whose rows
+        # make the thin layers themselves (hint_rows.hpp row_body FLY: hint_apply_kernel<REV, true>, hint_bwd_kernel_fly), odd
+        # tile counts, units of more than one row, the backward's active-lane boundaries
+        d = rng.choice([20, 26, 33, 43, 50, 64, 77, 100, 128])
+        depth = rng.randint(1, 3)
+        widths = [rng.choice([17, 24, 33, 48, 56, 64, 70, 100]) for _ in range(depth)]
+        dc = rng.choice([0, 0, 0, 0, 3])
+        B = rng.choice([1, 16, 33, 257, 1000])
     if not wide and d <= 16 and case % 10 == 7:
         B = rng.choice([4112, 6000])      # more row tiles than CUs: the launch picks the plan variant for large batches
     max_splits = rng.choice([-1, -1, 0, 1, 2])
