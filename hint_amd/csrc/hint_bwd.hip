@@ -22,6 +22,11 @@
 #ifndef HINT_PF_DIST
 #define HINT_PF_DIST 2
 #endif
+// (g2 / g1 tiles of groups that are not lean through LDS and out in whole lines at the next boundary: slower than the rows' own stores -
+//  cfg 5 backward 417 -> 396 us and part B, which reads them, 179 -> 172; d = 100 763 -> 754.  Lean staged groups keep g1 in LDS: their dW1 pass reads it.)
+#ifndef HINT_BWD_STAGE
+#define HINT_BWD_STAGE false
+#endif
 #include "hint_sub.hpp"
 
 using namespace hint;
@@ -170,8 +175,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 int qthreads = nthreads;                            // threads of the element-wise phase
                 // (the finished group's carving of the region: its g1 tiles and its slabs)
                 float* obuf = abuf + gp.ntiles * 256;
-                float* slab = obuf + (gp.staged ? gp.ntiles * 256 : 0);
-                if (has_prev && gp.staged) {
+                const bool gp_staged = gp.staged && (gp.lean || HINT_BWD_STAGE);      // (lean staged groups keep g1 in LDS for their dW1 pass)
+                float* slab = obuf + (gp_staged ? gp.ntiles * 256 : 0);
+                if (has_prev && gp_staged) {
                     const int need = (ROWS * a.d + 63) & ~63;
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
@@ -352,8 +358,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 STAMP(sid + 4)
                 // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
                 pc.out_thin = g.lean ? nullptr : (GLOBAL_AS float*)(blk.wsG1 + a.act_stride);
-                pc.obuf = g.staged ? (LDS_AS float*)(abuf + g.ntiles * 256) : nullptr;
-                pc.slab = (LDS_AS float*)(abuf + g.ntiles * 256 * (1 + g.staged));
+                const bool g_staged = g.staged && (g.lean || HINT_BWD_STAGE);
+                pc.obuf = g_staged ? (LDS_AS float*)(abuf + g.ntiles * 256) : nullptr;
+                pc.slab = (LDS_AS float*)(abuf + g.ntiles * 256 * (1 + g_staged));
                 {
                     int rnext = -1;         // the last row hands the weight ring to the wavefront's first row of the next group
                     if (slot > a.n_sub) {

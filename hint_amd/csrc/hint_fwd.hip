@@ -19,6 +19,9 @@
 #ifndef HINT_PF_DIST
 #define HINT_PF_DIST 2
 #endif
+#ifndef HINT_FWD_STAGE
+#define HINT_FWD_STAGE false
+#endif
 #ifndef HINT_FLY_ON
 #define HINT_FLY_ON true
 #endif
@@ -180,8 +183,12 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 pc.xs = (const LDS_AS float*)(XS);
                 pc.wcol0 = g.wcol0;
                 float* obuf = abuf + g.ntiles * 256;
-                float* slab = obuf + (g.staged ? g.ntiles * 256 : 0);
-                pc.obuf = g.staged ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
+                // (output tiles through LDS and out in whole lines by the element-wise phase's idle wavefronts - what the planner's "staged"
+                //  meant for the forward too until round 4 - is slower than the rows' own non-temporal stores: cfg 5 forward 300 -> 280 us,
+                //  d = 100 632 -> 604, h = 512 913 -> 923; off at compile time, the code path costs 10 us by being there)
+                const bool gstaged = g.staged && HINT_FWD_STAGE;
+                float* slab = obuf + (gstaged ? g.ntiles * 256 : 0);
+                pc.obuf = gstaged ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
                 pc.out_thin = (train && !g.lean) ? (GLOBAL_AS float*)blk.actA1 : nullptr;
                 const int sid = (cb * a.n_groups + gi) * 16;
                 (void)sid;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 //      tape (training), out of LDS, whole lines per batch row ----
                 const int nsub = g.ent_cnt <= 4 ? 4 : 16;
                 const int ncpl = ROWS * nsub;                     // threads of the coupling
-                if (train && g.staged) {
+                if (train && gstaged) {
                     const int soff = nthreads > ncpl ? ncpl : 0;   // (a workgroup of one coupling's size does both in turn)
                     if (tid >= soff) {
                         if (!g.lean) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);

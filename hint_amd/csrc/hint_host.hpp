@@ -105,6 +105,7 @@ struct hint_plan {
     int xld = 0, cld = 0, gld = 0, abuf_tiles = 0, slab_fwd = 0, slab_bwd = 0;
     int region_fwd = 0, region_bwd = 0;   // LDS floats of the per-group region [tiles | staged output tiles | slabs]
     int stage_out = 1;
+    int max_h = 0;              // widest hidden layer of the block
     int has_fly = 0;            // some general (not subtree) group is lean: the forward kernel's instance whose rows make such groups' first layer themselves
     int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
     int fuse_dw1 = 0;           // lean plans with LDS-staged outputs: dW1, db1 come from the backward kernel (per-workgroup slabs), g1 stays on chip

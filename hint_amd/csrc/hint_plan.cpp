@@ -564,6 +564,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
     P->lop_cnt = (int)rng.size();
     for (size_t b = 0; b <= groups.size(); ++b) rng.push_back(lops[b * (size_t)d].pad >> 16);
+    for (const Unit& u : units) P->max_h = std::max(P->max_h, (int)u.h);
     P->n_groups = (int)groups.size();
     P->n_units = (int)units.size();
     P->WT = wcol;
