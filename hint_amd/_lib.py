@@ -30,6 +30,8 @@ _PROTOS = {
     "hint_abi_version": (C.c_int, []),
     "hint_last_error": (C.c_char_p, []),
     "hint_build_info": (C.c_char_p, []),
+    "hint_debug_set_prefetch": (C.c_int, [C.c_int]),
+    "hint_debug_last_lds_bytes": (C.c_int32, [C.c_int32]),
     "hint_plan_create": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.POINTER(C.c_void_p)]),
     "hint_plan_check": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,

@@ -3,6 +3,8 @@
 // hint_wl_*.hip / hint_wgrad.hip / hint_pack.hip / hint_optim.hip.
 #include "hint_host.hpp"
 
+#include <atomic>
+
 using namespace hint;
 
 static thread_local std::string g_err;
@@ -84,30 +86,53 @@ int64_t ws_thin_off(const hint_plan* P, int B) {        // floats from the part-
     return (int64_t)splits * P->param_floats;
 }
 
+// Run-time knobs, read ONCE (getenv on the launch path is neither cheap nor safe beside a setenv in another thread; a captured
+// hipGraph keeps what was read at capture time anyway).  The L2 warm-up has an explicit setter for the tests and A/B runs
+// (hint_debug_set_prefetch): its initial value comes from HINT_PF (0 = off).
+static std::atomic<int> g_l2_prefetch{-1};
+static std::atomic<int> g_last_lds[2] = {{0}, {0}};     // dynamic LDS bytes of the last row-kernel launch: [0] forward / inverse, [1] backward part A
+bool l2_prefetch_on() {
+    int v = g_l2_prefetch.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = (std::getenv("HINT_PF") && env_int("HINT_PF") == 0) ? 0 : 1;
+        g_l2_prefetch.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+static int perm_lds_cap() { static const int cap = env_int("HINT_PERM_LDS_MAX") > 0 ? env_int("HINT_PERM_LDS_MAX") : PERM_LDS_MAX; return cap; }
+static bool plan_dump() { static const bool on = env_int("HINT_PLAN_DUMP") != 0; return on; }
+static bool no_bwd_fly() { static const bool off = env_int("HINT_NO_BWD_FLY") != 0; return off; }
+
+// the 256-byte sink of the general kernels' L2 warm-up (hint_device.hpp prefetch_consumer) behind everything else of the launch
+static int add_sink(const hint_plan* P, int total, KArgs* a) {
+    a->sink_lds = 0;
+    if (!P->wl && l2_prefetch_on() && total + 256 <= LDS_LIMIT) {
+        a->sink_lds = total / (int)sizeof(float);
+        total += 256;
+    }
+    return total;
+}
+
 // LDS bytes of the launch: the plan's, plus the chain's permutation matrices when they fit behind it
 int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a) {
     const long extra = (long)n_blocks * P->d * P->d * (long)sizeof(float);
     a->perm_lds = 0;
-    const int cap = env_int("HINT_PERM_LDS_MAX") > 0 ? env_int("HINT_PERM_LDS_MAX") : PERM_LDS_MAX;
-    if (env_int("HINT_PLAN_DUMP")) fprintf(stderr, "[hint plan] lds %d + perms %ld (cap %d)\n", lds_plan, extra, cap);
+    const int cap = perm_lds_cap();
+    if (plan_dump()) fprintf(stderr, "[hint plan] lds %d + perms %ld (cap %d)\n", lds_plan, extra, cap);
     int total = lds_plan;
     if (any_perm && extra <= cap && lds_plan + extra <= LDS_LIMIT) {
         a->perm_lds = lds_plan / (int)sizeof(float);
         total += (int)extra;
     }
     // the general kernels warm the L2 with the weights of what comes two phases later (hint_device.hpp prefetch_consumer): loads
-    // straight into a 256-byte sink behind everything else (HINT_PF=0: never).  Not the wave-local kernels: the same touch a block
-    // ahead is worth 6 us of 109 (forward) and 2 of 133 (backward) at cfg 2, but the call site - wherever it was put - costs their
-    // register allocation 10 / 8 us (SGPR spills in the level loop), and from the block's top the issuing wavefront's own loads
-    // wait for it (+14 / +9 us); as straight-line code - a `buffer_load ... lds` every wavefront always issues, with an out-of-bound
-    // offset for the lanes that are not to touch anything - +2 / +6 us
-    a->sink_lds = 0;
-    const bool pf_off = std::getenv("HINT_PF") && env_int("HINT_PF") == 0;
-    if (!P->wl && !pf_off && total + 256 <= LDS_LIMIT) {
-        a->sink_lds = total / (int)sizeof(float);
-        total += 256;
-    }
-    if (env_int("HINT_PLAN_DUMP")) fprintf(stderr, "[hint plan] packed lines %d: sink at %d, lds %d\n", a->packed_lines, a->sink_lds, total);
+    // straight into a 256-byte sink behind everything else (hint_debug_set_prefetch(0) / HINT_PF=0: never).  Not the wave-local
+    // kernels: the same touch a block ahead is worth 6 us of 109 (forward) and 2 of 133 (backward) at cfg 2, but the call site -
+    // wherever it was put - costs their register allocation 10 / 8 us (SGPR spills in the level loop), and from the block's top the
+    // issuing wavefront's own loads wait for it (+14 / +9 us); as straight-line code - a `buffer_load ... lds` every wavefront
+    // always issues, with an out-of-bound offset for the lanes that are not to touch anything - +2 / +6 us
+    total = add_sink(P, total, a);
+    if (plan_dump()) fprintf(stderr, "[hint plan] packed lines %d: sink at %d, lds %d\n", a->packed_lines, a->sink_lds, total);
+    g_last_lds[0].store(total, std::memory_order_relaxed);
     return total;
 }
 KArgs make_args(const hint_plan* P, int B, bool backward) {
@@ -171,10 +196,15 @@ int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* ch
         if (chain_host) for (int i = 0; i < n_chain; ++i) any_perm = any_perm || chain_host[i].perm != nullptr;
         const int lds = lds_with_perms(P, plan_lds(P, true, nr), n_chain, any_perm, &a);
         w.off_perm = a.perm_lds;
+        g_last_lds[1].store(lds, std::memory_order_relaxed);
         HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
     } else if (parts & 1) {
         // (the permutation matrices stay in global memory here: one d x d product per block)
-        HIP_TRY((P->has_fly && !env_int("HINT_NO_BWD_FLY") ? launch_bwd_fly : P->row_ntt <= 3 && P->rowdw_lds == 0 ? launch_bwd_n3 : launch_bwd)(make_args(P, B, true), P->lds_bwd, grid_for(P, B), one, chain, n_chain, x, c,
+        // (round 5: the backward's L2 warm-up gets its sink too - until then KArgs::sink_lds was 0 here and the block in hint_bwd.hip dead code)
+        KArgs a = make_args(P, B, true);
+        const int lds = add_sink(P, P->lds_bwd, &a);
+        g_last_lds[1].store(lds, std::memory_order_relaxed);
+        HIP_TRY((P->has_fly && !no_bwd_fly() ? launch_bwd_fly : P->row_ntt <= 3 && P->rowdw_lds == 0 ? launch_bwd_n3 : launch_bwd)(a, lds, grid_for(P, B), one, chain, n_chain, x, c,
                                                                g_z, g_J, g_x, g_c, gz_scale, gJ_const, s));
     }
     if (!(parts & 2)) return 0;
@@ -229,6 +259,12 @@ const char* hint_build_info(void) {
     return info.c_str();
 }
 const char* hint_last_error(void) { return g_err.c_str(); }
+
+int hint_debug_set_prefetch(int on) {
+    hint::l2_prefetch_on();        // (so that the previous value is the environment's, not "unread")
+    return g_l2_prefetch.exchange(on ? 1 : 0);
+}
+int32_t hint_debug_last_lds_bytes(int32_t backward) { return g_last_lds[backward ? 1 : 0].load(std::memory_order_relaxed); }
 
 int64_t hint_plan_param_floats(const hint_plan* P) { return P ? P->param_floats : -1; }
 // + 4 KiB of slack behind the bias region (a padded row's dummy steps load up to three tiles past its last)

@@ -163,6 +163,7 @@ void set_dw_stamps(unsigned long long* p);      // hint_wgrad.hip (diagnostic bu
 #endif
 
 // hint_abi.cpp
+bool l2_prefetch_on();       // the general kernels' L2 warm-up (HINT_PF / hint_debug_set_prefetch)
 const hint_plan* variant(const hint_plan* P, int B);
 int wl_nr_for(const hint_plan* Pv, int B);
 int64_t tape_act_off(const hint_plan* P, int B);

@@ -287,6 +287,14 @@ const char* hint_last_error(void);
  * runtime of the machine that loads it may differ - bench.py prints both) */
 const char* hint_build_info(void);
 
+/* Diagnostics (process-wide; no effect on any result).  The general kernels touch the packed weights of what runs two
+ * phases later into an LDS sink nobody reads (an L2 warm-up; on unless the environment says HINT_PF=0 when the library
+ * first launches): hint_debug_set_prefetch(0 / 1) switches it for the launches that follow and returns the previous
+ * setting - a launch already captured in a hipGraph keeps what it was captured with.  hint_debug_last_lds_bytes(backward)
+ * = dynamic LDS bytes of the process's last forward / inverse (0) or backward part-A (1) launch. */
+int hint_debug_set_prefetch(int on);
+int32_t hint_debug_last_lds_bytes(int32_t backward);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,13 +32,23 @@ WORKLOADS = [
     # (configs/uci_data/gas_hint_8.py:29-36,55-71 at its batch of 8192; power_hint_8 at the same size)
     ("cfg3_gas_hint_8_B8192", 8, 0, 8, [128, 64, 32, 16], 8192, 0.06),
     ("cfg2_power_hint_8_B8192", 6, 0, 8, [140, 70, 35, 17], 8192, 0.06),
+    # gradients at the batch sizes the general plans really run at: more row tiles than the chip has CUs (273 tiles, the last
+    # one ragged: the persistent tile loop of hint_apply_kernel / hint_bwd_kernel_fly and part B's row splits at d = 100 - the
+    # reference's own batch for cfg 4 is 10 000 rows, configs/plus_shape/conditional_hint_4_full.py:37), with and without a
+    # condition, and cfg 5's whole chain at its per-GPU batch (configs/uci_data/miniboone_hint_8.py; BASELINE cfg 5: 4096 rows per GPU)
+    ("cfg4_plus_x_lane_B4368", 100, 0, 2, [224, 112, 56], 4368, 0.03),
+    ("cfg4_plus_x_lane_cond_B4368", 100, 4, 2, [224, 112, 56], 4368, 0.03),
+    ("cfg5_miniboone_hint_10_B4096", 43, 0, 10, [67, 33, 16, 8], 4096, 0.06),
 ]
+LARGE = {"cfg4_plus_x_lane_B4368", "cfg4_plus_x_lane_cond_B4368", "cfg5_miniboone_hint_10_B4096"}
 # at most this share of a batch may be left out as "next to a ReLU kink": per workload the share observed on MI355X
 # (deterministic: seeded inputs, the float64 oracle decides) + 3 points; the counts of a run go to gpurun_out/kink_rows.json
 MAX_KINK_ROWS = {
     # observed (round 4, gpurun_out/kink_rows.json): 9/1024, 7/512, 16/160, 3/96, 3/200, 2/48, 96/8192, 78/8192
     "cfg2_power_hint_8": 0.04, "cfg3_gas_hint_8": 0.045, "cfg4_plus_x_lane": 0.13, "cfg4_plus_x_lane_cond": 0.065,
     "cfg5_miniboone_hint_10": 0.045, "plus_hint_4_big": 0.075, "cfg3_gas_hint_8_B8192": 0.042, "cfg2_power_hint_8_B8192": 0.04,
+    # (round 5, decided by the float64 oracle on the CPU: 138/4368, 156/4368, 64/4096)
+    "cfg4_plus_x_lane_B4368": 0.062, "cfg4_plus_x_lane_cond_B4368": 0.066, "cfg5_miniboone_hint_10_B4096": 0.046,
 }
 
 
@@ -104,8 +114,11 @@ def flat_grads(tr, flow):
     return out
 
 
-@pytest.mark.parametrize("name,d,dc,n_blocks,widths,B,scale", WORKLOADS, ids=[w[0] for w in WORKLOADS])
+@pytest.mark.parametrize("name,d,dc,n_blocks,widths,B,scale",
+                         [pytest.param(*w, marks=pytest.mark.timeout(900)) if w[0] in LARGE else w for w in WORKLOADS],
+                         ids=[w[0] for w in WORKLOADS])
 def test_chain_nll_gradient_and_inverse_match_oracle(name, d, dc, n_blocks, widths, B, scale):
+    torch.set_num_threads(min(16, torch.get_num_threads()))      # (the float64 oracle: a GPU box has 256 host cores)
     ref, flow = make_pair(d, dc, n_blocks, widths, scale)
     g = torch.Generator().manual_seed(7)
     x64 = torch.randn(B, d, generator=g, dtype=torch.float64).float().double()
@@ -192,10 +205,14 @@ def test_weight_gradients_are_deterministic(d, dc, n_blocks, widths, B):
 
 @pytest.mark.parametrize("d,dc,n_blocks,widths,B", [(43, 0, 3, [67, 33, 16, 8], 200), (100, 0, 2, [224, 112, 56], 96),
                                                     (100, 4, 2, [224, 112, 56], 48)])
-def test_l2_prefetch_changes_no_result(d, dc, n_blocks, widths, B, monkeypatch):
+def test_l2_prefetch_changes_no_result(d, dc, n_blocks, widths, B):
     """the general kernels' L2 warm-up (hint_device.hpp prefetch_consumer: loads into an LDS sink nobody reads, two
-    consumers ahead) is a hint: losses, z, log-dets and gradients with it (default) and without it (HINT_PF=0, read at
-    every launch) are bit-identical - subtree plan (cfg 5 shape), general plan (cfg 4's x lane), with a condition"""
+    consumers ahead) is a hint: losses, z, log-dets and gradients with it (default) and without it
+    (hint_debug_set_prefetch(0)) are bit-identical - subtree plan (cfg 5 shape), general plan (cfg 4's x lane), with a
+    condition.  That the switch reaches BOTH row kernels is read off the launches' LDS sizes: the sink is 256 bytes
+    behind everything else (round 4's backward launch never had one: its warm-up was dead code)."""
+    from hint_amd import _lib
+    lib = _lib.load()
     torch.manual_seed(11)
     flow = hint_amd.HintFlow(d, n_blocks, widths, ndim_c=dc).to(DEV)
     with torch.no_grad():
@@ -205,18 +222,25 @@ def test_l2_prefetch_changes_no_result(d, dc, n_blocks, widths, B, monkeypatch):
     c = torch.randn(B, dc, device=DEV) if dc else None
     tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
     tr._check_arenas()
-    outs = []
-    for pf in ("0", None, "0"):
-        if pf is None:
-            monkeypatch.delenv("HINT_PF", raising=False)
-        else:
-            monkeypatch.setenv("HINT_PF", pf)
-        tr.G.zero_()
-        tr._fwd_bwd(x, c)
-        torch.cuda.synchronize()
-        outs.append([tr.G.clone(), tr.loss_acc.clone()])      # flat gradient; the two loss sums (0.5 |z|^2, log-det) of the forward
+    outs, lds = [], []
+    before = lib.hint_debug_set_prefetch(1)
+    try:
+        for pf in (0, 1, 0):
+            lib.hint_debug_set_prefetch(pf)
+            tr.G.zero_()
+            tr._fwd_bwd(x, c)
+            torch.cuda.synchronize()
+            outs.append([tr.G.clone(), tr.loss_acc.clone()])      # flat gradient; the two loss sums (0.5 |z|^2, log-det) of the forward
+            lds.append((lib.hint_debug_last_lds_bytes(0), lib.hint_debug_last_lds_bytes(1)))
+    finally:
+        lib.hint_debug_set_prefetch(before)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     for a, b in zip(outs[1], outs[2]):
         assert torch.equal(a, b)
     assert torch.isfinite(outs[0][0]).all() and outs[0][0].abs().sum().item() > 0
+    assert lds[0] == lds[2]
+    # (a plan that fills the 160 KiB has no room for the sink: then the sizes agree and nothing was switched)
+    for k in (0, 1):
+        assert lds[1][k] in (lds[0][k], lds[0][k] + 256), lds
+    assert lds[1][0] == lds[0][0] + 256 and lds[1][1] == lds[0][1] + 256, lds
