@@ -48,6 +48,46 @@ __device__ __forceinline__ float kq_sum(float v) {
     return __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
 }
 
+// The fixed d x d matrix between two blocks (d <= 16: one 16-column tile) on a wavefront's PRIVATE lane tile, on the matrix pipe:
+// out[r][j] = sum_k in[r][k] M(k, j), M(k, j) = w[k d + j] (x' = x W) or, TRANS, w[j d + k] (x = x' W^T, g_x = g_x' W^T), transposed
+// like every product here (out^T = M^T in^T): lane (m, kq) supplies M(4 t + kq, m) and in[m][4 t + kq] to step t and ends with
+// columns 4 kq .. + 3 of row m.  All operand reads are in flight together, then ceil(d / 4) dependent MFMAs: as scalar code
+// (perm_dot: per element d dependent FMAs with two LDS reads each, two passes over the 16 x d tile) this cost every block of the
+// wave-local kernels ~1.5 k cycles in every wavefront - round 5 stamps.  k ascends inside an MFMA and across the steps, as it did.
+template <bool TRANS, typename WP>
+__device__ __forceinline__ void wl_perm(float* dst, const float* src, int ld, WP w, int d, int lane) {
+    const int m = lane & 15, kq = lane >> 4;
+    float av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = 4 * t + kq;
+        const int kc = k < d ? k : 0, mc = m < d ? m : 0;
+        av[t] = TRANS ? w[mc * d + kc] : w[kc * d + mc];
+        bv[t] = src[m * ld + kc];
+    }
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (4 * t < d) {        // (wave-uniform)
+            const bool ok = 4 * t + kq < d;
+            acc = mfma4((ok && m < d) ? av[t] : 0.f, ok ? bv[t] : 0.f, acc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (4 * kq + i < d) dst[m * ld + 4 * kq + i] = acc[i];
+}
+
+// A wavefront's share of a [16, d] tile -> a row-major [B, d] array: every wavefront holds the whole tile (its private copy), so
+// each stores 1 / nw of it - one pass of one store instruction per wavefront instead of two passes by ONE wavefront that the
+// other seven then wait for at the level's barrier (round 5 stamps: + 0.9 k cycles on the writing wavefront).
+__device__ __forceinline__ void wl_store_share(float* __restrict__ dst, const float* tile, int ld, int d, float inv_d, int nvalid,
+                                               int wave, int nw, int lane) {
+    const int per = (ROWS * d + nw - 1) / nw;        // <= 64 for d <= 16 on >= 4 wavefronts
+    const int i = wave * per + lane;
+    if (lane < per && i < nvalid) { const int r = fdiv(i, inv_d); dst[i] = tile[r * ld + (i - r * d)]; }
+}
+
 typedef unsigned wl_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 wl_as_f32x4(wl_u32x4 v) { return __builtin_bit_cast(f32x4, v); }
 // relu'(.) from four sign bits: bit i sign-extended to 0 / -1 and and-ed onto element i (two instructions per element)

@@ -282,12 +282,10 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
 #pragma unroll
-                for (int h = 0; h < NR; ++h)
-                    for (int i = lane; i < ROWS * a.d; i += 64) {
-                        const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        GO(h)[r * a.xld + j] = a.perm_lds > 0 ? perm_dot(GS(h) + r * a.xld, (const LDS_AS float*)(ptab + cb * pdd) + j * a.d, 1, a.d)
-                                                               : perm_dot(GS(h) + r * a.xld, (const GLOBAL_AS float*)perm + (size_t)j * a.d, 1, a.d);
-                    }
+                for (int h = 0; h < NR; ++h) {
+                    if (a.perm_lds > 0) wl_perm<true>(GO(h), GS(h), a.xld, (const LDS_AS float*)(ptab + cb * pdd), a.d, lane);
+                    else wl_perm<true>(GO(h), GS(h), a.xld, (const GLOBAL_AS float*)perm, a.d, lane);
+                }
                 gcur = tl - gcur;
             }
         }

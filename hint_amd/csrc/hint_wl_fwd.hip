@@ -111,21 +111,18 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             if (!REV && perm != nullptr) {
                 // fused fixed permutation in front of the block (power_hint_8.py:59-62): x' = x W
 #pragma unroll
-                for (int h = 0; h < NR; ++h)
-                    for (int i = lane; i < ROWS * a.d; i += 64) {
-                        const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        XO(h)[r * a.xld + j] = a.perm_lds > 0 ? perm_dot(XS(h) + r * a.xld, (const LDS_AS float*)(ptab + bi * pdd) + j, a.d, a.d)
-                                                               : perm_dot(XS(h) + r * a.xld, (const GLOBAL_AS float*)perm + j, a.d, a.d);
-                    }
+                for (int h = 0; h < NR; ++h) {
+                    if (a.perm_lds > 0) wl_perm<false>(XO(h), XS(h), a.xld, (const LDS_AS float*)(ptab + bi * pdd), a.d, lane);
+                    else wl_perm<false>(XO(h), XS(h), a.xld, (const GLOBAL_AS float*)perm, a.d, lane);
+                }
                 xcur = xflip - xcur;
             }
-            if (!REV && tape != nullptr && (perm != nullptr || cb > 0) && wave == tsel) {
+            if (!REV && tape != nullptr && (perm != nullptr || cb > 0)) {
                 // the block's input exists nowhere else: the top tape slice is what the backward pass starts from
+                // (every wavefront stores its share of its own copy)
 #pragma unroll
-                for (int h = 0; h < NR; ++h) {
-                    float* dst = tape + (size_t)(a.n_levels - 1) * lvl + (size_t)row0[h] * a.d;
-                    for (int i = lane; i < nvalid[h]; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS(h)[r * a.xld + (i - r * a.d)]; }
-                }
+                for (int h = 0; h < NR; ++h)
+                    wl_store_share(tape + (size_t)(a.n_levels - 1) * lvl + (size_t)row0[h] * a.d, XS(h), a.xld, a.d, inv_d, nvalid[h], wave, a.nw, lane);
             }
             // the next block's thin vectors and biases: in flight across this block's first group
             f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
@@ -231,23 +228,19 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     if (a.n_groups == 1) lds_barrier();
                 }
                 // training: the lane tile as it stands after each level except the root's (tape[level][B][d])
-                if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1 && wave == tsel) {
+                if (!REV && tape != nullptr && g.level_last && g.level < a.n_levels - 1) {
 #pragma unroll
-                    for (int h = 0; h < NR; ++h) {
-                        float* dst = tape + (size_t)g.level * lvl + (size_t)row0[h] * a.d;
-                        for (int i = lane; i < nvalid[h]; i += 64) { const int r = fdiv(i, inv_d); dst[i] = XS(h)[r * a.xld + (i - r * a.d)]; }
-                    }
+                    for (int h = 0; h < NR; ++h)
+                        wl_store_share(tape + (size_t)g.level * lvl + (size_t)row0[h] * a.d, XS(h), a.xld, a.d, inv_d, nvalid[h], wave, a.nw, lane);
                 }
                 STAMP(sid + 5)
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
 #pragma unroll
-                for (int h = 0; h < NR; ++h)
-                    for (int i = lane; i < ROWS * a.d; i += 64) {
-                        const int r = fdiv(i, inv_d), j = i - r * a.d;
-                        XO(h)[r * a.xld + j] = a.perm_lds > 0 ? perm_dot(XS(h) + r * a.xld, (const LDS_AS float*)(ptab + bi * pdd) + j * a.d, 1, a.d)
-                                                               : perm_dot(XS(h) + r * a.xld, (const GLOBAL_AS float*)perm + (size_t)j * a.d, 1, a.d);
-                    }
+                for (int h = 0; h < NR; ++h) {
+                    if (a.perm_lds > 0) wl_perm<true>(XO(h), XS(h), a.xld, (const LDS_AS float*)(ptab + bi * pdd), a.d, lane);
+                    else wl_perm<true>(XO(h), XS(h), a.xld, (const GLOBAL_AS float*)perm, a.d, lane);
+                }
                 xcur = xflip - xcur;
             }
         }
