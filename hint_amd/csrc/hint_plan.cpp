@@ -184,9 +184,14 @@ static std::vector<LaneOp> build_lane_ops(std::vector<Group>& groups, const std:
         }
         // the boundary's ACTIVE lanes (something to add or a coupling gradient to form), compacted: entry k's `pad` holds the k-th
         // active lane | count << 16 - the wave-local backward kernel walks 16 rows x count lanes instead of 16 x d
+        // (the lanes that carry a coupling first, the scatter-only lanes behind them: the wave-local kernel walks the list 4 lanes x 16
+        //  rows per pass, and a pass without a coupling skips atanf / expf - cfg 2's leaf boundary is 4 + 1 lanes, GAS's 4 + 2)
         int cnt = 0;
-        for (int col = 0; col < d; ++col)
-            if (lops[(size_t)b * d + col].sc_unit >= 0 || lops[(size_t)b * d + col].cp_ls >= 0) lops[(size_t)b * d + cnt++].pad = col;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int col = 0; col < d; ++col) {
+                const LaneOp& o = lops[(size_t)b * d + col];
+                if (pass == 0 ? o.cp_ls >= 0 : (o.cp_ls < 0 && o.sc_unit >= 0)) lops[(size_t)b * d + cnt++].pad = col;
+            }
         for (int k = 0; k < d; ++k) lops[(size_t)b * d + k].pad = (k < cnt ? lops[(size_t)b * d + k].pad : 0) | (cnt << 16);
         if (b < n_groups) groups[b].lop_begin = b * d;
     }

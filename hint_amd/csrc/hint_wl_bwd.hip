@@ -169,9 +169,9 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 //  three boundaries of a block have 3, 5 and 2 active lanes of 6)
                 const int nact = a.lops_off >= 0 ? (int)((unsigned)lds_i32((const LDS_AS int32_t*)(T.lops + lop0) + 3) >> 16)
                                                  : (int)((unsigned)rfl(((const GLOBAL_AS i32x4*)a.lops)[lop0].w) >> 16);
-                const float inv_act = frcp(nact > 0 ? nact : 1);
+                // (lane-major: a pass of the loop is four active lanes x 16 rows; the planner lists the lanes with a coupling first)
                 for (int idx = lane; idx < ROWS * nact; idx += 64) {
-                    const int row = fdiv(idx, inv_act), kk = idx - row * nact;
+                    const int row = idx & 15, kk = idx >> 4;
                     int col;
                     unsigned w0, w1, w2;
                     if (a.lops_off >= 0) {
