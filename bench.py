@@ -497,8 +497,18 @@ def run_flow(args, name, rank, world, dev, use_dist, dist, headline):
     # this process - the line says where it was read from
     pmc, pmc_file = newest_pmc(name) if B == cfg["batch"] else ({}, None)
 
-    def pmc_entry(kernel):             # rocprof's kernel names carry the template arguments: match on the prefix
-        return next((v for k, v in pmc.items() if k.replace(" ", "").startswith(kernel.replace(" ", ""))), None)
+    def pmc_entry(kernel):
+        # rocprof's kernel names carry the template arguments: the full name must match (hint_bwd_kernel is a prefix of
+        # hint_bwd_kernel_n3 and hint_bwd_kernel_fly); a summary of an older build, whose instances had fewer template
+        # arguments, matches when exactly one of its kernels has the same base name and leading arguments
+        want = kernel.replace(" ", "")
+        keys = {k.replace(" ", ""): v for k, v in pmc.items()}
+        if want in keys:
+            return keys[want]
+        base, _, targs = want.partition("<")
+        cand = [v for k, v in keys.items() if k.partition("<")[0] == base and
+                (not targs or not k.partition("<")[2] or targs.startswith(k.partition("<")[2].rstrip(">")))]
+        return cand[0] if len(cand) == 1 else None
 
     def mfma_roofline(kernel, us, flops):
         ach = flops / (us * 1e-6) / 1e12

@@ -249,6 +249,7 @@ struct WlArgs {
     int32_t off_priv;       // per wavefront: priv_stride floats = nr x priv_tile (+ backward: one scratch tile)
     int32_t priv_stride, priv_tile;
     int32_t off_misc;       // 32 floats shared: g_J of the tiles' rows
+    int32_t off_recs;       // the direction's row records (16 ints each, KArgs::total_rows of them), staged once per kernel
     int32_t nr;             // 16-row tiles per workgroup: 1, or 2 (a row pair on one weight stream)
 };
 

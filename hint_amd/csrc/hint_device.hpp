@@ -48,8 +48,9 @@ struct GBlock {
     GLOBAL_AS float* wsSlab;
     GLOBAL_AS float* gparams;
 };
+template <int MODE = 0>        // 0: whichever is there; 1: the table (chained launch); 2: the by-value block
 __device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ chain, const ChainBlock& one, int i) {
-    const ChainBlock b = (chain != nullptr) ? chain[i] : one;
+    const ChainBlock b = MODE == 1 ? chain[i] : MODE == 2 ? one : (chain != nullptr) ? chain[i] : one;
     GBlock g;
     g.params = (const GLOBAL_AS float*)b.params;
     g.packed = (const GLOBAL_AS float*)b.packed;

@@ -608,6 +608,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     const int par_f4 = (par_bias + (int)bmap.size() + 3) / 4;
     bool wl = P->lean && dc == 0 && d <= 4 * WL_LV && par_f4 <= WL_PAR_REGS * 64 * nw;
     for (const Unit& u : units) if (u.xoff > 255 || u.h > 32767) wl = false;
+    // (the wave-local kernels read the lane table from LDS only and keep per-group tables in the 64 lanes of a register)
+    if ((groups.size() + 1) * (size_t)d * sizeof(LaneOp) > 16 * 1024 || groups.size() + 1 > 64 || ents.size() > 65535) wl = false;
     if (const char* e = std::getenv("HINT_WL")) if (std::atoi(e) == 0) wl = false;
     // ---- LDS: the meta blob's size, then per group the region [its tiles | its output tiles, staged for the element-wise
     //      phase to stream out, when there is room | its slabs]; the launch reserves the largest group's ----
@@ -682,7 +684,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             wf.priv_tile = r4(2 * ROWS * P->xld); wf.priv_stride = nr * wf.priv_tile;
             wb.priv_tile = r4(4 * ROWS * P->xld + r4(ROWS * P->gld)); wb.priv_stride = nr * wb.priv_tile + 256;
             wf.off_misc = wf.off_priv + nw * wf.priv_stride; wb.off_misc = wb.off_priv + nw * wb.priv_stride;
-            wf.off_perm = wf.off_misc + 32; wb.off_perm = wb.off_misc + 32;
+            wf.off_recs = wf.off_misc + 32; wb.off_recs = wb.off_misc + 32;
+            wf.off_perm = wf.off_recs + 16 * (int)recs_f.size(); wb.off_perm = wb.off_recs + 16 * (int)recs_b.size();
             const bool fits = 4 * wf.off_perm <= LDS_LIMIT && 4 * wb.off_perm <= LDS_LIMIT && (nr == 1 || par_f4 <= WL_PAR_REGS2 * 64 * nw);
             if (nr == 1 && !fits) { wl = false; break; }
             if (fits) { P->wl_f[nr - 1] = wf; P->wl_b[nr - 1] = wb; if (nr == 2) P->wl_nr2 = 1; }

@@ -117,7 +117,7 @@ struct WlCtx {
     const GLOBAL_AS float* pk_next;      // ... of the block worked on next (the last row of a block hands the ring over)
     const GLOBAL_AS uint8_t* bits[2];    // backward: a2 sign bytes of the row tiles (this block, the next one)
     const GLOBAL_AS uint8_t* bits_next[2];
-    const void* recs;                    // this direction's row records
+    const LDS_AS int32_t* lrecs;         // this direction's row records, staged in LDS at kernel start (16 ints each)
     const LDS_AS float* par;             // the block's staged thin vectors and biases
     LDS_AS float* slab;                  // the group's slab set of row tile 0 (tile 1: + slab_h)
     const LDS_AS float* xs[2];           // private lane tiles: the inputs of the level's first layers
@@ -158,6 +158,34 @@ __device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float
         }
     }
 }
+
+// ---- bookkeeping without memory round trips (round 5) ----
+// Round 5's stamps: of a block's 33 k cycles in the forward kernel 2.7 k went into FINDING the wavefront's rows - per group a chain
+// of dependent LDS reads through the group and range tables, then a scalar load of the first row's record with its wait (which
+// drains the LDS counter as well) - and the plan is the same for every block of the chain.  Now:
+//  * per wavefront three tables in VGPR LANES, filled once per kernel: lane e = the e-th group in execution order; a group costs
+//    v_readlane instructions instead of LDS reads and waits;
+//  * the row records of the direction are staged in LDS once and travel in ONE VGPR (lane i holds int i of the 16), two rows ahead
+//    and ACROSS groups and blocks: the record that follows a group's last row is the next group's first - it is there when that
+//    group starts, and it costs a vector register, not sixteen scalar ones (they spill); fields are moved to scalar registers
+//    (v_readlane) where they are used.
+struct RecV { int v; };        // lane i (mod 16) holds int i of the record: ONE register
+__device__ __forceinline__ RecV wl_rec_fetch(const LDS_AS int32_t* lrecs, int idx, int lane) {
+    RecV r;
+    r.v = lrecs[idx * 16 + (lane & 15)];
+    return r;
+}
+__device__ __forceinline__ RowU wl_rec_decode(const RecV& v) {
+    i32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = __builtin_amdgcn_readlane(v.v, i);
+    return decode_rec(r);
+}
+__device__ __forceinline__ void wl_stage_recs(LDS_AS int32_t* lrecs, const void* recs_dir, int total_rows, int tid, int nthreads) {
+    const GLOBAL_AS i32x4* src = (const GLOBAL_AS i32x4*)recs_dir;
+    for (int i = tid; i < 4 * total_rows; i += nthreads) ((LDS_AS i32x4*)lrecs)[i] = src[i];
+}
+__device__ __forceinline__ int wl_lane_get(int table, int e) { return __builtin_amdgcn_readlane(table, e); }
 
 // One row: ntt (1..3) adjacent 16-feature tiles of one unit, for NR row tiles.  Ring slot 0 holds k-block 0 on entry; on
 // exit k-block 0 of row `nr` (fetched from pkn / bitsn: the next block's when the row is the wavefront's last of this
@@ -355,25 +383,28 @@ __device__ __forceinline__ void wl_row(const WlCtx& c, const RowU& cr, const Row
 
 // The wavefront's rows [r0, r1) of a group.  rnext: the record the last row hands the ring to (the wavefront's first row of the next group, of the next block when
 // other_block) or -1.
-struct WlCarry { int primed; };      // the record whose k-block 0 sits in ring slot 0 (index, or -1)
+struct WlCarry {
+    int primed;      // the record whose k-block 0 sits in ring slot 0 (index, or -1)
+    int held;        // the record `nrec` holds (index, or -1)
+    RecV nrec;       // ... fetched two rows ahead, carried across groups and blocks
+};
 template <int KIND, int NR>
 __device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL], WlCarry& cy, int r0, int r1, int rnext,
                                         bool other_block, int lane) {
     if (r0 >= r1) return;
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
-    // (carrying the handed-over row's record across the element-wise phases instead of fetching it again measured slower:
-    //  sixteen more live scalars)
-    RowU cr = decode_rec(load_rec(c.recs, r0));
+    if (cy.held != r0) cy.nrec = wl_rec_fetch(c.lrecs, r0, lane);      // (only a wavefront's first rows of a launch, or behind a group it had no rows in)
+    RowU cr = wl_rec_decode(cy.nrec);
     if (cy.primed != r0) wl_load<KIND, NR>(ring[0], c.pk, c.bits, cr, 0, lo);
     const int rlast = rnext >= 0 ? rnext : r1 - 1;
-    i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);
+    cy.nrec = wl_rec_fetch(c.lrecs, r0 + 1 < r1 ? r0 + 1 : rlast, lane);
     f32x4 part[NR];
 #pragma unroll
     for (int h = 0; h < NR; ++h) part[h] = zero4();
     for (int t = r0; t < r1; ++t) {
-        const RowU nr = decode_rec(nrec);
-        nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
+        const RowU nr = wl_rec_decode(cy.nrec);
+        cy.nrec = wl_rec_fetch(c.lrecs, t + 2 < r1 ? t + 2 : rlast, lane);
         const bool hand = t + 1 == r1 && other_block;
 #ifdef HINT_STAMPS
         const_cast<WlCtx&>(c).sid = 256 + ((c.sid0 >> 3) & 3) * 64 + (t - r0 < 2 ? t - r0 : 1) * 32;
@@ -384,6 +415,7 @@ __device__ __forceinline__ void wl_rows(const WlCtx& c, f32x4 (&ring)[RING][NEL]
         cr = nr;
     }
     cy.primed = rnext;
+    cy.held = rlast;
 }
 
 // The block's small parameters: 4 * par_f4 floats = [thin blobs: the start of the packed buffer | biases: at bias_src]

@@ -41,7 +41,7 @@ __device__ __forceinline__ void wl_level_commit(const WlLevel& p, float* xs, flo
     }
 }
 
-template <int NR>
+template <int NR, bool CH>        // (CH: chained launch or single block - hint_wl_fwd.hip)
 __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_wl_bwd_kernel(
     KArgs a, WlArgs w, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, const float* __restrict__ g_z, const float* __restrict__ g_J,
@@ -72,14 +72,20 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     const size_t lvl = (size_t)a.B * a.d;
     STAMP_DECL()
     copy_meta(a, lds, tid, nthreads);
+    LDS_AS int32_t* lrecs = (LDS_AS int32_t*)(lds + w.off_recs);
+    wl_stage_recs(lrecs, (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec), a.total_rows, tid, nthreads);
     if (a.perm_lds > 0) {
         for (int i = tid; i < n_chain * pdd; i += nthreads) {
             const int cbi = fdiv(i, frcp(pdd));
-            const float* pp = (chain != nullptr) ? chain[cbi].perm : one.perm;
+            const float* pp = CH ? chain[cbi].perm : one.perm;
             ptab[i] = pp != nullptr ? ((const GLOBAL_AS float*)pp)[i - cbi * pdd] : 0.f;
         }
     }
-#define HINT_CB(I) chain_block(chain, one, I)
+#define HINT_CB(I) chain_block<CH ? 1 : 2>(chain, one, I)
+    // the wavefront's tables (hint_wl.hpp), lane = boundary slot b (0 .. n_groups: the boundary in front of group b; n_groups: the
+    // one behind group 0): tr0 / tr1 its rows [r0, r1) of group b; tgi = level of group b | active lanes of boundary b << 8
+    int tr0 = 0, tr1 = 0, tgi = 0;
+    bool tabs_ready = false;
 #define LEVEL_SRC(TAPE, TOP, LV) ((LV) == 0 ? ((TOP) ? (TAPE) + (size_t)(a.n_levels - 1) * lvl : x) : (TAPE) + (size_t)((LV) - 1) * lvl)
 #define BITS_A2(BLK, R0) ((const GLOBAL_AS uint8_t*)((BLK).actA1 + a.bits_off) + a.bits_stride + (size_t)((R0) >> 4) * (a.WT >> 4) * 64)
 
@@ -120,8 +126,17 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             wl_par_commit(pf, par, w, tid, nthreads);
         }
         __syncthreads();
+        if (!tabs_ready) {
+            const int b = lane <= a.n_groups ? lane : 0;
+            const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + (b < a.n_groups ? b : 0));
+            const int row_begin = gp[3], rngb = gp[6];
+            tr0 = row_begin + T.rng[rngb + wave];
+            tr1 = row_begin + T.rng[rngb + wave + 1];
+            tgi = gp[7] | ((int)((unsigned)((const LDS_AS int32_t*)(T.lops + b * a.d))[3] >> 16) << 8);
+            tabs_ready = true;
+        }
         int phase = 0;
-        WlCarry primed; primed.primed = -1;
+        WlCarry primed; primed.primed = -1; primed.held = -1;
         f32x4 ring[RING][NEL];
 
         for (int cb = n_chain - 1; cb >= 0; --cb) {
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 c.xs[h] = (const LDS_AS float*)XSP(hh); c.gst[h] = (const LDS_AS float*)GSTP(hh);
                 c.a2[h] = nullptr; c.bits_out[h] = nullptr;
             }
-            c.recs = (const char*)a.recs + (size_t)a.total_rows * sizeof(RowRec);
+            c.lrecs = lrecs;
             c.par = (const LDS_AS float*)(par + (wi & 1) * par_floats);
             c.scratch = (LDS_AS float*)scratch;
             c.tw = blk.wsSlab + a.thin_slab_off + (size_t)blockIdx.x * a.tw_floats;
@@ -157,8 +172,10 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 // boundary BEHIND group 0 (scatter only)
                 const int slot = gi > 0 ? gi - 1 : a.n_groups;
                 const bool tail_only = gi == 0;
-                const GroupU g = load_group(T.groups + (tail_only ? 0 : slot));
-                const int lop0 = tail_only ? a.n_groups * a.d : g.lop_begin;
+                const int ginfo = wl_lane_get(tgi, slot);
+                struct { int level; } g;
+                g.level = ginfo & 0xff;
+                const int lop0 = slot * a.d;
                 const float* slab_prev = slabs + ((phase + 1) & 1) * NR * w.slab_floats;     // the g_v partials of the group just finished
                 const int sid = (wi * (a.n_groups + 1) + (a.n_groups - gi)) * 8;
                 (void)sid;
@@ -167,21 +184,16 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 // (only the boundary's ACTIVE lanes - something to add, or a coupling gradient to form: LaneOp::pad lists them -,
                 //  16 rows x nact elements: the lanes a boundary leaves alone cost a full pass of the loop for nothing - at d = 6 the
                 //  three boundaries of a block have 3, 5 and 2 active lanes of 6)
-                const int nact = a.lops_off >= 0 ? (int)((unsigned)lds_i32((const LDS_AS int32_t*)(T.lops + lop0) + 3) >> 16)
-                                                 : (int)((unsigned)rfl(((const GLOBAL_AS i32x4*)a.lops)[lop0].w) >> 16);
+                const int nact = ginfo >> 8;
                 // (lane-major: a pass of the loop is four active lanes x 16 rows; the planner lists the lanes with a coupling first)
                 for (int idx = lane; idx < ROWS * nact; idx += 64) {
                     const int row = idx & 15, kk = idx >> 4;
                     int col;
                     unsigned w0, w1, w2;
-                    if (a.lops_off >= 0) {
+                    {   // (the planner keeps a wave-local plan's lane table in LDS)
                         col = ((const LDS_AS int32_t*)(T.lops + lop0 + kk))[3] & 0xffff;
                         const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
                         w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
-                    } else {
-                        col = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + kk].w & 0xffff;
-                        const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + col];
-                        w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
                     }
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
@@ -194,16 +206,16 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                         for (int net = 0; net < 2; ++net) {
                             const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + sc_unit + net);
                             const int sl_n = up[21], gv_off = up[22];
+                            const bool more = __builtin_amdgcn_ballot_w64(sl_n > 4) != 0;       // (wave-uniform: a per-lane trip count is an exec-masked loop)
 #pragma unroll
                             for (int h = 0; h < NR; ++h) {
                                 const float* sp = slab_prev + h * w.slab_floats + gv_off + row * 4 + sc_k;
-                                for (int sl = 0; sl < sl_n; sl += 4) {       // (four reads in flight, added in slab order)
-                                    float v[4];
+                                float v[4];             // (the first four slabs in flight together, added in slab order)
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u) v[u] = sp[(sl + u < sl_n ? sl + u : sl_n - 1) * 64];
+                                for (int u = 0; u < 4; ++u) v[u] = sp[(u < sl_n ? u : sl_n - 1) * 64];
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u) gval[h] += sl + u < sl_n ? v[u] : 0.f;
-                                }
+                                for (int u = 0; u < 4; ++u) gval[h] += u < sl_n ? v[u] : 0.f;
+                                if (more) for (int sl = 4; sl < sl_n; ++sl) gval[h] += sp[sl * 64];
                             }
                         }
                     }
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 {
                     const bool block_switch = slot == 0;                     // next: root level of the block before
                     int nlevel = a.n_levels - 1;
-                    if (!block_switch) nlevel = lds_i32((const LDS_AS int32_t*)(T.groups + slot - 1) + 7);
+                    if (!block_switch) nlevel = wl_lane_get(tgi, slot - 1) & 0xff;
                     if (block_switch ? cb > 0 : nlevel != g.level) {
                         const float* ntape = block_switch ? (const float*)nblk.tape : tape;
                         const bool ntop = block_switch ? (nblk.perm != nullptr || cb > 1) : top;
@@ -255,7 +267,6 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                         lp_pending = true;
                     }
                 }
-                const LDS_AS int32_t* rng = T.rng + g.rng_begin;
                 c.slab = (LDS_AS float*)(slabs + (phase & 1) * NR * w.slab_floats);
                 ++phase;
                 {
@@ -263,13 +274,10 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     const bool wrap = slot == 0;
                     if (!wrap || has_next) {
                         const int gn = wrap ? a.n_groups - 1 : slot - 1;
-                        const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + gn);
-                        const int row_begin = lds_i32(gp + 3), rngb = lds_i32(gp + 6);
-                        const int n0 = lds_i32(T.rng + rngb + wave), n1 = lds_i32(T.rng + rngb + wave + 1);
-                        if (n0 < n1) rnext = row_begin + n0;
+                        const int n0 = wl_lane_get(tr0, gn), n1 = wl_lane_get(tr1, gn);
+                        if (n0 < n1) rnext = n0;
                     }
-                    wl_rows<K_BWD, NR>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
-                                       wrap, lane);
+                    wl_rows<K_BWD, NR>(c, ring, primed, wl_lane_get(tr0, slot), wl_lane_get(tr1, slot), rnext, wrap, lane);
                 }
                 STAMP(sid + 2)
                 if (lp_pending) {
@@ -313,19 +321,23 @@ namespace hint {
 hipError_t launch_wl_bwd(const KArgs& a, const WlArgs& w, int lds_bytes, int grid, const ChainBlock& one,
                          const ChainBlock* chain, int n_chain, const float* x, const float* g_z, const float* g_J,
                          float* g_x, float gz_scale, float gJ_const, hipStream_t stream) {
-    if (w.nr == 2)
-        hipLaunchKernelGGL(hint_wl_bwd_kernel<2>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x,
-                           g_z, g_J, g_x, gz_scale, gJ_const);
-    else
-        hipLaunchKernelGGL(hint_wl_bwd_kernel<1>, dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x,
-                           g_z, g_J, g_x, gz_scale, gJ_const);
+#define HINT_LAUNCH(NRV, CHV)                                                                                        \
+    hipLaunchKernelGGL((hint_wl_bwd_kernel<NRV, CHV>), dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, n_chain, x, \
+                       g_z, g_J, g_x, gz_scale, gJ_const)
+    if (w.nr == 2) { if (chain != nullptr) HINT_LAUNCH(2, true); else HINT_LAUNCH(2, false); }
+    else { if (chain != nullptr) HINT_LAUNCH(1, true); else HINT_LAUNCH(1, false); }
+#undef HINT_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t set_max_lds_wl_bwd(int bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)hint_wl_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)hint_wl_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const void* fns[4] = {(const void*)hint_wl_bwd_kernel<1, true>, (const void*)hint_wl_bwd_kernel<2, true>,
+                          (const void*)hint_wl_bwd_kernel<1, false>, (const void*)hint_wl_bwd_kernel<2, false>};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace hint

@@ -15,7 +15,9 @@
 
 using namespace hint;
 
-template <bool REV, int NR>
+// CH: a chained launch (the blocks' pointers come from the device table `chain`) or a single block (`one`, by value): as one
+// kernel the select between the two kept the 18 scalar registers of `one` alive through every chained launch.
+template <bool REV, int NR, bool CH>
 __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void hint_wl_apply_kernel(
     KArgs a, WlArgs w, ChainBlock one, const ChainBlock* __restrict__ chain, int n_chain,
     const float* __restrict__ x, float* __restrict__ z, float* __restrict__ J, const float* __restrict__ J_in,
@@ -38,14 +40,20 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     const size_t lvl = (size_t)a.B * a.d;
     STAMP_DECL()
     copy_meta(a, lds, tid, nthreads);
+    LDS_AS int32_t* lrecs = (LDS_AS int32_t*)(lds + w.off_recs);
+    wl_stage_recs(lrecs, a.recs, a.total_rows, tid, nthreads);
     if (a.perm_lds > 0) {
         for (int i = tid; i < n_chain * pdd; i += nthreads) {
             const int cbi = fdiv(i, frcp(pdd));
-            const float* pp = (chain != nullptr) ? chain[cbi].perm : one.perm;
+            const float* pp = CH ? chain[cbi].perm : one.perm;
             ptab[i] = pp != nullptr ? ((const GLOBAL_AS float*)pp)[i - cbi * pdd] : 0.f;
         }
     }
-#define HINT_CB(I) chain_block(chain, one, I)
+#define HINT_CB(I) chain_block<CH ? 1 : 2>(chain, one, I)
+    // the wavefront's tables (hint_wl.hpp): lane e = the e-th group in execution order.  tr0 / tr1: its rows [r0, r1) of the group
+    // (absolute record indices); tgi: ent_begin | ent_cnt << 16 | level << 24 | level_last << 30
+    int tr0 = 0, tr1 = 0, tgi = 0;
+    bool tabs_ready = false;
 
     for (int tg = blockIdx.x; tg < ngroups; tg += gridDim.x) {
         int row0[NR], nvalid[NR];
@@ -92,11 +100,20 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             wl_par_commit(pf, par, w, tid, nthreads);
         }
         __syncthreads();                          // meta, permutations, parameters visible
+        if (!tabs_ready) {
+            const int e = lane < a.n_groups ? lane : 0;
+            const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + (REV ? a.n_groups - 1 - e : e));
+            const int row_begin = gp[3], rngb = gp[6];
+            tr0 = row_begin + T.rng[rngb + wave];
+            tr1 = row_begin + T.rng[rngb + wave + 1];
+            tgi = gp[4] | (gp[5] << 16) | (gp[7] << 24) | (gp[8] << 30);
+            tabs_ready = true;
+        }
         float jpart[NR];                          // this lane's share of the log-det of batch row m
 #pragma unroll
         for (int h = 0; h < NR; ++h) jpart[h] = 0.f;
         int phase = 0;                            // slab set: alternates per group, across blocks
-        WlCarry primed; primed.primed = -1;
+        WlCarry primed; primed.primed = -1; primed.held = -1;
         f32x4 ring[RING][NEL];
 
         for (int cb = 0; cb < n_chain; ++cb) {
@@ -125,12 +142,13 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     wl_store_share(tape + (size_t)(a.n_levels - 1) * lvl + (size_t)row0[h] * a.d, XS(h), a.xld, a.d, inv_d, nvalid[h], wave, a.nw, lane);
             }
             // the next block's thin vectors and biases: in flight across this block's first group
+            // (fetched behind the first group's rows instead - 20-24 registers fewer across its k-loops - the commit waits for them: +1.4 us)
             f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
             wl_par_issue(pf, nblk.packed, w, tid, nthreads);
 
             WlCtx c;
             c.pk = blk.packed; c.pk_next = nblk.packed;
-            c.recs = a.recs;
+            c.lrecs = lrecs;
             c.par = (const LDS_AS float*)(par + (cb & 1) * par_floats);
             c.scratch = nullptr; c.tw = nullptr;
 #pragma unroll
@@ -145,9 +163,9 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             c.xld = a.xld; c.gld = 0; c.WT = a.WT; c.slab_h = w.slab_floats; c.train = train; c.first_tile = false;
 
             for (int gi = 0; gi < a.n_groups; ++gi) {
-                const int gidx = REV ? a.n_groups - 1 - gi : gi;
-                const GroupU g = load_group(T.groups + gidx);
-                const LDS_AS int32_t* rng = T.rng + g.rng_begin;
+                const int ginfo = wl_lane_get(tgi, gi);
+                struct { int ent_begin, ent_cnt, level, level_last; } g;
+                g.ent_begin = ginfo & 0xffff; g.ent_cnt = (ginfo >> 16) & 0xff; g.level = (ginfo >> 24) & 0x3f; g.level_last = (ginfo >> 30) & 1;
                 float* slab = slabs + (phase & 1) * NR * w.slab_floats;
                 ++phase;
 #pragma unroll
@@ -162,14 +180,11 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     int rnext = -1;
                     const bool wrap = gi + 1 == a.n_groups;
                     if (!wrap || has_next) {
-                        const int gn = wrap ? (REV ? a.n_groups - 1 : 0) : (REV ? gidx - 1 : gidx + 1);
-                        const LDS_AS int32_t* gp = (const LDS_AS int32_t*)(T.groups + gn);
-                        const int row_begin = lds_i32(gp + 3), rngb = lds_i32(gp + 6);
-                        const int n0 = lds_i32(T.rng + rngb + wave), n1 = lds_i32(T.rng + rngb + wave + 1);
-                        if (n0 < n1) rnext = row_begin + n0;
+                        const int en = wrap ? 0 : gi + 1;
+                        const int n0 = wl_lane_get(tr0, en), n1 = wl_lane_get(tr1, en);
+                        if (n0 < n1) rnext = n0;
                     }
-                    wl_rows<K_FWD, NR>(c, ring, primed, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext,
-                                       wrap, lane);
+                    wl_rows<K_FWD, NR>(c, ring, primed, wl_lane_get(tr0, gi), wl_lane_get(tr1, gi), rnext, wrap, lane);
                 }
                 STAMP(sid + 1)
                 // ---- coupling (hint.py:79-83) on this wavefront's copy of the lane tiles: lane group kq takes the
@@ -183,39 +198,41 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 STAMP(sid + 2)
                 lds_barrier();
                 STAMP(sid + 3)
-                for (int e = kq; e < g.ent_cnt; e += 4) {
+                // (passes of four entries, wave-uniform count; the lanes without an entry compute on a copy of entry 0 and store nothing:
+                //  a loop per lane group - `for (e = kq; e < ent_cnt; e += 4)` - and slab loops with per-lane trip counts were exec-masked
+                //  loops with a dozen scalar instructions of control each)
+                const int npass = (g.ent_cnt + 3) >> 2;
+                for (int ps = 0; ps < npass; ++ps) {
+                    const bool act = 4 * ps + kq < g.ent_cnt;
                     const int xcol = ent.x & 0xffff, sl_ns = ent.y & 0xffff, sl_nt = (int)((unsigned)ent.y >> 16);
+                    const bool more = __builtin_amdgcn_ballot_w64(sl_ns > 4 || sl_nt > 4) != 0;     // (a unit shared by more than four wavefronts: h > 192)
 #pragma unroll
                     for (int h = 0; h < NR; ++h) {
                         const float* sp = slab + h * w.slab_floats + ent.z + m * 4;
                         const float* tp = slab + h * w.slab_floats + ent.w + m * 4;
-                        // (the slabs of the wavefronts that share the unit, four reads in flight, added in slab order)
+                        // (the slabs of the wavefronts that share the unit: the first four of either net in flight together, added in slab order)
+                        float vs[4], vt[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { vs[u] = sp[(u < sl_ns ? u : sl_ns - 1) * 64]; vt[u] = tp[(u < sl_nt ? u : sl_nt - 1) * 64]; }
                         float s = 0.f, t = 0.f;
-                        for (int sl = 0; sl < sl_ns; sl += 4) {
-                            float v[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) v[u] = sp[(sl + u < sl_ns ? sl + u : sl_ns - 1) * 64];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) s += sl + u < sl_ns ? v[u] : 0.f;
-                        }
-                        for (int sl = 0; sl < sl_nt; sl += 4) {
-                            float v[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) v[u] = tp[(sl + u < sl_nt ? sl + u : sl_nt - 1) * 64];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) t += sl + u < sl_nt ? v[u] : 0.f;
+                        for (int u = 0; u < 4; ++u) { s += u < sl_ns ? vs[u] : 0.f; t += u < sl_nt ? vt[u] : 0.f; }
+                        if (more) {
+                            for (int sl = 4; sl < sl_ns; ++sl) s += sp[sl * 64];
+                            for (int sl = 4; sl < sl_nt; ++sl) t += tp[sl * 64];
                         }
                         const float aa = a.alpha * atanf(s);
                         // training: s goes to the tape ([n_levels + level][B][d], indexed by the lane it scales)
-                        if (train && tape != nullptr && wave == tsel && row0[h] + m < a.B)
+                        if (act && train && tape != nullptr && wave == tsel && row0[h] + m < a.B)
                             tape[(size_t)(a.n_levels + g.level) * lvl + (size_t)(row0[h] + m) * a.d + xcol] = s;
                         float xn;
-                        if (!REV) { xn = expf(aa) * xold[h] + t; jpart[h] += aa; }
-                        else      { xn = (xold[h] - t) * __builtin_amdgcn_rcpf(expf(aa)); jpart[h] -= aa; }      // (v_rcp_f32, 1 ulp, instead of a ten-instruction division)
-                        XS(h)[m * a.xld + xcol] = xn;
+                        if (!REV) { xn = expf(aa) * xold[h] + t; jpart[h] += act ? aa : 0.f; }
+                        else      { xn = (xold[h] - t) * __builtin_amdgcn_rcpf(expf(aa)); jpart[h] -= act ? aa : 0.f; }      // (v_rcp_f32, 1 ulp, instead of a ten-instruction division)
+                        if (act) XS(h)[m * a.xld + xcol] = xn;
                     }
-                    if (e + 4 < g.ent_cnt) {        // (more than four transformed lanes in the group: the next entry)
-                        ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + e + 4);
+                    if (ps + 1 < npass) {        // (more than four transformed lanes in the group: the next entries)
+                        const int en = 4 * (ps + 1) + kq;
+                        ent = *(const LDS_AS i32x4*)(T.ents + g.ent_begin + (en < g.ent_cnt ? en : 0));
 #pragma unroll
                         for (int h = 0; h < NR; ++h) xold[h] = XS(h)[m * a.xld + (ent.x & 0xffff)];
                     }
@@ -285,18 +302,23 @@ hipError_t launch_wl_apply(bool rev, const KArgs& a, const WlArgs& w, int lds_by
                            hipStream_t stream) {
     const unsigned long long* no_rng = nullptr;
     float* no_f = nullptr;
-#define HINT_LAUNCH(REV, NRV, LOSS, NOISE, RNG, XN)                                                                  \
-    hipLaunchKernelGGL((hint_wl_apply_kernel<REV, NRV>), dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, \
+#define HINT_LAUNCH(REV, NRV, CHV, LOSS, NOISE, RNG, XN)                                                             \
+    hipLaunchKernelGGL((hint_wl_apply_kernel<REV, NRV, CHV>), dim3(grid), dim3(64 * a.nw), lds_bytes, stream, a, w, one, chain, \
                        n_chain, x, z, J, J_in, LOSS, NOISE, RNG, XN)
-    if (rev) { if (w.nr == 2) HINT_LAUNCH(true, 2, no_f, 0.f, no_rng, no_f); else HINT_LAUNCH(true, 1, no_f, 0.f, no_rng, no_f); }
-    else { if (w.nr == 2) HINT_LAUNCH(false, 2, loss_acc, noise, rng_state, x_noisy); else HINT_LAUNCH(false, 1, loss_acc, noise, rng_state, x_noisy); }
+#define HINT_LAUNCH_CH(REV, NRV, LOSS, NOISE, RNG, XN)                                                               \
+    { if (chain != nullptr) HINT_LAUNCH(REV, NRV, true, LOSS, NOISE, RNG, XN); else HINT_LAUNCH(REV, NRV, false, LOSS, NOISE, RNG, XN); }
+    if (rev) { if (w.nr == 2) HINT_LAUNCH_CH(true, 2, no_f, 0.f, no_rng, no_f) else HINT_LAUNCH_CH(true, 1, no_f, 0.f, no_rng, no_f) }
+    else { if (w.nr == 2) HINT_LAUNCH_CH(false, 2, loss_acc, noise, rng_state, x_noisy) else HINT_LAUNCH_CH(false, 1, loss_acc, noise, rng_state, x_noisy) }
+#undef HINT_LAUNCH_CH
 #undef HINT_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t set_max_lds_wl_apply(int bytes) {
-    const void* fns[4] = {(const void*)hint_wl_apply_kernel<false, 1>, (const void*)hint_wl_apply_kernel<true, 1>,
-                          (const void*)hint_wl_apply_kernel<false, 2>, (const void*)hint_wl_apply_kernel<true, 2>};
+    const void* fns[8] = {(const void*)hint_wl_apply_kernel<false, 1, true>, (const void*)hint_wl_apply_kernel<true, 1, true>,
+                          (const void*)hint_wl_apply_kernel<false, 2, true>, (const void*)hint_wl_apply_kernel<true, 2, true>,
+                          (const void*)hint_wl_apply_kernel<false, 1, false>, (const void*)hint_wl_apply_kernel<true, 1, false>,
+                          (const void*)hint_wl_apply_kernel<false, 2, false>, (const void*)hint_wl_apply_kernel<true, 2, false>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;

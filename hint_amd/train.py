@@ -558,10 +558,13 @@ class FlowTrainer:
         import ctypes as C
         info = (C.c_int32 * 8)()
         _lib.check(self.lib.hint_plan_describe(self.engines[0].plan, B, info), "hint_plan_describe")
-        if info[0]:
-            return f"hint_wl_apply_kernel<false, {info[1]}>", f"hint_wl_bwd_kernel<{info[1]}>"
-        return (f"hint_apply_kernel<false, {'true' if info[7] else 'false'}>",
-                "hint_bwd_kernel_n3" if info[5] <= 3 and not info[6] else "hint_bwd_kernel")
+        if info[0]:     # (third template argument: a chained launch - the trainer's)
+            return f"hint_wl_apply_kernel<false, {info[1]}, true>", f"hint_wl_bwd_kernel<{info[1]}, true>"
+        if info[7] and os.environ.get("HINT_NO_BWD_FLY", "0") in ("", "0"):
+            bwd = "hint_bwd_kernel_fly"        # plans with lean general groups (hint_abi.cpp run_backward)
+        else:
+            bwd = "hint_bwd_kernel_n3" if info[5] <= 3 and not info[6] else "hint_bwd_kernel"
+        return f"hint_apply_kernel<false, {'true' if info[7] else 'false'}>", bwd
 
     def _capture(self, x, c):
         self._check_arenas()
