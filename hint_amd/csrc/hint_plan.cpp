@@ -678,7 +678,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             wf.nr = wb.nr = nr;
             wf.par_f4 = wb.par_f4 = par_f4; wf.par_bias = wb.par_bias = par_bias;
             wf.off_par = wb.off_par = P->meta_bytes / 4;
-            wf.off_slab = wb.off_slab = wf.off_par + 2 * 4 * par_f4;
+            wf.off_slab = wb.off_slab = wf.off_par + 2 * ((4 * par_f4 + 255) & ~255);      // (whole KiB: the next block's copy arrives by LDS-DMA, 1 KiB per wavefront instruction)
             wf.slab_floats = r4(P->slab_fwd); wb.slab_floats = r4(P->slab_bwd);
             wf.off_priv = wf.off_slab + 2 * nr * wf.slab_floats; wb.off_priv = wb.off_slab + 2 * nr * wb.slab_floats;
             wf.priv_tile = r4(2 * ROWS * P->xld); wf.priv_stride = nr * wf.priv_tile;

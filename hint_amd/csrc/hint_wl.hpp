@@ -429,6 +429,27 @@ __device__ __forceinline__ void wl_par_issue(f32x4 (&pf)[PR], const GLOBAL_AS fl
         pf[q] = *(const GLOBAL_AS f32x4*)(packed + (f < w.par_bias ? f : f - w.par_bias + w.bias_src));
     }
 }
+// The NEXT block's parameters straight into the other LDS buffer by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, 1 KiB
+// per wavefront instruction at M0 + 16 lane; the source address is per lane, so the [blobs | biases] gather is free): round 5's
+// stamps had the register-staged copy - six 16-byte loads per thread held across the block's first group, then six
+// ds_write_b128 by all eight wavefronts at once - at ~850 cycles per block on the LDS write path, behind the first group's
+// coupling, and 24 registers.  hipcc does not count an asm load: its own vmcnt waits only become stricter (the DMA is older than
+// every load the rows wait for); wl_par_dma_wait() drains it before the barrier that publishes the buffer.
+__device__ __forceinline__ void wl_par_dma(const GLOBAL_AS float* packed, const WlArgs& w, const LDS_AS float* dst, int wave, int nw, int lane) {
+    const int nchunk = (w.par_f4 + 63) >> 6;
+    const unsigned base = (unsigned)(unsigned long long)dst;
+    for (int c = wave; c < nchunk; c += nw) {
+        int i = c * 64 + lane;
+        i = i < w.par_f4 ? i : w.par_f4 - 1;       // (the buffer is padded to whole KiB: the tail lanes write a copy of the last float4 there)
+        const int f = 4 * i;
+        const GLOBAL_AS float* src = packed + (f < w.par_bias ? f : f - w.par_bias + w.bias_src);
+        const unsigned ldsb = (unsigned)rfl((int)(base + (unsigned)c * 1024u));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(ldsb) : "memory");
+    }
+}
+__device__ __forceinline__ void wl_par_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int PR>
 __device__ __forceinline__ void wl_par_commit(const f32x4 (&pf)[PR], float* dst, const WlArgs& w, int tid, int nthreads) {
 #pragma unroll

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #define G0P(H) (priv + (H) * w.priv_tile + 2 * tl)
 #define GSTP(H) (priv + (H) * w.priv_tile + 4 * tl)
     float* scratch = priv + NR * w.priv_tile;
-    const int par_floats = 4 * w.par_f4;
+    const int par_floats = (4 * w.par_f4 + 255) & ~255;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
     const int ngroups = (ntiles + NR - 1) / NR;
     const int pdd = a.d * a.d;
@@ -149,8 +149,13 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             const bool top = perm != nullptr || cb > 0;
             float* wsGST = (float*)blk.wsGST;
             const int tsel = wi & (a.nw - 1);                          // the wavefront that writes this block's g_st rows
-            f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
-            wl_par_issue(pf, nblk.packed, w, tid, nthreads);
+            // the next block's parameters -> the other buffer.  Row pairs: by LDS-DMA (hint_wl.hpp wl_par_dma) - the kernel is at the
+            // register limit and the staged copy's 20 registers across the root's k-loops were spills (GAS backward 223 -> 217 us);
+            // one row tile: through registers (the DMA measured + 1.6 us there: the first k-step's wait completes it in order)
+            constexpr bool PAR_DMA = NR == 2;
+            f32x4 pf[PAR_DMA ? 1 : WL_PAR_REGS];
+            if constexpr (PAR_DMA) { if (has_next) wl_par_dma(nblk.packed, w, (const LDS_AS float*)(par + ((wi + 1) & 1) * par_floats), wave, a.nw, lane); }
+            else wl_par_issue(pf, nblk.packed, w, tid, nthreads);
 
             WlCtx c;
             c.pk = blk.packed; c.pk_next = nblk.packed;
@@ -243,12 +248,6 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 }
                 c.sid0 = sid; c.sid = 256;
                 STAMP(sid + 1)
-                // the next block's parameters -> the other buffer, behind the first group's rows, barrier and this scatter (loaded
-                // long ago: nothing waits here); visible behind the next barrier (a one-group block: its own)
-                if (gi == a.n_groups - 1) {
-                    wl_par_commit(pf, par + ((wi + 1) & 1) * par_floats, w, tid, nthreads);
-                    if (a.n_groups == 1) lds_barrier();
-                }
                 if (tail_only) break;
 
                 // ---- lane tile and s of the level the NEXT boundary needs: global -> registers now, -> LDS behind the rows ----
@@ -280,6 +279,12 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                     wl_rows<K_BWD, NR>(c, ring, primed, wl_lane_get(tr0, slot), wl_lane_get(tr1, slot), rnext, wrap, lane);
                 }
                 STAMP(sid + 2)
+                // the next block's parameters -> the other buffer, in front of the first group's barrier (the wavefronts arrive there far
+                // apart: the early ones copy while they would wait; hint_wl_fwd.hip); visible behind that barrier
+                if (gi == a.n_groups) {
+                    if constexpr (PAR_DMA) wl_par_dma_wait();
+                    else wl_par_commit(pf, par + ((wi + 1) & 1) * par_floats, w, tid, nthreads);
+                }
                 if (lp_pending) {
 #pragma unroll
                     for (int h = 0; h < NR; ++h) wl_level_commit(lp[h], XSP(h), SBP(h), a.xld, a.d, nvalid[h], lane);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
     float* slabs = lds + w.off_slab;            // [2][NR][slab_floats]
     float* ptab = lds + w.off_perm;
     float* priv = lds + w.off_priv + wave * w.priv_stride;      // this wavefront's lane tiles: per row tile two (a fused permutation ping-pongs)
-    const int par_floats = 4 * w.par_f4;
+    const int par_floats = (4 * w.par_f4 + 255) & ~255;
     const int ntiles = (a.B + ROWS - 1) / ROWS;
     const int ngroups = (ntiles + NR - 1) / NR;                  // workgroup-sized pieces of the batch: NR adjacent row tiles
     const int pdd = a.d * a.d;
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             }
             // the next block's thin vectors and biases: in flight across this block's first group
             // (fetched behind the first group's rows instead - 20-24 registers fewer across its k-loops - the commit waits for them: +1.4 us)
+            // (by LDS-DMA instead - hint_wl.hpp wl_par_dma, what the row-pair backward kernel does: no gain here, GAS + 5 %)
             f32x4 pf[NR == 2 ? WL_PAR_REGS2 : WL_PAR_REGS];
             wl_par_issue(pf, nblk.packed, w, tid, nthreads);
 
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 STAMP(sid + 4)
                 // the next block's parameters -> the other buffer (loaded long ago: behind the rows, the barrier and the coupling
                 // nothing waits here); visible behind the next group's barrier (a one-group block: its own)
+                // (in front of the group's barrier instead, where the early wavefronts would copy while they wait: GAS + 3 %)
                 if (gi == 0) {
                     wl_par_commit(pf, par + ((cb + 1) & 1) * par_floats, w, tid, nthreads);
                     if (a.n_groups == 1) lds_barrier();
