@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HINT_AMD_LIB") or os.path.join(_HERE, "lib", "libhint_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HintAmdError(RuntimeError):
@@ -72,6 +72,10 @@ _PROTOS = {
     "hint_chain_backward_parts": (C.c_int, [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "hint_chain_wgrad_range": (C.c_int, [C.c_void_p] * 3 + [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hint_chain_inverse": (C.c_int, [C.c_void_p] * 7),
+    "hint_chain_set_block_io": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hint_chain_wgrad_adam": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p]),
+    "hint_block_forward_noisy": (C.c_int, [C.c_void_p] * 11 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hint_block_backward_rows": (C.c_int, [C.c_void_p] * 11 + [C.c_size_t, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "hint_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_void_p] + [C.c_float] * 6 + [C.c_int32, C.c_void_p]),
     "hint_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32] + [C.c_float] * 7 + [C.c_int32,
                                                                                                  C.c_void_p]),

@@ -143,6 +143,24 @@ class ConditionalHintFlow(nn.Module):
         return self._jac_x
 
 
+class _CondLoss:
+    """one of the two loss terms a step returns, evaluated when somebody looks (float(), .item(), arithmetic through
+    .value): no torch kernel runs inside the step or its captured graph for them"""
+
+    def __init__(self, trainer, k):
+        self._t, self._k = trainer, k
+
+    @property
+    def value(self) -> torch.Tensor:
+        return self._t.last_losses()[self._k]
+
+    def __float__(self):
+        return float(self.value)
+
+    def item(self):
+        return float(self.value)
+
+
 class ConditionalFlowTrainer:
     """Fast training step for a ConditionalHintFlow (what FlowTrainer is for a HintFlow): one
     iteration of /root/reference/train_conditional.py:120-150 -
@@ -157,10 +175,22 @@ class ConditionalFlowTrainer:
     launches per step), one re-pack launch, one gradient all-reduce (hint_amd/dp.py), one fused
     clamp+Adam launch.  The two lanes meet in the backward pass: dL/dy of block i is the sum of
     what ac_y_i and ac_y_to_x_i (through its condition) send back.
-    use_graph (one process): the whole iteration - re-pack, both lanes forward and backward, the small
-    torch ops between them, clamp+Adam - is captured once per batch shape into a hipGraph and replayed
+    use_graph (one process): the whole iteration is captured once per batch shape into a hipGraph and replayed
     (the step counter and Adam's bias corrections live in device memory, written by the re-pack
-    launch's prologue, so nothing in the graph depends on the host's step count)."""
+    launch's prologue, so nothing in the graph depends on the host's step count).
+
+    Round 5 - 25 launches per iteration, none of them torch's (HINT_COND_LEGACY=1: the ~65 of round 4):
+      * the y lane is a real chain - ac_y_0, [perm_y_1] ac_y_1, ... depend on y only - and runs as ONE forward launch
+        (hint_chain_forward: the 4 x 4 permutations fused; the permuted y the x lane takes as its condition is the top slice
+        of that block's tape) and ONE row-parallel backward launch, into which the gradients the x lane sends back through
+        its conditions enter per block (ChainBlock::g_add, hint_chain_set_block_io): the x lane's backward runs first;
+      * the x lane's eight modules are launches of their own (they are a graph, not a chain: every one needs the y lane),
+        forward (hint_block_forward_noisy: the dequantisation noise drawn in the first one) and row-parallel backward
+        (hint_block_backward_rows);
+      * the weight gradients of the modules of one plan - hac_x x 4, ac_y_to_x x 4, ac_y x 4 - are ONE part B and ONE slab
+        reduction per plan, with the clamp + Adam step in the reduction (hint_chain_wgrad_adam: 3 + 3 launches for 12 + 12 +
+        the optimizer's): the modules are gathered in chains whose blocks carry their own input and condition pointers;
+      * every intermediate lives in a buffer allocated once per batch size, so the chains' tables are built once."""
 
     def __init__(self, flow: ConditionalHintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
                  weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01, group=None,
@@ -208,7 +238,12 @@ class ConditionalFlowTrainer:
         # device-side step state (see FlowTrainer): opt_state = {lr, beta1, beta2, lr/(1-beta1^t),
         # 1/sqrt(1-beta2^t), ...}, rng_state[1] = step count; the re-pack launch's prologue advances them
         self.opt_state = torch.tensor([lr, betas[0], betas[1], 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
-        self.rng_state = torch.zeros(2, dtype=torch.int64, device=dev)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        rank = dp.world_info(group)[0]
+        self.rng_state = torch.tensor([(seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 63 - 1), 0], dtype=torch.int64, device=dev)
+        self._st = {}                # per batch size: static buffers and chains (_state_for)
+        import os
+        self._legacy = os.environ.get("HINT_COND_LEGACY", "0") not in ("", "0")
         self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)     # hint_block_forward_ex: the two loss sums
 
     @property
@@ -222,10 +257,84 @@ class ConditionalFlowTrainer:
 
     def __del__(self):
         try:
+            self._graph = None
+            for st in getattr(self, "_st", {}).values():
+                for h in st["chains"].values():
+                    self.lib.hint_chain_destroy(h)
+            self._st = {}
             if getattr(self, "_pack_group", None):
                 self.lib.hint_pack_group_destroy(self._pack_group)
         except Exception:
             pass
+
+    # ---- static buffers and chains of a batch size ----------------------------------------------------
+    KINDS = ("hac_x", "ac_y_to_x", "ac_y")
+
+    def _state_for(self, B: int):
+        import ctypes as C
+        flow, dev, nb = self.flow, self.device, self.flow.n_blocks
+        eng = dict(zip([(k, i) for k, i, _ in self.mods], self.engines))
+        sl = dict(zip([(k, i) for k, i, _ in self.mods], self.slices))
+        key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) + (self.G.data_ptr(),)
+        st = self._st.get(B)
+        if st is not None and st["key"] == key:
+            return st
+        if st is not None:                     # an arena or packed buffer moved: graphs and chains point at the old addresses
+            self._graph = None
+            for h in st["chains"].values():
+                self.lib.hint_chain_destroy(h)
+            del self._st[B]
+        dx, dy = flow.ndim_x, flow.ndim_y
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        st = {"key": key, "B": B}
+        st["xn"] = f32(B, dx)
+        st["xa"] = [f32(B, dx) for _ in range(nb)]; st["xb"] = [f32(B, dx) for _ in range(nb)]
+        st["Jxa"] = [f32(B) for _ in range(nb)]; st["Jxb"] = [f32(B) for _ in range(nb)]
+        st["zy"], st["Jy"], st["gy"] = f32(B, dy), f32(B), f32(B, dy)
+        st["gxa"] = [f32(B, dx) for _ in range(nb)]; st["gxb"] = [f32(B, dx) for _ in range(nb)]
+        st["gc"] = [f32(B, dy) for _ in range(nb)]
+        st["x_in"], st["y_in"] = f32(B, dx), f32(B, dy)          # the step's inputs (a captured graph reads them here)
+        # fixed matrices in front of the modules (composed with the modules' own node permutations: none here)
+        st["perm"] = {("hac_x", i): eng[("hac_x", i)].compose_perm(flow.perm_x[i].W if i > 0 else None) for i in range(nb)}
+        st["perm"].update({("ac_y", i): eng[("ac_y", i)].compose_perm(flow.perm_y[i].W if i > 0 else None) for i in range(nb)})
+        st["perm"].update({("ac_y_to_x", i): eng[("ac_y_to_x", i)].compose_perm(None) for i in range(nb)})
+        st["tapes"], st["ws"], st["wsb"], st["chains"] = {}, {}, {}, {}
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            for kind in self.KINDS:
+                e0 = eng[(kind, 0)]
+                if any(eng[(kind, i)].shape_key != e0.shape_key for i in range(nb)):
+                    raise HintAmdError("ConditionalFlowTrainer: the modules of one kind must share a plan")
+                tf = max(self.lib.hint_plan_tape_floats(e0.plan, B), 1)
+                wb = (self.lib.hint_plan_workspace_bytes(e0.plan, B) + 255) // 256 * 256
+                st["tapes"][kind] = torch.empty(nb, tf, dtype=torch.float32, device=dev)
+                st["ws"][kind] = torch.empty(nb, max(wb, 256), dtype=torch.uint8, device=dev)
+                st["wsb"][kind] = wb
+                h = C.c_void_p()
+                self._lib.check(self.lib.hint_chain_create(e0.plan, nb, B, C.byref(h)), "hint_chain_create")
+                st["chains"][kind] = h
+                for i in range(nb):
+                    e = eng[(kind, i)]
+                    a, _ = sl[(kind, i)]
+                    self._lib.check(self.lib.hint_chain_set_block(
+                        h, i, e.arena.data_ptr(), e.packed.data_ptr(), ptr(st["perm"][(kind, i)]), st["tapes"][kind][i].data_ptr(),
+                        st["ws"][kind][i].data_ptr(), wb, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
+            # the y lane after its permutation = the x lane's condition: block i's tape top slice (one level: the tape's start);
+            # block 0 has no permutation in front: the input itself
+            st["yp"] = [st["y_in"]] + [st["tapes"]["ac_y"][i][:B * dy].view(B, dy) for i in range(1, nb)]
+            st["hx0_in"] = st["xn"]
+            for i in range(nb):
+                self._lib.check(self.lib.hint_chain_set_block_io(st["chains"]["ac_y"], i, None, None, st["gc"][i].data_ptr()),
+                                "hint_chain_set_block_io")
+                hx_in = None if st["perm"][("hac_x", i)] is not None else (st["xn"] if i == 0 else st["xb"][i - 1])     # (block 0: _iteration keeps it in step with `noise`)
+                self._lib.check(self.lib.hint_chain_set_block_io(st["chains"]["hac_x"], i, ptr(hx_in), None, None),
+                                "hint_chain_set_block_io")
+                self._lib.check(self.lib.hint_chain_set_block_io(st["chains"]["ac_y_to_x"], i, st["xa"][i].data_ptr(),
+                                                                 st["yp"][i].data_ptr(), None), "hint_chain_set_block_io")
+            for kind in self.KINDS:
+                self._lib.check(self.lib.hint_chain_commit(st["chains"][kind]), "hint_chain_commit")
+        self._st[B] = st
+        return st
 
     def _pack_all(self, prologue: bool = False):
         import ctypes as C
@@ -278,14 +387,33 @@ class ConditionalFlowTrainer:
         if self._graph is None or self._static[0].shape != x.shape or self._static[1].shape != y.shape:
             if not self._capture(x, y):
                 return self._iteration(x, y, on_device_adam=False)
-        self._static[0].copy_(x)
-        self._static[1].copy_(y)
+        if x.data_ptr() != self._static[0].data_ptr():
+            self._static[0].copy_(x)
+        if y.data_ptr() != self._static[1].data_ptr():
+            self._static[1].copy_(y)
         self._graph.replay()
         self.step_count += 1
         return self._out
 
+    def input_buffers(self, x: torch.Tensor, y: torch.Tensor):
+        """the captured step's own input tensors holding a copy of the arguments (FlowTrainer.input_buffers)"""
+        if not self._graphable():
+            return x, y
+        for e in self.engines:
+            e.ensure_arena()
+        if self._graph is None or self._static[0].shape != x.shape or self._static[1].shape != y.shape:
+            if not self._capture(x, y):
+                return x, y
+        self._static[0].copy_(x); self._static[1].copy_(y)
+        return self._static
+
     def _capture(self, x, y):
-        sx, sy = x.clone(), y.clone()
+        if self._legacy:
+            sx, sy = x.clone(), y.clone()
+        else:                                  # the fast path reads its inputs from the batch size's static buffers
+            st = self._state_for(x.shape[0])
+            sx, sy = st["x_in"], st["y_in"]
+            sx.copy_(x); sy.copy_(y)
         snap = [t.clone() for t in (self.P, self.M, self.V)]
         state = (self.opt_state.clone(), self.rng_state.clone())
         side = torch.cuda.Stream(device=self.device)
@@ -318,7 +446,113 @@ class ConditionalFlowTrainer:
         return True
 
     def _iteration(self, x: torch.Tensor, y: torch.Tensor, on_device_adam: bool):
-        """Both lanes forward and backward as direct launches.  What FrEIA's graph does between the couplings is folded
+        """One iteration as 25 launches (class docstring): re-pack; y chain forward; per block hac_x, ac_y_to_x forward; per
+        block (last first) ac_y_to_x, hac_x row-parallel backward; y chain row-parallel backward (the conditions' gradients
+        enter per block); per plan part B + slab reduction with clamp + Adam in it.  Data-parallel jobs and the host-stepped
+        optimizer keep part B, the all-reduce and the optimizer launch apart."""
+        if self._legacy:
+            return self._iteration_legacy(x, y, on_device_adam)
+        flow, B, lib, chk = self.flow, x.shape[0], self.lib, self._lib.check
+        if B == 0:
+            raise HintAmdError("ConditionalFlowTrainer: empty batch")
+        st = self._state_for(B)
+        if x.data_ptr() != st["x_in"].data_ptr():
+            st["x_in"].copy_(x)
+        if y.data_ptr() != st["y_in"].data_ptr():
+            st["y_in"].copy_(y)
+        self._pack_all(prologue=on_device_adam)         # (its prologue clears loss_acc and advances the step / noise counter)
+        if not on_device_adam:
+            self.loss_acc.zero_()
+            self.rng_state[1] += 1
+        eng = dict(zip([(k, i) for k, i, _ in self.mods], self.engines))
+        nb = flow.n_blocks
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        noisy = self.noise > 0
+        x0 = st["xn"] if noisy else st["x_in"]           # what hac_x_0 saw
+        if st.get("hx0_in") is not x0:                   # (hac_x_0's own input pointer in its gathered chain follows `noise`)
+            if st["perm"][("hac_x", 0)] is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise HintAmdError("ConditionalFlowTrainer: `noise` switched on / off: call step() once outside a capture")
+                with torch.cuda.device(self.device):
+                    chk(lib.hint_chain_set_block_io(st["chains"]["hac_x"], 0, x0.data_ptr(), None, None), "hint_chain_set_block_io")
+                    chk(lib.hint_chain_commit(st["chains"]["hac_x"]), "hint_chain_commit")
+            st["hx0_in"] = x0
+        tape = lambda kind, i: st["tapes"][kind][i].data_ptr()
+        ws = lambda kind, i: st["ws"][kind][i].data_ptr()
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        fuse = on_device_adam and not dist_on
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            # ---- forward: the y lane (one launch), then the x lane's modules ----
+            chk(lib.hint_chain_forward(st["chains"]["ac_y"], st["y_in"].data_ptr(), None, st["zy"].data_ptr(), st["Jy"].data_ptr(), None,
+                                       self.loss_acc.data_ptr(), stream), "hint_chain_forward")
+            for i in range(nb):
+                e = eng[("hac_x", i)]
+                xin = st["x_in"] if i == 0 else st["xb"][i - 1]
+                nz = float(self.noise) if (i == 0 and noisy) else 0.0
+                chk(lib.hint_block_forward_noisy(e.plan, e.arena.data_ptr(), e.packed.data_ptr(), xin.data_ptr(), None, st["xa"][i].data_ptr(),
+                                                 st["Jxa"][i].data_ptr(), tape("hac_x", i), ptr(st["perm"][("hac_x", i)]),
+                                                 st["Jxb"][i - 1].data_ptr() if i > 0 else None, None, nz,
+                                                 self.rng_state.data_ptr() if nz else None, st["xn"].data_ptr() if nz else None, B, stream),
+                    "hint_block_forward_noisy")
+                e = eng[("ac_y_to_x", i)]
+                chk(lib.hint_block_forward_noisy(e.plan, e.arena.data_ptr(), e.packed.data_ptr(), st["xa"][i].data_ptr(), st["yp"][i].data_ptr(),
+                                                 st["xb"][i].data_ptr(), st["Jxb"][i].data_ptr(), tape("ac_y_to_x", i), None,
+                                                 st["Jxa"][i].data_ptr(), self.loss_acc.data_ptr() if i == nb - 1 else None, 0.0, None, None,
+                                                 B, stream), "hint_block_forward_noisy")
+            # ---- backward, row-parallel parts: the x lane (dL/dz = z / B and dL/dJ = -1/B applied on load), then the y chain ----
+            for i in reversed(range(nb)):
+                e = eng[("ac_y_to_x", i)]
+                gz = st["xb"][nb - 1] if i == nb - 1 else st["gxb"][i + 1]
+                chk(lib.hint_block_backward_rows(e.plan, e.arena.data_ptr(), e.packed.data_ptr(), st["xa"][i].data_ptr(), tape("ac_y_to_x", i),
+                                                 st["yp"][i].data_ptr(), gz.data_ptr(), None, st["gxa"][i].data_ptr(), st["gc"][i].data_ptr(),
+                                                 ws("ac_y_to_x", i), st["wsb"]["ac_y_to_x"], None, 1.0 / B if i == nb - 1 else 1.0, -1.0 / B,
+                                                 B, stream), "hint_block_backward_rows")
+                e = eng[("hac_x", i)]
+                xin = x0 if i == 0 else st["xb"][i - 1]
+                chk(lib.hint_block_backward_rows(e.plan, e.arena.data_ptr(), e.packed.data_ptr(), xin.data_ptr(), tape("hac_x", i), None,
+                                                 st["gxa"][i].data_ptr(), None, st["gxb"][i].data_ptr(), None, ws("hac_x", i),
+                                                 st["wsb"]["hac_x"], ptr(st["perm"][("hac_x", i)]), 1.0, -1.0 / B, B, stream),
+                    "hint_block_backward_rows")
+            chk(lib.hint_chain_backward_parts(st["chains"]["ac_y"], st["y_in"].data_ptr(), None, st["zy"].data_ptr(), None, st["gy"].data_ptr(),
+                                              None, 1.0 / B, -1.0 / B, 1, 1, stream), "hint_chain_backward_parts")
+            # ---- weight gradients: one part B + slab reduction per plan ----
+            for kind in self.KINDS:
+                xk = st["y_in"].data_ptr() if kind == "ac_y" else None
+                if fuse:
+                    chk(lib.hint_chain_wgrad_adam(st["chains"][kind], xk, None, self.P.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                                  self.n_floats, self.opt_state.data_ptr(), self.betas[0], self.betas[1], self.eps, self.wd,
+                                                  1.0, self.grad_clamp, stream), "hint_chain_wgrad_adam")
+                else:
+                    chk(lib.hint_chain_wgrad_range(st["chains"][kind], xk, None, 0, 0, nb, stream), "hint_chain_wgrad_range")
+        if not fuse:
+            scale = self._dp.allreduce_sum_(self.G, self.group)       # (no-op without a process group)
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                if on_device_adam:
+                    stt = lib.hint_adam_step_dev(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n_floats,
+                                                 self.opt_state.data_ptr(), self.betas[0], self.betas[1], self.eps, self.wd, scale,
+                                                 self.grad_clamp, 1, stream)
+                else:
+                    self.step_count += 1
+                    stt = lib.hint_adam_step(self.P.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.n_floats,
+                                             self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, scale,
+                                             self.grad_clamp, 1, stream)
+            chk(stt, "hint_adam_step")
+            if not on_device_adam:
+                self.rng_state[1] = self.step_count          # keep the device counter in step for a later capture
+        self.last = (st["zy"], st["xb"][nb - 1], st["Jxb"][nb - 1], st["Jy"])
+        self._last_B = B
+        return _CondLoss(self, 0), _CondLoss(self, 1)
+
+    def last_losses(self):
+        """(0.5 |z|^2 mean, -log|det J| mean) of the most recent step as device scalars, from the launches' loss sums (read
+        them before the next step: its re-pack launch clears the sums)"""
+        s = self.loss_acc.sum(dim=0)
+        return s[0] / self._last_B, -s[1] / self._last_B
+
+    def _iteration_legacy(self, x: torch.Tensor, y: torch.Tensor, on_device_adam: bool):
+        """Round 4's iteration (HINT_COND_LEGACY=1; kept for A/B runs): both lanes forward and backward as direct launches.  What FrEIA's graph does between the couplings is folded
         into them (hint_block_*_ex): the x lane's fixed permutation rides in front of hac_x, the log-dets accumulate
         through J_in, the two loss sums come from the last couplings' launches (loss_acc), dL/dz = z / B and
         dL/dJ = -1/B are applied on load.  Left to torch: the y lane's 4 x 4 permutation (the permuted y is also the

@@ -222,7 +222,8 @@ int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* ch
 
 static int apply(const hint_plan* P, bool rev, const float* params, const float* packed, const float* x,
                  const float* c, float* z, float* J, float* tape, const float* perm, const float* J_in,
-                 float* loss_acc, int32_t B, void* stream) {
+                 float* loss_acc, int32_t B, void* stream, float noise = 0.f, const uint64_t* rng_state = nullptr,
+                 float* x_noisy = nullptr) {
     const char* what = rev ? "inverse" : "forward";
     if (!P || !params || !packed || !x || !z || !J) return fail("hint_block_%s: null argument", what);
     if (P->dc > 0 && !c) return fail("hint_block_%s: plan has dc=%d but c is NULL", what, P->dc);
@@ -238,12 +239,12 @@ static int apply(const hint_plan* P, bool rev, const float* params, const float*
     if (P->wl) {
         WlArgs w = P->wl_f[nr - 1];
         w.off_perm = a.perm_lds;
-        HIP_TRY(launch_wl_apply(rev, a, w, lds, grid_for(P, B), one, nullptr, 1, x, z, J, J_in, loss_acc, 0.f, nullptr, nullptr,
-                                (hipStream_t)stream));
+        HIP_TRY(launch_wl_apply(rev, a, w, lds, grid_for(P, B), one, nullptr, 1, x, z, J, J_in, loss_acc, noise,
+                                (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
         return 0;
     }
-    HIP_TRY(launch_apply(rev, P->has_fly != 0, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, 0.f,
-                         nullptr, nullptr, (hipStream_t)stream));
+    HIP_TRY(launch_apply(rev, P->has_fly != 0, a, lds, grid_for(P, B), one, nullptr, 1, x, c, z, J, J_in, loss_acc, noise,
+                         (const unsigned long long*)rng_state, x_noisy, (hipStream_t)stream));
     return 0;
 }
 
@@ -361,6 +362,16 @@ int hint_block_forward_ex(const hint_plan* P, const float* params, const float* 
     return apply(P, false, params, packed, x, c, z, J, tape, perm, J_in, loss_acc, B, stream);
 }
 
+int hint_block_forward_noisy(const hint_plan* P, const float* params, const float* packed, const float* x,
+                             const float* c, float* z, float* J, float* tape, const float* perm,
+                             const float* J_in, float* loss_acc, float noise, const uint64_t* rng_state,
+                             float* x_noisy, int32_t B, void* stream) {
+    if (noise != 0.f && (!rng_state || !x_noisy)) return fail("hint_block_forward_noisy: noise needs rng_state and x_noisy");
+    if (noise != 0.f && perm) return fail("hint_block_forward_noisy: the noise is added to the block's input, in front of no permutation");
+    return apply(P, false, params, packed, x, c, z, J, tape, perm, J_in, loss_acc, B, stream, noise, noise != 0.f ? rng_state : nullptr,
+                 noise != 0.f ? x_noisy : nullptr);
+}
+
 int hint_block_inverse(const hint_plan* P, const float* params, const float* packed, const float* z,
                        const float* c, float* x, float* J, int32_t B, void* stream) {
     return apply(P, true, params, packed, z, c, x, J, nullptr, nullptr, nullptr, nullptr, B, stream);
@@ -389,14 +400,14 @@ int block_backward(const hint_plan* P, const float* params, const float* packed,
                           float* g_c, float* g_params, int32_t accumulate, void* workspace,
                           size_t workspace_bytes, const float* perm, float gz_scale, float gJ_const,
                           int32_t B, int parts, void* stream) {
-    if (!P || !params || !packed || (!x && !perm) || !g_x || !g_params) return fail("hint_block_backward: null argument");
+    if (!P || !params || !packed || (!x && !perm) || !g_x || (!g_params && (parts & 2))) return fail("hint_block_backward: null argument");
     if (perm && !tape) return fail("hint_block_backward_ex: a fused permutation needs the tape of hint_block_forward_ex");
     if (P->dc > 0 && !c) return fail("hint_block_backward: plan has dc=%d but c is NULL", P->dc);
     if (!tape && B > 0) return fail("hint_block_backward: tape is NULL (the backward pass reads the forward's lane tiles, s values and activations from it)");
     if (B < 0) return fail("negative batch");
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) {
-        if (!accumulate) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
+        if (!accumulate && g_params) HIP_TRY(launch_zero(g_params, (long)P->param_floats, P->num_cu, s));
         return 0;
     }
     P = variant(P, B);
@@ -404,7 +415,7 @@ int block_backward(const hint_plan* P, const float* params, const float* packed,
         return fail("hint_block_backward: workspace too small (%zu < %zu)", workspace_bytes,
                     hint_plan_workspace_bytes(P, B));
     if (((uintptr_t)workspace & 15) != 0) return fail("hint_block_backward: workspace must be 16-byte aligned");
-    if (((uintptr_t)g_params & 15) != 0) return fail("hint_block_backward: g_params must be 16-byte aligned");
+    if (g_params && ((uintptr_t)g_params & 15) != 0) return fail("hint_block_backward: g_params must be 16-byte aligned");
     ChainBlock one{};
     one.params = params; one.packed = packed; one.perm = perm;
     bind_tape(P, B, const_cast<float*>(tape), &one);
@@ -423,6 +434,16 @@ int hint_block_backward_ex(const hint_plan* P, const float* params, const float*
                            int32_t B, void* stream) {
     return block_backward(P, params, packed, x, tape, c, g_z, g_J, g_x, g_c, g_params, accumulate, workspace, workspace_bytes,
                           perm, gz_scale, gJ_const, B, 3, stream);
+}
+
+int hint_block_backward_rows(const hint_plan* P, const float* params, const float* packed, const float* x,
+                             const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
+                             float* g_c, void* workspace, size_t workspace_bytes, const float* perm, float gz_scale,
+                             float gJ_const, int32_t B, void* stream) {
+    // part A alone: g_x, g_c and the per-row factors of the weight gradients (left in `workspace` for a later
+    // hint_chain_wgrad_range / hint_chain_wgrad_adam over a chain that holds this block with the same tape and workspace)
+    return block_backward(P, params, packed, x, tape, c, g_z, g_J, g_x, g_c, nullptr, 1, workspace, workspace_bytes, perm, gz_scale,
+                          gJ_const, B, 1, stream);
 }
 
 #ifdef HINT_STAMPS

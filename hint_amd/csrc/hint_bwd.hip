@@ -396,6 +396,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 lds_barrier();
                 STAMP(sid + 6)
             }
+            if (blk.g_add != nullptr) {            // the second consumer of the block's (permuted) input: ChainBlock::g_add
+                const int nv = (a.B - row0 < ROWS ? a.B - row0 : ROWS) * a.d;
+                for (int i = tid; i < nv; i += nthreads) { const int r = fdiv(i, inv_d); gs[r * a.xld + (i - r * a.d)] += blk.g_add[(size_t)row0 * a.d + i]; }
+                __syncthreads();
+            }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
                 // (in place: the products wait in registers for the barrier)
                 f32x4 pacc[PERM_TQ];

@@ -62,6 +62,22 @@ int hint_chain_set_block(hint_chain* C, int32_t i, const float* params, const fl
     return 0;
 }
 
+int hint_chain_set_block_io(hint_chain* C, int32_t i, const float* x_in, const float* c_in, const float* g_add) {
+    if (!C) return fail("hint_chain_set_block_io: null argument");
+    if (i < 0 || i >= C->n) return fail("hint_chain_set_block_io: block %d out of range (chain has %d)", i, C->n);
+    if (!C->set[i]) return fail("hint_chain_set_block_io: hint_chain_set_block(%d) comes first", i);
+    if (c_in && C->plan->dc == 0) return fail("hint_chain_set_block_io: the plan has no condition");
+    C->host[i].x_in = x_in; C->host[i].c_in = c_in; C->host[i].g_add = g_add;
+    C->committed = false;
+    return 0;
+}
+
+// blocks gathered for part B only (they ran as launches of their own): no chained forward / inverse / part A over them
+static bool chain_gathered(const hint_chain* C) {
+    for (const ChainBlock& b : C->host) if (b.x_in != nullptr || b.c_in != nullptr) return true;
+    return false;
+}
+
 int hint_chain_commit(hint_chain* C) {
     if (!C) return fail("hint_chain_commit: null argument");
     for (int i = 0; i < C->n; ++i)
@@ -81,6 +97,7 @@ int hint_chain_forward_noisy(const hint_chain* C, const float* x, const float* c
                              float* x_noisy, void* stream) {
     if (!C || !x || !z || !J) return fail("hint_chain_forward: null argument");
     if (!C->committed) return fail("hint_chain_forward: hint_chain_commit() has not been called");
+    if (chain_gathered(C)) return fail("hint_chain_forward: the chain's blocks have inputs of their own (hint_chain_set_block_io): it serves part B only");
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_forward: plan has dc=%d but c is NULL", P->dc);
     KArgs a = make_args(P, C->B, false);
@@ -102,6 +119,7 @@ int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, floa
                        void* stream) {
     if (!C || !z || !x || !J) return fail("hint_chain_inverse: null argument");
     if (!C->committed) return fail("hint_chain_inverse: hint_chain_commit() has not been called");
+    if (chain_gathered(C)) return fail("hint_chain_inverse: the chain's blocks have inputs of their own (hint_chain_set_block_io): it serves part B only");
     const hint_plan* P = C->plan;
     if (P->dc > 0 && !c) return fail("hint_chain_inverse: plan has dc=%d but c is NULL", P->dc);
     KArgs a = make_args(P, C->B, false);
@@ -122,15 +140,18 @@ int hint_chain_inverse(const hint_chain* C, const float* z, const float* c, floa
 int hint_chain_backward_parts(const hint_chain* C, const float* x, const float* c, const float* g_z, const float* g_J,
                               float* g_x, float* g_c, float gz_scale, float gJ_const, int32_t accumulate,
                               int32_t parts, void* stream) {
-    if (!C || !g_z || !g_x) return fail("hint_chain_backward: null argument");
+    if (!C) return fail("hint_chain_backward: null argument");
     if (!C->committed) return fail("hint_chain_backward: hint_chain_commit() has not been called");
     const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_backward: plan has dc=%d but c is NULL", P->dc);
-    if (!x && !C->host[0].perm) return fail("hint_chain_backward: x is NULL but the first block has no fused permutation");
-    for (int i = 0; i < C->n; ++i)
+    if ((parts & 3) == 0) return fail("hint_chain_backward_parts: parts must select part A (1), part B (2) or both (3)");
+    if ((parts & 1) && chain_gathered(C)) return fail("hint_chain_backward: the chain's blocks have inputs of their own (hint_chain_set_block_io): part B only");
+    if ((parts & 1) && (!g_z || !g_x)) return fail("hint_chain_backward: null argument");
+    for (int i = 0; i < C->n; ++i) {
+        if (P->dc > 0 && !c && !C->host[i].c_in) return fail("hint_chain_backward: plan has dc=%d but block %d has no condition", P->dc, i);
         if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
             return fail("hint_chain_backward: block %d was set without workspace / g_params", i);
-    if ((parts & 3) == 0) return fail("hint_chain_backward_parts: parts must select part A (1), part B (2) or both (3)");
+    }
+    if (!x && !C->host[0].perm && !C->host[0].x_in) return fail("hint_chain_backward: x is NULL but the first block has no fused permutation");
     return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B,
                         accumulate ? 1 : 0, parts & 3, (hipStream_t)stream);
 }
@@ -142,11 +163,12 @@ int hint_chain_wgrad_range(const hint_chain* C, const float* x, const float* c, 
     if (block_begin < 0 || block_end > C->n || block_begin >= block_end)
         return fail("hint_chain_wgrad_range: blocks [%d, %d) out of range (chain has %d)", block_begin, block_end, C->n);
     const hint_plan* P = C->plan;
-    if (P->dc > 0 && !c) return fail("hint_chain_wgrad_range: plan has dc=%d but c is NULL", P->dc);
-    if (!x && !C->host[0].perm) return fail("hint_chain_wgrad_range: x is NULL but the first block has no fused permutation");
-    for (int i = block_begin; i < block_end; ++i)
+    if (!x && !C->host[0].perm && !C->host[0].x_in) return fail("hint_chain_wgrad_range: x is NULL but the first block has no fused permutation");
+    for (int i = block_begin; i < block_end; ++i) {
+        if (P->dc > 0 && !c && !C->host[i].c_in) return fail("hint_chain_wgrad_range: plan has dc=%d but block %d has no condition", P->dc, i);
         if (!C->host[i].wsG1 || !C->host[i].actA1 || !C->host[i].gparams)
             return fail("hint_chain_wgrad_range: block %d was set without workspace / g_params", i);
+    }
     return run_backward(P, C->host[block_begin], C->d_table + block_begin, C->host.data() + block_begin, block_end - block_begin,
                         block_begin, C->n, x, c, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, C->B, accumulate ? 1 : 0, 2, (hipStream_t)stream);
 }
@@ -177,6 +199,29 @@ int hint_chain_backward_adam(const hint_chain* C, const float* x, const float* c
     AdamFuse ad{params, exp_avg, exp_avg_sq, opt_state, beta1, beta2, eps, weight_decay, grad_scale,
                 grad_clamp > 0.f ? grad_clamp : 3.0e38f};
     return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, C->n, x, c, g_z, g_J, g_x, g_c, gz_scale, gJ_const, C->B, 1, 3,
+                        (hipStream_t)stream, &ad);
+}
+
+int hint_chain_wgrad_adam(const hint_chain* C, const float* x, const float* c, float* params, float* exp_avg, float* exp_avg_sq,
+                          int64_t n, const float* opt_state, float beta1, float beta2, float eps, float weight_decay,
+                          float grad_scale, float grad_clamp, void* stream) {
+    if (!C || !params || !exp_avg || !exp_avg_sq || !opt_state) return fail("hint_chain_wgrad_adam: null argument");
+    if (!C->committed) return fail("hint_chain_wgrad_adam: hint_chain_commit() has not been called");
+    const hint_plan* P = C->plan;
+    if ((((uintptr_t)params | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
+        return fail("hint_chain_wgrad_adam: the arenas must be 16-byte aligned");
+    if (!x && !C->host[0].perm && !C->host[0].x_in) return fail("hint_chain_wgrad_adam: x is NULL but the first block has no fused permutation");
+    for (int i = 0; i < C->n; ++i) {
+        const ChainBlock& b = C->host[i];
+        if (P->dc > 0 && !c && !b.c_in) return fail("hint_chain_wgrad_adam: plan has dc=%d but block %d has no condition", P->dc, i);
+        if (!b.wsG1 || !b.actA1 || !b.gparams) return fail("hint_chain_wgrad_adam: block %d was set without workspace / g_params", i);
+        const int64_t off = b.params - params;
+        if (off < 0 || off + P->param_floats > n || (off & 3) != 0)
+            return fail("hint_chain_wgrad_adam: block %d's parameters are not a 16-byte aligned slice of the arena [params, params + n)", i);
+    }
+    AdamFuse ad{params, exp_avg, exp_avg_sq, opt_state, beta1, beta2, eps, weight_decay, grad_scale,
+                grad_clamp > 0.f ? grad_clamp : 3.0e38f};
+    return run_backward(P, C->host[0], C->d_table, C->host.data(), C->n, 0, C->n, x, c, nullptr, nullptr, nullptr, nullptr, 1.f, 0.f, C->B, 1, 2,
                         (hipStream_t)stream, &ad);
 }
 

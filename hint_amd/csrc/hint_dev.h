@@ -71,6 +71,13 @@ struct ChainBlock {
     float* wsGST;          // workspace: coupling gradients [Bp][ST] (g_s | g_t columns of every unit)
     float* wsSlab;         // workspace: [splits][param_floats] partial weight gradients (part B)
     float* gparams;        // flat parameter gradient of this block
+    // round 5 (hint_chain_set_block_io): blocks that ran as launches of their OWN and are gathered in a chain only for part B -
+    // the modules of the conditional two-lane model - carry their own level-0 input and condition; g_add: a [B, d] gradient
+    // added to the block's input gradient before it goes back through the block's fused permutation (the second consumer of the
+    // block's permuted input: the y lane of the conditional model is also the x lane's condition)
+    const float* x_in;     // or nullptr: the chain's x (first block) / the tape's top slice
+    const float* c_in;     // or nullptr: the launch's c
+    const float* g_add;    // or nullptr
 };
 
 // one block's share of a multi-block pack launch (hint_pack_group_*)

@@ -47,6 +47,9 @@ struct GBlock {
     GLOBAL_AS float* wsGST;
     GLOBAL_AS float* wsSlab;
     GLOBAL_AS float* gparams;
+    const GLOBAL_AS float* x_in;
+    const GLOBAL_AS float* c_in;
+    const GLOBAL_AS float* g_add;
 };
 template <int MODE = 0>        // 0: whichever is there; 1: the table (chained launch); 2: the by-value block
 __device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ chain, const ChainBlock& one, int i) {
@@ -61,6 +64,9 @@ __device__ __forceinline__ GBlock chain_block(const ChainBlock* __restrict__ cha
     g.wsGST = (GLOBAL_AS float*)b.wsGST;
     g.wsSlab = (GLOBAL_AS float*)b.wsSlab;
     g.gparams = (GLOBAL_AS float*)b.gparams;
+    g.x_in = (const GLOBAL_AS float*)b.x_in;
+    g.c_in = (const GLOBAL_AS float*)b.c_in;
+    g.g_add = (const GLOBAL_AS float*)b.g_add;
     return g;
 }
 

@@ -66,11 +66,11 @@ __device__ __forceinline__ SrcRef wsrc(int src, int level, const GBlock& blk, bo
         case WSRC_X: {
             const GLOBAL_AS float* tape = blk.tape;
             const size_t lvl = (size_t)B * d;
-            r.p = level == 0 ? (top ? tape + (size_t)(n_levels - 1) * lvl : x) : tape + (size_t)(level - 1) * lvl;
+            r.p = level == 0 ? (top ? tape + (size_t)(n_levels - 1) * lvl : (blk.x_in != nullptr ? blk.x_in : x)) : tape + (size_t)(level - 1) * lvl;
             r.ld = d; r.rows = B;
             break;
         }
-        default: r.p = c; r.ld = dc; r.rows = B; break;
+        default: r.p = blk.c_in != nullptr ? blk.c_in : c; r.ld = dc; r.rows = B; break;
     }
     return r;
 }
@@ -364,7 +364,9 @@ __global__ __launch_bounds__(DW_WAVES * 64 HINT_DW_BOUND) void hint_wgrad_kernel
     const GBlock blk = chain_block(chain, one, cbi);
     const GLOBAL_AS float* xg = (const GLOBAL_AS float*)x;
     const GLOBAL_AS float* cg = (const GLOBAL_AS float*)c;
-    const bool top = blk.perm != nullptr || cbi + cb0 > 0;        // (cb0: position of the launch's first block in its chain)
+    // (cb0: position of the launch's first block in its chain; a block with an input of its own - hint_chain_set_block_io - ran as a
+    //  launch of its own: its forward left the top tape slice only in front of a fused permutation)
+    const bool top = blk.perm != nullptr || (blk.x_in == nullptr && cbi + cb0 > 0);
 
     int item, split;
     if ((splits & 7) == 0) {          // XCD-aware: split s lives on XCD s % 8

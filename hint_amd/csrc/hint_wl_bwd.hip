@@ -293,6 +293,14 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 lds_barrier();
                 STAMP(sid + 4)
             }
+            if (blk.g_add != nullptr) {            // the second consumer of the block's (permuted) input: ChainBlock::g_add
+#pragma unroll
+                for (int h = 0; h < NR; ++h)
+                    for (int i = lane; i < nvalid[h]; i += 64) {
+                        const int r = fdiv(i, inv_d);
+                        GS(h)[r * a.xld + (i - r * a.d)] += blk.g_add[(size_t)row0[h] * a.d + i];
+                    }
+            }
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
 #pragma unroll
                 for (int h = 0; h < NR; ++h) {

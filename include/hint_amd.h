@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HINT_AMD_ABI_VERSION 5
+#define HINT_AMD_ABI_VERSION 6
 
 /* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
  * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],
@@ -261,6 +261,36 @@ int hint_chain_backward_adam(const hint_chain* chain, const float* x, const floa
                              float* exp_avg_sq, int64_t n, const float* opt_state, float beta1, float beta2, float eps,
                              float weight_decay, float grad_scale, float grad_clamp, void* stream);
 void hint_chain_destroy(hint_chain* chain);
+
+/* ---- modules that run as launches of their own and share ONE part B (round 5; abi 6) ----
+ * The conditional two-lane model (configs/plus_shape/conditional_hint_4_full.py:58-94) is a graph, not a chain: its x lane's
+ * blocks take the y lane as their condition, so every module's forward and row-parallel backward is a launch of its own.
+ * Their weight gradients need not be: the modules of one plan are gathered in a chain whose blocks carry their OWN level-0
+ * input (x_in: what the module's forward was given; NULL when it had a fused permutation - the tape holds the permuted input)
+ * and condition (c_in), and hint_chain_wgrad_range / hint_chain_wgrad_adam run part B and its slab reduction for all of them
+ * in one launch each.  A chain with such blocks serves part B only.  g_add (any chain): a [B, d] gradient the backward's part A
+ * adds to block i's input gradient before it goes back through the block's fused permutation - the block's permuted input had
+ * a second consumer (the y lane after its permutation is also the x lane's condition, train_conditional.py:50-55 graph).
+ * Call between hint_chain_set_block(i) and hint_chain_commit. */
+int hint_chain_set_block_io(hint_chain* chain, int32_t i, const float* x_in, const float* c_in, const float* g_add);
+/* part B + slab reduction of every block of the chain with the clamp + Adam step in the reduction (hint_chain_backward_adam
+ * without part A): the row-parallel launches (hint_block_backward_rows, hint_chain_backward_parts(.., parts = 1, ..)) have
+ * left the per-row factors in the blocks' workspaces. */
+int hint_chain_wgrad_adam(const hint_chain* chain, const float* x, const float* c, float* params, float* exp_avg,
+                          float* exp_avg_sq, int64_t n, const float* opt_state, float beta1, float beta2, float eps,
+                          float weight_decay, float grad_scale, float grad_clamp, void* stream);
+/* hint_block_forward_ex with the dequantisation noise of train_conditional.py:121 drawn in the kernel (Philox4x32-10 keyed by
+ * rng_state = {seed, step}; x_noisy [B,d] receives the perturbed input the backward pass starts from); noise = 0: plain. */
+int hint_block_forward_noisy(const hint_plan* plan, const float* params, const float* packed, const float* x,
+                             const float* c, float* z, float* J, float* tape, const float* perm,
+                             const float* J_in, float* loss_acc, float noise, const uint64_t* rng_state,
+                             float* x_noisy, int32_t B, void* stream);
+/* the row-parallel part of hint_block_backward_ex alone: g_x, g_c, and the per-row factors of the weight gradients in
+ * `workspace` (hint_plan_workspace_bytes) for a later part B over a chain that holds this block with that workspace. */
+int hint_block_backward_rows(const hint_plan* plan, const float* params, const float* packed, const float* x,
+                             const float* tape, const float* c, const float* g_z, const float* g_J, float* g_x,
+                             float* g_c, void* workspace, size_t workspace_bytes, const float* perm, float gz_scale,
+                             float gJ_const, int32_t B, void* stream);
 
 /* Fused gradient clamp + Adam step over a flat fp32 arena of n parameters; replaces
  *   for p in params: p.grad.data.clamp_(-5, 5)        (train_unconditional.py:140-141)
