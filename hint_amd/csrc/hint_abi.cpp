@@ -188,6 +188,11 @@ int grid_for(const hint_plan* P, int B) {
 int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* chain, const ChainBlock* chain_host, int n_chain,
                  int cb0, int n_total, const float* x, const float* c, const float* g_z, const float* g_J, float* g_x, float* g_c,
                  float gz_scale, float gJ_const, int B, int accumulate, int parts, hipStream_t s, const AdamFuse* adam) {
+#ifdef HINT_ABLATE_STORE
+    // (a diagnostic build whose row kernels keep no activations cannot train: only with HINT_ABLATION_OK=1 in the environment -
+    //  the timing scripts set it - does it launch a backward pass at all)
+    { static const bool ok = env_int("HINT_ABLATION_OK") != 0; if (!ok) return fail("this is an ablation build (HINT_ABLATE_STORE): its gradients are wrong; set HINT_ABLATION_OK=1 for timing runs"); }
+#endif
     if ((parts & 1) && P->wl) {
         KArgs a = make_args(P, B, true);
         const int nr = wl_nr_for(P, B);
@@ -254,7 +259,11 @@ int hint_abi_version(void) { return HINT_AMD_ABI_VERSION; }
 
 const char* hint_build_info(void) {
     // what the shipped binary was compiled with (the box that runs it may carry another HIP runtime: bench.py prints both)
-    static const std::string info = std::string("libhint_amd abi ") + std::to_string(HINT_AMD_ABI_VERSION) + ", gfx950, HIP " +
+    static const std::string info = std::string("libhint_amd abi ") + std::to_string(HINT_AMD_ABI_VERSION) +
+#ifdef HINT_ABLATE_STORE
+                                    " ABLATION BUILD (no activation / gradient stores: timing only, results are wrong)" +
+#endif
+                                    ", gfx950, HIP " +
                                     std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." +
                                     std::to_string(HIP_VERSION_PATCH) + ", clang " + __clang_version__;
     return info.c_str();

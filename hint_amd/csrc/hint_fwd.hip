@@ -112,11 +112,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 xcur = xflip - xcur;
                 __syncthreads();
                 STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 11)
-#ifndef HINT_ABL_TAPE
                 if (tape != nullptr)      // the permuted input is what the backward pass starts from
-#else
-                if (tape != nullptr && a.B < 0)
-#endif
                     store_tile(tape + (size_t)(a.n_levels - 1) * a.B * a.d, XS, a.xld, a.d, row0, a.B, tid, nthreads);
             } else if (!REV && cb > 0 && tape != nullptr) {
                 // inner block of a chain without a permutation: its input exists nowhere else

@@ -141,11 +141,7 @@ __device__ __forceinline__ void wl_load(f32x4 (&dst)[NEL], const GLOBAL_AS float
 #pragma unroll
     for (int j = 0; j < NTT; ++j) {
         const int jj = j < r.ntt ? j : r.ntt - 1;
-#ifdef HINT_WL_ABL_W        // diagnostic: every k-block reads the row's first tiles again (L1 hits): what the weight stream's latency costs
-        dst[j] = wl_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rw, (int)lo.w, (r.base1 + jj + (kb & 0)) * 1024, 0));
-#else
         dst[j] = wl_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(rw, (int)lo.w, (r.base1 + jj * r.n1 + kb) * 1024, 0));
-#endif
     }
     if (KIND == K_BWD) {
         const int kc = kb < r.n1 ? kb : r.n1 - 1;

@@ -42,8 +42,10 @@ def linear_subnet_constructor(c_in, c_out, c_internal):
 def _checked_subnet(net, c_in, c_out):
     """a subnet the HIP kernels can run: nn.Sequential(Linear(c_in, h), ReLU, Linear(h, h), ReLU, Linear(h, c_out)), all with
     bias (what linear_subnet_constructor builds, hint.py:10-13); NotImplementedError otherwise"""
-    ok = isinstance(net, nn.Sequential) and len(net) == 5 and all(isinstance(net[i], nn.Linear) for i in (0, 2, 4)) \
-        and all(type(net[i]) is nn.ReLU for i in (1, 3)) and all(net[i].bias is not None for i in (0, 2, 4))
+    # (exactly nn.Linear / nn.ReLU: a subclass with a forward of its own - LoRA, quantised - would be computed as a plain layer)
+    ok = isinstance(net, nn.Sequential) and len(net) == 5 and all(type(net[i]) is nn.Linear for i in (0, 2, 4)) \
+        and all(type(net[i]) is nn.ReLU for i in (1, 3)) and all(net[i].bias is not None for i in (0, 2, 4)) \
+        and all(net[i].weight.dtype == torch.float32 for i in (0, 2, 4))
     if ok:
         h = net[0].out_features
         ok = net[0].in_features == c_in and net[2].in_features == h and net[2].out_features == h \

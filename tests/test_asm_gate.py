@@ -13,6 +13,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def test_untracked_loads_are_waited_for_on_every_path():
+    import shutil
+    import pytest
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if shutil.which(hipcc) is None:
+        pytest.skip(f"{hipcc} not found: the gate compiles the kernels to assembly")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "hint_amd", "csrc"), "gate"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "untracked loads checked" in r.stdout

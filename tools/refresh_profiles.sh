@@ -1,12 +1,12 @@
 #!/bin/bash
 # Re-collect the files under profiles/ for one round on the GPU box (run through gpurun):
-#   tools/refresh_profiles.sh r04 [pmc workloads ...]   -> gpurun_out/r04/summary/{r04_bench.json,r04_kernel_stats*.csv,r04_pmc_*.json,r04_workloads.json}
+#   tools/refresh_profiles.sh r05 [pmc workloads ...]   -> gpurun_out/r05/summary/{r05_bench.json,r05_kernel_stats*.csv,r05_pmc_*.json,r05_workloads.json}
 # (the raw rocprofv3 output is summarised on the box and removed: gpurun copies back at most 64 MiB)
-# then, back in the container:  cp gpurun_out/r04/summary/* profiles/
-# Counter passes: the headline workload always; further workloads (default: miniboone_hint_10 plus_hint_4
-# conditional_hint_4_full) get FETCH_SIZE / WRITE_SIZE / SQ passes of their own.
-R=${1:-r04}; shift
-PMC_WL=${@:-miniboone_hint_10 plus_hint_4 conditional_hint_4_full}
+# then, back in the container:  cp gpurun_out/r05/summary/* profiles/
+# Counter passes: the headline workload always; further workloads (default: gas_hint_8 miniboone_hint_10 plus_hint_4
+# conditional_hint_4_full - every BASELINE config) get FETCH_SIZE / WRITE_SIZE / SQ passes of their own.
+R=${1:-r05}; shift
+PMC_WL=${@:-gas_hint_8 miniboone_hint_10 plus_hint_4 conditional_hint_4_full}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; S=$O/summary; mkdir -p $S
@@ -35,6 +35,16 @@ for W in $PMC_WL; do
 done
 rm -f $O/workloads.jsonl
 for W in power_hint_4 plus_hint_4_big; do python bench.py --no-cpu-baseline --no-other-workloads --workload $W 2>/dev/null | tail -1 >> $O/workloads.jsonl; done
+# the N > 1 code path on ONE GPU (no multi-GPU node behind gpurun): a one-rank RCCL group, the gradient all-reduce captured in
+# the step's graph and the separate clamp + Adam launch instead of the optimizer inside the slab reduction - what leaving the
+# fused-optimizer path costs, tracked until a node exists
+HSA_ENABLE_IPC_MODE_LEGACY=0 HINT_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
+  bench.py --gpus 1 --no-cpu-baseline --no-other-workloads 2>$O/force_dist.err | tail -1 | python -c "
+import json,sys
+l=sys.stdin.read().strip()
+if l.startswith('{'):
+    r=json.loads(l); r['note']='HINT_FORCE_DIST=1: one-rank RCCL group on one GPU (all-reduce captured + separate hint_adam_kernel)'; print(json.dumps(r))
+" >> $O/workloads.jsonl
 # the headline workload at larger batches (row pairs: two 16-row tiles per workgroup on one weight stream)
 for B in 8192 16384; do python bench.py --no-cpu-baseline --batch $B 2>/dev/null | tail -1 >> $O/workloads.jsonl; done
 python -c "
