@@ -150,10 +150,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             pc.first_tile = tile == (int)blockIdx.x;
 
             f32x4 ring[RING][NEL];
+            RecCarry rcar; rcar.held = -1; rcar.v = 0;
             {   // the weight stream (and the a2 tiles) of the root group's first row: started before its coupling phase
                 const GroupU g0 = load_group(T.groups + (a.n_groups - 1));
                 const LDS_AS int32_t* rng0 = T.rng + g0.rng_begin;
-                rows_begin<K_BWD>(pc, ring, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
+                rows_begin<K_BWD>(pc, ring, rcar, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
             }
             for (int gi = a.n_groups; gi >= 0; --gi) {
                 // gi == 0 .. n_groups-1: the boundary in front of group gi (root first), then its GEMM phases;
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
                         if (n0 < n1) rnext = gn.row_begin + n0;
                     }
-                    rows_run<K_BWD, BWD_FLYK>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
+                    rows_run<K_BWD, BWD_FLYK>(pc, ring, rcar, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 5)

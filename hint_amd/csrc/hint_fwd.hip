@@ -144,6 +144,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             // the weight stream of a group's first row starts one phase early: before the block's first group
             // here, for the later ones right behind the rows of the group before (i.e. across its coupling phase)
             f32x4 ring[RING][NEL];
+            RecCarry rcar; rcar.held = -1; rcar.v = 0;
             const int ngen = a.n_groups - a.n_sub;        // the general groups: [n_sub, n_groups)
             auto pf = [&](int pos) {                      // consumer `pos` of this block's sequence [head | general groups in this direction's order], or of the next block's
                 const GLOBAL_AS float* pk = blk.packed;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             {
                 const GroupU g0 = load_group(T.groups + (REV ? a.n_groups - 1 : a.n_sub));
                 const LDS_AS int32_t* rng0 = T.rng + g0.rng_begin;
-                rows_begin<K_FWD>(pc, ring, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
+                rows_begin<K_FWD>(pc, ring, rcar, g0.row_begin + lds_i32(rng0 + wave), g0.row_begin + lds_i32(rng0 + wave + 1), lane);
             }
             for (int gi = 0; gi < ngen; ++gi) {
                 const GroupU g = load_group(T.groups + (REV ? a.n_groups - 1 - gi : a.n_sub + gi));
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
                         if (n0 < n1) rnext = gn.row_begin + n0;
                     }
-                    rows_run<K_FWD, FLYK>(pc, ring, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
+                    rows_run<K_FWD, FLYK>(pc, ring, rcar, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 3)

@@ -492,24 +492,45 @@ __device__ __forceinline__ void row_body(const PhaseCtx& c, const RowU& cr, cons
     STAMP(c.sid + 12)
 }
 
+// Row records as ONE vector register (round 5, what the wave-local kernels do - hint_wl.hpp): lane i (mod 16) holds int i of
+// the 64-byte record, fetched with one dword load per lane two rows ahead and carried ACROSS groups (the record behind a group's
+// last row is the next group's first); fields go to scalar registers by v_readlane where they are used.  A scalar load per record
+// was sixteen scalar registers in flight per row and, at every group's start, a wait that drains the LDS counter as well.
+struct RecCarry { int held; int v; };        // the record index `v` holds (or -1)
+__device__ __forceinline__ int recv_fetch(const void* recs, int idx, int lane) {
+    return ((const GLOBAL_AS int*)(unsigned long long)recs)[(size_t)idx * 16 + (lane & 15)];
+}
+__device__ __forceinline__ RowU recv_decode(int v) {
+    i32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = __builtin_amdgcn_readlane(v, i);
+    return decode_rec(r);
+}
+
 // One GEMM phase of one wavefront: records [r0, r1) of this direction's record list, in two calls so that the
 // first row's weight stream can be started a phase early (its loads do not depend on the element-wise phase
 // in between): rows_begin() primes the ring, rows_run() executes the rows.
 template <int KIND>
-__device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int lane) {
+__device__ __forceinline__ void rows_begin(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], RecCarry& rc, int r0, int r1, int lane) {
     if (r0 >= r1) return;
     LaneOff lo;
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)(lane >> 4) * 16u; lo.l = (unsigned)lane;
-    const RowU cr = decode_rec(load_rec(c.recs, r0));
+    RowU cr;
+    if constexpr (KIND == K_BWD) {
+        if (rc.held != r0) { rc.v = recv_fetch(c.recs, r0, lane); rc.held = r0; }
+        cr = recv_decode(rc.v);
+    } else {
+        cr = decode_rec(load_rec(c.recs, r0));
+    }
 #pragma unroll
     for (int s = 0; s < DIST; ++s) load_main3<KIND, NTT>(ring[s], c, cr, s, lo);     // (a padded row's first RING positions are main steps)
 }
 // rnext: the record whose first main steps the LAST row hands the ring over to - the wavefront's first row of the
 // next group of the block - or -1 (then it re-loads its own: never used)
 template <int KIND, bool FLYK = false>
-__device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], int r0, int r1, int rnext, int lane) {
+__device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][NEL], RecCarry& rc, int r0, int r1, int rnext, int lane) {
     if (r0 >= r1) {
-        if (rnext >= 0) rows_begin<KIND>(c, ring, rnext, rnext + 1, lane);     // nothing to do here, but the next group has work
+        if (rnext >= 0) rows_begin<KIND>(c, ring, rc, rnext, rnext + 1, lane);     // nothing to do here, but the next group has work
         return;
     }
     const int kq = lane >> 4;
@@ -517,13 +538,22 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
     lo.w = (unsigned)lane * 16u; lo.b = (unsigned)kq * 16u; lo.l = (unsigned)lane;
 
     STAMP(c.sid + 7)
-    RowU cr = decode_rec(load_rec(c.recs, r0));
+    // (vector records in the backward instances only: MINIBOONE's backward - 3.6 %, d = 100's - 0.8 %; the forward kernels lost 1-1.5 %
+    //  with them and keep the scalar loads)
+    constexpr bool VREC = KIND == K_BWD;
+    RowU cr;
+    if constexpr (VREC) { if (rc.held != r0) rc.v = recv_fetch(c.recs, r0, lane); cr = recv_decode(rc.v); }
+    else cr = decode_rec(load_rec(c.recs, r0));
     const int rlast = rnext >= 0 ? rnext : r1 - 1;                            // what follows the last row
-    i32x16 nrec = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);            // next row's record, one row ahead
+    int nrecv = 0;
+    i32x16 nrecs = {};
+    if constexpr (VREC) nrecv = recv_fetch(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast, lane);       // next row's record, one row ahead
+    else nrecs = load_rec(c.recs, r0 + 1 < r1 ? r0 + 1 : rlast);
     STAMP(c.sid + 8 + (cr.n1 > 1000 ? 1 : 0))
     for (int t = r0; t < r1; ++t) {
-        const RowU nr = decode_rec(nrec);
-        nrec = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast);
+        RowU nr;
+        if constexpr (VREC) { nr = recv_decode(nrecv); nrecv = recv_fetch(c.recs, t + 2 < r1 ? t + 2 : rlast, lane); }
+        else { nr = decode_rec(nrecs); nrecs = load_rec(c.recs, t + 2 < r1 ? t + 2 : rlast); }
         if (t == r0) { STAMP(c.sid + 9) }
         if constexpr (NTT >= 4 && FLYK) {
             if (c.fly) {
@@ -554,6 +584,7 @@ __device__ __forceinline__ void rows_run(const PhaseCtx& c, f32x4 (&ring)[RING][
         }
         cr = nr;
     }
+    if constexpr (VREC) { rc.v = nrecv; rc.held = rlast; }          // (the record behind the last row: the next group's first, when there is one)
     STAMP(c.sid + 13)
     STAMP(c.sid + 14)
 }
