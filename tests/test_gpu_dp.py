@@ -96,6 +96,62 @@ def test_two_rank_gpu_step_equals_single_process_global_batch(use_graph):
     np.testing.assert_array_equal(one[0][1], res[0][1])
 
 
+def _run_cond(rank, world, port, xs, ys, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import hint_amd
+    from hint_amd import dp
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = hint_amd.ConditionalHintFlow(10, 3, 2, 24).to(dev)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.add_(0.02 * torch.randn_like(p))
+    tr = hint_amd.ConditionalFlowTrainer(model, noise=0.0, lr=3e-3)      # (gloo: plain launches, the all-reduce from the host)
+    losses = []
+    for x, y in zip(xs, ys):
+        lo, hi = dp.shard_rows(x.shape[0], *dp.world_info())
+        l0, l1 = tr.step((4.0 * x[lo:hi]).to(dev), y[lo:hi].to(dev))
+        losses.append([float(l0), float(l1)])
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+    out_q.put((rank, flat, np.array(losses)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_conditional_step_equals_single_process_global_batch():
+    """the conditional two-lane trainer (round 5: 25-launch step; with a process group part B, the all-reduce and the optimizer
+    launch stay apart) on two ranks sharing the GPU over gloo: replicas bit-identical, equal to the one-process step on the
+    global batch (train_conditional.py:120-150 on the union of the shards)"""
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(256, 10, generator=g) for _ in range(3)]
+    ys = [torch.randn(256, 3, generator=g) for _ in range(3)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_run_cond, args=(0, 1, 0, xs, ys, q))
+    p0.start()
+    _, ref, ref_losses = q.get(timeout=240)
+    p0.join(timeout=60)
+    assert p0.exitcode == 0
+    port = _free_port()
+    procs = [ctx.Process(target=_run_cond, args=(r, 2, port, xs, ys, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, flat, losses = q.get(timeout=240)
+        res[r] = (flat, losses)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[0][0], ref, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(0.5 * (res[0][1] + res[1][1]), ref_losses, rtol=1e-4, atol=1e-5)
+
+
 def test_allreduce_captured_in_the_step_graph_and_host_side_fallback():
     """a one-rank RCCL group in this process: the gradient all-reduce and the optimizer are captured in
     the step's graph; when the collective cannot be captured (simulated) the trainer issues both from
