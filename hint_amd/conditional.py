@@ -284,6 +284,12 @@ class ConditionalFlowTrainer:
             for h in st["chains"].values():
                 self.lib.hint_chain_destroy(h)
             del self._st[B]
+        if len(self._st) >= 4:                 # ragged data: forget the batch sizes no live graph was captured on
+            keep = self._static[0].shape[0] if (self._graph is not None and self._static is not None) else None
+            for b in [b for b in self._st if b != keep]:
+                for h in self._st[b]["chains"].values():
+                    self.lib.hint_chain_destroy(h)
+                del self._st[b]
         dx, dy = flow.ndim_x, flow.ndim_y
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         st = {"key": key, "B": B}
