@@ -131,6 +131,17 @@ for case in range(n_cases):
                 e, row_err = compare(x[keep], [c[keep] for c in cond])
             else:
                 note = " [deviating rows are NOT on a ReLU kink]"
+    if e["rt"] > 1e-3:
+        # an ill-conditioned block (exp(a) spans several orders of magnitude): what does the float32 ORACLE's own round trip do, and
+        # does the GPU's inverse of the oracle's z agree with the oracle's inverse of it?
+        with torch.no_grad():
+            zo, _ = orc.block_apply(nodes, {k: v.clone() for k, v in P.items()}, x, cond, rev=False, clamp=clamp)
+            xro, _ = orc.block_apply(nodes, {k: v.clone() for k, v in P.items()}, zo, cond, rev=True, clamp=clamp)
+            (xrg,) = blk([zo.to(dev)], c=[c.to(dev) for c in cond], rev=True)
+        rt_o = (xro - x).abs().max().item() / sc(x)
+        inv_dev = (xrg.cpu() - xro).abs().max().item() / sc(x)
+        print(f"    case {case}: round trip {e['rt']:.1e} - the oracle's own {rt_o:.1e}; GPU inverse vs oracle inverse of the same z {inv_dev:.1e}", flush=True)
+        note += f" [ill-conditioned: oracle round trip {rt_o:.1e}]"
     bad = e["z"] > 1e-5 or e["J"] > 1e-5 or e["gx"] > 1e-4 or e["gw"] > 2e-4
     for k in worst: worst[k] = max(worst[k], e[k])
     if bad or note or case % 10 == 0:
