@@ -258,3 +258,31 @@ def test_conditional_trainer_full_size_matches_oracle_training(use_graph):
             assert rel <= 1e-3, (name, key, rel)
             assert float((a - b).abs().max()) <= 2.2 * lr * steps, (name, key, float((a - b).abs().max()))
     print(f"conditional full size ({'graph' if use_graph else 'eager'}): worst per-tensor weight deviation {worst:.2e}")
+
+
+def test_conditional_trainer_noise_is_drawn_in_the_first_launch():
+    """train_conditional.py:121 (x += 0.01 * randn_like(x)): the fast path draws the noise inside hac_x_0's forward launch
+    (hint_block_forward_noisy, Philox keyed by the device step counter).  The perturbed input has the asked standard deviation,
+    differs from step to step, and IS what the step was computed on: a noise-free trainer with the same weights, fed the perturbed
+    input, reports the same loss pair."""
+    import copy
+    torch.manual_seed(9)
+    nx, ny, nb, hidden, B = 10, 3, 2, 24, 512
+    m = hint_amd.ConditionalHintFlow(nx, ny, nb, hidden).to(DEV)
+    for p in m.parameters():
+        p.data.add_(0.02 * torch.randn_like(p))
+    m0 = copy.deepcopy(m)
+    x = torch.randn(B, nx, device=DEV); y = torch.randn(B, ny, device=DEV)
+    tr = hint_amd.ConditionalFlowTrainer(m, noise=0.05, lr=0.0, weight_decay=0.0, use_graph=True)
+    tr0 = hint_amd.ConditionalFlowTrainer(m0, noise=0.0, lr=0.0, weight_decay=0.0, use_graph=False)
+    seen = []
+    for _ in range(3):
+        l0, l1 = tr.step(x, y)
+        got = [float(l0), float(l1)]
+        xn = tr._st[B]["xn"].clone()
+        dlt = (xn - x).flatten()
+        assert abs(float(dlt.mean())) < 0.01 and 0.045 < float(dlt.std()) < 0.055, (float(dlt.mean()), float(dlt.std()))
+        seen.append(xn)
+        r0, r1 = tr0.step(xn, y)
+        np.testing.assert_allclose(got, [float(r0), float(r1)], rtol=1e-5, atol=1e-6)
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
