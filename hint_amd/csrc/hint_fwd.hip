@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
     float* cs = t0 + 2 * ROWS * a.xld;
     float* abuf = cs + ROWS * a.cld;          // per group: [a1 tiles | a2 tiles on their way to the tape (staged groups) | slabs]
     float* jac = abuf + a.region_floats;
-    float* red = jac + ROWS;                  // MAX_NW floats: loss partials
+    float* jac2 = jac + ROWS;                 // ... of the coupling phase's second half (P3)
+    float* red = jac2 + ROWS;                 // MAX_NW floats: loss partials
     float* thinb = lds + a.thin_lds;          // the block's thin-layer vectors (when the launch found LDS for them)
     const int ntiles = (a.B + ROWS - 1) / ROWS;
     STAMP_DECL()
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
 #define XO (t0 + (xflip - xcur))
         load_tile(XS, a.xld, x, a.d, row0, a.B, tid, nthreads);
         if (a.dc > 0) load_tile(cs, a.cld, c, a.dc, row0, a.B, tid, nthreads);
-        if (tid < ROWS) jac[tid] = 0.f;
+        if (tid < 2 * ROWS) jac[tid] = 0.f;
         __syncthreads();                      // meta and the lane tile visible
         if (!REV && rng_state != nullptr) {
             // x += noise * N(0,1), four values per Philox call, keyed by (seed, step, element group)
@@ -249,10 +250,21 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                     if (tid >= soff)
                         for (int i = tid - soff; i < g.ntiles * 4; i += nthreads - soff) dst[i] = ((const LDS_AS i32x4*)abuf)[i];
                 }
-                if (tid < ncpl) {
-                    const int sub = tid & (nsub - 1), row = nsub == 4 ? tid >> 2 : tid >> 4;
+                // (round 5: a group with 17 .. 24 transformed lanes - every general level of MINIBOONE's tree - splits them over two
+                //  sets of wavefronts that work at the same time: entries 0 .. 15 on wavefronts 0-3 as before, entries 16 .. on wavefronts
+                //  4-5, eight lanes per batch row, with log-det sums of their own (jac2); the second pass of the one set cost 0.4-0.9 k
+                //  cycles per group while four wavefronts waited.  The last wavefront keeps out: it issues the L2 warm-up.)
+                // (only in the instance without the lean-row code: the d = 100 plans' instance lost 1 % by the code's presence)
+                const bool halves = !FLYK && nsub == 16 && g.ent_cnt > 16 && g.ent_cnt <= 24 && nthreads >= 6 * 64;
+                if (tid < ncpl || (halves && tid < ncpl + 128)) {
+                    const bool second = halves && tid >= ncpl;
+                    const int t2 = tid - ncpl;
+                    const int ns = second ? 8 : nsub;
+                    const int sub = second ? (t2 & 7) : (tid & (nsub - 1));
+                    const int row = second ? (t2 >> 3) : (nsub == 4 ? tid >> 2 : tid >> 4);
+                    const int e0 = second ? 16 + sub : sub, e1 = (halves && !second) ? 16 : g.ent_cnt;
                     float part = 0.f;
-                    for (int e = sub; e < g.ent_cnt; e += nsub) {
+                    for (int e = e0; e < e1; e += ns) {
                         const LDS_AS int32_t* ep = (const LDS_AS int32_t*)(T.ents + g.ent_begin + e);
                         const unsigned w0 = (unsigned)ep[0], w1 = (unsigned)ep[1];
                         const int xcol = (int)(w0 & 0xffffu), sl_ns = (int)(w1 & 0xffffu), sl_nt = (int)(w1 >> 16);
@@ -270,11 +282,12 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                         if (!REV) { *px = expf(aa) * (*px) + t; part += aa; }
                         else      { *px = ((*px) - t) * __builtin_amdgcn_rcpf(expf(aa)); part -= aa; }      // (v_rcp_f32, 1 ulp, instead of a ten-instruction division)
                     }
-                    // deterministic butterfly over the nsub adjacent lanes that share a batch row
-                    if (nsub == 16) { part += __shfl_xor(part, 8, 16); part += __shfl_xor(part, 4, 16); }
+                    // deterministic butterfly over the adjacent lanes that share a batch row
+                    if (ns == 16) part += __shfl_xor(part, 8, 16);
+                    if (ns >= 8) part += __shfl_xor(part, 4, 16);
                     part += __shfl_xor(part, 2, 16);
                     part += __shfl_xor(part, 1, 16);
-                    if (sub == 0) jac[row] += part;
+                    if (sub == 0) (second ? jac2 : jac)[row] += part;
                 }
                 STAMP(sid + 5)
                 lds_barrier();
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             }
         }
         store_tile(z, XS, a.xld, a.d, row0, a.B, tid, nthreads);
-        if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = jac[tid] + (J_in != nullptr ? J_in[row0 + tid] : 0.f);
+        if (tid < ROWS && row0 + tid < a.B) J[row0 + tid] = (jac[tid] + jac2[tid]) + (J_in != nullptr ? J_in[row0 + tid] : 0.f);
         if (loss_acc != nullptr) {
             // per-workgroup partial sums of the two loss terms (train_unconditional.py:128-129):
             // slot[0] += sum_rows 0.5*|z|^2, slot[1] += sum_rows J_total
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 float t = 0.f;
                 for (int w = 0; w < a.nw; ++w) t += red[w];
                 float js = 0.f;
-                for (int r = 0; r < nvalid; ++r) js += jac[r] + (J_in != nullptr ? J_in[row0 + r] : 0.f);
+                for (int r = 0; r < nvalid; ++r) js += (jac[r] + jac2[r]) + (J_in != nullptr ? J_in[row0 + r] : 0.f);
                 // 64 slots of {sum 0.5|z|^2, sum J}: spreads the atomics of the workgroups
                 float* slot = loss_acc + 2 * (blockIdx.x & 63);
                 atomicAdd(slot, 0.5f * t);

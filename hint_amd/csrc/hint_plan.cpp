@@ -631,7 +631,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     const int sub_par_floats = P->sub_pf + P->sub_pb + P->sub_pbias;
     const int sub_f_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_f) + sub_par_floats + nw * 16) : 0;
     const int sub_b_bytes = P->n_sub > 0 ? 4 * (pad4(P->sub_slab_b) + sub_par_floats + nw * 512) : 0;
-    const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + ROWS + MAX_NW) + sub_f_bytes;
+    const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + 2 * ROWS + MAX_NW) + sub_f_bytes;     // (2 x ROWS: the log-det sums of the coupling phase's two halves)
     const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld) + sub_b_bytes;   // (+ the lanes of the level before: first-layer gradients)
     // Lean groups get their dW1 | db1 from the backward kernel: staged ones in a pass of their own (the g1 tiles wait in LDS),
     // the others - too large to stage - row by row (RowRec flag rowdw: one scratch tile per wavefront), so that g1 never travels
