@@ -231,36 +231,19 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     thin_staged = pc.thin_l != nullptr;
                 }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
-#ifdef HINT_BWD_FLY
-                // (this instance's trees keep the lane table in global memory: the boundary's ACTIVE lanes only, from the compacted copy -
-                //  16 x 40-60 elements instead of 16 x 100 in front of the deep groups, whose eight small nodes touch that many lanes)
-                const bool lop_c = a.lops_off < 0;
-                const int nact = lop_c ? lds_i32(T.rng + a.lop_cnt + (tail_only ? a.n_groups : slot)) : a.d;
-                const float inv_n = lop_c ? frcp(nact > 0 ? nact : 1) : inv_d;
+                // the boundary's ACTIVE lanes only (scatter target or transformed lane), from the table's compacted copy (hint_plan.cpp: entry k =
+                // the ops of the k-th active lane, its column in pad) in LDS, or in global memory for the large trees: 16 x 40-60 elements
+                // instead of 16 x 100 in front of d = 100's deep groups, 16 x 32 = ONE pass of the workgroup instead of 16 x 43 = two at d = 43
+                const bool lop_g = a.lops_off < 0;
+                const int nact = lds_i32(T.rng + a.lop_cnt + (tail_only ? a.n_groups : slot));
+                const float inv_n = frcp(nact > 0 ? nact : 1);
                 for (int idx = tid; idx < ROWS * nact && tid < qthreads; idx += qthreads) {
                     const int row = fdiv(idx, inv_n);
-                    int col = idx - row * nact;
-                    unsigned w0, w1, w2;
-                    if (!lop_c) {
-                        const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
-                        w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
-                    } else {
-                        const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lopsc)[lop0 + col];
-                        w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
-                        col = lq.w & 0xffff;
-                    }
-#else
-                for (int idx = tid; idx < ROWS * a.d && tid < qthreads; idx += qthreads) {
-                    const int row = fdiv(idx, inv_d), col = idx - row * a.d;
-                    unsigned w0, w1, w2;
-                    if (a.lops_off >= 0) {
-                        const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
-                        w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
-                    } else {                                    // (large trees: the table stays in global memory)
-                        const i32x4 lq = ((const GLOBAL_AS i32x4*)a.lops)[lop0 + col];
-                        w0 = (unsigned)lq.x; w1 = (unsigned)lq.y; w2 = (unsigned)lq.z;
-                    }
-#endif
+                    i32x4 lq;
+                    if (lop_g) lq = ((const GLOBAL_AS i32x4*)a.lopsc)[lop0 + idx - row * nact];
+                    else lq = *(const LDS_AS i32x4*)(T.lops + lop0 + idx - row * nact);
+                    const unsigned w0 = (unsigned)lq.x, w1 = (unsigned)lq.y, w2 = (unsigned)lq.z;
+                    const int col = lq.w & 0xffff;
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
                     const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);

@@ -779,7 +779,23 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
-    if (lops_lds) std::memcpy(meta.data() + P->lops_off, lops.data(), lops.size() * sizeof(LaneOp));
+    // per boundary the active lanes' entries first (entry k's pad names the k-th active lane: build_lane_ops), their column in pad:
+    // what the general backward kernels walk (LDS copy or KArgs::lopsc); the wave-local backward keeps the plain table
+    std::vector<LaneOp> lc(lops.size());
+    {
+        const int nb = (int)(lops.size() / (size_t)d);
+        for (int b = 0; b < nb; ++b) {
+            const int cnt = lops[(size_t)b * d].pad >> 16;
+            for (int k = 0; k < d; ++k) {
+                LaneOp op{};
+                op.sc_unit = -1; op.cp_ls = -1;
+                if (k < cnt) { const int col = lops[(size_t)b * d + k].pad & 0xffff; op = lops[(size_t)b * d + col]; op.pad = col; }
+                op.pad = (op.pad & 0xffff) | (cnt << 16);
+                lc[(size_t)b * d + k] = op;
+            }
+        }
+    }
+    if (lops_lds) std::memcpy(meta.data() + P->lops_off, P->wl ? lops.data() : lc.data(), lops.size() * sizeof(LaneOp));
     P->lds_fwd = (fixed_f - sub_f_bytes + 4 * P->region_fwd + 15) / 16 * 16;
     P->lds_bwd = (fixed_b - sub_b_bytes + 4 * P->region_bwd + 15) / 16 * 16;
     if (rowdw_bytes > 0) { P->rowdw_lds = P->lds_bwd / 4; P->lds_bwd += rowdw_bytes; }
@@ -918,22 +934,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
     if (e == hipSuccess) e = upload((void**)&P->d_lops, lops.data(), lops.size() * sizeof(LaneOp));
-    {
-        // per boundary the active lanes' entries first (entry k's pad names the k-th active lane: build_lane_ops), their column in pad
-        std::vector<LaneOp> lc(lops.size());
-        const int nb = (int)(lops.size() / (size_t)d);
-        for (int b = 0; b < nb; ++b) {
-            const int cnt = lops[(size_t)b * d].pad >> 16;
-            for (int k = 0; k < d; ++k) {
-                LaneOp op{};
-                op.sc_unit = -1; op.cp_ls = -1;
-                if (k < cnt) { const int col = lops[(size_t)b * d + k].pad & 0xffff; op = lops[(size_t)b * d + col]; op.pad = col; }
-                op.pad = (op.pad & 0xffff) | (cnt << 16);
-                lc[(size_t)b * d + k] = op;
-            }
-        }
-        if (e == hipSuccess) e = upload((void**)&P->d_lopsc, lc.data(), lc.size() * sizeof(LaneOp));
-    }
+    if (e == hipSuccess) e = upload((void**)&P->d_lopsc, lc.data(), lc.size() * sizeof(LaneOp));
     if (e == hipSuccess) {
         std::vector<ThinRec> both(thin_f);
         both.insert(both.end(), thin_b.begin(), thin_b.end());
