@@ -178,8 +178,10 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 float* obuf = abuf + gp.ntiles * 256;
                 const bool gp_staged = gp.staged && (gp.lean || HINT_BWD_STAGE);      // (lean staged groups keep g1 in LDS for their dW1 pass)
                 float* slab = obuf + (gp_staged ? gp.ntiles * 256 : 0);
+                // (slots of the boundary below: its threads; the others move the finished group's tiles meanwhile)
+                const int nact = lds_i32(T.rng + a.lop_cnt + (tail_only ? a.n_groups : slot));
                 if (has_prev && gp_staged) {
-                    const int need = (ROWS * a.d + 63) & ~63;
+                    const int need = (ROWS * (nact > a.dc ? nact : a.dc) + 63) & ~63;
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
                     if (tid >= soff) {
@@ -231,11 +233,11 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     thin_staged = pc.thin_l != nullptr;
                 }
                 // ---- Q1: scatter of the previous group's g_v + coupling backward of this one ----
-                // the boundary's ACTIVE lanes only (scatter target or transformed lane), from the table's compacted copy (hint_plan.cpp: entry k =
-                // the ops of the k-th active lane, its column in pad) in LDS, or in global memory for the large trees: 16 x 40-60 elements
-                // instead of 16 x 100 in front of d = 100's deep groups, 16 x 32 = ONE pass of the workgroup instead of 16 x 43 = two at d = 43
+                // the boundary's SLOTS (hint_plan.cpp): a thread adds the finished group's g_v partials onto one lane (`colb`) and forms the
+                // coupling gradients of one transformed lane (`col`) - the same lane, or a scatter-only and a coupling-only lane that share the
+                // slot (a wavefront runs through both halves whatever its lanes need); from the compacted table in LDS, or in global memory for
+                // the large trees.  16 x 20-23 slots at d = 43 (16 x 43 lanes: two passes of the workgroup), 16 x 30-40 at d = 100.
                 const bool lop_g = a.lops_off < 0;
-                const int nact = lds_i32(T.rng + a.lop_cnt + (tail_only ? a.n_groups : slot));
                 const float inv_n = frcp(nact > 0 ? nact : 1);
                 for (int idx = tid; idx < ROWS * nact && tid < qthreads; idx += qthreads) {
                     const int row = fdiv(idx, inv_n);
@@ -243,20 +245,23 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     if (lop_g) lq = ((const GLOBAL_AS i32x4*)a.lopsc)[lop0 + idx - row * nact];
                     else lq = *(const LDS_AS i32x4*)(T.lops + lop0 + idx - row * nact);
                     const unsigned w0 = (unsigned)lq.x, w1 = (unsigned)lq.y, w2 = (unsigned)lq.z;
-                    const int col = lq.w & 0xffff;
+                    const int col = lq.w & 0xffff, colb = (int)((unsigned)lq.w >> 16);
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
                     const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);
                     float gval = gs[row * a.xld + col];
                     if (sc_unit >= 0) {
+                        float gb = gs[row * a.xld + colb];
 #pragma unroll
                         for (int net = 0; net < 2; ++net) {
                             const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + sc_unit + net);
                             const int cin = up[15], sl_n = up[21], gv_off = up[22];
                             const int stride = 64 * ((cin + 3) >> 2);
                             const float* sp = slab + gv_off + ((sc_k >> 2) * 16 + row) * 4 + (sc_k & 3);
-                            for (int sl = 0; sl < sl_n; ++sl) gval += sp[sl * stride];
+                            for (int sl = 0; sl < sl_n; ++sl) gb += sp[sl * stride];
                         }
+                        if (colb == col) gval = gb;
+                        else gs[row * a.xld + colb] = gb;
                     }
                     if (!tail_only && cp_ls >= 0) {
                         const float s = sb[row * a.xld + col];

@@ -773,28 +773,48 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
 
 
+    // What the general backward kernels walk per boundary (LDS copy or KArgs::lopsc; the wave-local backward keeps the plain table):
+    // SLOTS of one thread's work each.  A lane can be a scatter target (an input of the finished group's nodes), a transformed lane
+    // of the group about to run, or both; the two halves of a slot's work are independent unless they meet in one lane, and a
+    // wavefront runs through both halves whatever its lanes need - so a coupling-only lane and a scatter-only lane share a slot:
+    // first the lanes that are both, then the pairs, then what is left of the longer list.  pad = column of the coupling (or only)
+    // lane | column of the scatter lane << 16; the slot counts replace the active-lane counts in the ranges table.
+    // (MINIBOONE d = 43: 22 / 22 / 23 / 20 slots for 22 / 32 / 33 / 20 active lanes - 16 x 33 elements were two passes of the 512 threads)
+    std::vector<LaneOp> lc(lops.size());
+    {
+        const int nb = (int)(lops.size() / (size_t)d);
+        for (int b = 0; b < nb; ++b) {
+            const LaneOp* src = lops.data() + (size_t)b * d;
+            std::vector<int> both, conly, sonly;
+            for (int col = 0; col < d; ++col) {
+                const bool sc = src[col].sc_unit >= 0, cp = src[col].cp_ls >= 0;
+                if (sc && cp) both.push_back(col); else if (cp) conly.push_back(col); else if (sc) sonly.push_back(col);
+            }
+            int k = 0;
+            for (int col : both) { LaneOp op = src[col]; op.pad = col | (col << 16); lc[(size_t)b * d + k++] = op; }
+            const size_t np = std::max(conly.size(), sonly.size());
+            for (size_t i = 0; i < np; ++i) {
+                LaneOp op{};
+                op.sc_unit = -1; op.cp_ls = -1;
+                int ca = -1, cb = -1;
+                if (i < conly.size()) { const LaneOp& o = src[conly[i]]; ca = conly[i]; op.cp_ls = o.cp_ls; op.cp_lt = o.cp_lt; op.cp_gs = o.cp_gs; op.cp_gt = o.cp_gt; }
+                if (i < sonly.size()) { const LaneOp& o = src[sonly[i]]; cb = sonly[i]; op.sc_unit = o.sc_unit; op.sc_k = o.sc_k; }
+                if (ca < 0) ca = cb;
+                if (cb < 0) cb = ca;
+                op.pad = ca | (cb << 16);
+                lc[(size_t)b * d + k++] = op;
+            }
+            if (!P->wl) rng[P->lop_cnt + b] = k;
+            for (; k < d; ++k) { LaneOp op{}; op.sc_unit = -1; op.cp_ls = -1; lc[(size_t)b * d + k] = op; }
+        }
+    }
+
     // ---- meta blob staged in LDS by the kernels ----
     std::vector<char> meta(P->meta_bytes, 0);
     std::memcpy(meta.data(), groups.data(), groups.size() * sizeof(Group));
     std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
-    // per boundary the active lanes' entries first (entry k's pad names the k-th active lane: build_lane_ops), their column in pad:
-    // what the general backward kernels walk (LDS copy or KArgs::lopsc); the wave-local backward keeps the plain table
-    std::vector<LaneOp> lc(lops.size());
-    {
-        const int nb = (int)(lops.size() / (size_t)d);
-        for (int b = 0; b < nb; ++b) {
-            const int cnt = lops[(size_t)b * d].pad >> 16;
-            for (int k = 0; k < d; ++k) {
-                LaneOp op{};
-                op.sc_unit = -1; op.cp_ls = -1;
-                if (k < cnt) { const int col = lops[(size_t)b * d + k].pad & 0xffff; op = lops[(size_t)b * d + col]; op.pad = col; }
-                op.pad = (op.pad & 0xffff) | (cnt << 16);
-                lc[(size_t)b * d + k] = op;
-            }
-        }
-    }
     if (lops_lds) std::memcpy(meta.data() + P->lops_off, P->wl ? lops.data() : lc.data(), lops.size() * sizeof(LaneOp));
     P->lds_fwd = (fixed_f - sub_f_bytes + 4 * P->region_fwd + 15) / 16 * 16;
     P->lds_bwd = (fixed_b - sub_b_bytes + 4 * P->region_bwd + 15) / 16 * 16;
