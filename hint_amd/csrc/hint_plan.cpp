@@ -773,7 +773,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     }
 
 
-    // What the general backward kernels walk per boundary (LDS copy or KArgs::lopsc; the wave-local backward keeps the plain table):
+    // What the backward kernels walk per boundary (LDS copy, or KArgs::lopsc for the large trees):
     // SLOTS of one thread's work each.  A lane can be a scatter target (an input of the finished group's nodes), a transformed lane
     // of the group about to run, or both; the two halves of a slot's work are independent unless they meet in one lane, and a
     // wavefront runs through both halves whatever its lanes need - so a coupling-only lane and a scatter-only lane share a slot:
@@ -804,7 +804,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
                 op.pad = ca | (cb << 16);
                 lc[(size_t)b * d + k++] = op;
             }
-            if (!P->wl) rng[P->lop_cnt + b] = k;
+            rng[P->lop_cnt + b] = k;
             for (; k < d; ++k) { LaneOp op{}; op.sc_unit = -1; op.cp_ls = -1; lc[(size_t)b * d + k] = op; }
         }
     }
@@ -815,7 +815,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     std::memcpy(meta.data() + P->units_off, units.data(), units.size() * sizeof(Unit));
     if (!ents.empty()) std::memcpy(meta.data() + P->ents_off, ents.data(), ents.size() * sizeof(Ent));
     std::memcpy(meta.data() + P->rng_off, rng.data(), rng.size() * sizeof(int32_t));
-    if (lops_lds) std::memcpy(meta.data() + P->lops_off, P->wl ? lops.data() : lc.data(), lops.size() * sizeof(LaneOp));
+    if (lops_lds) std::memcpy(meta.data() + P->lops_off, lc.data(), lc.size() * sizeof(LaneOp));
     P->lds_fwd = (fixed_f - sub_f_bytes + 4 * P->region_fwd + 15) / 16 * 16;
     P->lds_bwd = (fixed_b - sub_b_bytes + 4 * P->region_bwd + 15) / 16 * 16;
     if (rowdw_bytes > 0) { P->rowdw_lds = P->lds_bwd / 4; P->lds_bwd += rowdw_bytes; }

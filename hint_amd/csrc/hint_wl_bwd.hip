@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
             const int row_begin = gp[3], rngb = gp[6];
             tr0 = row_begin + T.rng[rngb + wave];
             tr1 = row_begin + T.rng[rngb + wave + 1];
-            tgi = gp[7] | ((int)((unsigned)((const LDS_AS int32_t*)(T.lops + b * a.d))[3] >> 16) << 8);
+            tgi = gp[7] | (T.rng[a.lop_cnt + b] << 8);
             tabs_ready = true;
         }
         int phase = 0;
@@ -186,20 +186,16 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
                 (void)sid;
                 STAMP(sid + 0)
                 // ---- scatter of the previous group's g_v + coupling backward of this one, on the wavefront's own tiles ----
-                // (only the boundary's ACTIVE lanes - something to add, or a coupling gradient to form: LaneOp::pad lists them -,
-                //  16 rows x nact elements: the lanes a boundary leaves alone cost a full pass of the loop for nothing - at d = 6 the
-                //  three boundaries of a block have 3, 5 and 2 active lanes of 6)
+                // (the boundary's SLOTS, hint_plan.cpp: a thread adds the finished group's g_v partials onto one lane - `colb` - and forms the
+                //  coupling gradients of one transformed lane - `col`: the same lane, or a scatter-only and a coupling-only lane sharing the slot,
+                //  since a wavefront runs through both halves whatever its lanes need.  16 rows x nact slots: at d = 6 the three boundaries of a
+                //  block have 3, 4 and 2 slots for 3, 5 and 2 active lanes of 6 - each ONE pass of four slots x 16 rows)
                 const int nact = ginfo >> 8;
-                // (lane-major: a pass of the loop is four active lanes x 16 rows; the planner lists the lanes with a coupling first)
                 for (int idx = lane; idx < ROWS * nact; idx += 64) {
                     const int row = idx & 15, kk = idx >> 4;
-                    int col;
-                    unsigned w0, w1, w2;
-                    {   // (the planner keeps a wave-local plan's lane table in LDS)
-                        col = ((const LDS_AS int32_t*)(T.lops + lop0 + kk))[3] & 0xffff;
-                        const LDS_AS int32_t* lp = (const LDS_AS int32_t*)(T.lops + lop0 + col);
-                        w0 = (unsigned)lp[0]; w1 = (unsigned)lp[1]; w2 = (unsigned)lp[2];
-                    }
+                    const i32x4 lq = *(const LDS_AS i32x4*)(T.lops + lop0 + kk);        // (the planner keeps a wave-local plan's table in LDS)
+                    const unsigned w0 = (unsigned)lq.x, w1 = (unsigned)lq.y, w2 = (unsigned)lq.z;
+                    const int col = lq.w & 0xffff, colb = (int)((unsigned)lq.w >> 16);
                     const int sc_unit = (int)(int16_t)(w0 & 0xffffu), sc_k = (int)(w0 >> 16);
                     const int cp_ls = (int)(int16_t)(w1 & 0xffffu), cp_lt = (int)(w1 >> 16);
                     const int cp_gs = (int)(w2 & 0xffffu), cp_gt = (int)(w2 >> 16);
@@ -207,6 +203,9 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
                     for (int h = 0; h < NR; ++h) gval[h] = GS(h)[row * a.xld + col];
                     if (sc_unit >= 0) {
+                        float gb[NR];
+#pragma unroll
+                        for (int h = 0; h < NR; ++h) gb[h] = GS(h)[row * a.xld + colb];
 #pragma unroll
                         for (int net = 0; net < 2; ++net) {
                             const LDS_AS int32_t* up = (const LDS_AS int32_t*)(T.units + sc_unit + net);
@@ -219,9 +218,14 @@ __global__ __launch_bounds__(64 * MAX_NW) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) v[u] = sp[(u < sl_n ? u : sl_n - 1) * 64];
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) gval[h] += u < sl_n ? v[u] : 0.f;
-                                if (more) for (int sl = 4; sl < sl_n; ++sl) gval[h] += sp[sl * 64];
+                                for (int u = 0; u < 4; ++u) gb[h] += u < sl_n ? v[u] : 0.f;
+                                if (more) for (int sl = 4; sl < sl_n; ++sl) gb[h] += sp[sl * 64];
                             }
+                        }
+#pragma unroll
+                        for (int h = 0; h < NR; ++h) {
+                            if (colb == col) gval[h] = gb[h];
+                            else GS(h)[row * a.xld + colb] = gb[h];
                         }
                     }
                     if (!tail_only && cp_ls >= 0) {
