@@ -139,7 +139,7 @@ KArgs make_args(const hint_plan* P, int B, bool backward) {
     KArgs a{};
     a.meta = P->d_meta; a.meta_bytes = P->meta_bytes; a.recs = P->d_recs; a.total_rows = P->total_rows; a.thins = P->d_thins; a.total_tiles = P->total_tiles;
     a.units_off = P->units_off; a.tmap_off = P->tmap_off; a.ents_off = P->ents_off; a.rng_off = P->rng_off;
-    a.lops_off = P->lops_off; a.lops = P->d_lops; a.lopsc = P->d_lopsc; a.lop_cnt = P->lop_cnt;
+    a.lops_off = P->lops_off; a.lopsc = P->d_lopsc; a.lop_cnt = P->lop_cnt;
     a.n_groups = P->n_groups; a.n_levels = P->n_levels; a.n_units = P->n_units; a.nw = P->nw;
     a.d = P->d; a.dc = P->dc; a.xld = P->xld; a.cld = P->cld;
     a.abuf_tiles = P->abuf_tiles; a.slab_floats = backward ? P->slab_bwd : P->slab_fwd; a.gld = P->gld;

@@ -130,7 +130,8 @@ struct LaneOp {
     int16_t sc_unit, sc_k;  // s unit (global index) of the node of the previous group that takes this lane as input k; -1: none
     int16_t cp_ls, cp_lt;   // column of g_s / g_t of this lane in the LDS coupling-gradient buffer; cp_ls = -1: lane not transformed
     int16_t cp_gs, cp_gt;   // the same columns in the global [Bp][ST] array
-    int32_t pad;            // entry k of a boundary: the boundary's k-th ACTIVE lane (sc_unit >= 0 or cp_ls >= 0) | their number << 16
+    int32_t pad;            // slot table (what the kernels read): column of the coupling lane | column of the scatter lane << 16 (equal when one lane is both, or
+                            // when the slot holds one lane only); the planner's per-lane working table: the boundary's k-th active lane | their number << 16
 };
 static_assert(sizeof(LaneOp) == 16, "LaneOp must be 16 bytes");
 
@@ -194,8 +195,7 @@ struct ThinRec {
 
 struct KArgs {
     const void* meta;              // [groups | units | tmap | ents | ranges | laneops] contiguous, copied to LDS at kernel start
-    const void* lops;              // LaneOp[(n_groups + 1) * d] in global memory (used when lops_off < 0: table too big for LDS)
-    const void* lopsc;             // the same table with every boundary's ACTIVE lanes first: entry k = the ops of the k-th active lane, pad = its column | count << 16 (hint_bwd_fly.hip)
+    const void* lopsc;             // the backward boundaries' SLOT table, LaneOp[(n_groups + 1) * d], in global memory (read when lops_off < 0: too big for LDS; the LDS copy is the same table)
     const void* thins;             // ThinRec[2][total_tiles]: forward records, then backward records, tiles in (group, unit) order
     int32_t total_tiles;
     const void* recs;              // RowRec[2][total_rows]: forward records, then backward records, rows in (group, wavefront, unit) order
@@ -234,7 +234,7 @@ struct KArgs {
     int32_t sub_misc;              // LDS float offset: forward nw x 16 log-det partials; backward two 256-float scratch tiles per wavefront
     int32_t sub_cols;              // index in the ranges table of the wavefronts' lane bounds: four per wavefront (hint_plan.cpp)
     int32_t packed_tiles, packed_lines;    // a block's packed buffer: 256-float tiles of [thin blobs | fragment tiles]; 128-byte lines with the biases behind them
-    int32_t lop_cnt;               // index in the ranges table of the backward boundaries' active-lane counts (boundary b = in front of group b; n_groups: the tail's)
+    int32_t lop_cnt;               // index in the ranges table of the backward boundaries' slot counts (boundary b = in front of group b; n_groups: the tail's)
     int32_t sink_lds;              // float offset in LDS of a 64-float sink for the L2 prefetch (hint_device.hpp prefetch_consumer); 0: no prefetch
     int32_t rowdw_lds;             // backward: float offset in LDS of one scratch tile (256 floats) per wavefront for the rows that compute dW1 | db1 themselves; 0: none do
 };

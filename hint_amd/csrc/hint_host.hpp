@@ -126,9 +126,8 @@ struct hint_plan {
     int num_cu = 256;
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
-    LaneOp* d_lops = nullptr;
-    int lop_cnt = 0;                // index in the ranges table of the boundaries' active-lane counts (n_groups + 1 of them)
-    LaneOp* d_lopsc = nullptr;      // compacted per boundary: active lanes first (KArgs::lopsc)
+    int lop_cnt = 0;                // index in the ranges table of the boundaries' slot counts (n_groups + 1 of them)
+    LaneOp* d_lopsc = nullptr;      // the boundaries' slot table (KArgs::lopsc)
     RowRec* d_recs = nullptr;
     ThinRec* d_thins = nullptr;
     int total_tiles = 0;

@@ -565,7 +565,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         rng.insert(rng.end(), sub_cols_v.begin(), sub_cols_v.end());
         P->sub_slab_f = 0; P->sub_slab_b = 0;       // (the nodes' partial sums stay in registers: no slabs in LDS; the offsets above are unused)
     }
-    // the backward lane tables (one boundary per group + the tail's); every boundary's count of active lanes rides in the ranges table
+    // the backward lane tables (one boundary per group + the tail's); every boundary's slot count rides in the ranges table (set where the slot table is built)
     std::vector<LaneOp> lops = build_lane_ops(groups, units, d);
     P->lop_cnt = (int)rng.size();
     for (size_t b = 0; b <= groups.size(); ++b) rng.push_back(lops[b * (size_t)d].pad >> 16);
@@ -953,7 +953,6 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     };
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = upload((void**)&P->d_meta, meta.data(), meta.size());
-    if (e == hipSuccess) e = upload((void**)&P->d_lops, lops.data(), lops.size() * sizeof(LaneOp));
     if (e == hipSuccess) e = upload((void**)&P->d_lopsc, lc.data(), lc.size() * sizeof(LaneOp));
     if (e == hipSuccess) {
         std::vector<ThinRec> both(thin_f);
@@ -1087,7 +1086,6 @@ void hint_plan_destroy(hint_plan* P) {
     for (hint_plan* L : P->inv_levels) hint_plan_destroy(L);
     (void)hipFree(P->d_inv_lower);
     (void)hipFree(P->d_meta);
-    (void)hipFree(P->d_lops);
     (void)hipFree(P->d_lopsc);
     (void)hipFree(P->d_recs);
     (void)hipFree(P->d_thins);
