@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 // the boundary's SLOTS (hint_plan.cpp): a thread adds the finished group's g_v partials onto one lane (`colb`) and forms the
                 // coupling gradients of one transformed lane (`col`) - the same lane, or a scatter-only and a coupling-only lane that share the
                 // slot (a wavefront runs through both halves whatever its lanes need); from the compacted table in LDS, or in global memory for
-                // the large trees.  16 x 20-23 slots at d = 43 (16 x 43 lanes: two passes of the workgroup), 16 x 30-40 at d = 100.
+                // the large trees.  16 x 22-27 slots at d = 43 (32-35 active lanes of 43: two passes of the workgroup), up to 16 x 52 at d = 100 (76 lanes).
                 const bool lop_g = a.lops_off < 0;
                 const float inv_n = frcp(nact > 0 ? nact : 1);
                 for (int idx = tid; idx < ROWS * nact && tid < qthreads; idx += qthreads) {

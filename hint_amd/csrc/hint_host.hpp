@@ -127,6 +127,7 @@ struct hint_plan {
     int meta_bytes = 0, units_off = 0, tmap_off = 0, ents_off = 0, rng_off = 0, lops_off = 0, n_bias = 0;
     void* d_meta = nullptr;
     int lop_cnt = 0;                // index in the ranges table of the boundaries' slot counts (n_groups + 1 of them)
+    int max_slots = 0;              // slots of the backward's widest boundary (hint_plan_check reports it)
     LaneOp* d_lopsc = nullptr;      // the boundaries' slot table (KArgs::lopsc)
     RowRec* d_recs = nullptr;
     ThinRec* d_thins = nullptr;

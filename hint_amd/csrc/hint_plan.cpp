@@ -779,7 +779,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // wavefront runs through both halves whatever its lanes need - so a coupling-only lane and a scatter-only lane share a slot:
     // first the lanes that are both, then the pairs, then what is left of the longer list.  pad = column of the coupling (or only)
     // lane | column of the scatter lane << 16; the slot counts replace the active-lane counts in the ranges table.
-    // (MINIBOONE d = 43: 22 / 22 / 23 / 20 slots for 22 / 32 / 33 / 20 active lanes - 16 x 33 elements were two passes of the 512 threads)
+    // (MINIBOONE d = 43: 22 / 22 / 23 / 24 / 27 slots for 22 / 32 / 33 / 32 / 35 active lanes - 16 x 33 elements were two passes of the 512
+    //  threads; d = 100: up to 52 slots for 76 active lanes.  HINT_PLAN_DUMP=1 prints the list)
     std::vector<LaneOp> lc(lops.size());
     {
         const int nb = (int)(lops.size() / (size_t)d);
@@ -806,6 +807,40 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             rng[P->lop_cnt + b] = k;
             for (; k < d; ++k) { LaneOp op{}; op.sc_unit = -1; op.cp_ls = -1; lc[(size_t)b * d + k] = op; }
+        }
+    }
+
+    {   // self-check: per boundary every scatter target is the scatter lane of exactly one slot, every transformed lane the coupling
+        // lane of exactly one, with its own fields, and no slot names a lane that has neither
+        const int nb = (int)(lops.size() / (size_t)d);
+        for (int b = 0; b < nb; ++b) {
+            const int cnt = rng[P->lop_cnt + b];
+            std::vector<int> sc_seen(d, 0), cp_seen(d, 0);
+            bool ok = cnt >= 0 && cnt <= d;
+            for (int k = 0; ok && k < cnt; ++k) {
+                const LaneOp& o = lc[(size_t)b * d + k];
+                const int ca = o.pad & 0xffff, cb = (int)((uint32_t)o.pad >> 16);
+                if (ca >= d || cb >= d || (o.sc_unit < 0 && o.cp_ls < 0)) { ok = false; break; }
+                const LaneOp& pa = lops[(size_t)b * d + ca];
+                const LaneOp& pb = lops[(size_t)b * d + cb];
+                if (o.cp_ls >= 0) { ++cp_seen[ca]; ok = ok && pa.cp_ls == o.cp_ls && pa.cp_lt == o.cp_lt && pa.cp_gs == o.cp_gs && pa.cp_gt == o.cp_gt; }
+                if (o.sc_unit >= 0) { ++sc_seen[cb]; ok = ok && pb.sc_unit == o.sc_unit && pb.sc_k == o.sc_k; }
+                if (ca != cb) ok = ok && pa.sc_unit < 0 && pb.cp_ls < 0 && o.cp_ls >= 0 && o.sc_unit >= 0;      // a pair: a coupling-only and a scatter-only lane
+            }
+            for (int col = 0; ok && col < d; ++col) {
+                const LaneOp& pl = lops[(size_t)b * d + col];
+                ok = cp_seen[col] == (pl.cp_ls >= 0 ? 1 : 0) && sc_seen[col] == (pl.sc_unit >= 0 ? 1 : 0);
+            }
+            if (!ok) {
+                delete P;
+                return fail("hint_plan_create: internal error (boundary slots)");
+            }
+            P->max_slots = std::max(P->max_slots, cnt);
+        }
+        if (std::getenv("HINT_PLAN_DUMP")) {
+            std::fprintf(stderr, "[hint plan] backward boundary slots (active lanes):");
+            for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %d (%d)", rng[P->lop_cnt + b], lops[(size_t)b * d].pad >> 16);
+            std::fprintf(stderr, "\n");
         }
     }
 
@@ -1073,7 +1108,7 @@ int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int
         stats[0] = P->n_groups; stats[1] = P->n_levels; stats[2] = P->WT; stats[3] = P->ST;
         stats[4] = P->lds_fwd; stats[5] = P->lds_bwd; stats[6] = P->nw; stats[7] = P->n_wjobs;
         stats[8] = P->param_floats; stats[9] = P->packed_floats; stats[10] = P->n_units; stats[11] = P->abuf_tiles;
-        stats[12] = P->n_sub; stats[13] = P->wl; stats[14] = P->n_wsmall; stats[15] = 0;
+        stats[12] = P->n_sub; stats[13] = P->wl; stats[14] = P->n_wsmall; stats[15] = P->max_slots;
     }
     delete P->alt4;
     delete P;                   // (host-only plans own no device memory)

@@ -66,7 +66,8 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
  * stats[16] = { groups, levels, WT (activation columns), ST (coupling-gradient columns), LDS bytes forward,
  * LDS bytes backward, wavefronts per workgroup, part-B tile jobs, parameter floats, packed floats, units,
  * fragment tiles of the widest group, subtree groups (the deepest levels that run one subtree per wavefront; 0: none),
- * 1 when the block runs on the wave-local kernels, single-tile part-B jobs that share workgroups, 0 }.
+ * 1 when the block runs on the wave-local kernels, single-tile part-B jobs that share workgroups,
+ * slots (threads per batch row) of the backward's widest boundary }.
  * For tests and tools; same return convention as hint_plan_create. */
 int hint_plan_check(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp,
                     int64_t* stats);

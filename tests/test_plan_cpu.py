@@ -1,7 +1,7 @@
 """Planner (hint_amd/csrc/hint_plan.cpp) without a GPU: hint_plan_check builds the launch plan of a block
 on the host, lets the planner verify its own schedule (every fragment tile of every group in exactly one
-wavefront's range of either GEMM phase, slices consistent with the ranges) and reports the plan's
-figures.  Covers the BASELINE configs' block shapes, the conditional lanes, wide
+wavefront's range of either GEMM phase, slices consistent with the ranges; every scatter target and every
+transformed lane of a backward boundary in exactly one slot) and reports the plan's figures.  Covers the BASELINE configs' block shapes, the conditional lanes, wide
 (h = 512) nodes and ragged widths."""
 import ctypes as C
 
@@ -13,7 +13,7 @@ from hint_amd import _lib
 from hint_amd.hint import node_descs
 
 STAT = ["groups", "levels", "WT", "ST", "lds_fwd", "lds_bwd", "nw", "wjobs", "params", "packed", "units", "abuf_tiles",
-        "sub_groups", "wave_local", "small_jobs", "reserved"]
+        "sub_groups", "wave_local", "small_jobs", "max_slots"]
 
 
 def check(tree, d, dc, clamp=4.0):
@@ -125,3 +125,18 @@ def test_planner_subtree_groups(d, widths, sub_groups, wave_local):
         assert st["small_jobs"] > 0 and st["groups"] > st["sub_groups"]
     elif wave_local:
         assert st["small_jobs"] == 0
+
+
+@pytest.mark.parametrize("d,widths,slots", [
+    (6, [140, 70, 35, 17], 4),        # cfg 2: the boundary between the levels has 5 active lanes - 2 both, 2 coupling-only, 1 scatter-only
+    (8, [128, 64, 32, 16], 4),        # cfg 3: 6 active lanes, 2 + 2 + 2
+    (43, [67, 33, 16, 8], 27),        # cfg 5: up to 33-38 active lanes of 43 (16 x 33 were two passes of the backward's 512 threads)
+])
+def test_backward_boundary_slots_pair_coupling_only_with_scatter_only_lanes(d, widths, slots):
+    """hint_plan.cpp (slot table): a thread of a backward boundary takes a lane that is scatter target AND transformed, or one of each
+    kind, so the widest boundary has fewer slots than the tree has lanes - and one pass of the workgroup covers it (the planner's
+    self-check, run by hint_plan_check, proves that every lane's work is in exactly one slot)."""
+    blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], dims_c=[], c_internal=widths)
+    st, nodes, _ = check(blk.tree, d, 0)
+    assert st["max_slots"] == slots < d
+    assert 16 * st["max_slots"] <= 64 * st["nw"] or st["wave_local"]
