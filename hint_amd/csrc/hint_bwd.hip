@@ -358,7 +358,15 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                         const int n0 = lds_i32(rngn + wave), n1 = lds_i32(rngn + wave + 1);
                         if (n0 < n1) rnext = gn.row_begin + n0;
                     }
+#if defined(HINT_BWD_FLY) || defined(HINT_BWD_PRIO_ALL)
+                    // (the SIMD's younger wavefront first while the rows run - see hint_wl_bwd.hip; measured: the lean-groups instance -2.2 % at d = 100,
+                    //  the MINIBOONE instance +-0, the forward / inverse kernels +1-3 %)
+                    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
                     rows_run<K_BWD, BWD_FLYK>(pc, ring, rcar, g.row_begin + lds_i32(rng + wave), g.row_begin + lds_i32(rng + wave + 1), rnext, lane);
+#if defined(HINT_BWD_FLY) || defined(HINT_BWD_PRIO_ALL)
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 }
                 STAMP(sid + 15)
                 STAMP(sid + 5)
