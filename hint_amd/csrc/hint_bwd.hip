@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
             if (perm != nullptr) {                 // chain rule through x' = x W:  g_x = g_x' W^T
                 // (in place: the products wait in registers for the barrier)
                 f32x4 pacc[PERM_TQ];
-                perm_mfma<true>(pacc, gs, a.xld, perm, a.d, wave, a.nw, lane);
+                perm_mfma<true>(pacc, gs, a.xld, (const GLOBAL_AS float*)perm, a.d, wave, a.nw, lane);
                 __syncthreads();
                 perm_store(pacc, gs, a.xld, a.d, wave, a.nw, lane);
                 __syncthreads();

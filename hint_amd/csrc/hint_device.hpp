@@ -147,8 +147,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float*
 // time.  (As scalar code - 16 d outputs of d FMAs with two loads each, perm_dot below - the product cost a d = 43 block 7 k
 // cycles per kernel; k ascends in both, so the sums agree.)
 constexpr int PERM_TQ = 2;
-template <bool TRANS>
-__device__ __forceinline__ void perm_mfma(f32x4 (&acc)[PERM_TQ], const float* in, int ld, const float* __restrict__ w, int d,
+// (WP: the matrix through an LDS or a global pointer - a pointer that may be either is read with flat_load, whose waits drain both counters)
+template <bool TRANS, typename WP>
+__device__ __forceinline__ void perm_mfma(f32x4 (&acc)[PERM_TQ], const float* in, int ld, WP w, int d,
                                           int wave, int nw, int lane) {
     const int m = lane & 15, kq = lane >> 4;
     const int nt = (d + 15) >> 4, ns = (d + 3) >> 2;

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
             STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 9)
             if (!REV && perm != nullptr) {
                 // fused fixed inter-block permutation (power_hint_8.py:59-62): x' = x W
-                const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
                 f32x4 pacc[PERM_TQ];
-                perm_mfma<false>(pacc, XS, a.xld, w, a.d, wave, a.nw, lane);
+                if (a.perm_lds > 0) perm_mfma<false>(pacc, XS, a.xld, (const LDS_AS float*)(ptab + bi * pdd), a.d, wave, a.nw, lane);
+                else perm_mfma<false>(pacc, XS, a.xld, (const GLOBAL_AS float*)perm, a.d, wave, a.nw, lane);
                 STAMP((cb * a.n_groups + a.n_groups - a.n_sub) * 16 + 10)
                 perm_store(pacc, XO, a.xld, a.d, wave, a.nw, lane);
                 xcur = xflip - xcur;
@@ -303,9 +303,9 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 if (tid < ROWS) { float t = 0.f; for (int w = 0; w < a.nw; ++w) t += (lds + a.sub_misc)[w * ROWS + tid]; jac[tid] += t; }
             }
             if (REV && perm != nullptr) {     // inverse of the fused permutation: x = x' W^T
-                const float* w = a.perm_lds > 0 ? ptab + bi * pdd : perm;
                 f32x4 pacc[PERM_TQ];
-                perm_mfma<true>(pacc, XS, a.xld, w, a.d, wave, a.nw, lane);
+                if (a.perm_lds > 0) perm_mfma<true>(pacc, XS, a.xld, (const LDS_AS float*)(ptab + bi * pdd), a.d, wave, a.nw, lane);
+                else perm_mfma<true>(pacc, XS, a.xld, (const GLOBAL_AS float*)perm, a.d, wave, a.nw, lane);
                 perm_store(pacc, XO, a.xld, a.d, wave, a.nw, lane);
                 xcur = xflip - xcur;
                 __syncthreads();
