@@ -18,6 +18,8 @@ re-gathered automatically whenever a parameter stops aliasing it (`p.data = ...`
 from __future__ import annotations
 
 import ctypes as C
+import os
+import time
 from typing import List, Optional, Sequence
 
 import torch
@@ -27,9 +29,99 @@ from . import _lib
 from ._lib import HintAmdError, NodeDesc
 
 __all__ = ["linear_subnet_constructor", "HierarchicalAffineCouplingTree",
-           "HierarchicalAffineCouplingBlock", "HintAmdError"]
+           "HierarchicalAffineCouplingBlock", "HintAmdError", "set_param_grad_mode", "set_pack_cache"]
 
 _ALIGN = 4  # floats; every tensor starts 16-byte aligned inside the arena
+
+# ---- how parameter gradients reach `p.grad` on the module (autograd) route ------------------------------------------
+# "direct" (default): the backward kernels write the flat gradient of a block (of the whole flow on HintFlow's fused
+#   route) into ONE persistent buffer and every `p.grad` is a cached view into it - what `loss.backward()` leaves for the
+#   reference loop's `p.grad.data.clamp_` / `optim.step()` (train_unconditional.py:137-144), without 36 autograd edges,
+#   views and AccumulateGrad nodes per block and pass (they cost 10x the kernels at cfg 2).  The usual accumulation rules
+#   hold (`p.grad is None` -> set; a gradient left by an earlier backward -> added to).  What does NOT happen: hooks on the
+#   parameters (`p.register_hook`, DistributedDataParallel's reducer) do not fire and `torch.autograd.grad(loss, params)`
+#   does not see the parameters.
+# "autograd": every parameter is an input of the autograd node and its gradient is returned through autograd (the
+#   behaviour of rounds 1-5) - for code that needs the hooks or the functional API.
+_PARAM_GRADS = os.environ.get("HINT_PARAM_GRADS", "direct")
+# Re-pack skipping is OFF by default: `p.data.add_(...)`-style edits do not advance `p._version` (a `.data` alias has a
+# version counter of its own), so no host-side key can prove the packed copy current; the re-pack is one 6 us launch.
+# set_pack_cache(True) / HINT_PACK_CACHE=1 skips it when no parameter's (`data_ptr`, `_version`) moved since the last pack -
+# for loops that only ever change weights through optimizers / load_state_dict / `p.data = ...`.
+_PACK_CACHE = os.environ.get("HINT_PACK_CACHE", "0") not in ("", "0")
+
+
+def set_param_grad_mode(mode: str) -> str:
+    """'direct' or 'autograd' (see above); returns the previous mode.  Takes effect at the next forward."""
+    global _PARAM_GRADS
+    if mode not in ("direct", "autograd"):
+        raise ValueError("mode must be 'direct' or 'autograd'")
+    prev, _PARAM_GRADS = _PARAM_GRADS, mode
+    return prev
+
+
+def set_pack_cache(on: bool) -> bool:
+    global _PACK_CACHE
+    prev, _PACK_CACHE = _PACK_CACHE, bool(on)
+    return prev
+
+
+# ---- where a step's time goes (bench.py's module_path entry): host clock + HIP events around hint_amd's entry points ----
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = {"host": 0.0, "events": [], "calls": 0}
+    return _PROF
+
+
+def profile_stop(prof, n_steps: int):
+    global _PROF
+    _PROF = None
+    torch.cuda.synchronize()
+    dev_ms = sum(a.elapsed_time(b) for a, b in prof["events"])
+    return {"hint_amd_host_ms": prof["host"] * 1e3 / n_steps, "hint_amd_device_ms": dev_ms / n_steps,
+            "hint_amd_calls_per_step": prof["calls"] / n_steps}
+
+
+class _Region:
+    """`with _Region():` around an entry point: nothing unless profile_start() is active"""
+    __slots__ = ("pr", "t0", "e0")
+
+    def __enter__(self):
+        self.pr = _PROF
+        if self.pr is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        pr = self.pr
+        if pr is not None:
+            pr["host"] += time.perf_counter() - self.t0
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            pr["events"].append((self.e0, e1))
+            pr["calls"] += 1
+        return False
+
+
+class _Lease:
+    """hands a pooled buffer back when the autograd node that holds it dies (not at the end of backward():
+    retain_graph=True may run the node again)"""
+    __slots__ = ("pool", "item")
+
+    def __init__(self, pool, item):
+        self.pool, self.item = pool, item
+
+    def __del__(self):
+        try:
+            if len(self.pool) < 2:
+                self.pool.append(self.item)
+        except Exception:
+            pass
 
 
 def linear_subnet_constructor(c_in, c_out, c_internal):
@@ -110,6 +202,14 @@ class _Engine:
         self._ext_arena: Optional[torch.Tensor] = None
         self._ptrs: List[int] = []
         self._regathered = False
+        self._sizes = {}            # B -> (tape floats, workspace bytes) of this plan
+        self._tape_pool = {}        # (B, stream) -> free tape buffers (handed back when the autograd node that used one dies)
+        self._ws = {}               # (B, stream) -> the backward workspace (scratch inside one stream-ordered call)
+        self._pack_key = None       # (data_ptr, _version) of every parameter at the last pack (set_pack_cache)
+        self._gathers = 0           # times the arena was re-gathered (a gather can restore every data_ptr with new contents)
+        self._gflat: Optional[torch.Tensor] = None      # 'direct' parameter gradients: the block's flat gradient ...
+        self._gviews: List[torch.Tensor] = []           # ... and one cached view per parameter (what p.grad becomes)
+        self._anchor: Optional[torch.Tensor] = None     # the autograd edge that makes backward() run in 'direct' mode
         # reshuffle=True: the per-node matrices act top-down before any coupling of their subtree
         # (hint.py:64-65), so all of them compose into ONE [d,d] orthogonal matrix in front of the
         # block (and its transpose behind the inverse), which the kernels apply fused
@@ -178,18 +278,65 @@ class _Engine:
                     p.data = view
         self.arena = arena
         self._regathered = True
+        self._gathers += 1
         base = arena.data_ptr()
         self._ptrs = [base + 4 * off for off in self.offsets]
 
     def ensure_arena(self):
-        if self.arena is None:
+        # (one list comparison: 36 data_ptr() calls are 2.4 us; `p.data = ...` / `.to()` cannot be seen any cheaper)
+        if self.arena is None or [p.data_ptr() for p in self.params] != self._ptrs:
             self._gather()
-            return
-        ptrs = self._ptrs
-        for i, p in enumerate(self.params):
-            if p.data_ptr() != ptrs[i]:
-                self._gather()
-                return
+
+    def sizes(self, B: int):
+        """(tape floats, workspace bytes) for a batch of B rows, asked of the library once per batch size"""
+        v = self._sizes.get(B)
+        if v is None:
+            v = (max(self.lib.hint_plan_tape_floats(self.plan, B), 1),
+                 max(int(self.lib.hint_plan_workspace_bytes(self.plan, B)), 16))
+            if len(self._sizes) > 64:
+                self._sizes.clear()
+            self._sizes[B] = v
+        return v
+
+    def take_tape(self, B: int, device):
+        """-> (tape, lease): a tape buffer for one training forward.  Buffers are pooled per (batch size, stream); the lease
+        object belongs on the autograd node - when the node dies the buffer returns to the pool (a forward that runs while an
+        older node of this block is still alive simply gets another buffer)"""
+        n = self.sizes(B)[0]
+        key = (B, torch.cuda.current_stream(device).cuda_stream)
+        pool = self._tape_pool.get(key)
+        if pool is None:
+            if len(self._tape_pool) >= 4:          # ragged batch sizes: keep the pools of the latest ones only
+                self._tape_pool.clear()
+            pool = self._tape_pool[key] = []
+        tape = pool.pop() if pool else torch.empty(n, dtype=torch.float32, device=device)
+        return tape, _Lease(pool, tape)
+
+    def workspace(self, B: int, device):
+        nbytes = self.sizes(B)[1]
+        key = (B, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 4:
+                self._ws.clear()
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return ws, nbytes
+
+    # ---- 'direct' parameter gradients ---------------------------------------------------------
+    def anchor(self) -> torch.Tensor:
+        if self._anchor is None or self._anchor.device != self.device:
+            self._anchor = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
+        return self._anchor
+
+    def grad_views(self):
+        if self._gflat is None or self._gflat.device != self.device:
+            self._gflat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+            self._gviews = self.split_flat(self._gflat)
+        return self._gflat, self._gviews
+
+    def invalidate_packed(self):
+        """the packed copy no longer matches the arena (a trainer's kernels updated the weights in place)"""
+        self._pack_key = None
 
     def split_flat(self, flat: torch.Tensor):
         return [flat[off:off + n].view(shp) for off, n, shp in zip(self.offsets, self.numels, self.shapes)]
@@ -205,19 +352,29 @@ class _Engine:
         if self.packed is None or self.packed.device != self.device:
             self.packed = torch.empty(self.lib.hint_plan_packed_floats(self.plan), dtype=torch.float32,
                                       device=self.device)
+            self._pack_key = None
+        if _PACK_CACHE:
+            key = [self._gathers] + [(p.data_ptr(), p._version) for p in self.params]
+            if key == self._pack_key:
+                return
+            self._pack_key = key
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_pack(self.plan, self.arena.data_ptr(), self.packed.data_ptr(), self._stream())
         _lib.check(st, "hint_block_pack")
 
-    def apply(self, x: torch.Tensor, c: Optional[torch.Tensor], rev: bool, with_tape: bool = False):
-        """-> (out, J) or, with_tape (training forward), (out, J, tape)"""
+    def apply(self, x: torch.Tensor, c: Optional[torch.Tensor], rev: bool, with_tape: bool = False, lease=None):
+        """-> (out, J) or, with_tape (training forward), (out, J, tape); lease: a list that receives the pooled tape's
+        lease object (to be kept on the autograd node) - without it the tape is a plain allocation"""
         B = x.shape[0]
         out = torch.empty_like(x)
         J = torch.empty(B, dtype=torch.float32, device=x.device)
         tape = None
         if with_tape:
-            tape = torch.empty(max(self.lib.hint_plan_tape_floats(self.plan, B), 1), dtype=torch.float32,
-                               device=x.device)
+            if lease is not None:
+                tape, ls = self.take_tape(B, x.device)
+                lease.append(ls)
+            else:
+                tape = torch.empty(self.sizes(B)[0], dtype=torch.float32, device=x.device)
         if B > 0:
             cptr = c.data_ptr() if c is not None else None
             perm = self.total_perm()
@@ -242,8 +399,7 @@ class _Engine:
         J = torch.empty(B, dtype=torch.float32, device=x.device)
         tape = None
         if with_tape:
-            tape = torch.empty(max(self.lib.hint_plan_tape_floats(self.plan, B), 1), dtype=torch.float32,
-                               device=x.device)
+            tape = torch.empty(self.sizes(B)[0], dtype=torch.float32, device=x.device)
         if B > 0:
             ptr = lambda t: t.data_ptr() if t is not None else None
             with torch.cuda.device(self.device):
@@ -258,8 +414,7 @@ class _Engine:
         gx = torch.empty_like(gz)
         if B == 0:
             return gx
-        nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
-        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gz.device)
+        ws, nbytes = self.workspace(B, gz.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_backward_ex(
@@ -284,8 +439,7 @@ class _Engine:
             if not accumulate:
                 g_params.zero_()
             return gx, gc, g_params
-        nbytes = self.lib.hint_plan_workspace_bytes(self.plan, B)
-        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        ws, nbytes = self.workspace(B, x.device)
         perm = self.compose_perm(front)
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_backward_ex(
@@ -321,58 +475,116 @@ class _Engine:
         return gz, gc, g_params
 
 
+def deliver_param_grads(params, views, flat, run, fresh):
+    """'direct' mode: make `p.grad` of every parameter hold the gradient `run(g_params, accumulate)` computes (the launch that
+    writes the flat gradient of `params` - a block's or a whole flow's - into a buffer of `flat`'s layout).
+      every p.grad is None (after optim.zero_grad())        -> overwrite `flat`, p.grad = the cached views
+      every p.grad is still our view (no zero_grad between) -> the kernels add to `flat`
+      anything else (foreign gradients, a mix)              -> into a fresh buffer, then per parameter as autograd would
+    `fresh()` allocates such a buffer and returns (buffer, views)."""
+    grads = [p.grad for p in params]
+    if all(g is None for g in grads):
+        run(flat, 0)
+        for p, v in zip(params, views):
+            p.grad = v
+        return
+    if all(g is v for g, v in zip(grads, views)):
+        run(flat, 1)
+        return
+    buf, vs = fresh()
+    run(buf, 0)
+    for p, g, v in zip(params, grads, vs):
+        if g is None:
+            p.grad = v
+        else:
+            g.add_(v)
+
+
 class _RevCouplingFn(torch.autograd.Function):
     """autograd node of one block INVERSE (rev=True with gradients: differentiable in the reference, hint.py:82-88;
     its own loops only sample under no_grad).  Saves the output; the backward rebuilds the tapes level by level
-    (_Engine.inverse_backward)."""
+    (_Engine.inverse_backward).  direct: see _PARAM_GRADS (then `params` is the engine's anchor alone)."""
 
     @staticmethod
-    def forward(ctx, engine, z, c, *params):
+    def forward(ctx, engine, direct, z, c, *params):
         x, J = engine.apply(z, c, rev=True)
         ctx.engine = engine
+        ctx.direct = direct
+        ctx.n_params = len(params)
         ctx.has_c = c is not None
         ctx.save_for_backward(x, c) if c is not None else ctx.save_for_backward(x)
         return x, J
 
     @staticmethod
     def backward(ctx, gx, gJ):
-        engine = ctx.engine
-        saved = ctx.saved_tensors
-        x = saved[0]
-        c = saved[1] if ctx.has_c else None
-        gx = gx.contiguous() if gx is not None else None
-        gJ = gJ.contiguous() if gJ is not None else None
-        need_gc = ctx.has_c and ctx.needs_input_grad[2]
-        engine.ensure_arena()
-        gz, gc, gflat = engine.inverse_backward(x, c, gx, gJ, need_gc)
-        return (None, gz, gc, *engine.split_flat(gflat))
+        with _Region():
+            engine = ctx.engine
+            saved = ctx.saved_tensors
+            x = saved[0]
+            c = saved[1] if ctx.has_c else None
+            gx = gx.contiguous() if gx is not None else None
+            gJ = gJ.contiguous() if gJ is not None else None
+            need_gc = ctx.has_c and ctx.needs_input_grad[3]
+            engine.ensure_arena()
+            gz, gc, gflat = engine.inverse_backward(x, c, gx, gJ, need_gc)
+            if not ctx.direct:
+                return (None, None, gz, gc, *(engine.split_flat(gflat) if ctx.n_params else ()))
+            for p, v in zip(engine.params, engine.split_flat(gflat)):      # (a convenience path: no cached views)
+                if p.requires_grad:
+                    if p.grad is None:
+                        p.grad = v
+                    else:
+                        p.grad.add_(v)
+            return None, None, gz, gc, None
 
 
 class _CouplingFn(torch.autograd.Function):
-    """autograd node of one block forward.  Saves the input and the tape the forward kernel wrote: the lanes at
+    """autograd node of one block forward.  Keeps the input and the tape the forward kernel wrote: the lanes at
     every level, the coupling arguments s, the hidden activations a2 of every subnet and one sign byte per four
     activations (a1 as well, except for the subnets with at most four inputs and outputs: theirs is rebuilt from the
-    level's lanes where it is needed - DESIGN.md section 3).  The backward kernels never re-run the h x h layers."""
+    level's lanes where it is needed - DESIGN.md section 3).  The backward kernels never re-run the h x h layers.
+    direct: the parameter gradients go straight to `p.grad` (see _PARAM_GRADS; `params` is the engine's anchor alone)."""
 
     @staticmethod
-    def forward(ctx, engine, x, c, *params):
-        z, J, tape = engine.apply(x, c, rev=False, with_tape=True)
+    def forward(ctx, engine, direct, x, c, *params):
+        lease = []
+        z, J, tape = engine.apply(x, c, rev=False, with_tape=True, lease=lease)
         ctx.engine = engine
+        ctx.direct = direct
+        ctx.n_params = len(params)
         ctx.has_c = c is not None
-        ctx.save_for_backward(x, tape, c) if c is not None else ctx.save_for_backward(x, tape)
+        ctx.tape, ctx.lease = tape, lease          # (the tape is the library's scratch, not an autograd-visible tensor)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, c) if c is not None else ctx.save_for_backward(x)
         return z, J
 
     @staticmethod
     def backward(ctx, gz, gJ):
-        engine = ctx.engine
-        saved = ctx.saved_tensors
-        x, tape = saved[0], saved[1]
-        c = saved[2] if ctx.has_c else None
-        gz = gz.contiguous() if gz is not None else None
-        gJ = gJ.contiguous() if gJ is not None else None
-        need_gc = ctx.has_c and ctx.needs_input_grad[2]
-        gx, gc, gflat = engine.backward(x, tape, c, gz, gJ, need_gc)
-        return (None, gx, gc, *engine.split_flat(gflat))
+        with _Region():
+            engine = ctx.engine
+            saved = ctx.saved_tensors
+            x, tape = saved[0], ctx.tape
+            c = saved[1] if ctx.has_c else None
+            gz = gz.contiguous() if gz is not None else None
+            gJ = gJ.contiguous() if gJ is not None else None
+            need_gc = ctx.has_c and ctx.needs_input_grad[3]
+            if not ctx.direct:
+                gx, gc, gflat = engine.backward(x, tape, c, gz, gJ, need_gc)
+                return (None, None, gx, gc, *(engine.split_flat(gflat) if ctx.n_params else ()))
+            out = []
+
+            def run(g_params, accumulate):
+                out.append(engine.backward(x, tape, c, gz, gJ, need_gc, g_params=g_params, accumulate=bool(accumulate)))
+
+            flat, views = engine.grad_views()
+
+            def fresh():
+                buf = torch.empty(engine.total, dtype=torch.float32, device=x.device)
+                return buf, engine.split_flat(buf)
+
+            deliver_param_grads(engine.params, views, flat, run, fresh)
+            gx, gc, _ = out[0]
+            return None, None, gx, gc, None
 
 
 def _as_f32_2d(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -509,14 +721,26 @@ class HierarchicalAffineCouplingTree(nn.Module):
             cc = cs[0] if len(cs) == 1 else torch.cat(cs, dim=1)
             if cc.shape[1] != self.condition_length or cc.shape[0] != x.shape[0]:
                 raise HintAmdError("condition shape %s does not match dims_c / batch" % (tuple(cc.shape),))
-        eng = self.engine(x.device)
-        eng.ensure_arena()
-        eng.pack()
-        needs_grad = torch.is_grad_enabled() and (
-            x.requires_grad or (cc is not None and cc.requires_grad) or any(p.requires_grad for p in eng.params))
-        if not needs_grad:
-            return eng.apply(x, cc, rev=rev)
-        return (_RevCouplingFn if rev else _CouplingFn).apply(eng, x, cc, *eng.params)
+        with _Region():
+            eng = self._engine
+            if eng is None or eng.device != x.device:
+                eng = self.engine(x.device)
+            eng.ensure_arena()
+            eng.pack()
+            if not torch.is_grad_enabled():
+                return eng.apply(x, cc, rev=rev)
+            req = [p.requires_grad for p in eng.params]
+            n_req = sum(req)
+            if n_req == 0 and not (x.requires_grad or (cc is not None and cc.requires_grad)):
+                return eng.apply(x, cc, rev=rev)
+            fn = _RevCouplingFn if rev else _CouplingFn
+            # 'direct' needs every parameter trainable (a partly frozen block takes the autograd route, which returns
+            # gradients for exactly the inputs that ask for one)
+            if _PARAM_GRADS == "direct" and n_req == len(req):
+                return fn.apply(eng, True, x, cc, eng.anchor())
+            if n_req == 0:
+                return fn.apply(eng, False, x, cc)
+            return fn.apply(eng, False, x, cc, *eng.params)
 
 
 class HierarchicalAffineCouplingBlock(nn.Module):

@@ -80,19 +80,17 @@ class FlowTrainer:
                 e.pack()
         self.loss_acc = torch.zeros(64, 2, dtype=torch.float32, device=dev)   # per-slot partial loss sums
         self._loss_single = self.loss_acc      # (step_many points loss_acc at its last iteration's sums)
-        self._pack_group, self._pack_key = None, None
-        for i in range(flow.n_blocks):          # the kernels read W through its raw pointer (row-major)
-            if flow.has_perm(i) and not flow.perms[i].W.is_contiguous():
-                flow.perms[i].W = flow.perms[i].W.contiguous()
+        # chain handles, the one-launch re-pack and the inference chains (sample()) are the flow's ChainRunner's
+        self._runner = flow.runner(dev)
+        self._runner.perms()                    # (makes the permutation matrices contiguous: the kernels read raw pointers)
         self._graph = None
         self._static = None
         # identical blocks (the configs stack copies of one block) run as ONE forward launch and
         # TWO backward launches for the whole flow (hint_chain_*)
-        self._chainable = use_chain and all(e.shape_key == self.engines[0].shape_key for e in self.engines)
+        self._chainable = use_chain and self._runner.chainable
         # one chain (handle, tapes, workspaces) per batch size: a captured graph keeps raw pointers into
         # its chain's buffers, so a chain is never destroyed while a graph that used it is alive
         self._chains = {}
-        self._ichains = {}          # inference chains (sample()): no tape, no workspace - a few hundred bytes each
         # state of the in-kernel noise generator (hint_chain_forward_noisy): {seed, step}; every rank
         # of a data-parallel job draws its own stream
         if seed is None:
@@ -131,26 +129,15 @@ class FlowTrainer:
             for handle, _, _ in getattr(self, "_chains", {}).values():
                 self.lib.hint_chain_destroy(handle)
             self._chains = {}
-            for handle, _, _ in getattr(self, "_ichains", {}).values():
-                self.lib.hint_chain_destroy(handle)
-            self._ichains = {}
-            if getattr(self, "_pack_group", None):
-                self.lib.hint_pack_group_destroy(self._pack_group)
-                self._pack_group = None
         except Exception:
             pass
 
     def _chain_for(self, B: int):
         """the chain handle for batch size B: tapes and backward workspaces of all blocks are
-        allocated once and the pointer table uploaded; rebuilt when B or any buffer moved"""
-        import ctypes as C
-        flow = self.flow
-        # permutation in front of block i: the flow's fixed matrix, then the block's own node
-        # permutations (reshuffle=True trees), composed into one [d,d] matrix
-        front = [flow.perms[i].W if flow.has_perm(i) else None for i in range(flow.n_blocks)]
-        perms = [e.compose_perm(f) for e, f in zip(self.engines, front)]
-        key = (B,) + tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) \
-            + tuple(p.data_ptr() if p is not None else 0 for p in perms) + (self.G.data_ptr(),)
+        allocated once and the pointer table uploaded (ChainRunner.build_chain); rebuilt when B or any buffer moved"""
+        run = self._runner
+        perms = run.perms()
+        key = run.chain_key(B, perms, self.G)
         have = self._chains.get(B)
         if have is not None and have[1] == key:
             return have[0]
@@ -159,6 +146,7 @@ class FlowTrainer:
             # addresses - drop them all (they are re-captured on their next use), then the stale chain
             self._graph = self._graph_many = None
             self._static = None
+            torch.cuda.synchronize(self.device)        # (launches that read its device table may still be queued)
             self.lib.hint_chain_destroy(have[0])
             del self._chains[B]
         elif len(self._chains) >= 8:
@@ -167,57 +155,17 @@ class FlowTrainer:
             st = getattr(self, "_static_many", None)
             if getattr(self, "_graph_many", None) is not None and st is not None:
                 keep.add(st["x"].shape[1])
+            torch.cuda.synchronize(self.device)
             for b in [b for b in self._chains if b not in keep]:
                 self.lib.hint_chain_destroy(self._chains[b][0])
                 del self._chains[b]
-        e0, n = self.engines[0], len(self.engines)
-        tape_floats = max(self.lib.hint_plan_tape_floats(e0.plan, B), 1)
-        ws_bytes = (self.lib.hint_plan_workspace_bytes(e0.plan, B) + 255) // 256 * 256
-        tapes = torch.empty(n, tape_floats, dtype=torch.float32, device=self.device)
-        ws = torch.empty(n, max(ws_bytes, 256), dtype=torch.uint8, device=self.device)
-        handle = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.hint_chain_create(e0.plan, n, B, C.byref(handle)), "hint_chain_create")
-            for i, e in enumerate(self.engines):
-                a, _ = self.slices[i]
-                _lib.check(self.lib.hint_chain_set_block(
-                    handle, i, e.arena.data_ptr(), e.packed.data_ptr(),
-                    perms[i].data_ptr() if perms[i] is not None else None, tapes[i].data_ptr(),
-                    ws[i].data_ptr(), ws_bytes, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
-            _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
-        self._chains[B] = (handle, key, (tapes, ws, perms))
+        handle, bufs = run.build_chain(B, perms, self.G)
+        self._chains[B] = (handle, key, bufs)
         return handle
 
     def _chain_infer(self, B: int):
-        """the chain handle of the sampling / evaluation direction for batch size B: blocks set WITHOUT tape and
-        workspace (hint_chain_inverse and an inference forward touch neither) - a 100 k-row evaluation batch costs
-        no memory beyond its own rows, and asking for a new batch size never evicts a training chain"""
-        import ctypes as C
-        flow = self.flow
-        front = [flow.perms[i].W if flow.has_perm(i) else None for i in range(flow.n_blocks)]
-        perms = [e.compose_perm(f) for e, f in zip(self.engines, front)]
-        key = (B,) + tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) \
-            + tuple(p.data_ptr() if p is not None else 0 for p in perms)
-        have = self._ichains.get(B)
-        if have is not None and have[1] == key:
-            return have[0]
-        if have is not None:
-            self.lib.hint_chain_destroy(have[0])
-            del self._ichains[B]
-        elif len(self._ichains) >= 32:
-            for b in list(self._ichains):
-                self.lib.hint_chain_destroy(self._ichains[b][0])
-                del self._ichains[b]
-        handle = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.hint_chain_create(self.engines[0].plan, len(self.engines), B, C.byref(handle)), "hint_chain_create")
-            for i, e in enumerate(self.engines):
-                _lib.check(self.lib.hint_chain_set_block(
-                    handle, i, e.arena.data_ptr(), e.packed.data_ptr(),
-                    perms[i].data_ptr() if perms[i] is not None else None, None, None, 0, None), "hint_chain_set_block")
-            _lib.check(self.lib.hint_chain_commit(handle), "hint_chain_commit")
-        self._ichains[B] = (handle, key, perms)
-        return handle
+        """the chain handle of the sampling / evaluation direction for batch size B (no tape, no workspace)"""
+        return self._runner.chain_infer(B)
 
     def _dp_overlap(self) -> bool:
         """the bucket all-reduces are issued from inside the backward pass (side stream) when the backend is RCCL
@@ -323,31 +271,12 @@ class FlowTrainer:
         return B
 
     def _pack_all(self, step_prologue: bool = False):
-        """one launch re-packs every block (hint_pack_group_*); the group is rebuilt whenever an
-        arena or packed buffer moved.  step_prologue: the launch also zeroes the loss sums and
-        advances the noise counter."""
-        import ctypes as C
-        key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines)
-        if self._pack_key != key:
-            if self._pack_group:
-                self.lib.hint_pack_group_destroy(self._pack_group)
-            n = len(self.engines)
-            plans = (C.c_void_p * n)(*[e.plan.value for e in self.engines])
-            params = (C.c_void_p * n)(*[e.arena.data_ptr() for e in self.engines])
-            packed = (C.c_void_p * n)(*[e.packed.data_ptr() for e in self.engines])
-            handle = C.c_void_p()
-            with torch.cuda.device(self.device):
-                _lib.check(self.lib.hint_pack_group_create(plans, params, packed, n, C.byref(handle)),
-                           "hint_pack_group_create")
-            self._pack_group, self._pack_key = handle, key
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            if step_prologue:
-                st = self.lib.hint_pack_group_run_ex(self._pack_group, self.loss_acc.data_ptr(), self.loss_acc.numel(),
-                                                     self.rng_state.data_ptr(), self.opt_state.data_ptr(), stream)
-            else:
-                st = self.lib.hint_pack_group_run(self._pack_group, stream)
-        _lib.check(st, "hint_pack_group_run")
+        """one launch re-packs every block (ChainRunner.pack_all).  step_prologue: the launch also zeroes the loss sums,
+        advances the noise counter and writes Adam's factors of the step."""
+        if step_prologue:
+            self._runner.pack_all(self.loss_acc, self.rng_state, self.opt_state)
+        else:
+            self._runner.pack_all()
 
     def _check_arenas(self):
         """parameters rebound from outside (p.data = ..., load_state_dict into new storage)
@@ -393,6 +322,8 @@ class FlowTrainer:
                 self._static["c"].copy_(c)
             self._graph.replay()
         self._last_B = x.shape[0]
+        for e in self.engines:                 # the step's kernels changed the weights in place: packed copies are stale
+            e._pack_key = None
         if self.use_graph and self._adam_in_graph:
             self.step_count += 1               # the optimizer ran inside the graph
         else:
@@ -462,6 +393,8 @@ class FlowTrainer:
         if cs is not None and cs.data_ptr() != st["c"].data_ptr():
             st["c"].copy_(cs)
         self._graph_many.replay()
+        for e in self.engines:
+            e._pack_key = None
         self.loss_acc = self._loss_all[K - 1]
         self.step_count += K
         self._last_B = B

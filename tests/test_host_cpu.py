@@ -145,3 +145,19 @@ def test_conditional_lane_modules_structure():
         hint_amd.ExternalAffineCoupling([(5,)])                  # needs a condition
     with pytest.raises(hint_amd.HintAmdError):
         m([torch.randn(3, 4), torch.randn(3, 100)])              # CPU tensors: no fallback
+
+
+def test_data_alias_edits_do_not_advance_the_version_counter():
+    """why hint_amd.hint.set_pack_cache is opt-in: an in-place edit through `p.data` - `p.data.add_(...)`, `p.data.clamp_(...)` -
+    changes the weights without touching `p._version` or `p.data_ptr()`, so no host-side key can prove a packed copy current;
+    optimizer updates (in place under no_grad) and `p.data = ...` rebinding are visible"""
+    import torch
+    p = torch.nn.Parameter(torch.randn(8))
+    v0, a0 = p._version, p.data_ptr()
+    p.data.add_(1.0)
+    assert (p._version, p.data_ptr()) == (v0, a0)
+    with torch.no_grad():
+        p.add_(1.0)
+    assert p._version == v0 + 1
+    p.data = torch.randn(8)
+    assert p.data_ptr() != a0
