@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HINT_AMD_LIB") or os.path.join(_HERE, "lib", "libhint_amd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HintAmdError(RuntimeError):
@@ -31,6 +31,7 @@ _PROTOS = {
     "hint_last_error": (C.c_char_p, []),
     "hint_build_info": (C.c_char_p, []),
     "hint_debug_set_prefetch": (C.c_int, [C.c_int]),
+    "hint_debug_reload_knobs": (C.c_int, []),
     "hint_debug_last_lds_bytes": (C.c_int32, [C.c_int32]),
     "hint_plan_create": (C.c_int, [C.POINTER(NodeDesc), C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.POINTER(C.c_void_p)]),

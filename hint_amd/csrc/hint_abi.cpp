@@ -12,6 +12,40 @@ static unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only (hi
 
 namespace hint {
 
+static Knobs read_knobs() {
+    Knobs k;
+    auto get = [&](const char* name, int* out) {
+        const char* e = std::getenv(name);
+        if (!e || !*e) return false;
+        *out = std::atoi(e);
+        k.non_default += (k.non_default.empty() ? "" : " ") + std::string(name) + "=" + e;
+        return true;
+    };
+    int v;
+    if (get("HINT_PLAN_DUMP", &v)) k.plan_dump = v != 0;
+    if (get("HINT_WL", &v)) k.wl = v != 0;
+    if (get("HINT_WL_NR", &v)) k.wl_nr = v;
+    if (get("HINT_SUB", &v)) k.sub = v != 0;
+    if (get("HINT_NW", &v)) k.nw = v;
+    if (get("HINT_LEAN", &v)) k.lean = v != 0;
+    if (get("HINT_LEANW", &v)) k.leanw = v != 0;
+    if (get("HINT_FUSE_DW1", &v)) k.fuse_dw1 = v != 0;
+    if (get("HINT_PF", &v)) k.pf = v != 0 ? 1 : 0;
+    if (get("HINT_NO_BWD_FLY", &v)) k.no_bwd_fly = v != 0;
+    if (get("HINT_DW_SPLITS", &v)) k.dw_splits = v;
+    if (get("HINT_DW_SMALL", &v)) k.dw_small = v != 0 ? 1 : 0;
+    if (get("HINT_ABLATION_OK", &v)) k.ablation_ok = v != 0;
+    if (get("HINT_ABL_NO_DW2", &v)) k.abl_no_dw2 = v != 0;
+    return k;
+}
+static std::mutex g_knobs_mu;
+static Knobs* g_knobs = nullptr;          // (replaced, never freed: a reader may hold the old one across hint_debug_reload_knobs)
+const Knobs& knobs() {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    if (!g_knobs) g_knobs = new Knobs(read_knobs());
+    return *g_knobs;
+}
+
 int fail(const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -33,7 +67,7 @@ const hint_plan* variant(const hint_plan* P, int B) {
     if (!P || !P->alt4) return P;
     const int ntiles = (B + ROWS - 1) / ROWS;
     if (ntiles <= P->num_cu) return P;
-    static const int nr_forced = env_int("HINT_WL_NR");
+    const int nr_forced = knobs().wl_nr;
     if (P->wl && P->wl_nr2 && nr_forced != 1) {
         const hint_plan* A = P->alt4;
         const bool alt_twice = A->wl && A->wl_nr2 && std::max(plan_lds(A, false, 2), plan_lds(A, true, 2)) + 4096 <= LDS_LIMIT / 2;
@@ -43,7 +77,7 @@ const hint_plan* variant(const hint_plan* P, int B) {
 }
 int wl_nr_for(const hint_plan* Pv, int B) {       // Pv: the variant already picked
     if (!Pv->wl || !Pv->wl_nr2) return 1;
-    static const int nr_forced = env_int("HINT_WL_NR");
+    const int nr_forced = knobs().wl_nr;
     if (nr_forced == 1 || nr_forced == 2) return nr_forced;
     return (B + ROWS - 1) / ROWS > Pv->num_cu ? 2 : 1;
 }
@@ -63,7 +97,7 @@ void wgrad_splits(const hint_plan* P, int B, int n_chain, int* splits_out, int* 
     const long Bp = rows_padded(B);
     int splits = 8;
     while ((long)splits * P->n_wjobs * n_chain < (long)P->num_cu && Bp / (splits * 2) >= 128) splits *= 2;
-    static const int forced = env_int("HINT_DW_SPLITS");          // (experiments)
+    const int forced = knobs().dw_splits;          // (experiments)
     if (forced > 0 && Bp / forced >= 16) splits = forced;
     int rows_per_wg = (int)((Bp + splits - 1) / splits);
     rows_per_wg = (rows_per_wg + 15) / 16 * 16;
@@ -86,22 +120,21 @@ int64_t ws_thin_off(const hint_plan* P, int B) {        // floats from the part-
     return (int64_t)splits * P->param_floats;
 }
 
-// Run-time knobs, read ONCE (getenv on the launch path is neither cheap nor safe beside a setenv in another thread; a captured
-// hipGraph keeps what was read at capture time anyway).  The L2 warm-up has an explicit setter for the tests and A/B runs
-// (hint_debug_set_prefetch): its initial value comes from HINT_PF (0 = off).
+// The L2 warm-up has an explicit setter for the tests and A/B runs (hint_debug_set_prefetch): its initial value comes from
+// HINT_PF (0 = off; hint_host.hpp Knobs).
 static std::atomic<int> g_l2_prefetch{-1};
 static std::atomic<int> g_last_lds[2] = {{0}, {0}};     // dynamic LDS bytes of the last row-kernel launch: [0] forward / inverse, [1] backward part A
 bool l2_prefetch_on() {
     int v = g_l2_prefetch.load(std::memory_order_relaxed);
     if (v < 0) {
-        v = (std::getenv("HINT_PF") && env_int("HINT_PF") == 0) ? 0 : 1;
+        v = knobs().pf;
         g_l2_prefetch.store(v, std::memory_order_relaxed);
     }
     return v != 0;
 }
-static int perm_lds_cap() { static const int cap = env_int("HINT_PERM_LDS_MAX") > 0 ? env_int("HINT_PERM_LDS_MAX") : PERM_LDS_MAX; return cap; }
-static bool plan_dump() { static const bool on = env_int("HINT_PLAN_DUMP") != 0; return on; }
-static bool no_bwd_fly() { static const bool off = env_int("HINT_NO_BWD_FLY") != 0; return off; }
+static int perm_lds_cap() { return PERM_LDS_MAX; }
+static bool plan_dump() { return knobs().plan_dump; }
+static bool no_bwd_fly() { return knobs().no_bwd_fly; }
 
 // the 256-byte sink of the general kernels' L2 warm-up (hint_device.hpp prefetch_consumer) behind everything else of the launch
 static int add_sink(const hint_plan* P, int total, KArgs* a) {
@@ -191,8 +224,9 @@ int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* ch
 #ifdef HINT_ABLATE_STORE
     // (a diagnostic build whose row kernels keep no activations cannot train: only with HINT_ABLATION_OK=1 in the environment -
     //  the timing scripts set it - does it launch a backward pass at all)
-    { static const bool ok = env_int("HINT_ABLATION_OK") != 0; if (!ok) return fail("this is an ablation build (HINT_ABLATE_STORE): its gradients are wrong; set HINT_ABLATION_OK=1 for timing runs"); }
+    if (!knobs().ablation_ok) return fail("this is an ablation build (HINT_ABLATE_STORE): its gradients are wrong; set HINT_ABLATION_OK=1 for timing runs");
 #endif
+    if (knobs().abl_no_dw2 && !knobs().ablation_ok) return fail("HINT_ABL_NO_DW2 drops weight-gradient jobs: its gradients are wrong; set HINT_ABLATION_OK=1 for timing runs");
     if ((parts & 1) && P->wl) {
         KArgs a = make_args(P, B, true);
         const int nr = wl_nr_for(P, B);
@@ -258,17 +292,30 @@ extern "C" {
 int hint_abi_version(void) { return HINT_AMD_ABI_VERSION; }
 
 const char* hint_build_info(void) {
-    // what the shipped binary was compiled with (the box that runs it may carry another HIP runtime: bench.py prints both)
-    static const std::string info = std::string("libhint_amd abi ") + std::to_string(HINT_AMD_ABI_VERSION) +
+    // what the shipped binary was compiled with (the box that runs it may carry another HIP runtime: bench.py prints both), its
+    // source stamp (-DHINT_SRC_STAMP: a hash of hint_amd/csrc + include, Makefile) and the HINT_* knobs set in this process
+    static thread_local std::string info;
+    info = std::string("libhint_amd abi ") + std::to_string(HINT_AMD_ABI_VERSION) +
 #ifdef HINT_ABLATE_STORE
                                     " ABLATION BUILD (no activation / gradient stores: timing only, results are wrong)" +
 #endif
                                     ", gfx950, HIP " +
                                     std::to_string(HIP_VERSION_MAJOR) + "." + std::to_string(HIP_VERSION_MINOR) + "." +
-                                    std::to_string(HIP_VERSION_PATCH) + ", clang " + __clang_version__;
+                                    std::to_string(HIP_VERSION_PATCH) + ", clang " + __clang_version__ +
+#ifdef HINT_SRC_STAMP
+                                    ", src " HINT_SRC_STAMP +
+#endif
+                                    (knobs().non_default.empty() ? std::string("") : ", knobs: " + knobs().non_default);
     return info.c_str();
 }
 const char* hint_last_error(void) { return g_err.c_str(); }
+
+int hint_debug_reload_knobs(void) {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    g_knobs = new Knobs(read_knobs());
+    g_l2_prefetch.store(g_knobs->pf, std::memory_order_relaxed);
+    return 0;
+}
 
 int hint_debug_set_prefetch(int on) {
     hint::l2_prefetch_on();        // (so that the previous value is the environment's, not "unread")

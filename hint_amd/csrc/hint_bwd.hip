@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                     const int soff = need < nthreads ? need : 0;
                     if (soff > 0) qthreads = soff;
                     if (tid >= soff) {
-                        if (!gp.lean) stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        if (!gp.nothin) stream_tiles((float*)blk.wsG1 + a.act_stride, abuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         if (!(a.fuse_dw1 && gp.lean)) {
                             stream_tiles((float*)blk.wsG1, obuf, gp.ntiles, gp.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         } else {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_bwd_kernel(
                 }
                 STAMP(sid + 4)
                 // ---- Q3: g1 = (W2^T (g2' .* relu'(a2))) .* relu'(a1);  g_v partial = W1^T g1 ----
-                pc.out_thin = g.lean ? nullptr : (GLOBAL_AS float*)(blk.wsG1 + a.act_stride);
+                pc.out_thin = g.nothin ? nullptr : (GLOBAL_AS float*)(blk.wsG1 + a.act_stride);       // (lean and lean-wide groups keep no g2)
                 const bool g_staged = g.staged && (g.lean || HINT_BWD_STAGE);
                 pc.obuf = g_staged ? (LDS_AS float*)(abuf + g.ntiles * 256) : nullptr;
                 pc.slab = (LDS_AS float*)(abuf + g.ntiles * 256 * (1 + g_staged));

@@ -31,6 +31,7 @@ constexpr int MAX_NW = HINT_MAX_NW;   // wavefronts per workgroup (plan-time cho
 constexpr int NTT = HINT_NTT;         // fragment tiles per row (hint_rows.hpp): 3 by default (planner, wave-local kernels); hint_fwd.hip / hint_bwd.hip define 4
 constexpr int MAX_RT = 4;       // 16-wide tiles of a unit's output (r <= 64) and of its input (cin <= 64 + dc)
 constexpr int MAX_CT = 12;      // 16-wide tiles of a unit's input v = [u | c] (cin <= 192)
+constexpr int LEANW_MAX = 28;   // widest thin layer (inputs / outputs) part B still rebuilds instead of reading a1 / g2 (7 k-blocks of four)
 constexpr int LV_REGS = 4;      // hint_bwd.hip holds a prefetched [16, d] tile in LV_REGS floats per thread: 16 * d <= LV_REGS * threads (the planner picks the wavefront count for it)
 
 // ---------------------------------------------------------------------------------------
@@ -112,6 +113,8 @@ struct Group {
                                                         // lean: bit 0 = every unit of the group has 1..4 inputs, <= 4 outputs, no condition: its a1 / g2 tiles are never stored;
                                                         // bit 1 = the group's output tiles (a2 / g1) are staged in LDS and streamed out by the element-wise phase;
                                                         // bit 2 = subtree group (hint_sub.hpp): rng's second half holds the wavefronts' ranges in the group's entry list
+                                                        // bit 3 = lean-wide (round 6): not lean, but every unit has at most LEANW_MAX inputs and outputs and no condition - the thin phases
+                                                        //         run as for any group, yet a1 / g2 are not stored: part B rebuilds them with ceil(cin / 4) + ceil(r / 4) K = 4 MFMAs per tile
 };
 static_assert(sizeof(Group) == 64, "Group must be 4 x 16 bytes");
 

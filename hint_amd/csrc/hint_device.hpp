@@ -89,7 +89,8 @@ __device__ __forceinline__ UnitU load_unit(const LDS_AS Unit* u) {
 }
 struct GroupU {
     int unit_begin, unit_end, ntiles, row_begin, ent_begin, ent_cnt, rng_begin, level, level_last, gcol0, gcols,
-        lop_begin, level_first, tile_begin, wcol0, lean, staged, sub;
+        lop_begin, level_first, tile_begin, wcol0, lean, staged, sub,
+        nothin;     // lean, or lean-wide (Group::lean bit 3): the group's a1 / g2 tiles are not stored - part B rebuilds them
 };
 __device__ __forceinline__ GroupU load_group(const LDS_AS Group* g) {
     const LDS_AS i32x4* p = (const LDS_AS i32x4*)g;
@@ -99,6 +100,7 @@ __device__ __forceinline__ GroupU load_group(const LDS_AS Group* g) {
     r.ent_begin = rfl(q1.x); r.ent_cnt = rfl(q1.y); r.rng_begin = rfl(q1.z); r.level = rfl(q1.w);
     r.level_last = rfl(q2.x); r.gcol0 = rfl(q2.y); r.gcols = rfl(q2.z); r.lop_begin = rfl(q2.w);
     r.level_first = rfl(q3.x); r.tile_begin = rfl(q3.y); r.wcol0 = rfl(q3.z); r.lean = rfl(q3.w) & 1; r.staged = (rfl(q3.w) >> 1) & 1; r.sub = (rfl(q3.w) >> 2) & 1;
+    r.nothin = (rfl(q3.w) & 9) != 0 ? 1 : 0;
     return r;
 }
 __device__ __forceinline__ int lds_i32(const LDS_AS int32_t* p) { return rfl(*p); }

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 const bool gstaged = g.staged && HINT_FWD_STAGE;
                 float* slab = obuf + (gstaged ? g.ntiles * 256 : 0);
                 pc.obuf = gstaged ? (LDS_AS float*)obuf : nullptr; pc.slab = (LDS_AS float*)slab;
-                pc.out_thin = (train && !g.lean) ? (GLOBAL_AS float*)blk.actA1 : nullptr;
+                pc.out_thin = (train && !g.nothin) ? (GLOBAL_AS float*)blk.actA1 : nullptr;       // (lean and lean-wide groups keep no a1)
                 const int sid = (cb * a.n_groups + gi) * 16;
                 (void)sid;
                 pc.sid = sid;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * MAX_NW) void hint_apply_kernel(
                 if (train && gstaged) {
                     const int soff = nthreads > ncpl ? ncpl : 0;   // (a workgroup of one coupling's size does both in turn)
                     if (tid >= soff) {
-                        if (!g.lean) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
+                        if (!g.nothin) stream_tiles(actA1, abuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                         stream_tiles(actA1 + a.a2_off, obuf, g.ntiles, g.wcol0, a.WT, row0, tid - soff, nthreads - soff);
                     }
                 }

@@ -90,7 +90,29 @@ static constexpr int LDS_ATTR = LDS_LIMIT;
 static constexpr int PERM_LDS_MAX = 16 * 1024;   // the chain's permutation matrices ride in LDS up to this size
 static constexpr int WS_SLACK = 64;              // floats of slack behind every [Bp][W] array
 
-inline int env_int(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : 0; }
+// Every HINT_* environment variable the LIBRARY reads (the Python host's own are listed in INTEGRATION.md), read ONCE at first use
+// (getenv on a launch path is neither cheap nor safe beside a setenv in another thread; a captured hipGraph keeps what was read at
+// capture time anyway).  Tests and A/B tools that change the environment inside one process call hint_debug_reload_knobs().
+// `non_default`: "HINT_X=v HINT_Y=w" of the variables that are set - appended to hint_build_info(), so that a bench line or a
+// counter summary says which kernels its numbers belong to.
+struct Knobs {
+    bool plan_dump = false;     // HINT_PLAN_DUMP=1   the planner prints groups, rows per wavefront, LDS sizes, kernel decisions, boundary slots
+    bool wl = true;             // HINT_WL=0          no wave-local kernels (narrow trees run on the general ones)
+    int wl_nr = 0;              // HINT_WL_NR=1|2     wave-local kernels: row tiles per workgroup forced
+    bool sub = true;            // HINT_SUB=0         no subtree groups
+    int nw = 0;                 // HINT_NW=4|8        wavefronts per workgroup of the general kernels (0: the planner picks)
+    bool lean = true;           // HINT_LEAN=0        keep a1 / g2 in HBM (no lean, lean-wide or subtree groups)
+    bool leanw = false;         // HINT_LEANW=1       lean-wide groups (round 6; off until part B rebuilds wide thin layers)
+    bool fuse_dw1 = true;       // HINT_FUSE_DW1=0    first-layer weight gradients in part B instead of the backward kernel
+    int pf = 1;                 // HINT_PF=0          general kernels: no L2 warm-up of the packed weights (hint_debug_set_prefetch switches it later)
+    bool no_bwd_fly = false;    // HINT_NO_BWD_FLY=1  plans with lean general groups on the shared backward kernel
+    int dw_splits = 0;          // HINT_DW_SPLITS=n   batch splits of part B
+    int dw_small = -1;          // HINT_DW_SMALL=0|1  single-tile part-B jobs one per wavefront of a shared workgroup: never / always (-1: trees with subtree groups)
+    bool ablation_ok = false;   // HINT_ABLATION_OK=1 lets an ablation build / an ablation knob run a backward pass (its gradients are wrong: timing only)
+    bool abl_no_dw2 = false;    // HINT_ABL_NO_DW2=1  timing experiment: lean-wide units' dW2 jobs are dropped (needs HINT_ABLATION_OK=1)
+    std::string non_default;
+};
+const Knobs& knobs();
 
 }  // namespace hint
 

@@ -240,7 +240,8 @@ static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, con
     for (size_t ui = 0; ui < units.size(); ++ui) {
         const Unit& u = units[ui];
         const hint_node_desc& n = nodes[unit_node[ui]];
-        const bool lean = unit_lean[ui] != 0, fused = unit_fused[ui] != 0;     // (operands rebuilt; dW1 / db1 from the backward kernel)
+        const bool lean = unit_lean[ui] != 0, fused = unit_fused[ui] != 0;     // (operands rebuilt - lean or lean-wide; dW1 / db1 from the backward kernel)
+        const bool skip_dw2 = unit_lean[ui] == 2 && knobs().abl_no_dw2;     // (timing experiment, refused by run_backward unless HINT_ABLATION_OK=1)
         const int net = (int)(ui & 1);
         const int64_t* po = n.p_off + net * 6;
         const int level = max_depth - n.depth;
@@ -265,8 +266,9 @@ static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, con
                     wjobs->push_back(j);
                 }
         };
-        add_jobs(lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
-                 lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
+        if (!skip_dw2)
+            add_jobs(lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
+                     lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
         add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
         if (u.ku > 0 && !fused)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
@@ -314,9 +316,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int i = 0; i < n_nodes; ++i)
             if (nodes[i].k < 1 || nodes[i].k > 4 || nodes[i].r < 1 || nodes[i].r > 4) all_lean = false;
         bool on = dc == 0 && !(all_lean && d <= 4 * WL_LV);
-        if (const char* e = std::getenv("HINT_SUB")) on = on && std::atoi(e) != 0;
-        if (const char* e = std::getenv("HINT_LEAN")) on = on && std::atoi(e) != 0;
-        if (const char* e = std::getenv("HINT_FUSE_DW1")) on = on && std::atoi(e) != 0;
+        on = on && knobs().sub && knobs().lean && knobs().fuse_dw1;
         for (int dep = max_depth; on && dep >= 1; --dep) {
             int cnt = 0, tiles = 0, last_off = -1;
             bool ok = true;
@@ -368,7 +368,6 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         for (int i = 0; i < n_nodes; ++i)
             if (nodes[i].k < 1 || nodes[i].k > 4 || nodes[i].r < 1 || nodes[i].r > 4) narrow = false;
         if (narrow) ntt_max = NTT;
-        if (const char* e = std::getenv("HINT_GEN_NTT")) { const int v = std::atoi(e); if (v >= 1 && v <= GEN_NTT && !narrow) ntt_max = v; }
     }
     int sub_off3 = 0, sub_offv = 0;       // the subtree groups' slabs: one area for all of them (the wavefronts are at different levels at any time)
     bool sub_closed = false;             // the first group above the subtree levels has been seen
@@ -526,7 +525,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             P->slab_fwd = std::max(P->slab_fwd, off3);
             P->slab_bwd = std::max(P->slab_bwd, offv);
         }
-        if (std::getenv("HINT_PLAN_DUMP")) {
+        if (knobs().plan_dump) {
             std::fprintf(stderr, "[hint plan] group %d level %d: %d units, %d tiles, %d rows\n", (int)groups.size(), g.level,
                          g.unit_end - g.unit_begin, tiles, (int)rows.size());
             for (int w = 0; w < nw; ++w) {
@@ -586,8 +585,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     // lean groups: thin layers narrow enough that part B rebuilds a1 and g2 instead of reading them - every unit of the
     // group has 1..4 inputs, at most 4 outputs and no condition (HINT_LEAN=0: never).  P->lean: all groups are, and the
     // a1 / g2 arrays do not exist at all.
-    bool lean_on = dc == 0;
-    if (const char* e = std::getenv("HINT_LEAN")) if (std::atoi(e) == 0) lean_on = false;
+    const bool lean_on = dc == 0 && knobs().lean;
     std::vector<char> unit_lean(units.size(), 0);
     P->lean = 1;
     for (Group& g : groups) {
@@ -597,9 +595,17 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             const hint_node_desc& n = nodes[unit_node[ui]];
             if (units[ui].cin < 1 || units[ui].cin > 4 || n.r < 1 || n.r > 4) g.lean = 0;
         }
-        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)g.lean;
+        // lean-wide (round 6): not lean, yet thin enough that part B rebuilds a1 / g2 per 16-row step (ceil(cin / 4) + ceil(r / 4)
+        // K = 4 MFMAs per tile) instead of reading them: the forward stores no a1, the backward no g2 (HINT_LEANW=0: never)
+        bool leanw = !g.lean && lean_on && knobs().leanw;
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
+            const hint_node_desc& n = nodes[unit_node[ui]];
+            if (units[ui].cin < 1 || units[ui].cin > LEANW_MAX || n.r < 1 || n.r > LEANW_MAX) leanw = false;
+        }
+        for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)(g.lean ? 1 : leanw ? 2 : 0);
         if (!g.lean) P->lean = 0;
         if (g.lean && !sub_bit) P->has_fly = 1;
+        if (leanw) g.lean |= 8;
         g.lean |= sub_bit;
     }
     // ---- wave-local plans (hint_wl.hpp): every group lean, narrow lane tile, the block's thin vectors and biases small
@@ -610,7 +616,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     for (const Unit& u : units) if (u.xoff > 255 || u.h > 32767) wl = false;
     // (the wave-local kernels read the lane table from LDS only and keep per-group tables in the 64 lanes of a register)
     if ((groups.size() + 1) * (size_t)d * sizeof(LaneOp) > 16 * 1024 || groups.size() + 1 > 64 || ents.size() > 65535) wl = false;
-    if (const char* e = std::getenv("HINT_WL")) if (std::atoi(e) == 0) wl = false;
+    if (!knobs().wl) wl = false;
     // ---- LDS: the meta blob's size, then per group the region [its tiles | its output tiles, staged for the element-wise
     //      phase to stream out, when there is room | its slabs]; the launch reserves the largest group's ----
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -634,10 +640,8 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     const int fixed_f = P->meta_bytes + 4 * (2 * ROWS * P->xld + ROWS * P->cld + 2 * ROWS + MAX_NW) + sub_f_bytes;     // (2 x ROWS: the log-det sums of the coupling phase's two halves)
     const int fixed_b = P->meta_bytes + 4 * (3 * ROWS * P->xld + 2 * ROWS * P->cld + ROWS * P->gld + ROWS + ROWS * P->xld) + sub_b_bytes;   // (+ the lanes of the level before: first-layer gradients)
     // Lean groups get their dW1 | db1 from the backward kernel: staged ones in a pass of their own (the g1 tiles wait in LDS),
-    // the others - too large to stage - row by row (RowRec flag rowdw: one scratch tile per wavefront), so that g1 never travels
-    // (HINT_ROW_DW1=0: only the staged ones).  The scratch tiles count against the LDS the staging decision sees: two passes.
-    const bool rowdw_on = !(std::getenv("HINT_ROW_DW1") && std::atoi(std::getenv("HINT_ROW_DW1")) == 0) && !wl &&
-                          !(std::getenv("HINT_FUSE_DW1") && std::atoi(std::getenv("HINT_FUSE_DW1")) == 0);
+    // the others - too large to stage - row by row (RowRec flag rowdw: one scratch tile per wavefront), so that g1 never travels.  The scratch tiles count against the LDS the staging decision sees: two passes.
+    const bool rowdw_on = !wl && knobs().fuse_dw1;
     int rowdw_bytes = 0;
     std::vector<char> unit_fused(units.size(), 0), unit_rowdw(units.size(), 0);
     for (int pass = 0; pass < 2; ++pass) {
@@ -668,7 +672,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     if (!any_rowdw) rowdw_bytes = 0;
     break;
     }
-    if (const char* e = std::getenv("HINT_FUSE_DW1")) if (std::atoi(e) == 0) std::fill(unit_fused.begin(), unit_fused.end(), 0);
+    if (!knobs().fuse_dw1) std::fill(unit_fused.begin(), unit_fused.end(), 0);
     if (wl) {
         // LDS of the wave-local kernels (float offsets): [meta | 2 x staged parameters | 2 x nr slab sets | per wavefront: its own
         // tiles of nr row tiles | 32 floats shared] (+ the chain's permutation matrices behind, when the launch finds room)
@@ -692,11 +696,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         }
     }
     P->wl = wl ? 1 : 0;
-    if (std::getenv("HINT_PLAN_DUMP"))
+    if (knobs().plan_dump)
         std::fprintf(stderr, "[hint plan] nw %d: wave-local %d (lean %d, par_f4 %d of %d, LDS fwd %d bwd %d bytes; row pairs %d: %d / %d)\n", nw, P->wl,
                      P->lean, par_f4, WL_PAR_REGS * 64 * nw, 4 * P->wl_f[0].off_perm, 4 * P->wl_b[0].off_perm, P->wl_nr2,
                      4 * P->wl_f[1].off_perm, 4 * P->wl_b[1].off_perm);
-    if (std::getenv("HINT_PLAN_DUMP") && P->n_sub > 0)
+    if (knobs().plan_dump && P->n_sub > 0)
         std::fprintf(stderr, "[hint plan] nw %d: %d subtree groups (depth >= %d): parameters %d + %d + %d floats, slabs %d / %d floats\n", nw,
                      P->n_sub, sub_depth, P->sub_pf, P->sub_pb, P->sub_pbias, P->sub_slab_f, P->sub_slab_b);
     if (wl) std::fill(unit_fused.begin(), unit_fused.end(), 1);      // dW1 / db1 always come from the backward kernel
@@ -837,7 +841,7 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
             }
             P->max_slots = std::max(P->max_slots, cnt);
         }
-        if (std::getenv("HINT_PLAN_DUMP")) {
+        if (knobs().plan_dump) {
             std::fprintf(stderr, "[hint plan] backward boundary slots (active lanes):");
             for (int b = 0; b < nb; ++b) std::fprintf(stderr, " %d (%d)", rng[P->lop_cnt + b], lops[(size_t)b * d].pad >> 16);
             std::fprintf(stderr, "\n");
@@ -864,7 +868,6 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     P->thin_b_off = (int)blob_f_pad; P->thin_b_floats = (int)((blob_b + 3) / 4 * 4);
     // (small ones always; larger ones when the block's LDS already rules out two workgroups per CU, or still allows them)
     auto stage_thin = [&](int lds, int blob) {
-        if (const char* e = std::getenv("HINT_THIN_LDS")) if (std::atoi(e) == 0) return false;     // (diagnostic: read the thin vectors from L2)
         return lds + blob <= LDS_LIMIT && (blob <= THIN_LDS_MAX || lds > LDS_LIMIT / 2 || lds + blob <= LDS_LIMIT / 2);
     };
     if (stage_thin(P->lds_fwd, P->thin_f_floats * 4)) {
@@ -876,11 +879,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         P->lds_bwd += P->thin_b_floats * 4;
     }
     // blobs too large for that (the d = 100 trees: 300 KB): one group's vectors at a time - a run of thin tiles reading them from L2
-    // costs 5 k cycles, from LDS 2 k (HINT_THIN_GRP=0: never)
+    // costs 5 k cycles, from LDS 2 k
     {
         // (the buffer: the largest group slice that fits; larger groups - the roots, whose wide thin layers run on the matrix pipe
         //  and read one bias vector per tile - keep reading from L2)
-        const bool on = !(std::getenv("HINT_THIN_GRP") && std::atoi(std::getenv("HINT_THIN_GRP")) == 0) && !(std::getenv("HINT_THIN_LDS") && std::atoi(std::getenv("HINT_THIN_LDS")) == 0);
+        const bool on = true;
         auto avail = [&](int lds) { return lds > LDS_LIMIT / 2 ? LDS_LIMIT - lds : LDS_LIMIT / 2 - lds; };
         const int av_f = avail(P->lds_fwd) / 4, av_b = avail(P->lds_bwd) / 4;
         int gmax_f = 0, gmax_b = 0;
@@ -941,22 +944,21 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     make_wgrad_jobs(P, nodes, units, unit_node, unit_lean, unit_fused, max_depth, &wjobs, &real);
     {   // single-tile jobs last: eight of them share a workgroup (hint_wgrad.hip) - for the trees with subtree groups, whose part B
         // is hundreds of 8 x 8 jobs (MINIBOONE: 272 -> 239 us); the d = 100 trees' single-tile jobs are column remainders of wide
-        // arrays, and one wavefront walking 512 rows of a 9600-column array alone is slower (+6 %).  HINT_DW_SMALL=0 / 1 overrides.
-        bool small_on = P->n_sub > 0;
-        if (const char* e = std::getenv("HINT_DW_SMALL")) small_on = std::atoi(e) != 0;
+        // arrays, and one wavefront walking 512 rows of a 9600-column array alone is slower (+6 %).  HINT_DW_SMALL=0 / 1 overrides (experiments).
+        const bool small_on = knobs().dw_small >= 0 ? knobs().dw_small != 0 : P->n_sub > 0;
         // (single-tile jobs that rebuild their operands read no wide array: for every tree on the general kernels - the d = 100 flows' part B
         //  -4 %; the narrow trees of the wave-local kernels have a handful of them with long batches per split: GAS +5 %, left alone)
-        const bool nat_on = env_int("HINT_DW_SMALL_NAT") != -1 && !P->wl;
+        const bool nat_on = !P->wl;
         auto is_small = [&](const WJob& j) { return j.mw <= 1 && j.nw <= 1 && (small_on || (nat_on && j.psrc == WSRC_G2R)); };
         std::stable_partition(wjobs.begin(), wjobs.end(), [&](const WJob& j) { return !is_small(j); });
-        if (env_int("HINT_DW_SORT") == 1 || (P->wl && env_int("HINT_DW_SORT") != -1)) {
+        if (P->wl) {
             // the workgroups' jobs longest first (tile products per 16-row step): the launch's last wave of workgroups is the short ones
             // (narrow trees: POWER -7 %, GAS -4 %; the d = 100 trees +12 % - there a unit's jobs next to each other share their
-            //  operands' rows in L2, which is worth more: not sorted; HINT_DW_SORT=1 / -1 forces either)
+            //  operands' rows in L2, which is worth more: not sorted)
             const auto nbig = std::count_if(wjobs.begin(), wjobs.end(), [&](const WJob& j) { return !is_small(j); });
             std::stable_sort(wjobs.begin(), wjobs.begin() + nbig, [](const WJob& x, const WJob& y) {
                 return x.mw * std::max(1, x.nw) > y.mw * std::max(1, y.nw); });
-            P->wsorted = env_int("HINT_DW_INTERLEAVE") != -1;
+            P->wsorted = 1;
         }
         P->n_wsmall = (int)std::count_if(wjobs.begin(), wjobs.end(), is_small);
     }
@@ -1022,15 +1024,11 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
     return 0;
 }
 
-// wavefronts per workgroup: HINT_NW (4 or 8) overrides; otherwise 8 (4 only for blocks narrow enough
+// wavefronts per workgroup: HINT_NW (4 or 8) overrides (experiments); otherwise 8 (4 only for blocks narrow enough
 // for the backward kernel's register-held [16, d] tile)
 static int pick_nw(int d) {
     int nw = 8;
-    if (const char* s = std::getenv("HINT_NW")) {
-        const int v = std::atoi(s);
-        if (v == 4 || v == 8 || v == 16) nw = v;
-        if (nw > MAX_NW) nw = MAX_NW;
-    }
+    if (knobs().nw == 4 || knobs().nw == 8 || knobs().nw == 16) nw = std::min(knobs().nw, MAX_NW);
     while (nw < MAX_NW && ROWS * d > LV_REGS * 64 * nw) nw *= 2;
     return nw;
 }
@@ -1040,8 +1038,8 @@ static int pick_nw(int d) {
 static int plan_for(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, int32_t dc, float clamp, int nw, hint_plan** out) {
     for (int unit_waves = nw; unit_waves >= 1; unit_waves /= 2)
         // (64 tiles = 16 rows of four: two per wavefront; 72 gave 18 rows - three for two of the wavefronts, everybody waits for them:
-        //  the d = 100 flows +4 %; HINT_TILE_CAP overrides)
-        for (int tile_cap = env_int("HINT_TILE_CAP") >= 8 ? env_int("HINT_TILE_CAP") : 64; tile_cap >= 8; tile_cap -= 16) {
+        //  the d = 100 flows +4 %)
+        for (int tile_cap = 64; tile_cap >= 8; tile_cap -= 16) {
             bool retry = false;
             const int st = build_plan(nodes, n_nodes, d, dc, clamp, nw, tile_cap, unit_waves, out, &retry);
             if (st != 2) return st;
@@ -1078,7 +1076,7 @@ int hint_plan_create(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, in
     if (st != 0) return st;
     // batches of more row tiles than CUs run two 4-wavefront workgroups per CU instead of one 8-wavefront workgroup
     // after the other (when the block fits twice and the backward kernel's register-held lane tile allows 256 threads)
-    if (nw == 8 && !std::getenv("HINT_NW") && ROWS * d <= LV_REGS * 64 * 4) {
+    if (nw == 8 && knobs().nw == 0 && ROWS * d <= LV_REGS * 64 * 4) {
         const std::string keep = last_error_ref();
         hint_plan* alt = nullptr;
         if (plan_for(nodes, n_nodes, d, dc, clamp, 4, &alt) == 0) {

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HINT_AMD_ABI_VERSION 6
+#define HINT_AMD_ABI_VERSION 7
 
 /* index into hint_node_desc.p_off: [net][tensor]; net 0 = s, net 1 = t (hint.py:44-45);
  * tensors in nn.Sequential order (hint.py:11-13): W1 [h,cin], b1 [h], W2 [h,h], b2 [h],
@@ -314,8 +314,10 @@ int hint_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_a
 
 int hint_abi_version(void);
 const char* hint_last_error(void);
-/* what the library binary was built with: "libhint_amd abi N, gfx950, HIP x.y.z, clang ..." (static string; the HIP
- * runtime of the machine that loads it may differ - bench.py prints both) */
+/* what the library binary was built with and runs with: "libhint_amd abi N, gfx950, HIP x.y.z, clang ..., src <12 hex digits: hash
+ * of the sources it was compiled from>[, knobs: HINT_X=v ...]" - the last part lists the HINT_* environment variables the library
+ * found set (they change which kernels run).  Valid until the thread's next call; the HIP runtime of the machine that loads the
+ * library may differ - bench.py prints both. */
 const char* hint_build_info(void);
 
 /* Diagnostics (process-wide; no effect on any result).  The general kernels touch the packed weights of what runs two
@@ -324,6 +326,9 @@ const char* hint_build_info(void);
  * setting - a launch already captured in a hipGraph keeps what it was captured with.  hint_debug_last_lds_bytes(backward)
  * = dynamic LDS bytes of the process's last forward / inverse (0) or backward part-A (1) launch. */
 int hint_debug_set_prefetch(int on);
+/* The library reads its HINT_* environment variables once (the list: INTEGRATION.md); this re-reads them - for tests and A/B tools
+ * that change the environment inside one process.  Plans already built keep what they were built with. */
+int hint_debug_reload_knobs(void);
 int32_t hint_debug_last_lds_bytes(int32_t backward);
 
 #ifdef __cplusplus

@@ -39,6 +39,8 @@ WORKLOADS = [
     ("cfg4_plus_x_lane_B4368", 100, 0, 2, [224, 112, 56], 4368, 0.03),
     ("cfg4_plus_x_lane_cond_B4368", 100, 4, 2, [224, 112, 56], 4368, 0.03),
     ("cfg5_miniboone_hint_10_B4096", 43, 0, 10, [67, 33, 16, 8], 4096, 0.06),
+    # BASELINE cfg 1 at its exact shape: configs/uci_data/power_hint_4.py:29-30,66 - 4 blocks [200,100,50,25], batch 512
+    ("cfg1_power_hint_4_B512", 6, 0, 4, [200, 100, 50, 25], 512, 0.06),
 ]
 LARGE = {"cfg4_plus_x_lane_B4368", "cfg4_plus_x_lane_cond_B4368", "cfg5_miniboone_hint_10_B4096"}
 # at most this share of a batch may be left out as "next to a ReLU kink": per workload the share observed on MI355X
@@ -49,6 +51,7 @@ MAX_KINK_ROWS = {
     "cfg5_miniboone_hint_10": 0.045, "plus_hint_4_big": 0.075, "cfg3_gas_hint_8_B8192": 0.042, "cfg2_power_hint_8_B8192": 0.04,
     # (round 5, decided by the float64 oracle on the CPU: 138/4368, 156/4368, 64/4096)
     "cfg4_plus_x_lane_B4368": 0.062, "cfg4_plus_x_lane_cond_B4368": 0.066, "cfg5_miniboone_hint_10_B4096": 0.046,
+    "cfg1_power_hint_4_B512": 0.045,
 }
 
 
@@ -85,8 +88,9 @@ def make_pair(d, dc, n_blocks, widths, scale, seed=0):
 KINK = 5e-7
 
 
-def rows_off_the_kinks(ref, x64, cr):
-    """mask of the rows none of whose hidden pre-activations (whole chain, float64) lies within KINK of zero"""
+def rows_off_the_kinks(ref, x64, cr, out=None):
+    """mask of the rows none of whose hidden pre-activations (whole chain, float64) lies within KINK of zero; out (a list)
+    receives the oracle's (z, J) of ALL rows - a row next to a kink has an ambiguous subgradient, not an ambiguous forward"""
     dist = torch.full((x64.shape[0],), float("inf"), dtype=torch.float64)
     relu = torch.relu
 
@@ -99,7 +103,9 @@ def rows_off_the_kinks(ref, x64, cr):
     torch.relu = spy
     try:
         with torch.no_grad():
-            ref.forward(x64, cr)
+            zJ = ref.forward(x64, cr)
+            if out is not None:
+                out.append(zJ)
     finally:
         torch.relu = relu
     return dist > KINK
@@ -124,11 +130,33 @@ def test_chain_nll_gradient_and_inverse_match_oracle(name, d, dc, n_blocks, widt
     x64 = torch.randn(B, d, generator=g, dtype=torch.float64).float().double()
     c64 = torch.randn(B, dc, generator=g, dtype=torch.float64).float().double() if dc else None
     cr = (c64,) if dc else ()
-    keep = rows_off_the_kinks(ref, x64, cr)
+    all_rows = []
+    keep = rows_off_the_kinks(ref, x64, cr, out=all_rows)
     dropped = B - int(keep.sum())
     print(f"{name}: {dropped} of {B} rows left out (pre-activation within {KINK} of a ReLU kink)")
     record_kink_rows(name, dropped, B)
     assert dropped <= MAX_KINK_ROWS[name] * B, f"{dropped} of {B} rows next to a ReLU kink (cap {MAX_KINK_ROWS[name]:.0%})"
+    # the exclusion waives the SUBGRADIENT choice only: z and log-det of every row - the dropped ones too - are checked here,
+    # on the chained training forward (tape and all) at the full batch
+    z_all, J_all = all_rows[0]
+    tr0 = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
+    tr0._check_arenas()
+    tr0._pack_all()
+    chain = tr0._chain_for(B)
+    xa = x64.float().to(DEV)
+    ca = c64.float().to(DEV) if dc else None
+    zg, Jg = torch.empty_like(xa), torch.empty(B, device=DEV)
+    from hint_amd import _lib
+    _lib.check(tr0.lib.hint_chain_forward(chain, xa.data_ptr(), ca.data_ptr() if dc else None, zg.data_ptr(), Jg.data_ptr(), None,
+                                          None, torch.cuda.current_stream().cuda_stream), "hint_chain_forward")
+    zs = max(1.0, float(z_all.abs().max()))
+    dz = (zg.double().cpu() - z_all).abs().max(dim=1).values
+    dJ = (Jg.double().cpu() - J_all).abs()
+    assert float(dz.max()) <= 1e-4 * zs and float(dJ.max()) <= 1e-4 * max(1.0, float(J_all.abs().max())), \
+        (name, float(dz.max()), float(dJ.max()))
+    if dropped:
+        print(f"{name}: dropped rows' forward: |dz| <= {float(dz[~keep].max()):.2e}, |dJ| <= {float(dJ[~keep].max()):.2e}")
+    del tr0
     x64 = x64[keep]
     if dc:
         c64 = c64[keep]

@@ -286,3 +286,105 @@ def test_conditional_trainer_noise_is_drawn_in_the_first_launch():
         r0, r1 = tr0.step(xn, y)
         np.testing.assert_allclose(got, [float(r0), float(r1)], rtol=1e-5, atol=1e-6)
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
+@pytest.mark.timeout(900)
+def test_conditional_trainer_gradient_at_4096_rows():
+    """BASELINE cfg 4's per-GPU batch: the two-lane model of conditional_hint_4_full.py:58-94 (x d = 100, y d = 4, width 224,
+    4 blocks) on ConditionalFlowTrainer's fast path as ONE hipGraph replay over 4096 rows - the persistent tile loop of the
+    x lane's kernels, the conditions' gradients entering the y chain (`g_add`), one part B per plan - against the float64
+    composition of oracle blocks: loss pair and x_jac (train_conditional.py:50-55) to 1e-4, every parameter tensor's gradient to
+    1e-4 of its norm.  The gradient is read out of the optimizer's first moment: with beta1 = 0, no weight decay, no clamp and
+    lr = 0 the fused clamp + Adam epilogue leaves exp_avg = g and the weights where they were.  The 4096 rows are the first
+    4096 of a pool whose float64 pre-activations all keep 5e-7 away from a ReLU kink (either subgradient is right there);
+    the pool's remaining rows - the ones next to a kink included - are checked on the forward results (z_x, z_y, x_jac)."""
+    import math
+    from test_gpu_chain_workloads import KINK
+    torch.manual_seed(5)
+    nx, ny, nb, hidden, B, POOL = 100, 4, 4, 224, 4096, 4608
+    m = hint_amd.ConditionalHintFlow(nx, ny, nb, hidden).to(DEV)
+    gw = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.data = (0.03 * torch.randn(p.shape, generator=gw)).to(DEV)
+    gx = torch.Generator().manual_seed(6)
+    xp = torch.randn(POOL, nx, generator=gx)
+    yp = torch.randn(POOL, ny, generator=gx)
+    mods = []
+    for i in range(nb):
+        mods += [(f"hac_x.{i}", m.hac_x[i], 0), (f"ac_y_to_x.{i}", m.ac_y_to_x[i], ny), (f"ac_y.{i}", m.ac_y[i], 0)]
+    Po = {name: {k: v.detach().cpu().double().requires_grad_(True) for k, v in sub.state_dict().items()} for name, sub, _ in mods}
+    nodes = {name: oracle_nodes(sub.tree, dc) for name, sub, dc in mods}
+    clamp = {name: sub.tree.clamp for name, sub, _ in mods}
+    Wy = [m.perm_y[i].W.cpu().double() if i > 0 else None for i in range(nb)]
+    Wx = [m.perm_x[i].W.cpu().double() if i > 0 else None for i in range(nb)]
+
+    def oracle(x, y):
+        xo, yo = x, y
+        jx = jy = 0
+        for i in range(nb):
+            if i > 0:
+                yo = yo @ Wy[i]; xo = xo @ Wx[i]
+            n = f"hac_x.{i}"; xo, j = orc.block_apply(nodes[n], Po[n], xo, [], clamp=clamp[n]); jx = jx + j
+            n = f"ac_y_to_x.{i}"; xo, j = orc.block_apply(nodes[n], Po[n], xo, [yo], clamp=clamp[n]); jx = jx + j
+            n = f"ac_y.{i}"; yo, j = orc.block_apply(nodes[n], Po[n], yo, [], clamp=clamp[n]); jy = jy + j
+        return xo, yo, jx, jy
+
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, nt))
+    try:
+        # the pool's forward in float64, with the distance of every row to its nearest ReLU kink
+        dist = torch.full((POOL,), float("inf"), dtype=torch.float64)
+        relu = torch.relu
+
+        def spy(t):
+            nonlocal dist
+            if t.numel() > 0:
+                a = t.detach().abs().reshape(t.shape[0], -1)
+                dist = torch.minimum(dist, a.min(dim=1).values / a.max(dim=1).values.clamp(min=1e-3))
+            return relu(t)
+        torch.relu = spy
+        try:
+            with torch.no_grad():
+                zx_all, zy_all, jx_all, jy_all = oracle(xp.double(), yp.double())
+        finally:
+            torch.relu = relu
+        keep = torch.nonzero(dist > KINK).flatten()
+        assert keep.numel() >= B, f"only {keep.numel()} of {POOL} rows off the kinks"
+        print(f"conditional 4096: {POOL - keep.numel()} of {POOL} pool rows next to a ReLU kink")
+        idx = keep[:B]
+        x, y = xp[idx], yp[idx]
+        xo, yo, jx, jy = oracle(x.double(), y.double())
+        z = torch.cat([xo, yo], dim=-1)
+        l0, l1 = 0.5 * torch.sum(z ** 2, dim=1).mean(), -(jx + jy).mean()      # train_conditional.py:132-143
+        (l0 + l1).backward()
+    finally:
+        torch.set_num_threads(nt)
+
+    tr = hint_amd.ConditionalFlowTrainer(m, noise=0.0, use_graph=True, lr=0.0, betas=(0.0, 0.95), weight_decay=0.0, grad_clamp=0.0)
+    w0 = tr.P.clone()
+    g0, g1 = tr.step(x.to(DEV), y.to(DEV))
+    assert tr._graph is not None
+    assert abs(float(g0) - float(l0)) <= 1e-4 * abs(float(l0)) and abs(float(g1) - float(l1)) <= 1e-4 * max(1.0, abs(float(l1)))
+    Jx = tr.last[2].detach().double().cpu()
+    assert float((Jx - jx.detach()).abs().max()) <= 1e-4 * max(1.0, float(jx.detach().abs().max()))
+    assert torch.equal(tr.P, w0)                          # lr = 0: the weights did not move
+    gmax = max(float(p.grad.abs().max()) for d_ in Po.values() for p in d_.values())
+    num = den = 0.0
+    for (name, sub, _), (a, b), eng in zip(mods, tr.slices, tr.engines):
+        named = {id(q): k for k, q in sub.named_parameters()}
+        for p, g in zip(eng.params, eng.split_flat(tr.M[a:b])):
+            r = Po[name][named[id(p)]].grad
+            gg = g.detach().double().cpu()
+            tn, tr_ = float(((gg - r) ** 2).sum()) ** 0.5, float((r ** 2).sum()) ** 0.5
+            num += tn * tn; den += tr_ * tr_
+            assert tn <= 1e-4 * tr_ + 1e-6 * gmax * math.sqrt(r.numel()), (name, named[id(p)], tn, tr_)
+    assert math.sqrt(num / den) <= 1e-4
+
+    # the rest of the pool (kink rows included), forward only: z_x, z_y and x_jac of every row on the same fast path
+    rest = torch.ones(POOL, dtype=torch.bool); rest[idx] = False
+    ridx = torch.nonzero(rest).flatten()
+    tr.step(xp[ridx].to(DEV), yp[ridx].to(DEV))
+    zy_g, zx_g, Jx_g, Jy_g = [t.detach().double().cpu() for t in tr.last]
+    for got, ref in ((zx_g, zx_all[ridx]), (zy_g, zy_all[ridx]), (Jx_g, jx_all[ridx]), (Jy_g, jy_all[ridx])):
+        assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))

@@ -73,8 +73,11 @@ def test_subtree_groups_equal_general_groups(monkeypatch):
     P = orc.init_params(nodes, seed=3, scale=None)
     x = torch.randn(B, d, generator=torch.Generator().manual_seed(8)).to(DEV)
     outs = []
+    from hint_amd import _lib
+    lib = _lib.load()
     for sub in ("1", "0"):
         monkeypatch.setenv("HINT_SUB", sub)
+        lib.hint_debug_reload_knobs()             # (the library reads its environment once)
         blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=list(widths))
         blk.load_state_dict({k: v.clone() for k, v in P.items()})
         blk = blk.to(DEV)
@@ -83,6 +86,8 @@ def test_subtree_groups_equal_general_groups(monkeypatch):
         J = blk.jacobian(None)
         (0.5 * (z ** 2).sum(1).mean() - J.mean()).backward()
         outs.append((z.detach().cpu(), J.detach().cpu(), xd.grad.cpu(), {k: p.grad.cpu() for k, p in blk.named_parameters()}))
+    monkeypatch.delenv("HINT_SUB")
+    lib.hint_debug_reload_knobs()
     (z1, J1, g1, p1), (z0, J0, g0, p0) = outs
     np.testing.assert_allclose(z1.numpy(), z0.numpy(), rtol=1e-5, atol=1e-5 * float(z0.abs().max()))
     np.testing.assert_allclose(J1.numpy(), J0.numpy(), rtol=1e-5, atol=1e-5 * float(J0.abs().max()))

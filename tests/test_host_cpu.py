@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hint_abi_version() == 6
+    assert lib.hint_abi_version() == 7
 
 
 def test_nodedesc_matches_header_layout():
