@@ -143,22 +143,17 @@ class ConditionalHintFlow(nn.Module):
         return self._jac_x
 
 
-class _CondLoss:
-    """one of the two loss terms a step returns, evaluated when somebody looks (float(), .item(), arithmetic through
-    .value): no torch kernel runs inside the step or its captured graph for them"""
+class _LossPair:
+    """what step() returns on every path: unpacks to the two loss terms as DEVICE SCALARS (torch tensors: `l0 + l1`,
+    `sum(batch_losses)`, `torch.stack`, `.item()` all work), evaluated when it is unpacked so that no torch kernel runs inside the
+    step or its captured graph.  The sums live in a buffer the next step's prologue clears: unpack before stepping again
+    (FlowTrainer.step returns the same type)."""
 
-    def __init__(self, trainer, k):
-        self._t, self._k = trainer, k
+    def __init__(self, trainer):
+        self._t = trainer
 
-    @property
-    def value(self) -> torch.Tensor:
-        return self._t.last_losses()[self._k]
-
-    def __float__(self):
-        return float(self.value)
-
-    def item(self):
-        return float(self.value)
+    def __iter__(self):
+        return iter(self._t.last_losses())
 
 
 class ConditionalFlowTrainer:
@@ -194,7 +189,7 @@ class ConditionalFlowTrainer:
 
     def __init__(self, flow: ConditionalHintFlow, lr: float = 0.01 * 3e-2, betas=(0.9, 0.95), eps: float = 1e-4,
                  weight_decay: float = 1.86e-5, grad_clamp: float = 5.0, noise: float = 0.01, group=None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, seed: Optional[int] = None):
         from . import _lib, dp
         self._lib, self._dp = _lib, dp
         self.lib = _lib.load()
@@ -238,7 +233,9 @@ class ConditionalFlowTrainer:
         # device-side step state (see FlowTrainer): opt_state = {lr, beta1, beta2, lr/(1-beta1^t),
         # 1/sqrt(1-beta2^t), ...}, rng_state[1] = step count; the re-pack launch's prologue advances them
         self.opt_state = torch.tensor([lr, betas[0], betas[1], 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if seed is None:            # (not from torch's global generator: building a trainer must not shift the caller's random stream)
+            import os
+            seed = int.from_bytes(os.urandom(8), "little") >> 2
         rank = dp.world_info(group)[0]
         self.rng_state = torch.tensor([(seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 63 - 1), 0], dtype=torch.int64, device=dev)
         self._st = {}                # per batch size: static buffers and chains (_state_for)
@@ -281,11 +278,13 @@ class ConditionalFlowTrainer:
             return st
         if st is not None:                     # an arena or packed buffer moved: graphs and chains point at the old addresses
             self._graph = None
+            torch.cuda.synchronize(dev)        # (launches that read the chains' device tables may still be queued)
             for h in st["chains"].values():
                 self.lib.hint_chain_destroy(h)
             del self._st[B]
         if len(self._st) >= 4:                 # ragged data: forget the batch sizes no live graph was captured on
             keep = self._static[0].shape[0] if (self._graph is not None and self._static is not None) else None
+            torch.cuda.synchronize(dev)
             for b in [b for b in self._st if b != keep]:
                 for h in self._st[b]["chains"].values():
                     self.lib.hint_chain_destroy(h)
@@ -325,9 +324,11 @@ class ConditionalFlowTrainer:
                     self._lib.check(self.lib.hint_chain_set_block(
                         h, i, e.arena.data_ptr(), e.packed.data_ptr(), ptr(st["perm"][(kind, i)]), st["tapes"][kind][i].data_ptr(),
                         st["ws"][kind][i].data_ptr(), wb, self.G.data_ptr() + 4 * a), "hint_chain_set_block")
-            # the y lane after its permutation = the x lane's condition: block i's tape top slice (one level: the tape's start);
-            # block 0 has no permutation in front: the input itself
-            st["yp"] = [st["y_in"]] + [st["tapes"]["ac_y"][i][:B * dy].view(B, dy) for i in range(1, nb)]
+            # the y lane after its permutation = the x lane's condition: block i's tape TOP slice - the kernels keep a block's permuted
+            # input at tape + (n_levels - 1) * B * d (hint_fwd.hip store_tile, hint_wgrad.hip wsrc); block 0 has no permutation in
+            # front: the input itself
+            top = max(dep for _, _, dep in flow.ac_y[0].tree._flat_nodes()) * B * dy          # (n_levels - 1) slices down
+            st["yp"] = [st["y_in"]] + [st["tapes"]["ac_y"][i][top:top + B * dy].view(B, dy) for i in range(1, nb)]
             st["hx0_in"] = st["xn"]
             for i in range(nb):
                 self._lib.check(self.lib.hint_chain_set_block_io(st["chains"]["ac_y"], i, None, None, st["gc"][i].data_ptr()),
@@ -385,11 +386,17 @@ class ConditionalFlowTrainer:
         return torch.distributed.get_backend(self.group) == "nccl" and os.environ.get("HINT_GRAPH_ALLREDUCE", "1") != "0"
 
     def step(self, x: torch.Tensor, y: torch.Tensor):
-        """one iteration on this rank's rows; returns device scalars (0.5*|z|^2 mean, -log|det J| mean)"""
+        """one iteration on this rank's rows; returns a pair that unpacks to the device scalars (0.5*|z|^2 mean, -log|det J| mean)
+        - `l0, l1 = trainer.step(x, y)`; unpack it before the next step (its prologue clears the sums)"""
         for e in self.engines:
             e.ensure_arena()
         if not self._graphable():
             return self._iteration(x, y, on_device_adam=False)
+        if self._graph is not None and not self._legacy:
+            # an arena or packed buffer that moved after the capture (ensure_arena above re-gathers): the graph holds the old addresses
+            st = self._st.get(self._static[0].shape[0])
+            if st is None or st["key"] != tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines) + (self.G.data_ptr(),):
+                self._graph = None
         if self._graph is None or self._static[0].shape != x.shape or self._static[1].shape != y.shape:
             if not self._capture(x, y):
                 return self._iteration(x, y, on_device_adam=False)
@@ -479,6 +486,9 @@ class ConditionalFlowTrainer:
             if st["perm"][("hac_x", 0)] is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise HintAmdError("ConditionalFlowTrainer: `noise` switched on / off: call step() once outside a capture")
+                # (hint_chain_commit copies the table with a synchronous hipMemcpy on the null stream: the launches of the step before
+                #  - possibly on a non-blocking stream - must be through with the old one)
+                torch.cuda.current_stream(self.device).synchronize()
                 with torch.cuda.device(self.device):
                     chk(lib.hint_chain_set_block_io(st["chains"]["hac_x"], 0, x0.data_ptr(), None, None), "hint_chain_set_block_io")
                     chk(lib.hint_chain_commit(st["chains"]["hac_x"]), "hint_chain_commit")
@@ -549,7 +559,7 @@ class ConditionalFlowTrainer:
                 self.rng_state[1] = self.step_count          # keep the device counter in step for a later capture
         self.last = (st["zy"], st["xb"][nb - 1], st["Jxb"][nb - 1], st["Jy"])
         self._last_B = B
-        return _CondLoss(self, 0), _CondLoss(self, 1)
+        return _LossPair(self)
 
     def last_losses(self):
         """(0.5 |z|^2 mean, -log|det J| mean) of the most recent step as device scalars, from the launches' loss sums (read
@@ -627,4 +637,5 @@ class ConditionalFlowTrainer:
             self._lib.check(st, "hint_adam_step")
             self.rng_state[1] = self.step_count          # keep the device counter in step for a later capture
         self.last = (zy, zx, Jx, Jy)
-        return l0, l1
+        self._last_B = B
+        return _LossPair(self)

@@ -29,13 +29,13 @@ static Knobs read_knobs() {
     if (get("HINT_NW", &v)) k.nw = v;
     if (get("HINT_LEAN", &v)) k.lean = v != 0;
     if (get("HINT_LEANW", &v)) k.leanw = v != 0;
+    if (get("HINT_LEANW_MAX", &v)) k.leanw_max = std::min(std::max(v, 4), LEANW_MAX);
     if (get("HINT_FUSE_DW1", &v)) k.fuse_dw1 = v != 0;
     if (get("HINT_PF", &v)) k.pf = v != 0 ? 1 : 0;
     if (get("HINT_NO_BWD_FLY", &v)) k.no_bwd_fly = v != 0;
     if (get("HINT_DW_SPLITS", &v)) k.dw_splits = v;
     if (get("HINT_DW_SMALL", &v)) k.dw_small = v != 0 ? 1 : 0;
     if (get("HINT_ABLATION_OK", &v)) k.ablation_ok = v != 0;
-    if (get("HINT_ABL_NO_DW2", &v)) k.abl_no_dw2 = v != 0;
     return k;
 }
 static std::mutex g_knobs_mu;
@@ -147,7 +147,7 @@ static int add_sink(const hint_plan* P, int total, KArgs* a) {
 }
 
 // LDS bytes of the launch: the plan's, plus the chain's permutation matrices when they fit behind it
-int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a) {
+int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a, bool backward) {
     const long extra = (long)n_blocks * P->d * P->d * (long)sizeof(float);
     a->perm_lds = 0;
     const int cap = perm_lds_cap();
@@ -165,7 +165,7 @@ int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm
     // always issues, with an out-of-bound offset for the lanes that are not to touch anything - +2 / +6 us
     total = add_sink(P, total, a);
     if (plan_dump()) fprintf(stderr, "[hint plan] packed lines %d: sink at %d, lds %d\n", a->packed_lines, a->sink_lds, total);
-    g_last_lds[0].store(total, std::memory_order_relaxed);
+    g_last_lds[backward ? 1 : 0].store(total, std::memory_order_relaxed);
     return total;
 }
 KArgs make_args(const hint_plan* P, int B, bool backward) {
@@ -226,16 +226,15 @@ int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* ch
     //  the timing scripts set it - does it launch a backward pass at all)
     if (!knobs().ablation_ok) return fail("this is an ablation build (HINT_ABLATE_STORE): its gradients are wrong; set HINT_ABLATION_OK=1 for timing runs");
 #endif
-    if (knobs().abl_no_dw2 && !knobs().ablation_ok) return fail("HINT_ABL_NO_DW2 drops weight-gradient jobs: its gradients are wrong; set HINT_ABLATION_OK=1 for timing runs");
+
     if ((parts & 1) && P->wl) {
         KArgs a = make_args(P, B, true);
         const int nr = wl_nr_for(P, B);
         WlArgs w = P->wl_b[nr - 1];
         bool any_perm = one.perm != nullptr;
         if (chain_host) for (int i = 0; i < n_chain; ++i) any_perm = any_perm || chain_host[i].perm != nullptr;
-        const int lds = lds_with_perms(P, plan_lds(P, true, nr), n_chain, any_perm, &a);
+        const int lds = lds_with_perms(P, plan_lds(P, true, nr), n_chain, any_perm, &a, true);
         w.off_perm = a.perm_lds;
-        g_last_lds[1].store(lds, std::memory_order_relaxed);
         HIP_TRY(launch_wl_bwd(a, w, lds, grid_for(P, B), one, chain, n_chain, x, g_z, g_J, g_x, gz_scale, gJ_const, s));
     } else if (parts & 1) {
         // (the permutation matrices stay in global memory here: one d x d product per block)
@@ -253,7 +252,7 @@ int run_backward(const hint_plan* P, const ChainBlock& one, const ChainBlock* ch
                          rows_padded(B), rows_per_wg, act_stride(P, B), P->lean ? 0 : act_stride(P, B),
                          (P->lean ? 1 : 2) * act_stride(P, B) * 4 + bits_stride(P, B), P->param_floats, x, c, P->d_real,
                          accumulate, P->fuse_dw1 ? P->d_twmap : nullptr, P->tw_floats, ws_thin_off(P, B), grid_for(P, B),
-                         P->num_cu, adam, s));
+                         P->num_cu, adam, P->has_leanw != 0, s));
     return 0;
 }
 

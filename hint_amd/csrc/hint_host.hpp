@@ -42,7 +42,7 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
-                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, hipStream_t stream);
+                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, bool wide, hipStream_t stream);
 hipError_t launch_bwd_n3(const KArgs& a, int lds_bytes, int grid, const ChainBlock& one, const ChainBlock* chain,
                          int n_chain, const float* x, const float* c, const float* g_z, const float* g_J,
                          float* g_x, float* g_c, float gz_scale, float gJ_const, hipStream_t stream);      // (hint_bwd3.hip: rows of <= 3 tiles)
@@ -102,14 +102,15 @@ struct Knobs {
     bool sub = true;            // HINT_SUB=0         no subtree groups
     int nw = 0;                 // HINT_NW=4|8        wavefronts per workgroup of the general kernels (0: the planner picks)
     bool lean = true;           // HINT_LEAN=0        keep a1 / g2 in HBM (no lean, lean-wide or subtree groups)
-    bool leanw = false;         // HINT_LEANW=1       lean-wide groups (round 6; off until part B rebuilds wide thin layers)
+    bool leanw = true;          // HINT_LEANW=0       no lean-wide groups (round 6: a1 / g2 of thin layers with 5 .. 28 inputs / outputs rebuilt by part B)
     bool fuse_dw1 = true;       // HINT_FUSE_DW1=0    first-layer weight gradients in part B instead of the backward kernel
     int pf = 1;                 // HINT_PF=0          general kernels: no L2 warm-up of the packed weights (hint_debug_set_prefetch switches it later)
     bool no_bwd_fly = false;    // HINT_NO_BWD_FLY=1  plans with lean general groups on the shared backward kernel
     int dw_splits = 0;          // HINT_DW_SPLITS=n   batch splits of part B
     int dw_small = -1;          // HINT_DW_SMALL=0|1  single-tile part-B jobs one per wavefront of a shared workgroup: never / always (-1: trees with subtree groups)
-    bool ablation_ok = false;   // HINT_ABLATION_OK=1 lets an ablation build / an ablation knob run a backward pass (its gradients are wrong: timing only)
-    bool abl_no_dw2 = false;    // HINT_ABL_NO_DW2=1  timing experiment: lean-wide units' dW2 jobs are dropped (needs HINT_ABLATION_OK=1)
+    int leanw_max = 12;         // HINT_LEANW_MAX=n   widest thin layer (inputs / outputs) of a lean-wide group: 5 .. 28 (default 12: three k-blocks;
+                                //                    wider ones cost part B more MFMAs than their a1 / g2 traffic is worth - NOTES.md section 10)
+    bool ablation_ok = false;   // HINT_ABLATION_OK=1 lets an ablation build (-DHINT_ABLATE_STORE) run a backward pass (its gradients are wrong: timing only)
     std::string non_default;
 };
 const Knobs& knobs();
@@ -130,6 +131,7 @@ struct hint_plan {
     int max_h = 0;              // widest hidden layer of the block
     int has_fly = 0;            // some general (not subtree) group is lean: the forward kernel's instance whose rows make such groups' first layer themselves
     int lean = 0;               // a1 / g2 are rebuilt by the weight-gradient kernel instead of kept in HBM
+    int has_leanw = 0;          // some group is lean-wide (Group::lean bit 3): part B runs the instance that rebuilds wide thin layers
     int fuse_dw1 = 0;           // lean plans with LDS-staged outputs: dW1, db1 come from the backward kernel (per-workgroup slabs), g1 stays on chip
     int tw_floats = 0;          // floats of one such slab
     int32_t* d_twmap = nullptr; // slab index -> offset in the flat parameter layout (or -1)
@@ -192,7 +194,7 @@ int64_t tape_act_off(const hint_plan* P, int B);
 int64_t act_stride(const hint_plan* P, int B);
 int64_t bits_stride(const hint_plan* P, int B);
 int grid_for(const hint_plan* P, int B);
-int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a);
+int lds_with_perms(const hint_plan* P, int lds_plan, int n_blocks, bool any_perm, KArgs* a, bool backward = false);     // (backward: which slot of hint_debug_last_lds_bytes the launch's size goes to)
 KArgs make_args(const hint_plan* P, int B, bool backward);
 void split_workspace(const hint_plan* P, int B, void* workspace, ChainBlock* b);
 void bind_tape(const hint_plan* P, int B, float* tape, ChainBlock* b);

@@ -183,9 +183,9 @@ static std::vector<LaneOp> build_lane_ops(std::vector<Group>& groups, const std:
             lops[(size_t)b * d + col] = op;
         }
         // the boundary's ACTIVE lanes (something to add or a coupling gradient to form), compacted: entry k's `pad` holds the k-th
-        // active lane | count << 16 - the wave-local backward kernel walks 16 rows x count lanes instead of 16 x d
-        // (the lanes that carry a coupling first, the scatter-only lanes behind them: the wave-local kernel walks the list 4 lanes x 16
-        //  rows per pass, and a pass without a coupling skips atanf / expf - cfg 2's leaf boundary is 4 + 1 lanes, GAS's 4 + 2)
+        // active lane | count << 16.  The kernels read the SLOT table built from this one further down (order: lanes that are both,
+        // pairs of a coupling-only and a scatter-only lane, the rest); this per-lane table is the planner's working copy, and its
+        // count is what HINT_PLAN_DUMP prints beside the slots.
         int cnt = 0;
         for (int pass = 0; pass < 2; ++pass)
             for (int col = 0; col < d; ++col) {
@@ -241,7 +241,6 @@ static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, con
         const Unit& u = units[ui];
         const hint_node_desc& n = nodes[unit_node[ui]];
         const bool lean = unit_lean[ui] != 0, fused = unit_fused[ui] != 0;     // (operands rebuilt - lean or lean-wide; dW1 / db1 from the backward kernel)
-        const bool skip_dw2 = unit_lean[ui] == 2 && knobs().abl_no_dw2;     // (timing experiment, refused by run_backward unless HINT_ABLATION_OK=1)
         const int net = (int)(ui & 1);
         const int64_t* po = n.p_off + net * 6;
         const int level = max_depth - n.depth;
@@ -266,9 +265,8 @@ static void make_wgrad_jobs(const hint_plan* P, const hint_node_desc* nodes, con
                     wjobs->push_back(j);
                 }
         };
-        if (!skip_dw2)
-            add_jobs(lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
-                     lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
+        add_jobs(lean ? WSRC_G2R : WSRC_G2, u.wcol, n.h, P->WT - 1, lean ? WSRC_A1R : WSRC_A1, u.wcol, n.h, P->WT - 1,
+                 lean ? level : 0, n.h, po[HINT_W2], po[HINT_B2]);
         add_jobs(WSRC_GST, u.gcol, n.r, P->ST - 1, WSRC_A2, u.wcol, n.h, P->WT - 1, 0, n.h, po[HINT_W3], po[HINT_B3]);
         if (u.ku > 0 && !fused)
             add_jobs(WSRC_G1, u.wcol, n.h, P->WT - 1, WSRC_X, u.xoff, u.ku, d - 1, level, u.cin, po[HINT_W1], po[HINT_B1]);
@@ -600,12 +598,12 @@ static int build_plan(const hint_node_desc* nodes, int32_t n_nodes, int32_t d, i
         bool leanw = !g.lean && lean_on && knobs().leanw;
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) {
             const hint_node_desc& n = nodes[unit_node[ui]];
-            if (units[ui].cin < 1 || units[ui].cin > LEANW_MAX || n.r < 1 || n.r > LEANW_MAX) leanw = false;
+            if (units[ui].cin < 1 || units[ui].cin > knobs().leanw_max || n.r < 1 || n.r > knobs().leanw_max) leanw = false;
         }
         for (int ui = g.unit_begin; ui < g.unit_end; ++ui) unit_lean[ui] = (char)(g.lean ? 1 : leanw ? 2 : 0);
         if (!g.lean) P->lean = 0;
         if (g.lean && !sub_bit) P->has_fly = 1;
-        if (leanw) g.lean |= 8;
+        if (leanw) { g.lean |= 8; P->has_leanw = 1; }
         g.lean |= sub_bit;
     }
     // ---- wave-local plans (hint_wl.hpp): every group lean, narrow lane tile, the block's thin vectors and biases small

@@ -203,6 +203,118 @@ __device__ __forceinline__ void dw_lean(f32x4 (&acc)[3][3], float (&psum)[3], co
     }
 }
 
+// lean-WIDE dW2 (round 6; Group::lean bit 3): the unit's thin layers have up to LEANW_MAX inputs / outputs, so a1 and g2 are
+// KBV = ceil(cin / 4) resp. KBG = ceil(r / 4) chained K = 4 MFMAs per tile instead of one.  The weights of those products -
+// lane l of step kb: W1[feature l&15 of tile t][4 kb + (l>>4)] and W3[4 kb + (l>>4)][feature] - are staged once per job in LDS in
+// lane order (`lw`: [t][kb][64] of W1, then of W3: conflict-free b32 reads), the inputs are KBV + KBG floats and NTM sign words
+// per lane and 16-row step, double buffered.  What it replaces: reading a1 and g2 ([Bp][WT] columns the forward / backward
+// kernels no longer write) - at cfg 5 315 MB of 1.52 GB per step.
+constexpr int LWK = (LEANW_MAX + 3) / 4;        // k-blocks of the widest thin layer
+// KBM: compile-time bound of both k-block counts (3 or LWK: the input registers are arrays of that size)
+template <int NTM, int NTN, int KBM>
+__device__ __forceinline__ void dw_leanw(f32x4 (&acc)[3][3], float (&psum)[3], const WJob& job, const LeanSrc& ls, const DwCtx& cx,
+                                         const LDS_AS float* lw, int lane) {
+    const int nl = cx.nl, kq = cx.kq;
+    const int KBV = (job.r_cin + 3) >> 2, KBG = (job.r_r + 3) >> 2;
+    const LDS_AS float* lw1 = lw + lane;
+    const LDS_AS float* lw3 = lw + NTN * KBV * 64 + lane;
+    float b1s[NTN];                           // (one register per tile: the bias vector is rebuilt in front of every chain)
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+        const int fq = job.qcol - job.r_wcol + 16 * t + nl;
+        b1s[t] = fq < job.r_h ? ls.prm[job.r_b1 + fq] : 0.f;
+    }
+    // per-lane offsets of a full k-block (every lane has an input) and of the last one (the lanes past the last input read
+    // beyond the bound = zero); k-block kb adds 16 kb bytes through the scalar offset
+    const int voff_v = (nl * ls.vs.ld + job.r_xoff + kq) * 4, voff_g = (nl * ls.ST + job.r_gcol + kq) * 4;
+    const int voff_vl = 4 * (KBV - 1) + kq < job.r_cin ? voff_v : BUF_OOB, voff_gl = 4 * (KBG - 1) + kq < job.r_r ? voff_g : BUF_OOB;
+    const int voff_b = 16 * (nl >> 2) + 4 * kq;
+    const int bit0 = nl & 3;                  // where the lane's four mask bits sit in its word of sign bytes: bit0 + 8 i
+    SrcRef gsr; gsr.p = ls.gst; gsr.ld = ls.ST; gsr.rows = 0x7fffffff;
+    const int nsteps = (cx.b_end - cx.bb0 + cx.step - 1) / cx.step;
+    if (nsteps <= 0) return;
+    const int last_bb = cx.bb0 + (nsteps - 1) * cx.step;
+    const int v_last = rows_valid(ls.vs, last_bb);
+    struct In { float v[KBM], g[KBM]; unsigned s[NTM]; };
+    auto load_in = [&](int BB) {
+        In in;
+        const __amdgpu_buffer_rsrc_t rv = rows_rsrc(ls.vs, BB, BB == last_bb ? v_last : 16), rg = rows_rsrc(gsr, BB, 16);
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            in.v[kb] = kb < KBV ? as_f32(__builtin_amdgcn_raw_buffer_load_b32(rv, kb == KBV - 1 ? voff_vl : voff_v, 16 * kb, 0)) : 0.f;
+            in.g[kb] = kb < KBG ? as_f32(__builtin_amdgcn_raw_buffer_load_b32(rg, kb == KBG - 1 ? voff_gl : voff_g, 16 * kb, 0)) : 0.f;
+        }
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(ls.bits + ((size_t)(BB >> 4) * ls.ntiles + (job.pcol >> 4)) * 64), 0, NTM * 64, BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) in.s[t] = __builtin_amdgcn_raw_buffer_load_b32(rb, voff_b + 64 * t, 0, 0);
+        return in;
+    };
+    // one 16-row step: the operand tiles from `in` (KBV + KBG chained MFMAs per tile, the tiles' chains interleaved), then - the
+    // inputs are spent - the NEXT step's loads, in flight across the NTM x NTN x 4 products
+    In in = load_in(cx.bb0);
+    int bb = cx.bb0;
+    for (int j = 0; j < nsteps; ++j) {
+        f32x4 p[NTM], q[NTN];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) q[t] = f32x4{b1s[t], b1s[t], b1s[t], b1s[t]};
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) p[t] = zero4();
+#pragma unroll
+        for (int kb = 0; kb < KBM; ++kb) {
+            if (kb < KBV) {
+#pragma unroll
+                for (int t = 0; t < NTN; ++t) q[t] = mfma4(in.v[kb], lw1[(t * KBV + kb) * 64], q[t]);
+            }
+            if (kb < KBG) {
+#pragma unroll
+                for (int t = 0; t < NTM; ++t) p[t] = mfma4(in.g[kb], lw3[(t * KBG + kb) * 64], p[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[t][i] = relu1(q[t][i]);
+#pragma unroll
+        for (int t = 0; t < NTM; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = __builtin_amdgcn_sbfe((int)in.s[t], bit0 + 8 * i, 1);
+                p[t][i] = as_f32((unsigned)(as_i32(p[t][i]) & m));
+            }
+        bb += cx.step;
+        in = load_in(min(bb, last_bb));
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) psum[t] += (p[t].x + p[t].y) + (p[t].z + p[t].w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) acc[tm][tn] = mfma4(p[tm][i], q[tn][i], acc[tm][tn]);
+    }
+}
+// the staged weights of dw_leanw: NTN x KBV + NTM x KBG vectors of 64 floats; `nw` wavefronts (1: a solo job's own) share the work
+__device__ __forceinline__ void stage_leanw(LDS_AS float* lw, const WJob& job, const GLOBAL_AS float* prm, int ntm, int ntn, int lane,
+                                            int w, int nw) {
+    const int nl = lane & 15, kq = lane >> 4;
+    const int KBV = (job.r_cin + 3) >> 2, KBG = (job.r_r + 3) >> 2;
+    const int n1 = ntn * KBV, n3 = ntm * KBG;
+    for (int idx = w; idx < n1 + n3; idx += nw) {
+        float val = 0.f;
+        if (idx < n1) {
+            const int t = idx / KBV, kb = idx - t * KBV, k = 4 * kb + kq;
+            const int fq = job.qcol - job.r_wcol + 16 * t + nl;
+            if (k < job.r_cin && fq < job.r_h) val = prm[job.r_w1 + (size_t)fq * job.r_cin + k];
+        } else {
+            const int i3 = idx - n1, t = i3 / KBG, kb = i3 - t * KBG, k = 4 * kb + kq;
+            const int fp = job.pcol - job.r_wcol + 16 * t + nl;
+            if (k < job.r_r && fp < job.r_h) val = prm[job.r_w3 + (size_t)k * job.r_h + fp];
+        }
+        lw[idx * 64 + lane] = val;
+    }
+}
+
 // the general products: P columns [pcol, pcol + 16 NTM) x Q columns [qcol, qcol + 16 NTN) over the rows of the split (NTN = 0: the
 // column sums of P only); PVEC / QVEC: a full 48-column group inside its array - one 12-byte load per lane and row
 template <int NTM, int NTN, bool PVEC, bool QVEC>
@@ -326,7 +438,8 @@ __device__ __forceinline__ void dw_solo8(f32x4 (&acc)[3][3], float (&psum)[3], c
 
 // SMALL: the job list ends in single-tile jobs that share workgroups (n_small > 0); plans without them (the wave-local ones)
 // run the instance that holds none of that code
-template <bool SMALL>
+// WIDE: the plan has lean-wide groups (dw_leanw); the other plans run the instances without that code
+template <bool SMALL, bool WIDE>
 __global__ __launch_bounds__(DW_WAVES * 64 HINT_DW_BOUND) void hint_wgrad_kernel(
     const WJob* __restrict__ jobs, int n_jobs, int n_small, int splits, ChainBlock one, const ChainBlock* __restrict__ chain,
     int grid_pb, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg, int64_t act_stride,
@@ -414,6 +527,21 @@ __global__ __launch_bounds__(DW_WAVES * 64 HINT_DW_BOUND) void hint_wgrad_kernel
         ls.gst = blk.wsGST;
         ls.bits = (const GLOBAL_AS uint8_t*)blk.actA1 + bits_a2_off;           // a2 sign bytes [row tile][tile][64]
         ls.ntiles = WT >> 4; ls.ST = ST;
+        if (WIDE && (job.r_cin > 4 || job.r_r > 4)) {
+            // the thin layers' weights -> LDS (the combine buffer `red` is free until the rows are done): one copy per workgroup,
+            // or per wavefront for the single-tile jobs that share a workgroup (no workgroup barrier on that path)
+            LDS_AS float* lw = (LDS_AS float*)&red[0][0][0][0] + (solo ? wave * (9 * 64 * 4) : 0);
+            stage_leanw(lw, job, blk.params, ntm, ntn, lane, solo ? 0 : wave, solo ? 1 : DW_WAVES);
+            if (!solo) __syncthreads();
+            const bool few = job.r_cin <= 12 && job.r_r <= 12;       // (at most three k-blocks either way: the instances with small input arrays)
+            switch (ntm * 4 + ntn) {
+#define DW_CASE(M_, N_) case M_ * 4 + N_: if (few) dw_leanw<M_, N_, 3>(acc, psum, job, ls, cx, lw, lane); else dw_leanw<M_, N_, LWK>(acc, psum, job, ls, cx, lw, lane); break;
+                DW_CASE(1, 1) DW_CASE(1, 2) DW_CASE(1, 3) DW_CASE(2, 1) DW_CASE(2, 2) DW_CASE(2, 3) DW_CASE(3, 1) DW_CASE(3, 2)
+                default: if (few) dw_leanw<3, 3, 3>(acc, psum, job, ls, cx, lw, lane); else dw_leanw<3, 3, LWK>(acc, psum, job, ls, cx, lw, lane); break;
+#undef DW_CASE
+            }
+            if (!solo) __syncthreads();       // (the staged weights are read to the last step: `red` takes the partials below)
+        } else
         switch (ntm * 4 + ntn) {
 #define DW_CASE(M_, N_) case M_ * 4 + N_: dw_lean<M_, N_>(acc, psum, job, ls, cx); break;
             DW_CASE(1, 1) DW_CASE(1, 2) DW_CASE(1, 3) DW_CASE(2, 1) DW_CASE(2, 2) DW_CASE(2, 3) DW_CASE(3, 1) DW_CASE(3, 2)
@@ -654,7 +782,7 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
                         int n_chain, int cb0, int WT, int ST, int d, int dc, int n_levels, int B, int Bp, int rows_per_wg,
                         int64_t act_stride, int64_t a2_off, int64_t bits_a2_off, int64_t param_floats, const float* x,
                         const float* c, const uint8_t* real, int accumulate, const int32_t* twmap, int tw_floats,
-                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, hipStream_t stream) {
+                        int64_t thin_slab_off, int thin_slabs, int num_cu, const AdamFuse* adam, bool wide, hipStream_t stream) {
     const bool interleave = n_small < 0;       // (flag in the sign: the planner sorted the jobs)
     if (interleave) n_small = -n_small - 1;
 #ifdef HINT_DW_SOLO_ALL
@@ -664,22 +792,17 @@ hipError_t launch_wgrad(const WJob* jobs, int n_jobs, int n_small, int splits, c
     const int grid_pb = n_chain > 1 ? (used + 7) / 8 * 8 : used;
     if (used > 0) {
         const int gpb = (interleave && n_chain > 1 && (splits & 7) == 0) ? -grid_pb : grid_pb;
-        if (n_small > 0)
-            hipLaunchKernelGGL(hint_wgrad_kernel<true>, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits,
-                               one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off,
-                               param_floats, x, c
 #ifdef HINT_STAMPS
-                               , h_dw_stamps
+#define HINT_DW_LAUNCH(S_, W_) hipLaunchKernelGGL((hint_wgrad_kernel<S_, W_>), dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits, \
+                               one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off, param_floats, x, c, h_dw_stamps)
+#else
+#define HINT_DW_LAUNCH(S_, W_) hipLaunchKernelGGL((hint_wgrad_kernel<S_, W_>), dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits, \
+                               one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off, param_floats, x, c)
 #endif
-                               );
-        else
-            hipLaunchKernelGGL(hint_wgrad_kernel<false>, dim3(grid_pb * n_chain), dim3(DW_WAVES * 64), 0, stream, jobs, n_jobs, n_small, splits,
-                               one, chain, gpb, cb0, WT, ST, d, dc, n_levels, B, Bp, rows_per_wg, act_stride, a2_off, bits_a2_off,
-                               param_floats, x, c
-#ifdef HINT_STAMPS
-                               , h_dw_stamps
-#endif
-                               );
+        if (wide) { if (n_small > 0) HINT_DW_LAUNCH(true, true); else HINT_DW_LAUNCH(false, true); }
+        else if (n_small > 0) HINT_DW_LAUNCH(true, false);
+        else HINT_DW_LAUNCH(false, false);
+#undef HINT_DW_LAUNCH
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -93,8 +93,8 @@ class FlowTrainer:
         self._chains = {}
         # state of the in-kernel noise generator (hint_chain_forward_noisy): {seed, step}; every rank
         # of a data-parallel job draws its own stream
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if seed is None:            # (not from torch's global generator: building a trainer must not shift the caller's random stream)
+            seed = int.from_bytes(os.urandom(8), "little") >> 2
         rank = dp.world_info(group)[0] if hasattr(dp, "world_info") else 0
         self.rng_state = torch.tensor([(seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 63 - 1), 0], dtype=torch.int64,
                                       device=dev)

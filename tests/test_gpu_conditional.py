@@ -388,3 +388,32 @@ def test_conditional_trainer_gradient_at_4096_rows():
     zy_g, zx_g, Jx_g, Jy_g = [t.detach().double().cpu() for t in tr.last]
     for got, ref in ((zx_g, zx_all[ridx]), (zy_g, zy_all[ridx]), (Jx_g, jx_all[ridx]), (Jy_g, jy_all[ridx])):
         assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_conditional_step_returns_device_scalars_and_seeded_noise_repeats(use_graph):
+    """step() returns ONE type on every path: a pair that unpacks to two device scalars the reference loop's statements work on
+    (`sum(batch_losses)`, `l0 + l1`, `torch.stack`, `.item()`: train_conditional.py:132-146); `seed=` makes the in-kernel noise
+    repeatable, and building a trainer leaves torch's global random stream alone"""
+    import copy
+    torch.manual_seed(11)
+    m = hint_amd.ConditionalHintFlow(10, 3, 2, 24).to(DEV)
+    for p in m.parameters():
+        p.data.add_(0.02 * torch.randn_like(p))
+    m2 = copy.deepcopy(m)
+    x = torch.randn(300, 10, device=DEV); y = torch.randn(300, 3, device=DEV)
+    torch.manual_seed(123)
+    before = torch.rand(3)
+    torch.manual_seed(123)
+    tr = hint_amd.ConditionalFlowTrainer(m, noise=0.05, use_graph=use_graph, seed=7)
+    assert torch.equal(torch.rand(3), before)
+    tr2 = hint_amd.ConditionalFlowTrainer(m2, noise=0.05, use_graph=use_graph, seed=7)
+    for _ in range(2):
+        l0, l1 = tr.step(x, y)
+        batch_losses = [l0, l1]
+        assert isinstance(l0, torch.Tensor) and l0.is_cuda and l0.dim() == 0
+        total = sum(batch_losses)
+        assert abs(float(total) - (l0.item() + l1.item())) < 1e-6 * max(1.0, abs(float(total)))
+        assert torch.stack([l0, l1]).shape == (2,) and float(l0 + l1) == float(total)
+        r0, r1 = tr2.step(x, y)
+        assert float(r0) == float(l0) and float(r1) == float(l1)      # same seed, same weights: the same noise

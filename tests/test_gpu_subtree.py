@@ -94,3 +94,45 @@ def test_subtree_groups_equal_general_groups(monkeypatch):
     np.testing.assert_allclose(g1.numpy(), g0.numpy(), rtol=1e-4, atol=1e-5 * float(g0.abs().max()))
     for k in p0:
         np.testing.assert_allclose(p1[k].numpy(), p0[k].numpy(), rtol=1e-4, atol=2e-5 * max(1e-6, float(p0[k].abs().max())), err_msg=k)
+
+
+@pytest.mark.parametrize("d,widths,B", [(43, [67, 33, 16, 8], 333), (100, [224, 112, 56], 200), (22, [40, 24], 4112)])
+def test_lean_wide_groups_equal_stored_operands(monkeypatch, d, widths, B):
+    """lean-wide groups (round 6: thin layers with 5 .. HINT_LEANW_MAX inputs / outputs - the forward stores no a1, the backward no
+    g2, part B rebuilds both with chained K = 4 MFMAs) against the same block with every operand kept in HBM (HINT_LEANW=0): the
+    forward is bit-identical (only stores are skipped), every gradient agrees to rounding; at the default width limit (12) and
+    at the widest the kernels take (28: MINIBOONE's root with 21 inputs / 22 outputs, the d = 100 tree's 25-wide level)"""
+    from hint_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(4)
+    x = torch.randn(B, d, generator=torch.Generator().manual_seed(9)).to(DEV)
+    ref_flow = hint_amd.HintFlow(d, 2, widths)
+    state = {k: v.clone() + 0.05 * torch.randn_like(v) for k, v in ref_flow.state_dict().items()}
+    outs = {}
+    try:
+        for name, env in (("off", {"HINT_LEANW": "0"}), ("default", {}), ("max", {"HINT_LEANW_MAX": "28"})):
+            for k in ("HINT_LEANW", "HINT_LEANW_MAX"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            lib.hint_debug_reload_knobs()
+            flow = hint_amd.HintFlow(d, 2, widths)
+            flow.load_state_dict(state)
+            flow = flow.to(DEV)
+            tr = hint_amd.FlowTrainer(flow, noise=0.0, use_graph=False)
+            tr._check_arenas()
+            tr.G.zero_()
+            tr._fwd_bwd(x, None)
+            torch.cuda.synchronize()
+            outs[name] = (tr.loss_acc.clone(), tr.G.clone())
+            del tr, flow
+    finally:
+        for k in ("HINT_LEANW", "HINT_LEANW_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        lib.hint_debug_reload_knobs()
+    gref = outs["off"][1].double()
+    for name in ("default", "max"):
+        assert torch.equal(outs[name][0], outs["off"][0]), name              # the loss sums of the forward: bit for bit
+        g = outs[name][1].double()
+        assert float((g - gref).norm() / gref.norm()) < 2e-6, (name, float((g - gref).norm() / gref.norm()))
+        assert float((g - gref).abs().max()) < 1e-5 * float(gref.abs().max()), name
