@@ -120,6 +120,28 @@ def newest_pmc(workload):
         return {}, None
 
 
+def newest_kernel_stats(workload):
+    """{kernel name without spaces: average ns} from the committed `rocprofv3 --kernel-trace --stats` summary of the newest round
+    (profiles/rNN_kernel_stats.csv: the headline's bench run; profiles/rNN_kernel_stats_<workload>.csv the others'), and its path"""
+    pat = "profiles/r*_kernel_stats.csv" if workload == "power_hint_8" else f"profiles/r*_kernel_stats_{workload}.csv"
+    best, best_r = None, -1
+    for f in glob.glob(os.path.join(ROOT, pat)):
+        m = re.match(r"r(\d+)_kernel_stats", os.path.basename(f))
+        if m and int(m.group(1)) > best_r:
+            best, best_r = f, int(m.group(1))
+    if best is None:
+        return {}, None
+    import csv
+    out = {}
+    try:
+        for r in csv.DictReader(open(best)):
+            name = r["Name"].split("(")[0].replace("void ", "").replace(" ", "")
+            out[name] = float(r["AverageNs"])
+    except Exception:      # noqa: BLE001
+        return {}, None
+    return out, os.path.relpath(best, ROOT)
+
+
 def timed_reps(step, barrier, steps, reps, use_dist, dist, dev):
     """`reps` repetitions of: barrier + synchronize, exactly `steps` steps, barrier + synchronize; per repetition the
     max over ranks.  Returns the list of elapsed seconds."""
@@ -496,13 +518,18 @@ def run_flow(args, name, rank, world, dev, use_dist, dist, headline):
     # HBM traffic per launch comes from rocprofv3 PMC passes run separately (tools/refresh_profiles.sh); it is NOT measured in
     # this process - the line says where it was read from
     pmc, pmc_file = newest_pmc(name) if B == cfg["batch"] else ({}, None)
+    kstats, kstats_file = newest_kernel_stats(name) if B == cfg["batch"] else ({}, None)
+    pmc_build = pmc.get("_build", {}) if isinstance(pmc, dict) else {}
+    lib_info = res["config"].get("library_build", "")
+    lib_stamp = re.search(r"src ([0-9a-f]+)", lib_info)
+    lib_stamp = lib_stamp.group(1) if lib_stamp else None
 
     def pmc_entry(kernel):
         # rocprof's kernel names carry the template arguments: the full name must match (hint_bwd_kernel is a prefix of
         # hint_bwd_kernel_n3 and hint_bwd_kernel_fly); a summary of an older build, whose instances had fewer template
         # arguments, matches when exactly one of its kernels has the same base name and leading arguments
         want = kernel.replace(" ", "")
-        keys = {k.replace(" ", ""): v for k, v in pmc.items()}
+        keys = {k.replace(" ", ""): v for k, v in pmc.items() if k != "_build"}
         if want in keys:
             return keys[want]
         base, _, targs = want.partition("<")
@@ -514,9 +541,18 @@ def run_flow(args, name, rank, world, dev, use_dist, dist, headline):
         ach = flops / (us * 1e-6) / 1e12
         e = pmc_entry(kernel) or {}
         issued = e.get("sq", {}).get("SQ_INSTS_MFMA")
+        # the same kernel's average launch in the committed rocprofv3 --kernel-trace --stats summary: the second opinion on `frac`
+        ns = kstats.get(kernel.replace(" ", ""))
+        src = None
+        if e:
+            src = (f"{pmc_file} (rocprofv3 --pmc passes of tools/steps.py, builder-run, not measured in this run; counters taken on library "
+                   f"src {pmc_build.get('src_stamp')}, git {pmc_build.get('git_head')}; this run's library: src {lib_stamp}; "
+                   f"same sources: {pmc_build.get('src_stamp') is not None and pmc_build.get('src_stamp') == lib_stamp})")
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": e.get("hbm_bytes_per_launch"),
-                "traffic_source": f"{pmc_file} (rocprofv3 --pmc passes of tools/steps.py, builder-run; not measured in this run)" if e else None,
+                "traffic_source": src,
+                "frac_rocprof": (flops / (ns * 1e-9) / 1e12 / PEAK_F32_MFMA_TFLOPS) if ns else None,
+                "frac_rocprof_source": f"{kstats_file}: average launch {ns / 1e3:.1f} us" if ns else None,
                 "avg_launch_us": us, "timing": "HIP events around the launch inside 20 un-captured training steps (FlowTrainer.timed_step); "
                                                "`value` is timed on graph replays",
                 "algorithmic_flops_per_launch": flops, "blocks_per_launch": nb,

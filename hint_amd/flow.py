@@ -243,6 +243,7 @@ class _ChainFn(torch.autograd.Function):
         inst, lease = runner.acquire(B)
         z = torch.empty_like(x)
         J = torch.empty(B, dtype=torch.float32, device=x.device)
+        runner.pack_all()           # (behind all host-side preparation: the re-pack and the forward launch go out back to back)
         with torch.cuda.device(runner.device):
             _lib.check(runner.lib.hint_chain_forward(inst[0], x.data_ptr(), c.data_ptr() if c is not None else None,
                                                      z.data_ptr(), J.data_ptr(), None, None,
@@ -375,13 +376,13 @@ class HintFlow(nn.Module):
             x = x.contiguous()
             c = c.contiguous() if c is not None else None
             run.check_arenas()
-            run.pack_all()
             if needs:
                 return _ChainFn.apply(run, x, c, run.anchor())
             B = x.shape[0]
             out = torch.empty_like(x)
             J = torch.empty(B, dtype=torch.float32, device=x.device)
             chain = run.chain_infer(B)
+            run.pack_all()
             with torch.cuda.device(run.device):
                 stream = torch.cuda.current_stream(run.device).cuda_stream
                 cp = c.data_ptr() if c is not None else None

@@ -132,7 +132,10 @@ def test_lean_wide_groups_equal_stored_operands(monkeypatch, d, widths, B):
         lib.hint_debug_reload_knobs()
     gref = outs["off"][1].double()
     for name in ("default", "max"):
-        assert torch.equal(outs[name][0], outs["off"][0]), name              # the loss sums of the forward: bit for bit
+        if B <= 1024:           # one workgroup per loss slot: the forward's loss sums bit for bit (beyond, the slots' atomic adds come in any order)
+            assert torch.equal(outs[name][0], outs["off"][0]), name
+        else:
+            assert torch.allclose(outs[name][0].sum(0), outs["off"][0].sum(0), rtol=1e-6), name
         g = outs[name][1].double()
         assert float((g - gref).norm() / gref.norm()) < 2e-6, (name, float((g - gref).norm() / gref.norm()))
         assert float((g - gref).abs().max()) < 1e-5 * float(gref.abs().max()), name

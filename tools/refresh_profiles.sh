@@ -5,7 +5,8 @@
 # then, back in the container:  cp gpurun_out/r05/summary/* profiles/
 # Counter passes: the headline workload always; further workloads (default: gas_hint_8 miniboone_hint_10 plus_hint_4
 # conditional_hint_4_full - every BASELINE config) get FETCH_SIZE / WRITE_SIZE / SQ passes of their own.
-R=${1:-r05}; shift
+R=${1:-r06}; shift
+export GIT_REV=${GIT_REV:-unknown}       # (.git does not travel to the GPU box: pass the commit the tree is at, tools/pmc_summary.py records it)
 PMC_WL=${@:-gas_hint_8 miniboone_hint_10 plus_hint_4 conditional_hint_4_full}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
