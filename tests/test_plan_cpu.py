@@ -140,3 +140,35 @@ def test_backward_boundary_slots_pair_coupling_only_with_scatter_only_lanes(d, w
     st, nodes, _ = check(blk.tree, d, 0)
     assert st["max_slots"] == slots < d
     assert 16 * st["max_slots"] <= 64 * st["nw"] or st["wave_local"]
+
+
+@pytest.mark.parametrize("env", [{"HINT_LEANW": "0"}, {}, {"HINT_LEANW_MAX": "28"}])
+def test_lean_wide_knobs_change_no_layout(monkeypatch, env):
+    """lean-wide groups (Group::lean bit 3: a1 / g2 of thin layers with 5 .. HINT_LEANW_MAX inputs / outputs rebuilt by part B) only
+    switch stores off and re-source the dW2 jobs: arrays, parameters, jobs and LDS of a plan are the same with and without them,
+    and the knobs that are set show up in hint_build_info()"""
+    lib = _lib.load()
+    for k in ("HINT_LEANW", "HINT_LEANW_MAX"):
+        monkeypatch.delenv(k, raising=False)
+    lib.hint_debug_reload_knobs()
+    base = {}
+    for d, widths in ((43, [67, 33, 16, 8]), (100, [224, 112, 56])):
+        blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths)
+        base[d] = check(blk.tree, d, 0)[0]
+    try:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lib.hint_debug_reload_knobs()
+        info = lib.hint_build_info().decode()
+        for k, v in env.items():
+            assert f"{k}={v}" in info
+        assert ("knobs:" in info) == bool(env)
+        for d, widths in ((43, [67, 33, 16, 8]), (100, [224, 112, 56])):
+            blk = hint_amd.HierarchicalAffineCouplingBlock([(d,)], c_internal=widths)
+            got = check(blk.tree, d, 0)[0]
+            # (single-tile dW2 jobs that rebuild their operands share workgroups, one per wavefront: their count follows the knob)
+            assert {k: v for k, v in got.items() if k != "small_jobs"} == {k: v for k, v in base[d].items() if k != "small_jobs"}
+    finally:
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        lib.hint_debug_reload_knobs()

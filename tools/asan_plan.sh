@@ -1,6 +1,6 @@
 #!/bin/bash
 # The planner and the host side of the C ABI under AddressSanitizer + UBSan (CPU only: hint_plan_check
-# builds and verifies plans without a device).  Last run: 48 tests, no report.
+# builds and verifies plans without a device).  Last run (round 6): 61 tests, no report.
 set -e
 cd "$(dirname "$0")/.."
 make -C hint_amd/csrc asan
