@@ -727,18 +727,10 @@ __global__ __launch_bounds__(256) void hint_wreduce_kernel(ChainBlock one, const
     const int64_t n4 = param_floats >> 2;        // param_floats is a multiple of 4 (hint_plan_param_floats)
     for (int64_t i4 = (int64_t)bid * 256 + threadIdx.x; i4 < n4; i4 += (int64_t)blocks_pb * 256) {
         const uchar4 rl = ((const uchar4*)real)[i4];      // 1: from part B's slabs; 2: from the backward kernel's (above); 0: padding
-        // (eight slabs' loads in flight at a time, added in split order - one load per iteration was a chain of `splits` L2 / HBM
-        //  latencies: 9.0 us for 8 splits at cfg 2)
+        // (a plain loop: eight slabs' loads in flight at a time - round 6 - gained 0.8 us in the stand-alone reduction and LOST 1.5 us of
+        //  the captured cfg 2 step with the optimizer folded in, three A/B pairs: NOTES.md section 10)
         f32x4 s = zero4();
-        int sp = 0;
-        for (; sp + 8 <= splits; sp += 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ((const f32x4*)(slab + (size_t)(sp + u) * param_floats))[i4];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; sp < splits; ++sp) s += ((const f32x4*)(slab + (size_t)sp * param_floats))[i4];
+        for (int sp = 0; sp < splits; ++sp) s += ((const f32x4*)(slab + (size_t)sp * param_floats))[i4];
         if (fuse) {
             f32x4* pp = (f32x4*)(ad.p + aoff) + i4; f32x4* pm = (f32x4*)(ad.m + aoff) + i4; f32x4* pv = (f32x4*)(ad.v + aoff) + i4;
             f32x4 p4 = *pp, m4 = *pm, v4 = *pv;
