@@ -142,6 +142,44 @@ def newest_kernel_stats(workload):
     return out, os.path.relpath(best, ROOT)
 
 
+def live_hbm_traffic(workload, steps=10, timeout=240):
+    """HBM bytes per launch of every hint_* kernel of `workload`'s training step, MEASURED IN THIS RUN: two child processes
+    `rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python3 tools/steps.py <workload> <steps>` (separate passes, as
+    MI355X_MICROARCH.md prescribes; children, started from /tmp - the profiler never wraps this process), corrected the same way
+    as tools/pmc_summary.py: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 tallies 128-byte reads as 64).  Returns
+    ({kernel name without spaces: bytes}, note) or ({}, why not)."""
+    import csv, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    per = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hint_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3",
+                                os.path.join(ROOT, "tools", "steps.py"), workload, str(steps)],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            if b"\nok " not in b"\n" + r.stdout:
+                return {}, f"the {counter} pass did not finish ({r.returncode})"
+            acc = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace(" ", "")
+                    acc.setdefault(k, []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                per.setdefault(k, {})[counter] = sum(v) / len(v)
+        except Exception as e:      # noqa: BLE001
+            return {}, f"the {counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in per.items() if "hint_" in k and len(v) == 2}
+    return out, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two child processes of tools/steps.py "
+                 f"({steps} un-captured steps each), (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch")
+
+
 def timed_reps(step, barrier, steps, reps, use_dist, dist, dev):
     """`reps` repetitions of: barrier + synchronize, exactly `steps` steps, barrier + synchronize; per repetition the
     max over ranks.  Returns the list of elapsed seconds."""
@@ -548,9 +586,11 @@ def run_flow(args, name, rank, world, dev, use_dist, dist, headline):
             src = (f"{pmc_file} (rocprofv3 --pmc passes of tools/steps.py, builder-run, not measured in this run; counters taken on library "
                    f"src {pmc_build.get('src_stamp')}, git {pmc_build.get('git_head')}; this run's library: src {lib_stamp}; "
                    f"same sources: {pmc_build.get('src_stamp') is not None and pmc_build.get('src_stamp') == lib_stamp})")
+        lv = live.get(kernel.replace(" ", ""))
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": e.get("hbm_bytes_per_launch"),
-                "traffic_source": src,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": lv if lv is not None else e.get("hbm_bytes_per_launch"),
+                "traffic_source": live_note if lv is not None else src,
+                "traffic_committed": e.get("hbm_bytes_per_launch"), "traffic_committed_source": src if lv is not None else None,
                 "frac_rocprof": (flops / (ns * 1e-9) / 1e12 / PEAK_F32_MFMA_TFLOPS) if ns else None,
                 "frac_rocprof_source": f"{kstats_file}: average launch {ns / 1e3:.1f} us" if ns else None,
                 "avg_launch_us": us, "timing": "HIP events around the launch inside 20 un-captured training steps (FlowTrainer.timed_step); "
@@ -558,6 +598,12 @@ def run_flow(args, name, rank, world, dev, use_dist, dist, headline):
                 "algorithmic_flops_per_launch": flops, "blocks_per_launch": nb,
                 "mfma_issued_over_algorithmic": (issued * 2048.0 / flops) if issued else None}
 
+    # HBM bytes per launch measured in THIS run (headline, one process): child processes under rocprofv3's counters
+    live, live_note = ({}, None)
+    if headline and world == 1 and not use_dist and B == cfg["batch"] and not args.no_live_traffic:
+        live, live_note = live_hbm_traffic(name)
+    if live_note and not live:
+        res["live_traffic_note"] = live_note
     if in_step:
         fwd_name, bwd_name = trainer.kernel_names(B)
         # dominant kernel = the row-parallel backward kernel, one launch for all blocks: dX through the three
@@ -702,6 +748,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the oracle cross-checks")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default single-GPU run: do not time BASELINE's other configs after the headline")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="default single-GPU run: do not measure the headline kernels' HBM bytes under rocprofv3 (two child processes); "
+                         "roofline.traffic then comes from the committed counter summary")
     ap.add_argument("--no-module-path", action="store_true",
                     help="default single-GPU run: do not time the drop-in module route (extra.module_path) after the headline")
     ap.add_argument("--batch", type=int, default=0,

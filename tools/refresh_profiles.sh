@@ -13,7 +13,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/$R; S=$O/summary; mkdir -p $S
 python bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | python -m json.tool > $S/${R}_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o final -- python3 bench.py --no-cpu-baseline --no-other-workloads --no-module-path > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o final -- python3 bench.py --no-cpu-baseline --no-other-workloads --no-module-path --no-live-traffic > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $S/${R}_kernel_stats.csv
 SQ1="SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH"
@@ -35,7 +35,7 @@ for W in $PMC_WL; do
   python tools/pmc_summary.py $S/${R}_pmc_$W.json $NB $O/pmc_${W}_FETCH_SIZE $O/pmc_${W}_WRITE_SIZE $O/pmc_${W}_SQ $O/pmc_${W}_MIX > $O/pmc_summary_$W.log 2>&1
 done
 rm -f $O/workloads.jsonl
-for W in power_hint_4 plus_hint_4_big; do python bench.py --no-cpu-baseline --no-other-workloads --workload $W 2>/dev/null | tail -1 >> $O/workloads.jsonl; done
+for W in power_hint_4 plus_hint_4_big; do python bench.py --no-cpu-baseline --no-other-workloads --no-live-traffic --workload $W 2>/dev/null | tail -1 >> $O/workloads.jsonl; done
 # the N > 1 code path on ONE GPU (no multi-GPU node behind gpurun): a one-rank RCCL group, the gradient all-reduce captured in
 # the step's graph and the separate clamp + Adam launch instead of the optimizer inside the slab reduction - what leaving the
 # fused-optimizer path costs, tracked until a node exists
