@@ -229,7 +229,13 @@ class ChainRunner:
             handle, keep = self.build_chain(B, perms, G, ws=ws)
             self._wsbuf[skey] = keep[1]
             inst = (handle, key, keep)
-        return inst, _Lease(pool, inst)
+        return inst, _Lease(pool, inst, self._drop_instance)
+
+    def _drop_instance(self, inst):
+        """a chain instance that does not go back to its (full) pool: its launches are through when its autograd node dies on
+        the stream that ran them; destroy the handle (the tapes are plain tensors)"""
+        torch.cuda.synchronize(self.device)
+        self.lib.hint_chain_destroy(inst[0])
 
 
 class _ChainFn(torch.autograd.Function):

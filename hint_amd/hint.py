@@ -110,16 +110,18 @@ class _Region:
 
 class _Lease:
     """hands a pooled buffer back when the autograd node that holds it dies (not at the end of backward():
-    retain_graph=True may run the node again)"""
-    __slots__ = ("pool", "item")
+    retain_graph=True may run the node again); a pool keeps two - what a third one owns besides memory is released by `drop`"""
+    __slots__ = ("pool", "item", "drop")
 
-    def __init__(self, pool, item):
-        self.pool, self.item = pool, item
+    def __init__(self, pool, item, drop=None):
+        self.pool, self.item, self.drop = pool, item, drop
 
     def __del__(self):
         try:
             if len(self.pool) < 2:
                 self.pool.append(self.item)
+            elif self.drop is not None:
+                self.drop(self.item)
         except Exception:
             pass
 

@@ -271,3 +271,24 @@ def test_trainer_steps_then_module_forward_sees_the_new_weights():
         np.testing.assert_allclose(z1.cpu().numpy(), z2.cpu().numpy(), rtol=1e-5, atol=1e-5)
     finally:
         H.set_pack_cache(prev)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_more_live_forwards_than_the_pool_keeps(fuse):
+    """four forwards alive at once (a pool keeps two buffers / chain instances; the others are plain allocations released when
+    their autograd nodes die), backward in reverse order, then the same again: every gradient as from a lone forward"""
+    flow = make_flow(d=6, nb=2, widths=(32, 16))
+    flow.fuse_chain = fuse
+    ps = list(flow.parameters())
+    xs = [torch.randn(200, 6, device=DEV) for _ in range(4)]
+    want = [grads_of(flow, x, fuse=fuse)[3] for x in xs]
+    flow.fuse_chain = fuse
+    for _ in range(2):
+        losses = [loss_of(flow, x) for x in xs]
+        for k in reversed(range(4)):
+            for p in ps:
+                p.grad = None
+            losses[k].backward()
+            for p, g in zip(ps, want[k]):
+                assert rel_err(p.grad.cpu().numpy(), g.cpu().numpy()) < 1e-6
+        del losses
