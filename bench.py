@@ -822,7 +822,7 @@ def main():
             res.setdefault("extra", {})["module_path"] = {
                 "what": "train_unconditional.py:114-144 verbatim (zero_grad, noise, model(x), log_jacobian, two loss terms + .item(), backward, "
                         "per-parameter clamp_, torch.optim.Adam.step) on hint_amd.HintFlow; hint_amd_host_ms = host clock inside hint_amd's "
-                        "entry points, hint_amd_device_ms = HIP events around them, loop_own_ms = the rest of the step (autograd engine, "
+                        "entry points, hint_amd_device_ms = HIP events around their launches (first launch to last, host gaps between them included), loop_own_ms = the rest of the step (autograd engine, "
                         "the loop's ATen work: 288 clamp_ calls, foreach Adam); the step is host-bound",
                 "fast_path_kernels_ms": fast_ms, "hintflow": fused, "block_walk": walk}
         except Exception as e:      # noqa: BLE001 - the headline line must come out whatever happens here

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import hint as _hint
-from .hint import HierarchicalAffineCouplingBlock, HintAmdError, _Lease, _Region
+from .hint import HierarchicalAffineCouplingBlock, HintAmdError, _Lease, _Region, _mark_launch
 
 
 def random_orthogonal(d: int, seed: int) -> torch.Tensor:
@@ -111,6 +111,7 @@ class ChainRunner:
         """one launch re-packs every block (hint_pack_group_*); the group is rebuilt whenever an arena or packed buffer
         moved.  With zero_buf / rng_state / opt_state the launch is a training step's prologue (hint_pack_group_run_ex)."""
         key = tuple((e.arena.data_ptr(), e.packed.data_ptr()) for e in self.engines)
+        _mark_launch()
         if self._pack_key != key:
             if self._pack_group:
                 self.lib.hint_pack_group_destroy(self._pack_group)
@@ -276,6 +277,7 @@ class _ChainFn(torch.autograd.Function):
 
             def run(g_params, accumulate):
                 # (the chain's blocks write their gradient slices of runner.G: g_params IS runner.G on this route)
+                _mark_launch()
                 with torch.cuda.device(runner.device):
                     _lib.check(runner.lib.hint_chain_backward(chain, x.data_ptr(), ptr(c), ptr(gz), ptr(gJ), gx.data_ptr(), ptr(gc),
                                                               1.0, 0.0, accumulate,

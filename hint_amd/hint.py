@@ -72,7 +72,7 @@ _PROF = None
 
 def profile_start():
     global _PROF
-    _PROF = {"host": 0.0, "events": [], "calls": 0}
+    _PROF = {"host": 0.0, "events": [], "calls": 0, "cur": None}
     return _PROF
 
 
@@ -86,14 +86,16 @@ def profile_stop(prof, n_steps: int):
 
 
 class _Region:
-    """`with _Region():` around an entry point: nothing unless profile_start() is active"""
+    """`with _Region():` around an entry point: nothing unless profile_start() is active.  Host clock over the whole entry; the
+    HIP events bracket its LAUNCHES (first one: _mark_launch() at the launch sites - the host-side preparation in front of it is
+    host time, not device time)"""
     __slots__ = ("pr", "t0", "e0")
 
     def __enter__(self):
         self.pr = _PROF
         if self.pr is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            self.e0 = None
+            self.pr["cur"] = self
             self.t0 = time.perf_counter()
         return self
 
@@ -101,11 +103,23 @@ class _Region:
         pr = self.pr
         if pr is not None:
             pr["host"] += time.perf_counter() - self.t0
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            pr["events"].append((self.e0, e1))
+            if self.e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                pr["events"].append((self.e0, e1))
+            pr["cur"] = None
             pr["calls"] += 1
         return False
+
+
+def _mark_launch():
+    """the first launch of the current entry point is about to go out (profile_start() only)"""
+    pr = _PROF
+    if pr is not None:
+        cur = pr.get("cur")
+        if cur is not None and cur.e0 is None:
+            cur.e0 = torch.cuda.Event(enable_timing=True)
+            cur.e0.record()
 
 
 class _Lease:
@@ -355,6 +369,7 @@ class _Engine:
             self.packed = torch.empty(self.lib.hint_plan_packed_floats(self.plan), dtype=torch.float32,
                                       device=self.device)
             self._pack_key = None
+        _mark_launch()
         if _PACK_CACHE:
             key = [self._gathers] + [(p.data_ptr(), p._version) for p in self.params]
             if key == self._pack_key:
@@ -443,6 +458,7 @@ class _Engine:
             return gx, gc, g_params
         ws, nbytes = self.workspace(B, x.device)
         perm = self.compose_perm(front)
+        _mark_launch()
         with torch.cuda.device(self.device):
             st = self.lib.hint_block_backward_ex(
                 self.plan, self.arena.data_ptr(), self.packed.data_ptr(), x.data_ptr(),
@@ -465,6 +481,7 @@ class _Engine:
         g_params = torch.empty(self.total, dtype=torch.float32, device=x.device)
         perm = self.total_perm()
         ptr = lambda t: t.data_ptr() if t is not None else None
+        _mark_launch()
         with torch.cuda.device(self.device):
             nbytes = self.lib.hint_plan_inverse_workspace_bytes(self.plan, B) if B > 0 else 0
             if B > 0 and nbytes == 0:
