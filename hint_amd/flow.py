@@ -13,6 +13,7 @@ state_dict.  "parity unpinned" applies to that stand-in only, not to the couplin
 from __future__ import annotations
 
 import ctypes as C
+import operator
 from typing import List, Optional, Sequence
 
 import torch
@@ -20,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import hint as _hint
-from .hint import HierarchicalAffineCouplingBlock, HintAmdError, _Lease, _Region, _mark_launch
+from .hint import HierarchicalAffineCouplingBlock, HintAmdError, _Lease, _Region, _mark_launch, _NONES
 
 
 def random_orthogonal(d: int, seed: int) -> torch.Tensor:
@@ -46,6 +47,10 @@ class FixedOrthogonal(nn.Module):
 
     def output_dims(self, input_dims):
         return input_dims
+
+
+_REQUIRES_GRAD = operator.attrgetter("requires_grad")
+_GRAD = operator.attrgetter("grad")
 
 
 class ChainRunner:
@@ -286,12 +291,12 @@ class _ChainFn(torch.autograd.Function):
 
             G, views = runner.grad_views()
             params = runner.params
-            grads = [p.grad for p in params]
-            if all(g is None for g in grads):
+            grads = list(map(_GRAD, params))
+            if all(map(operator.is_, grads, _NONES)):
                 run(G, 0)
                 for p, v in zip(params, views):
                     p.grad = v
-            elif all(g is v for g, v in zip(grads, views)):
+            elif all(map(operator.is_, grads, views)):
                 run(G, 1)
             else:
                 # foreign gradients or a mix: the chain can only write G, so G's content (gradients some p.grad may alias)
@@ -376,7 +381,7 @@ class HintFlow(nn.Module):
         if not run.chainable:
             return None
         grad = torch.is_grad_enabled()
-        n_req = sum(p.requires_grad for p in run.params) if grad else 0
+        n_req = sum(map(_REQUIRES_GRAD, run.params)) if grad else 0
         needs = grad and (n_req > 0 or x.requires_grad or (c is not None and c.requires_grad))
         if needs and (rev or _hint._PARAM_GRADS != "direct" or n_req != len(run.params)):
             return None

@@ -18,6 +18,7 @@ re-gathered automatically whenever a parameter stops aliasing it (`p.data = ...`
 from __future__ import annotations
 
 import ctypes as C
+import operator
 import os
 import time
 from typing import List, Optional, Sequence
@@ -494,6 +495,10 @@ class _Engine:
         return gz, gc, g_params
 
 
+import itertools
+_NONES = itertools.repeat(None)
+
+
 def deliver_param_grads(params, views, flat, run, fresh):
     """'direct' mode: make `p.grad` of every parameter hold the gradient `run(g_params, accumulate)` computes (the launch that
     writes the flat gradient of `params` - a block's or a whole flow's - into a buffer of `flat`'s layout).
@@ -502,12 +507,12 @@ def deliver_param_grads(params, views, flat, run, fresh):
       anything else (foreign gradients, a mix)              -> into a fresh buffer, then per parameter as autograd would
     `fresh()` allocates such a buffer and returns (buffer, views)."""
     grads = [p.grad for p in params]
-    if all(g is None for g in grads):
+    if all(map(operator.is_, grads, _NONES)):
         run(flat, 0)
         for p, v in zip(params, views):
             p.grad = v
         return
-    if all(g is v for g, v in zip(grads, views)):
+    if all(map(operator.is_, grads, views)):
         run(flat, 1)
         return
     buf, vs = fresh()

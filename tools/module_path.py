@@ -43,6 +43,8 @@ def run(name="power_hint_8", steps=60, warmup=10, per_block=False, dev=None, pro
     for _ in range(warmup):
         body()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()                          # (the caller's garbage - bench.py's other workloads - is not this loop's)
     t0 = time.perf_counter()
     for _ in range(steps):
         body()
