@@ -17,7 +17,7 @@ mkdir -p gpurun_out
 OUT=gpurun_out/scale_$MODE.jsonl; rm -f $OUT
 for N in 1 2 4 8; do
   if [ $N -eq 1 ]; then
-    python bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --scaling $MODE --no-cpu-baseline --no-other-workloads | tail -1 >> $OUT
+    python bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --scaling $MODE --no-cpu-baseline --no-other-workloads --no-module-path --no-live-traffic | tail -1 >> $OUT
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) \
       bench.py --gpus $N --steps $STEPS --warmup $WARMUP --scaling $MODE --no-cpu-baseline | tail -1 >> $OUT
