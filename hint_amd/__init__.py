@@ -4,7 +4,7 @@ Public surface mirrors /root/reference/hint.py (see hint_amd/hint.py); the compu
 hint_amd/csrc behind the C ABI of include/hint_amd.h.
 """
 from .hint import (HierarchicalAffineCouplingBlock, HierarchicalAffineCouplingTree,  # noqa: F401
-                   HintAmdError, linear_subnet_constructor)
+                   HintAmdError, linear_subnet_constructor, set_pack_cache, set_param_grad_mode)
 
 from .flow import FixedOrthogonal, HintFlow  # noqa: F401,E402
 from .train import FlowTrainer  # noqa: F401,E402
